@@ -1,0 +1,106 @@
+"""CPU: the oracle restatement (oracle/mmvae_ref.py) reproduces the golden vectors that
+oracle/make_golden.py captured from the imported reference (reference never needed here)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mmvae_ref as R
+
+
+def _unpack(fx, B, widths):
+    out = []
+    for i in range(2):
+        out.append([torch.from_numpy(np.unpackbits(fx[f"mask_{i}_{j}"], axis=1)[:, :w].astype(np.float32))
+                    for j, w in enumerate(widths)])
+    return out
+
+
+def _run(ds, fx):
+    B, D = int(fx["B"]), int(fx["D"])
+    wm = bool(fx["with_masks"])
+    P = R.formula_params(ds, D, requires_grad=True)
+    image, second = R.formula_inputs(ds, B)
+    full = "eps_0" in fx
+    if full:
+        eps = [torch.from_numpy(fx[f"eps_{k}"]) for k in range(3)]
+    else:  # scalar-only records were drawn with torch.manual_seed(seed0+k)
+        eps = []
+        for k in range(3):
+            torch.manual_seed(int(fx["seed0"]) + k)
+            eps.append(torch.empty(B, D).normal_())
+    if ds == "multimnist":
+        em = None
+        if wm:
+            m = _unpack(fx, B, (400, 200))
+            em = (m[0], m[1], None)
+        losses, outs = R.multimnist_step_losses(P, image, second, True, 1e-3, eps, em,
+                                                enc_drop_p=0.1 if wm else 0.0, gru_drop_p=0.0)
+    elif ds == "mnist":
+        losses, outs = R.mnist_step_losses(P, image.view(-1, 784), second, True, eps)
+    else:
+        em = None
+        if wm:
+            m = _unpack(fx, B, (1024,))
+            em = (m[0][0], m[1][0], None)
+        losses, outs = R.celeba_step_losses(P, image, second, True, eps, em, 0.1 if wm else 0.0)
+    (losses[0] + losses[1] + losses[2]).backward()
+    return P, losses, outs
+
+
+CASES = [("multimnist", "multimnist_b8"), ("multimnist", "multimnist_b8_masks"), ("mnist", "mnist_b8"),
+         ("mnist", "mnist_b128_scalars"), ("celeba", "celeba_b4"), ("celeba", "celeba_b4_masks")]
+
+
+@pytest.mark.parametrize("ds,name", CASES)
+def test_oracle_matches_golden(ds, name, golden_dir):
+    fx = np.load(os.path.join(golden_dir, name + ".npz"))
+    P, losses, outs = _run(ds, fx)
+    D = int(fx["D"])
+    names = [n for n, _ in R.param_table(ds, D)]
+    np.testing.assert_allclose([l.item() for l in losses], fx["loss"], rtol=2e-5)
+    gn = torch.sqrt(sum(P[n].grad.double().pow(2).sum() for n in names)).item()
+    np.testing.assert_allclose(gn, float(fx["total_grad_norm"]), rtol=2e-4)
+    if "mu_0" in fx:
+        for k in range(3):
+            np.testing.assert_allclose(outs[k][2].detach().numpy(), fx[f"mu_{k}"], atol=2e-5)
+            np.testing.assert_allclose(outs[k][3].detach().numpy(), fx[f"logvar_{k}"], atol=2e-5)
+            np.testing.assert_allclose(outs[k][1].detach().numpy(), fx[f"second_recon_{k}"], atol=5e-5)
+            s = outs[k][0].detach().double().reshape(-1)
+            np.testing.assert_allclose(s.sum().item(), fx[f"image_recon_stats_{k}"][0], rtol=1e-5)
+        gs = fx["grad_stats"]
+        for i, n in enumerate(names):
+            g = P[n].grad.double()
+            np.testing.assert_allclose(g.norm().item(), gs[i, 1], rtol=5e-4, atol=1e-5 * gn)
+        for key in fx.files:
+            if key.startswith("buf:"):
+                np.testing.assert_allclose(P[key[4:]].numpy(), fx[key], rtol=1e-4, atol=1e-6)
+    else:
+        np.testing.assert_allclose([P[n].grad.double().norm().item() for n in names], fx["grad_norms"],
+                                   rtol=1e-3, atol=1e-5 * gn)
+
+
+def test_tokens_and_margins_recorded(golden_dir):
+    fx = np.load(os.path.join(golden_dir, "multimnist_b8.npz"))
+    assert fx["tokens_0"].shape == (8, 4)
+    assert float(fx["margin_0"].min()) > 0
+
+
+def test_param_table_counts():
+    # SURVEY 8 a10/a12/a13 [probed]: 2,338,392 / 806,604 / 8,808,802 parameters
+    def count(ds, D):
+        return sum(int(np.prod(s)) for _, s in R.param_table(ds, D))
+    assert count("multimnist", 100) == 2338392
+    assert len(R.param_table("multimnist", 100)) == 52
+    assert count("mnist", 20) == 806604
+    assert count("celeba", 100) == 8808802
+
+
+def test_poe_is_variance_weighted():
+    # SURVEY 2.2 K9 [probed]: experts mu=(0,1), var=(1,3) -> mu=0.75
+    mu = torch.tensor([[[0.0]], [[1.0]]])
+    lv = torch.log(torch.tensor([[[1.0]], [[3.0]]]))
+    m, l = R.product_of_experts(mu, lv)
+    assert abs(m.item() - 0.75) < 1e-6
+    assert abs(l.exp().item() - 0.75) < 1e-6
