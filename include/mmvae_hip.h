@@ -1,0 +1,132 @@
+/* libmmvae_hip.so -- C-ABI of the MI355X (gfx950) MMVAE ELBO engine.
+ *
+ * The reference (wenxuanliu/multimodal-vae) has no FFI: its hot path is reached through the Python module surface
+ * of <ds>/model.py and loss_function in <ds>/train.py.  Each entry point below names the reference code it
+ * replaces (paths under the reference repo).  Conventions:
+ *   - plain C types only; every device buffer is owned by the caller (e.g. tensor.data_ptr()); the library never
+ *     allocates or frees device memory; scratch comes from a caller-provided workspace whose size is queried;
+ *   - all work is enqueued on the caller's hipStream_t (passed as void*), no hidden synchronisation;
+ *   - returns 0 on success or a negative MMVAE_E* code; mmvae_last_error() gives a thread-local message;
+ *   - plans (mmvae_mm_t) are host-side descriptors: one host thread per plan, one process per GPU.
+ */
+#ifndef MMVAE_HIP_H
+#define MMVAE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMVAE_OK 0
+#define MMVAE_EINVAL (-1)
+#define MMVAE_EHIP (-2)
+#define MMVAE_ENOSPC (-3)
+#define MMVAE_ESTATE (-4)
+
+int mmvae_init(int device);                 /* checks the device is gfx950, makes it current */
+const char* mmvae_last_error(void);
+const char* mmvae_version(void);
+
+/* ---------------------------------------------------------------- MultiMNIST plan (multimnist/model.py:21-93) */
+typedef struct MMPlan mmvae_mm_t;
+mmvae_mm_t* mmvae_mm_create(int n_latents, int batch);      /* MultimodalVAE(n_latents) at a fixed batch size */
+void mmvae_mm_destroy(mmvae_mm_t*);
+long long mmvae_mm_param_count(const mmvae_mm_t*);          /* scalars in the flat fp32 parameter buffer */
+int mmvae_mm_num_params(const mmvae_mm_t*);                 /* tensors, state_dict order (52) */
+/* name (<=127 chars), ndim, shape[4], element offset of parameter i */
+int mmvae_mm_param_info(const mmvae_mm_t*, int i, char* name, int* ndim, int* shape, long long* offset);
+long long mmvae_mm_bn_floats(const mmvae_mm_t*);            /* running_mean|running_var of every BatchNorm */
+int mmvae_mm_num_bn(const mmvae_mm_t*);
+int mmvae_mm_bn_info(const mmvae_mm_t*, int i, char* prefix, int* channels, long long* offset);
+long long mmvae_mm_packed_elems(const mmvae_mm_t*);         /* bf16 elements of the packed weights */
+long long mmvae_mm_packed_vec_elems(const mmvae_mm_t*);     /* fp32 */
+long long mmvae_mm_gpk_elems(const mmvae_mm_t*);            /* fp32 elements of the packed weight gradients */
+long long mmvae_mm_gpk_vec_elems(const mmvae_mm_t*);
+size_t mmvae_mm_desc_bytes(const mmvae_mm_t*, int which);   /* which: 0 = weight table, 1 = gradient table */
+int mmvae_mm_desc_copy(const mmvae_mm_t*, int which, void* host_out);   /* caller uploads it to the device */
+size_t mmvae_mm_workspace_bytes(const mmvae_mm_t*);
+int mmvae_mm_bind(mmvae_mm_t*, float* params, float* grads, float* bn_stats, long long* bn_num_batches_tracked,
+                  void* packed_bf16, float* packed_vec, float* gpk, float* gpk_vec, void* desc_dev, void* gdesc_dev);
+int mmvae_mm_pack_weights(mmvae_mm_t*, void* stream);       /* refresh bf16 GEMM-layout copies after params change */
+
+/* One 3-pass ELBO step (multimnist/train.py:150-168): forward of (image,text), (image), (text), the three
+ * loss_function sums and -- if do_backward -- the gradient of loss_1+loss_2+loss_3 accumulated into `grads`
+ * (the caller zeroes `grads`, like optimizer.zero_grad()). */
+typedef struct {
+    void* ws; size_t ws_bytes;
+    const long long* step_counter;          /* device int64 keying the RNG streams, may be NULL */
+    const float* image;                     /* [B][1][50][50] */
+    const long long* text;                  /* [B][4] */
+    const float* eps;                       /* [3][B][D] or NULL (Philox) */
+    const uint8_t* enc_mask1;               /* [2][B][400] keep flags or NULL */
+    const uint8_t* enc_mask2;               /* [2][B][200] keep flags or NULL */
+    const uint8_t* gru_keep;                /* [4][3B][100] keep flags or NULL */
+    int enc_dropout, gru_dropout;           /* 0 turns the respective dropout off (p = 0 fixtures) */
+    const long long* force_tokens;          /* [3B][4] or NULL: overrides the greedy feedback (test hook) */
+    float kl_lambda;
+    float lambda_xy[3], lambda_yx[3];
+    unsigned long long seed;
+    float* sums;                            /* out [16]: [0..2] BCE sums, [4..6] NLL sums, [8..10] KL sums */
+    float* recon_image;                     /* out [3][B][2500] or NULL */
+    float* recon_text;                      /* out [3][B][4][12] or NULL */
+    float* mu; float* logvar;               /* out [3][B][D] or NULL */
+    long long* tokens;                      /* out [3][B][4] or NULL */
+} mmvae_mm_step_io;
+int mmvae_mm_step(mmvae_mm_t*, const mmvae_mm_step_io*, int training, int do_backward, void* stream);
+
+/* Granular modules (drop-in for ImageEncoder/ImageDecoder/TextEncoder/TextDecoder.forward + autograd backward).
+ * Every forward keeps its saved activations in the workspace passed to it; pass the same one to the backward. */
+int mmvae_mm_image_encoder_fwd(mmvae_mm_t*, void* ws, size_t ws_bytes, const float* image, const uint8_t* mask1,
+                               const uint8_t* mask2, int training, float* out_mu_logvar, void* stream);   /* model.py:183-188 */
+int mmvae_mm_image_encoder_bwd(mmvae_mm_t*, void* ws, size_t ws_bytes, const float* d_out, const uint8_t* mask1,
+                               const uint8_t* mask2, void* stream);
+int mmvae_mm_image_decoder_fwd(mmvae_mm_t*, void* ws, size_t ws_bytes, const float* z, int training, float* recon,
+                               void* stream);                                                           /* model.py:211-216 */
+int mmvae_mm_image_decoder_bwd(mmvae_mm_t*, void* ws, size_t ws_bytes, const float* d_recon, const float* recon,
+                               float* dz, void* stream);
+int mmvae_mm_text_encoder_fwd(mmvae_mm_t*, void* ws, size_t ws_bytes, const long long* text, float* out_mu_logvar,
+                              void* stream);                                                            /* model.py:237-247 */
+int mmvae_mm_text_encoder_bwd(mmvae_mm_t*, void* ws, size_t ws_bytes, const long long* text, const float* d_out,
+                              void* stream);
+int mmvae_mm_text_decoder_fwd(mmvae_mm_t*, void* ws, size_t ws_bytes, const float* z, int training, const uint8_t* keep,
+                              const long long* force_tokens, float* words, long long* tokens, void* stream); /* model.py:268-288 */
+int mmvae_mm_text_decoder_bwd(mmvae_mm_t*, void* ws, size_t ws_bytes, const float* z, const uint8_t* keep,
+                              const long long* force_tokens, const float* words, const long long* tokens,
+                              const float* d_words, float* dz, void* stream);
+/* Runs one named GEMM of the step `iters` times on the workspace contents of the last step (profiling aid). */
+int mmvae_mm_bench_layer(mmvae_mm_t*, void* ws, size_t ws_bytes, const char* layer, int iters, void* stream);
+double mmvae_mm_layer_flops(const mmvae_mm_t*, const char* layer);
+/* test aid: byte offset of a named intermediate inside the workspace (-1 if unknown) */
+long long mmvae_mm_debug_offset(mmvae_mm_t*, const char* name);
+
+/* ---------------------------------------------------------------- dataset-independent ops */
+/* ProductOfExperts.forward (multimnist/model.py:355-360) over M stacked experts of n scalars each */
+int mmvae_poe_fwd(const float* mu, const float* logvar, int M, int n, float* out_mu, float* out_logvar, void* stream);
+int mmvae_poe_bwd(const float* mu, const float* logvar, int M, int n, const float* g_mu, const float* g_logvar,
+                  float* d_mu, float* d_logvar, void* stream);
+/* MultimodalVAE.reparametrize (multimnist/model.py:33-39), train mode */
+int mmvae_reparam_fwd(const float* mu, const float* logvar, const float* eps, int n, float* z, void* stream);
+int mmvae_reparam_bwd(const float* logvar, const float* eps, const float* dz, int n, float* d_mu, float* d_logvar, void* stream);
+/* KL term of loss_function (multimnist/train.py:85): out[0] += -0.5*sum(1+lv-mu^2-exp(lv)) */
+int mmvae_kl_fwd(const float* mu, const float* logvar, int n, float* out_sum, void* stream);
+int mmvae_kl_bwd(const float* mu, const float* logvar, int n, float coef, float* d_mu, float* d_logvar, void* stream);
+/* F.binary_cross_entropy on probabilities (multimnist/train.py:75): out[0] += sum of terms; bwd = coef * d/dp */
+int mmvae_bce_fwd(const float* p, const float* target, long long n, float* out_sum, void* stream);
+int mmvae_bce_bwd(const float* p, const float* target, long long n, float coef, float* d_p, void* stream);
+/* F.nll_loss on log-probs [rows][classes] (multimnist/train.py:79) */
+int mmvae_nll_fwd(const float* logp, const long long* target, int rows, int classes, float* out_sum, void* stream);
+int mmvae_nll_bwd(const long long* target, int rows, int classes, float coef, float* d_logp, void* stream);
+/* counter-based RNG (Philox4x32-10) */
+int mmvae_normal(float* out, long long n, unsigned long long seed, const long long* step_counter, unsigned stream_id, void* stream);
+int mmvae_keep_mask(uint8_t* out, long long n, float p, unsigned long long seed, const long long* step_counter,
+                    unsigned stream_id, void* stream);
+/* torch.optim.Adam defaults (multimnist/train.py:129,173) on flat buffers; state = device int64[2] {step, ticket},
+ * zero-initialised by the caller; grad_scale multiplies g first (1/world_size after a sum all-reduce). */
+int mmvae_adam_step(float* p, const float* g, float* m, float* v, long long n, long long* state, float lr, float beta1,
+                    float beta2, float eps, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

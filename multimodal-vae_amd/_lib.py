@@ -1,0 +1,119 @@
+"""ctypes binding of libmmvae_hip.so (include/mmvae_hip.h).  No CPU fallback: if the library is missing or
+no gfx950 device is usable, calls raise."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmmvae_hip.so")
+
+
+class MMVAEError(RuntimeError):
+    pass
+
+
+class StepIO(C.Structure):
+    """mmvae_mm_step_io"""
+    _fields_ = [
+        ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
+        ("step_counter", C.c_void_p),
+        ("image", C.c_void_p), ("text", C.c_void_p), ("eps", C.c_void_p),
+        ("enc_mask1", C.c_void_p), ("enc_mask2", C.c_void_p), ("gru_keep", C.c_void_p),
+        ("enc_dropout", C.c_int), ("gru_dropout", C.c_int),
+        ("force_tokens", C.c_void_p),
+        ("kl_lambda", C.c_float),
+        ("lambda_xy", C.c_float * 3), ("lambda_yx", C.c_float * 3),
+        ("seed", C.c_ulonglong),
+        ("sums", C.c_void_p), ("recon_image", C.c_void_p), ("recon_text", C.c_void_p),
+        ("mu", C.c_void_p), ("logvar", C.c_void_p), ("tokens", C.c_void_p),
+    ]
+
+
+_P, _I, _F, _LL, _SZ, _ULL, _U = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_size_t, C.c_ulonglong, C.c_uint
+
+# name -> (restype, argtypes); restype int means "status code, raise on != 0"
+SIGNATURES = {
+    "mmvae_init": (_I, [_I]),
+    "mmvae_last_error": (C.c_char_p, []),
+    "mmvae_version": (C.c_char_p, []),
+    "mmvae_mm_create": (_P, [_I, _I]),
+    "mmvae_mm_destroy": (None, [_P]),
+    "mmvae_mm_param_count": (_LL, [_P]),
+    "mmvae_mm_num_params": (_I, [_P]),
+    "mmvae_mm_param_info": (_I, [_P, _I, C.c_char_p, C.POINTER(_I), C.POINTER(_I), C.POINTER(_LL)]),
+    "mmvae_mm_bn_floats": (_LL, [_P]),
+    "mmvae_mm_num_bn": (_I, [_P]),
+    "mmvae_mm_bn_info": (_I, [_P, _I, C.c_char_p, C.POINTER(_I), C.POINTER(_LL)]),
+    "mmvae_mm_packed_elems": (_LL, [_P]),
+    "mmvae_mm_packed_vec_elems": (_LL, [_P]),
+    "mmvae_mm_gpk_elems": (_LL, [_P]),
+    "mmvae_mm_gpk_vec_elems": (_LL, [_P]),
+    "mmvae_mm_desc_bytes": (_SZ, [_P, _I]),
+    "mmvae_mm_desc_copy": (_I, [_P, _I, _P]),
+    "mmvae_mm_workspace_bytes": (_SZ, [_P]),
+    "mmvae_mm_bind": (_I, [_P] * 11),
+    "mmvae_mm_pack_weights": (_I, [_P, _P]),
+    "mmvae_mm_step": (_I, [_P, C.POINTER(StepIO), _I, _I, _P]),
+    "mmvae_mm_image_encoder_fwd": (_I, [_P, _P, _SZ, _P, _P, _P, _I, _P, _P]),
+    "mmvae_mm_image_encoder_bwd": (_I, [_P, _P, _SZ, _P, _P, _P, _P]),
+    "mmvae_mm_image_decoder_fwd": (_I, [_P, _P, _SZ, _P, _I, _P, _P]),
+    "mmvae_mm_image_decoder_bwd": (_I, [_P, _P, _SZ, _P, _P, _P, _P]),
+    "mmvae_mm_text_encoder_fwd": (_I, [_P, _P, _SZ, _P, _P, _P]),
+    "mmvae_mm_text_encoder_bwd": (_I, [_P, _P, _SZ, _P, _P, _P]),
+    "mmvae_mm_text_decoder_fwd": (_I, [_P, _P, _SZ, _P, _I, _P, _P, _P, _P, _P]),
+    "mmvae_mm_text_decoder_bwd": (_I, [_P, _P, _SZ, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "mmvae_mm_bench_layer": (_I, [_P, _P, _SZ, C.c_char_p, _I, _P]),
+    "mmvae_mm_layer_flops": (C.c_double, [_P, C.c_char_p]),
+    "mmvae_mm_debug_offset": (_LL, [_P, C.c_char_p]),
+    "mmvae_poe_fwd": (_I, [_P, _P, _I, _I, _P, _P, _P]),
+    "mmvae_poe_bwd": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "mmvae_reparam_fwd": (_I, [_P, _P, _P, _I, _P, _P]),
+    "mmvae_reparam_bwd": (_I, [_P, _P, _P, _I, _P, _P, _P]),
+    "mmvae_kl_fwd": (_I, [_P, _P, _I, _P, _P]),
+    "mmvae_kl_bwd": (_I, [_P, _P, _I, _F, _P, _P, _P]),
+    "mmvae_bce_fwd": (_I, [_P, _P, _LL, _P, _P]),
+    "mmvae_bce_bwd": (_I, [_P, _P, _LL, _F, _P, _P]),
+    "mmvae_nll_fwd": (_I, [_P, _P, _I, _I, _P, _P]),
+    "mmvae_nll_bwd": (_I, [_P, _I, _I, _F, _P, _P]),
+    "mmvae_normal": (_I, [_P, _LL, _ULL, _P, _U, _P]),
+    "mmvae_keep_mask": (_I, [_P, _LL, _F, _ULL, _P, _U, _P]),
+    "mmvae_adam_step": (_I, [_P, _P, _P, _P, _LL, _P, _F, _F, _F, _F, _F, _P]),
+}
+_STATUS = {n for n, (r, _) in SIGNATURES.items() if r is _I and n not in ("mmvae_mm_num_params", "mmvae_mm_num_bn")}
+
+_lib = None
+_inited = set()
+
+
+def load():
+    """dlopen the library and declare every prototype (works without a GPU)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MMVAEError("%s not found: run `python multimodal-vae_amd/build.py` (hipcc, gfx950). "
+                             "There is no CPU fallback." % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if name in _STATUS and rc != 0:
+        raise MMVAEError("%s failed (%d): %s" % (name, rc, lib.mmvae_last_error().decode()))
+    return rc
+
+
+def init_device(index):
+    if index not in _inited:
+        call("mmvae_init", int(index))
+        _inited.add(index)
+
+
+def ptr(t):
+    """data pointer of a tensor (None -> NULL)"""
+    return None if t is None else C.c_void_p(t.data_ptr())

@@ -1,0 +1,178 @@
+// extern "C" boundary of libmmvae_hip.so (see include/mmvae_hip.h).
+#include "../../include/mmvae_hip.h"
+#include "multimnist.h"
+#include <cstring>
+#include <exception>
+
+const char* mmvae_error_string();
+
+#define API_GUARD_BEGIN try {
+#define API_GUARD_END                                                   \
+    } catch (const std::exception& e) {                                 \
+        mmvae_set_error("internal exception: %s", e.what());            \
+        return MMVAE_ESTATE;                                            \
+    } catch (...) {                                                     \
+        mmvae_set_error("internal exception");                          \
+        return MMVAE_ESTATE;                                            \
+    }
+
+static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+extern "C" {
+
+const char* mmvae_last_error(void) { return mmvae_error_string(); }
+const char* mmvae_version(void) { return "mmvae-hip 0.1 (gfx950)"; }
+
+int mmvae_init(int device) {
+    API_GUARD_BEGIN
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) { mmvae_set_error("no HIP device visible"); return MMVAE_EHIP; }
+    MMVAE_REQUIRE(device >= 0 && device < n, "device %d out of range (%d visible)", device, n);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { mmvae_set_error("hipGetDeviceProperties failed"); return MMVAE_EHIP; }
+    MMVAE_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    if (hipSetDevice(device) != hipSuccess) { mmvae_set_error("hipSetDevice failed"); return MMVAE_EHIP; }
+    return MMVAE_OK;
+    API_GUARD_END
+}
+
+mmvae_mm_t* mmvae_mm_create(int n_latents, int batch) {
+    try { return mm_create(n_latents, batch); } catch (...) { mmvae_set_error("mm_create failed"); return nullptr; }
+}
+void mmvae_mm_destroy(mmvae_mm_t* p) { mm_destroy(p); }
+long long mmvae_mm_param_count(const mmvae_mm_t* p) { return mm_param_count(p); }
+int mmvae_mm_num_params(const mmvae_mm_t* p) { return (int)mm_params(p).size(); }
+int mmvae_mm_param_info(const mmvae_mm_t* p, int i, char* name, int* ndim, int* shape, long long* offset) {
+    const auto& v = mm_params(p);
+    MMVAE_REQUIRE(i >= 0 && i < (int)v.size(), "param index %d out of range", i);
+    strncpy(name, v[i].name.c_str(), 127); name[127] = 0;
+    *ndim = v[i].ndim;
+    for (int k = 0; k < 4; ++k) shape[k] = k < v[i].ndim ? v[i].shape[k] : 1;
+    *offset = v[i].offset;
+    return MMVAE_OK;
+}
+long long mmvae_mm_bn_floats(const mmvae_mm_t* p) { return mm_bn_floats(p); }
+int mmvae_mm_num_bn(const mmvae_mm_t* p) { return mm_num_bn(p); }
+int mmvae_mm_bn_info(const mmvae_mm_t* p, int i, char* prefix, int* channels, long long* offset) {
+    std::string s; int c; long long o;
+    MMVAE_TRY(mm_bn_info(p, i, s, c, o));
+    strncpy(prefix, s.c_str(), 127); prefix[127] = 0; *channels = c; *offset = o;
+    return MMVAE_OK;
+}
+long long mmvae_mm_packed_elems(const mmvae_mm_t* p) { return mm_packed_elems(p); }
+long long mmvae_mm_packed_vec_elems(const mmvae_mm_t* p) { return mm_packed_vec_elems(p); }
+long long mmvae_mm_gpk_elems(const mmvae_mm_t* p) { return mm_gpk_elems(p); }
+long long mmvae_mm_gpk_vec_elems(const mmvae_mm_t* p) { return mm_gpk_vec_elems(p); }
+size_t mmvae_mm_desc_bytes(const mmvae_mm_t* p, int which) {
+    return sizeof(PackDesc) * (size_t)(which == 0 ? mm_ndesc(p) : mm_ngdesc(p));
+}
+int mmvae_mm_desc_copy(const mmvae_mm_t* p, int which, void* host_out) {
+    memcpy(host_out, which == 0 ? mm_desc_host(p) : mm_gdesc_host(p), mmvae_mm_desc_bytes(p, which));
+    return MMVAE_OK;
+}
+size_t mmvae_mm_workspace_bytes(const mmvae_mm_t* p) { return mm_workspace_bytes(p); }
+int mmvae_mm_bind(mmvae_mm_t* p, float* params, float* grads, float* bn_stats, long long* nbt, void* packed, float* packed_vec,
+                  float* gpk, float* gpk_vec, void* desc_dev, void* gdesc_dev) {
+    API_GUARD_BEGIN
+    MMBuffers b;
+    b.params = params; b.grads = grads; b.bn_stats = bn_stats; b.bn_nbt = nbt; b.packed = (bf16*)packed; b.packed_vec = packed_vec;
+    b.gpk = gpk; b.gpk_vec = gpk_vec; b.desc_dev = (PackDesc*)desc_dev; b.gdesc_dev = (PackDesc*)gdesc_dev;
+    return mm_bind(p, b);
+    API_GUARD_END
+}
+int mmvae_mm_pack_weights(mmvae_mm_t* p, void* stream) {
+    API_GUARD_BEGIN
+    return mm_pack_weights(p, S(stream));
+    API_GUARD_END
+}
+int mmvae_mm_step(mmvae_mm_t* p, const mmvae_mm_step_io* io, int training, int do_backward, void* stream) {
+    API_GUARD_BEGIN
+    MMVAE_REQUIRE(p && io, "mmvae_mm_step: null argument");
+    MMStepIO s;
+    s.ws = io->ws; s.ws_bytes = io->ws_bytes; s.step_ctr = io->step_counter; s.image = io->image; s.text = io->text; s.eps = io->eps;
+    s.enc_mask1 = io->enc_mask1; s.enc_mask2 = io->enc_mask2; s.gru_keep = io->gru_keep;
+    s.enc_dropout = io->enc_dropout; s.gru_dropout = io->gru_dropout; s.force_tokens = io->force_tokens;
+    s.kl_lambda = io->kl_lambda;
+    for (int k = 0; k < 3; ++k) { s.lambda_xy[k] = io->lambda_xy[k]; s.lambda_yx[k] = io->lambda_yx[k]; }
+    s.seed = io->seed; s.sums = io->sums; s.recon_image = io->recon_image; s.recon_text = io->recon_text;
+    s.mu = io->mu; s.logvar = io->logvar; s.tokens = io->tokens;
+    return mm_step_fwd_bwd(p, s, training, do_backward, S(stream));
+    API_GUARD_END
+}
+int mmvae_mm_image_encoder_fwd(mmvae_mm_t* p, void* ws, size_t wsb, const float* image, const uint8_t* m1, const uint8_t* m2,
+                               int training, float* out, void* stream) {
+    API_GUARD_BEGIN
+    return mm_image_encoder_fwd(p, ws, wsb, image, m1, m2, training, out, S(stream));
+    API_GUARD_END
+}
+int mmvae_mm_image_encoder_bwd(mmvae_mm_t* p, void* ws, size_t wsb, const float* d_out, const uint8_t* m1, const uint8_t* m2, void* stream) {
+    API_GUARD_BEGIN
+    return mm_image_encoder_bwd(p, ws, wsb, d_out, m1, m2, S(stream));
+    API_GUARD_END
+}
+int mmvae_mm_image_decoder_fwd(mmvae_mm_t* p, void* ws, size_t wsb, const float* z, int training, float* recon, void* stream) {
+    API_GUARD_BEGIN
+    return mm_image_decoder_fwd(p, ws, wsb, z, training, recon, S(stream));
+    API_GUARD_END
+}
+int mmvae_mm_image_decoder_bwd(mmvae_mm_t* p, void* ws, size_t wsb, const float* d_recon, const float* recon, float* dz, void* stream) {
+    API_GUARD_BEGIN
+    return mm_image_decoder_bwd(p, ws, wsb, d_recon, recon, dz, S(stream));
+    API_GUARD_END
+}
+int mmvae_mm_text_encoder_fwd(mmvae_mm_t* p, void* ws, size_t wsb, const long long* text, float* out, void* stream) {
+    API_GUARD_BEGIN
+    return mm_text_encoder_fwd(p, ws, wsb, text, out, S(stream));
+    API_GUARD_END
+}
+int mmvae_mm_text_encoder_bwd(mmvae_mm_t* p, void* ws, size_t wsb, const long long* text, const float* d_out, void* stream) {
+    API_GUARD_BEGIN
+    return mm_text_encoder_bwd(p, ws, wsb, text, d_out, S(stream));
+    API_GUARD_END
+}
+int mmvae_mm_text_decoder_fwd(mmvae_mm_t* p, void* ws, size_t wsb, const float* z, int training, const uint8_t* keep,
+                              const long long* force_tokens, float* words, long long* tokens, void* stream) {
+    API_GUARD_BEGIN
+    return mm_text_decoder_fwd(p, ws, wsb, z, training, keep, force_tokens, words, tokens, S(stream));
+    API_GUARD_END
+}
+int mmvae_mm_text_decoder_bwd(mmvae_mm_t* p, void* ws, size_t wsb, const float* z, const uint8_t* keep, const long long* force_tokens,
+                              const float* words, const long long* tokens, const float* d_words, float* dz, void* stream) {
+    API_GUARD_BEGIN
+    return mm_text_decoder_bwd(p, ws, wsb, z, keep, force_tokens, words, tokens, d_words, dz, S(stream));
+    API_GUARD_END
+}
+int mmvae_mm_bench_layer(mmvae_mm_t* p, void* ws, size_t wsb, const char* layer, int iters, void* stream) {
+    API_GUARD_BEGIN
+    return mm_bench_layer(p, ws, wsb, layer, iters, S(stream));
+    API_GUARD_END
+}
+double mmvae_mm_layer_flops(const mmvae_mm_t* p, const char* layer) { return mm_layer_flops(p, layer); }
+long long mmvae_mm_debug_offset(mmvae_mm_t* p, const char* name) { return mm_debug_offset(p, name); }
+
+int mmvae_poe_fwd(const float* mu, const float* lv, int M, int n, float* omu, float* olv, void* s) { return launch_poe_fwd(mu, lv, M, n, omu, olv, S(s)); }
+int mmvae_poe_bwd(const float* mu, const float* lv, int M, int n, const float* gmu, const float* glv, float* dmu, float* dlv, void* s) {
+    return launch_poe_bwd(mu, lv, M, n, gmu, glv, dmu, dlv, S(s));
+}
+int mmvae_reparam_fwd(const float* mu, const float* lv, const float* eps, int n, float* z, void* s) { return launch_reparam_fwd(mu, lv, eps, n, z, S(s)); }
+int mmvae_reparam_bwd(const float* lv, const float* eps, const float* dz, int n, float* dmu, float* dlv, void* s) {
+    return launch_reparam_bwd(lv, eps, dz, n, dmu, dlv, S(s));
+}
+int mmvae_kl_fwd(const float* mu, const float* lv, int n, float* out, void* s) { return launch_kl_fwd(mu, lv, n, out, S(s)); }
+int mmvae_kl_bwd(const float* mu, const float* lv, int n, float coef, float* dmu, float* dlv, void* s) { return launch_kl_bwd(mu, lv, n, coef, dmu, dlv, S(s)); }
+int mmvae_bce_fwd(const float* p, const float* t, long long n, float* out, void* s) { return launch_bce_fwd(p, t, n, out, S(s)); }
+int mmvae_bce_bwd(const float* p, const float* t, long long n, float coef, float* dp, void* s) { return launch_bce_bwd(p, t, n, coef, dp, S(s)); }
+int mmvae_nll_fwd(const float* lp, const long long* tg, int rows, int classes, float* out, void* s) { return launch_nll_fwd(lp, tg, rows, classes, out, S(s)); }
+int mmvae_nll_bwd(const long long* tg, int rows, int classes, float coef, float* dlp, void* s) { return launch_nll_bwd(tg, rows, classes, coef, dlp, S(s)); }
+int mmvae_normal(float* out, long long n, unsigned long long seed, const long long* ctr, unsigned sid, void* s) { return launch_normal(out, n, seed, ctr, sid, S(s)); }
+int mmvae_keep_mask(uint8_t* out, long long n, float p, unsigned long long seed, const long long* ctr, unsigned sid, void* s) {
+    return launch_keep_mask(out, n, p, seed, ctr, sid, S(s));
+}
+int mmvae_adam_step(float* p, const float* g, float* m, float* v, long long n, long long* state, float lr, float b1, float b2,
+                    float eps, float grad_scale, void* s) {
+    AdamArgs a{};
+    a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.step = state; a.lr = lr; a.b1 = b1; a.b2 = b2; a.eps = eps; a.grad_scale = grad_scale;
+    return launch_adam(a, S(s));
+}
+
+}  // extern "C"

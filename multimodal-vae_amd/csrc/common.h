@@ -1,0 +1,88 @@
+// Shared device/host helpers for libmmvae_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+#define MMVAE_OK 0
+#define MMVAE_EINVAL (-1)
+#define MMVAE_EHIP (-2)
+#define MMVAE_ENOSPC (-3)
+#define MMVAE_ESTATE (-4)
+
+// thread-local last error (include/mmvae_hip.h: mmvae_last_error)
+void mmvae_set_error(const char* fmt, ...);
+int mmvae_check_launch(const char* what);
+
+#define MMVAE_REQUIRE(cond, ...)                      \
+    do {                                              \
+        if (!(cond)) {                                \
+            mmvae_set_error(__VA_ARGS__);             \
+            return MMVAE_EINVAL;                      \
+        }                                             \
+    } while (0)
+
+#define MMVAE_TRY(expr)                               \
+    do {                                              \
+        int _rc = (expr);                             \
+        if (_rc != MMVAE_OK) return _rc;              \
+    } while (0)
+
+enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2 };
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float act_fwd(int act, float x) {
+    if (act == ACT_SWISH) return x * sigmoidf_(x);
+    if (act == ACT_RELU) return x > 0.f ? x : 0.f;
+    return x;
+}
+// derivative of act at pre-activation x
+__device__ __forceinline__ float act_bwd(int act, float x) {
+    if (act == ACT_SWISH) {
+        float s = sigmoidf_(x);
+        return s * (1.0f + x * (1.0f - s));
+    }
+    if (act == ACT_RELU) return x > 0.f ? 1.f : 0.f;
+    return 1.f;
+}
+
+__device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
+__device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---- Philox4x32-10 counter RNG (production eps / dropout masks) ----
+struct Philox {
+    __device__ static inline uint32_t mulhi(uint32_t a, uint32_t b) { return __umulhi(a, b); }
+    __device__ static inline void round(uint32_t (&c)[4], uint32_t (&k)[2]) {
+        const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+        uint32_t hi0 = mulhi(M0, c[0]), lo0 = M0 * c[0];
+        uint32_t hi1 = mulhi(M1, c[2]), lo1 = M1 * c[2];
+        uint32_t n0 = hi1 ^ c[1] ^ k[0], n1 = lo1, n2 = hi0 ^ c[3] ^ k[1], n3 = lo0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+    }
+    __device__ static inline void gen(uint64_t seed, uint64_t ctr, uint32_t stream, uint32_t (&out)[4]) {
+        uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), stream, 0x5bd1e995u};
+        uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+#pragma unroll
+        for (int i = 0; i < 10; ++i) round(c, k);
+        out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+    }
+};
+__device__ __forceinline__ float u01(uint32_t x) { return ((x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+__host__ __device__ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }

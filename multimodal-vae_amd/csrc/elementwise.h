@@ -1,0 +1,120 @@
+// Streaming (HBM/L2-bound) kernels around the MFMA GEMMs: thin-layer im2col, BatchNorm finalize / backward
+// apply, sigmoid+BCE, product-of-experts / reparametrisation / KL, Adam, weight packing.  See elementwise.hip.
+#pragma once
+#include "common.h"
+
+// ---- weight packing (fp32 reference-layout master  <->  bf16 GEMM-layout copies / fp32 packed grads) ----
+struct PackDesc {
+    long long dst_off;      // element offset in the packed buffer (bf16 units for matrices, float units for vectors)
+    long long src_off;      // element offset in the flat fp32 parameter buffer
+    int Npad, Kpad, N, K;   // packed matrix [Npad][Kpad]; entries outside [N][K] are zero
+    int NL;                 // row n = n_hi*NL + n_lo
+    int s_nhi, s_nlo;       // source strides of n_hi / n_lo
+    int TW, C;              // column k = (ty*TW + tx)*C + c
+    int s_ty, s_tx, s_c;    // source strides
+    int o_ty, o_tx, step_t; // kernel index = o + t*step
+    int is_f32;             // destination is fp32 (bias vectors, Kpad == 1)
+    long long bias_off;     // >= 0: column K of every row holds a bias folded into the GEMM (operand column K == 1.0)
+    int b_nhi, b_nlo;       // source strides of that bias vector
+    int first_block;        // prefix sum of 256-thread blocks over the table
+};
+
+int launch_pack(const PackDesc* table_dev, const PackDesc* table_host, int ndesc, const float* params,
+                bf16* packed_bf, float* packed_f32, hipStream_t s);
+// grads_flat[src] += packed_grad[dst]  (inverse of the matrix packing, fp32 -> fp32)
+int launch_unpack_grads(const PackDesc* table_dev, const PackDesc* table_host, int ndesc, const float* gpk_mat,
+                        const float* gpk_vec, float* grads_flat, hipStream_t s);
+
+int launch_im2col_small(const float* src, int Nimg, int Cin, int H, int W, int KH, int KW, int stride, int pad,
+                        int OH, int OW, bf16* dst, int ld, hipStream_t s);
+
+struct BnFinalizeArgs {
+    const float2* stats;     // [G][C] (sum, sumsq) of the raw conv/linear output
+    int G, C;
+    float count;             // elements per channel per group
+    const float* gamma; const float* beta;
+    float* running_mean; float* running_var; long long* num_batches_tracked;   // may be null (no update)
+    int updates_per_group;   // how many forward calls each group's statistics stand for (encoder dedup: 2)
+    float2* affine;          // [G][C] (scale, shift):  y = x*scale + shift
+    float2* meanrstd;        // [G][C]
+    float eps, momentum;
+    int training;            // 0: affine from running statistics (stats ignored)
+};
+int launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s);
+
+struct BnBwdApplyArgs {
+    const bf16* db;          // [rows][ld] grad wrt BN output (after d-activation)
+    const bf16* db2;         // optional second contribution for the same rows (encoder features shared by 2 passes)
+    const bf16* r;           // [rows][ld] raw (pre-BN) tensor
+    bf16* dr;                // [rows][ld] out (may alias db)
+    int rows, C, ld, rows_per_group, G;
+    const float2* red;       // [G][C] (sum db, sum db*xhat)
+    const float2* meanrstd;  // [G][C]
+    const float* gamma;
+    float* dgamma; float* dbeta;   // flat grads, += (may be null)
+    float* dbias;            // optional: += column sums of dr (Linear bias in front of the BN), may be null
+};
+int launch_bn_bwd_apply(const BnBwdApplyArgs& a, hipStream_t s);
+
+struct BceArgs {
+    const float* logits;     // NHWC [G*B][H][W][ldl] (channel c at +c)
+    int ldl;
+    const float* target;     // NCHW [B][C][H][W], shared by all groups
+    int G, B, C, H, W;
+    float* recon;            // NCHW [G*B][C][H][W] or null
+    float* dlogit;           // NCHW [G*B][C][H][W] or null:  coef[g] * dBCE/dlogit
+    float coef[4];
+    float* loss_sum;         // [G] += sum of BCE terms
+};
+int launch_sigmoid_bce(const BceArgs& a, hipStream_t s);
+
+// ---- drop-in granular latent ops (ProductOfExperts / reparametrize / KL) ----
+int launch_poe_fwd(const float* mu, const float* logvar, int M, int n, float* out_mu, float* out_logvar, hipStream_t s);
+int launch_poe_bwd(const float* mu, const float* logvar, int M, int n, const float* g_mu, const float* g_logvar,
+                   float* d_mu, float* d_logvar, hipStream_t s);
+int launch_reparam_fwd(const float* mu, const float* logvar, const float* eps, int n, float* z, hipStream_t s);
+int launch_reparam_bwd(const float* logvar, const float* eps, const float* dz, int n, float* d_mu, float* d_logvar, hipStream_t s);
+int launch_kl_fwd(const float* mu, const float* logvar, int n, float* kl_sum, hipStream_t s);
+int launch_kl_bwd(const float* mu, const float* logvar, int n, float coef, float* d_mu, float* d_logvar, hipStream_t s);
+int launch_normal(float* out, long long n, unsigned long long seed, const long long* step_counter, unsigned stream_id, hipStream_t s);
+int launch_keep_mask(uint8_t* out, long long n, float p, unsigned long long seed, const long long* step_counter,
+                     unsigned stream_id, hipStream_t s);
+
+// ---- fused 3-pass latent block of the ELBO step (multimnist/train.py:154-166) ----
+struct Latent3Args {
+    int B, D;
+    const float* img_out;    // [2][B][2D]  image encoder (mu|logvar) of pass 1 and pass 2
+    const float* txt_out;    // [B][2D]
+    const float* eps;        // [3][B][D]
+    float* mu; float* logvar;   // [3][B][D]
+    float* z_f32;            // [3B][D]
+    bf16* z_bf;              // [3B][ldz], pad columns zeroed
+    int ldz;
+    float* kl_sum;           // [3] +=
+    int training;
+};
+int launch_latent3_fwd(const Latent3Args& a, hipStream_t s);
+struct Latent3BwdArgs {
+    Latent3Args f;
+    const float* dz_a;       // [3B][D] (image decoder) may be null
+    const float* dz_b;       // [3B][D] (text decoder) may be null
+    float kl_coef[3];        // kl_lambda / B (or the MNIST divisor) per pass
+    bf16* d_img_out_bf;      // [2][B][2D]
+    float* d_img_bias;       // [2D] += column sums over both passes (classifier last bias), may be null
+    float* d_txt_out;        // [B][2D]
+};
+int launch_latent3_bwd(const Latent3BwdArgs& a, hipStream_t s);
+
+struct AdamArgs {
+    float* p; const float* g; float* m; float* v;
+    long long n;
+    long long* step;         // device counter, incremented by the kernel (first call sees 0 -> t=1)
+    float lr, b1, b2, eps;
+    float grad_scale;        // applied to g before the update (1/world for data-parallel averaging)
+};
+int launch_adam(const AdamArgs& a, hipStream_t s);
+int launch_fill_zero(void* p, size_t bytes, hipStream_t s);
+int launch_bce_fwd(const float* p, const float* t, long long n, float* out, hipStream_t s);
+int launch_bce_bwd(const float* p, const float* t, long long n, float coef, float* dp, hipStream_t s);
+int launch_nll_fwd(const float* lp, const long long* tg, int rows, int classes, float* out, hipStream_t s);
+int launch_nll_bwd(const long long* tg, int rows, int classes, float coef, float* dlp, hipStream_t s);

@@ -1,0 +1,585 @@
+// Streaming kernels (HBM/L2 bound; 16-B vector accesses, wave reductions + one atomic per block).
+#include "elementwise.h"
+#include <math.h>
+
+namespace {
+
+constexpr int TPB = 256;
+inline int nblocks(long long n, int per = TPB, int cap = 4096) {
+    long long b = (n + per - 1) / per;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (int)b;
+}
+
+// ------------------------------------------------------------------ pack / unpack
+__device__ __forceinline__ int find_desc(const PackDesc* t, int nd, int block) {
+    int lo = 0, hi = nd - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (t[mid].first_block <= block) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+__device__ __forceinline__ long long pack_src(const PackDesc& d, int n, int k) {
+    int nhi = n / d.NL, nlo = n - nhi * d.NL;
+    int tap = k / d.C, c = k - tap * d.C;
+    int ty = tap / d.TW, tx = tap - ty * d.TW;
+    return d.src_off + (long long)nhi * d.s_nhi + (long long)nlo * d.s_nlo +
+           (long long)(d.o_ty + ty * d.step_t) * d.s_ty + (long long)(d.o_tx + tx * d.step_t) * d.s_tx + (long long)c * d.s_c;
+}
+
+__global__ __launch_bounds__(TPB) void pack_kernel(const PackDesc* __restrict__ table, int nd, const float* __restrict__ params,
+                                                   bf16* __restrict__ packed_bf, float* __restrict__ packed_f32) {
+    const int di = find_desc(table, nd, blockIdx.x);
+    const PackDesc d = table[di];
+    const long long e = (long long)(blockIdx.x - d.first_block) * TPB + threadIdx.x;
+    const long long total = (long long)d.Npad * d.Kpad;
+    if (e >= total) return;
+    const int n = (int)(e / d.Kpad), k = (int)(e - (long long)n * d.Kpad);
+    float v = 0.f;
+    if (n < d.N && k < d.K) v = params[pack_src(d, n, k)];
+    else if (n < d.N && k == d.K && d.bias_off >= 0) {
+        int nhi = n / d.NL, nlo = n - nhi * d.NL;
+        v = params[d.bias_off + (long long)nhi * d.b_nhi + (long long)nlo * d.b_nlo];
+    }
+    if (d.is_f32) packed_f32[d.dst_off + e] = v;
+    else packed_bf[d.dst_off + e] = (bf16)v;
+}
+
+__global__ __launch_bounds__(TPB) void unpack_kernel(const PackDesc* __restrict__ table, int nd, const float* __restrict__ gmat,
+                                                     const float* __restrict__ gvec, float* __restrict__ grads) {
+    const int di = find_desc(table, nd, blockIdx.x);
+    const PackDesc d = table[di];
+    const long long e = (long long)(blockIdx.x - d.first_block) * TPB + threadIdx.x;
+    const long long total = (long long)d.Npad * d.Kpad;
+    if (e >= total) return;
+    const int n = (int)(e / d.Kpad), k = (int)(e - (long long)n * d.Kpad);
+    if (n < d.N && k < d.K) {
+        float v = d.is_f32 ? gvec[d.dst_off + e] : gmat[d.dst_off + e];
+        grads[pack_src(d, n, k)] += v;
+    } else if (n < d.N && k == d.K && d.bias_off >= 0) {
+        int nhi = n / d.NL, nlo = n - nhi * d.NL;
+        grads[d.bias_off + (long long)nhi * d.b_nhi + (long long)nlo * d.b_nlo] += gmat[d.dst_off + e];
+    }
+}
+
+int table_blocks(const PackDesc* host, int nd) {
+    const PackDesc& l = host[nd - 1];
+    return l.first_block + (int)(((long long)l.Npad * l.Kpad + TPB - 1) / TPB);
+}
+
+// ------------------------------------------------------------------ im2col for thin (1/3-channel) inputs
+__global__ __launch_bounds__(TPB) void im2col_small_kernel(const float* __restrict__ src, int Nimg, int Cin, int H, int W,
+                                                           int KH, int KW, int stride, int pad, int OH, int OW,
+                                                           bf16* __restrict__ dst, int ld) {
+    const long long nvec = (long long)Nimg * OH * OW * (ld / 8);
+    const int K = KH * KW * Cin;
+    for (long long v = (long long)blockIdx.x * TPB + threadIdx.x; v < nvec; v += (long long)gridDim.x * TPB) {
+        const int vpr = ld / 8;
+        const long long row = v / vpr;
+        const int k0 = (int)(v - row * vpr) * 8;
+        const int n = (int)(row / (OH * OW));
+        const int rem = (int)(row - (long long)n * OH * OW);
+        const int oy = rem / OW, ox = rem - oy * OW;
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + j;
+            float val = 0.f;
+            if (k < K) {
+                int tap = k / Cin, ci = k - tap * Cin;
+                int kh = tap / KW, kw = tap - kh * KW;
+                int y = oy * stride - pad + kh, x = ox * stride - pad + kw;
+                if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+                    val = src[((long long)(n * Cin + ci) * H + y) * W + x];
+            }
+            o[j] = (bf16)val;
+        }
+        *reinterpret_cast<bf16x8*>(dst + row * ld + k0) = o;
+    }
+}
+
+// ------------------------------------------------------------------ BatchNorm finalize
+__global__ void bn_finalize_kernel(const BnFinalizeArgs a) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.C) return;
+    const float gamma = a.gamma[c], beta = a.beta[c];
+    if (!a.training) {
+        float rstd = rsqrtf(a.running_var[c] + a.eps);
+        float mean = a.running_mean[c];
+        for (int g = 0; g < a.G; ++g) {
+            a.affine[g * a.C + c] = make_float2(gamma * rstd, beta - mean * gamma * rstd);
+            a.meanrstd[g * a.C + c] = make_float2(mean, rstd);
+        }
+        return;
+    }
+    float rm = a.running_mean ? a.running_mean[c] : 0.f;
+    float rv = a.running_var ? a.running_var[c] : 0.f;
+    for (int g = 0; g < a.G; ++g) {
+        float2 s = a.stats[g * a.C + c];
+        float mean = s.x / a.count;
+        float var = fmaxf(s.y / a.count - mean * mean, 0.f);
+        float rstd = rsqrtf(var + a.eps);
+        a.affine[g * a.C + c] = make_float2(gamma * rstd, beta - mean * gamma * rstd);
+        a.meanrstd[g * a.C + c] = make_float2(mean, rstd);
+        float unbiased = var * a.count / (a.count - 1.f);
+        for (int u = 0; u < a.updates_per_group; ++u) {
+            rm = (1.f - a.momentum) * rm + a.momentum * mean;
+            rv = (1.f - a.momentum) * rv + a.momentum * unbiased;
+        }
+    }
+    if (a.running_mean) { a.running_mean[c] = rm; a.running_var[c] = rv; }
+    if (c == 0 && a.num_batches_tracked) *a.num_batches_tracked += (long long)a.G * a.updates_per_group;
+}
+
+// ------------------------------------------------------------------ BatchNorm backward apply
+__global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const BnBwdApplyArgs a) {
+    const int vpr = a.C / 8;
+    const long long nvec = (long long)a.rows * vpr;
+    const float inv_cnt = 1.f / (float)a.rows_per_group;
+    for (long long v = (long long)blockIdx.x * TPB + threadIdx.x; v < nvec; v += (long long)gridDim.x * TPB) {
+        const long long row = v / vpr;
+        const int c0 = (int)(v - row * vpr) * 8;
+        const int g = (int)(row / a.rows_per_group);
+        bf16x8 dbv = *reinterpret_cast<const bf16x8*>(a.db + row * a.ld + c0);
+        bf16x8 rv = *reinterpret_cast<const bf16x8*>(a.r + row * a.ld + c0);
+        float dbf[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dbf[j] = (float)dbv[j];
+        if (a.db2) {
+            bf16x8 d2 = *reinterpret_cast<const bf16x8*>(a.db2 + row * a.ld + c0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dbf[j] += (float)d2[j];
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = c0 + j;
+            float2 red = a.red[g * a.C + c];
+            float2 mr = a.meanrstd[g * a.C + c];
+            float xh = ((float)rv[j] - mr.x) * mr.y;
+            float d = a.gamma[c] * mr.y * (dbf[j] - red.x * inv_cnt - xh * red.y * inv_cnt);
+            o[j] = (bf16)d;
+        }
+        *reinterpret_cast<bf16x8*>(a.dr + row * a.ld + c0) = o;
+    }
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < a.C; c += TPB) {
+            float sg = 0.f, sb = 0.f;
+            for (int g = 0; g < a.G; ++g) { sg += a.red[g * a.C + c].y; sb += a.red[g * a.C + c].x; }
+            if (a.dgamma) a.dgamma[c] += sg;
+            if (a.dbeta) a.dbeta[c] += sb;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ sigmoid + binary cross entropy
+__global__ __launch_bounds__(TPB) void sigmoid_bce_kernel(const BceArgs a) {
+    const int g = blockIdx.y;
+    const long long per_group = (long long)a.B * a.C * a.H * a.W;
+    float acc = 0.f;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < per_group; i += (long long)gridDim.x * TPB) {
+        // i indexes NCHW of the target
+        const int x = (int)(i % a.W);
+        long long t1 = i / a.W;
+        const int y = (int)(t1 % a.H);
+        t1 /= a.H;
+        const int c = (int)(t1 % a.C);
+        const int n = (int)(t1 / a.C);
+        const long long ng = (long long)g * a.B + n;
+        const float l = a.logits[((ng * a.H + y) * a.W + x) * a.ldl + c];
+        const float t = a.target[i];
+        const float p = 1.0f / (1.0f + expf(-l));                  // F.sigmoid
+        const float lp = fmaxf(logf(p), -100.f);                    // F.binary_cross_entropy clamps both logs at -100
+        const float lq = fmaxf(logf(1.0f - p), -100.f);
+        acc += -(t * lp + (1.0f - t) * lq);
+        const long long o = g * per_group + i;
+        if (a.recon) a.recon[o] = p;
+        if (a.dlogit) {
+            const float pq = p * (1.0f - p);
+            a.dlogit[o] = a.coef[g] * (p - t) / fmaxf(pq, 1e-12f) * pq;   // BCE backward (EPS 1e-12) x sigmoid backward
+        }
+    }
+    acc = wave_sum(acc);
+    __shared__ float part[TPB / 64];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int w = 0; w < TPB / 64; ++w) s += part[w];
+        atomicAdd(a.loss_sum + g, s);
+    }
+}
+
+// ------------------------------------------------------------------ product of experts / reparam / KL
+struct Poe2 { float mu, lv; };
+// forward of multimnist/model.py:355-360 for M experts held in registers
+template <int M>
+__device__ __forceinline__ Poe2 poe_fwd_m(const float (&mu)[M], const float (&lv)[M]) {
+    float s0 = 0.f, s1 = 0.f, t = 0.f;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        float var = expf(lv[i]) + 1e-8f;
+        s0 += var; s1 += mu[i] * var; t += 1.0f / var;
+    }
+    Poe2 o;
+    o.mu = s1 / s0;
+    o.lv = logf(1.0f / t);
+    return o;
+}
+template <int M>
+__device__ __forceinline__ void poe_bwd_m(const float (&mu)[M], const float (&lv)[M], float gmu, float glv,
+                                          float (&dmu)[M], float (&dlv)[M]) {
+    float s0 = 0.f, s1 = 0.f, t = 0.f;
+    float var[M];
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        var[i] = expf(lv[i]) + 1e-8f;
+        s0 += var[i]; s1 += mu[i] * var[i]; t += 1.0f / var[i];
+    }
+    const float pm = s1 / s0;
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+        dmu[i] = gmu * var[i] / s0;
+        float dvar = gmu * (mu[i] - pm) / s0 + glv / (t * var[i] * var[i]);
+        dlv[i] = dvar * expf(lv[i]);
+    }
+}
+
+__global__ __launch_bounds__(TPB) void poe_fwd_kernel(const float* mu, const float* lv, int M, int n, float* omu, float* olv) {
+    int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    float s0 = 0.f, s1 = 0.f, t = 0.f;
+    for (int m = 0; m < M; ++m) {
+        float var = expf(lv[(long long)m * n + i]) + 1e-8f;
+        s0 += var; s1 += mu[(long long)m * n + i] * var; t += 1.0f / var;
+    }
+    omu[i] = s1 / s0;
+    olv[i] = logf(1.0f / t);
+}
+__global__ __launch_bounds__(TPB) void poe_bwd_kernel(const float* mu, const float* lv, int M, int n, const float* gmu,
+                                                      const float* glv, float* dmu, float* dlv) {
+    int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    float s0 = 0.f, s1 = 0.f, t = 0.f;
+    for (int m = 0; m < M; ++m) {
+        float var = expf(lv[(long long)m * n + i]) + 1e-8f;
+        s0 += var; s1 += mu[(long long)m * n + i] * var; t += 1.0f / var;
+    }
+    const float pm = s1 / s0, a = gmu[i], b = glv[i];
+    for (int m = 0; m < M; ++m) {
+        float e = expf(lv[(long long)m * n + i]);
+        float var = e + 1e-8f;
+        dmu[(long long)m * n + i] = a * var / s0;
+        dlv[(long long)m * n + i] = (a * (mu[(long long)m * n + i] - pm) / s0 + b / (t * var * var)) * e;
+    }
+}
+__global__ __launch_bounds__(TPB) void reparam_fwd_kernel(const float* mu, const float* lv, const float* eps, int n, float* z) {
+    int i = blockIdx.x * TPB + threadIdx.x;
+    if (i < n) z[i] = eps[i] * expf(0.5f * lv[i]) + mu[i];
+}
+__global__ __launch_bounds__(TPB) void reparam_bwd_kernel(const float* lv, const float* eps, const float* dz, int n, float* dmu, float* dlv) {
+    int i = blockIdx.x * TPB + threadIdx.x;
+    if (i < n) { dmu[i] = dz[i]; dlv[i] = dz[i] * eps[i] * 0.5f * expf(0.5f * lv[i]); }
+}
+__global__ __launch_bounds__(TPB) void kl_fwd_kernel(const float* mu, const float* lv, int n, float* out) {
+    float acc = 0.f;
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB)
+        acc += -0.5f * (1.0f + lv[i] - mu[i] * mu[i] - expf(lv[i]));
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+__global__ __launch_bounds__(TPB) void kl_bwd_kernel(const float* mu, const float* lv, int n, float coef, float* dmu, float* dlv) {
+    int i = blockIdx.x * TPB + threadIdx.x;
+    if (i < n) { dmu[i] = coef * mu[i]; dlv[i] = -0.5f * coef * (1.0f - expf(lv[i])); }
+}
+
+__global__ __launch_bounds__(TPB) void normal_kernel(float* out, long long n, unsigned long long seed, const long long* step, unsigned stream_id) {
+    const unsigned long long st = step ? (unsigned long long)*step : 0ull;
+    for (long long q = (long long)blockIdx.x * TPB + threadIdx.x; q * 4 < n; q += (long long)gridDim.x * TPB) {
+        uint32_t r[4];
+        Philox::gen(seed ^ (st * 0x9E3779B97F4A7C15ull), (uint64_t)q, stream_id, r);
+        float u0 = u01(r[0]), u1 = u01(r[1]), u2 = u01(r[2]), u3 = u01(r[3]);
+        float m0 = sqrtf(-2.0f * logf(u0)), m1 = sqrtf(-2.0f * logf(u2));
+        float v[4] = {m0 * cosf(6.28318530718f * u1), m0 * sinf(6.28318530718f * u1),
+                      m1 * cosf(6.28318530718f * u3), m1 * sinf(6.28318530718f * u3)};
+        for (int j = 0; j < 4; ++j)
+            if (q * 4 + j < n) out[q * 4 + j] = v[j];
+    }
+}
+__global__ __launch_bounds__(TPB) void keep_mask_kernel(uint8_t* out, long long n, float p, unsigned long long seed, const long long* step, unsigned stream_id) {
+    const unsigned long long st = step ? (unsigned long long)*step : 0ull;
+    for (long long q = (long long)blockIdx.x * TPB + threadIdx.x; q * 4 < n; q += (long long)gridDim.x * TPB) {
+        uint32_t r[4];
+        Philox::gen(seed ^ (st * 0x9E3779B97F4A7C15ull), (uint64_t)q, stream_id, r);
+        for (int j = 0; j < 4; ++j)
+            if (q * 4 + j < n) out[q * 4 + j] = u01(r[j]) >= p ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------ standalone loss pieces (drop-in loss_function)
+__global__ __launch_bounds__(TPB) void bce_fwd_kernel(const float* p, const float* t, long long n, float* out) {
+    float acc = 0.f;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long long)gridDim.x * TPB) {
+        const float lp = fmaxf(logf(p[i]), -100.f), lq = fmaxf(logf(1.0f - p[i]), -100.f);
+        acc += -(t[i] * lp + (1.0f - t[i]) * lq);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+__global__ __launch_bounds__(TPB) void bce_bwd_kernel(const float* p, const float* t, long long n, float coef, float* dp) {
+    long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (i < n) dp[i] = coef * (p[i] - t[i]) / fmaxf((1.0f - p[i]) * p[i], 1e-12f);
+}
+__global__ __launch_bounds__(TPB) void nll_fwd_kernel(const float* lp, const long long* tg, int rows, int classes, float* out) {
+    float acc = 0.f;
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < rows; i += gridDim.x * TPB) acc += -lp[(size_t)i * classes + tg[i]];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+__global__ __launch_bounds__(TPB) void nll_bwd_kernel(const long long* tg, int rows, int classes, float coef, float* dlp) {
+    int i = blockIdx.x * TPB + threadIdx.x;
+    if (i < rows * classes) dlp[i] = (i % classes == (int)tg[i / classes]) ? -coef : 0.f;
+}
+
+// ------------------------------------------------------------------ fused 3-pass latent block
+// pass 0: experts {image(pass-1 encoder output), text}; pass 1: {image(pass-2 output)}; pass 2: {text}
+__global__ __launch_bounds__(TPB) void latent3_fwd_kernel(const Latent3Args a) {
+    const int n = a.B * a.D;
+    float kl[3] = {0.f, 0.f, 0.f};
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < a.B * a.ldz; i += gridDim.x * TPB) {
+        const int b = i / a.ldz, d = i - b * a.ldz;
+        if (d >= a.D) {        // column D carries the 1.0 that multiplies the folded bias; the other pads are zero
+            for (int k = 0; k < 3; ++k) a.z_bf[(size_t)(k * a.B + b) * a.ldz + d] = (bf16)(d == a.D ? 1.f : 0.f);
+            continue;
+        }
+        const int D2 = 2 * a.D;
+        const float im0 = a.img_out[(size_t)b * D2 + d], il0 = a.img_out[(size_t)b * D2 + a.D + d];
+        const float im1 = a.img_out[(size_t)(a.B + b) * D2 + d], il1 = a.img_out[(size_t)(a.B + b) * D2 + a.D + d];
+        const float tm = a.txt_out[(size_t)b * D2 + d], tl = a.txt_out[(size_t)b * D2 + a.D + d];
+        Poe2 o[3];
+        { float m[2] = {im0, tm}, l[2] = {il0, tl}; o[0] = poe_fwd_m<2>(m, l); }
+        { float m[1] = {im1}, l[1] = {il1}; o[1] = poe_fwd_m<1>(m, l); }
+        { float m[1] = {tm}, l[1] = {tl}; o[2] = poe_fwd_m<1>(m, l); }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const size_t e = (size_t)k * n + (size_t)b * a.D + d;
+            a.mu[e] = o[k].mu; a.logvar[e] = o[k].lv;
+            float z = a.training ? a.eps[e] * expf(0.5f * o[k].lv) + o[k].mu : o[k].mu;
+            a.z_f32[e] = z;
+            a.z_bf[(size_t)(k * a.B + b) * a.ldz + d] = (bf16)z;
+            kl[k] += -0.5f * (1.0f + o[k].lv - o[k].mu * o[k].mu - expf(o[k].lv));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float s = wave_sum(kl[k]);
+        if ((threadIdx.x & 63) == 0) atomicAdd(a.kl_sum + k, s);
+    }
+}
+
+__global__ __launch_bounds__(TPB) void latent3_bwd_kernel(const Latent3BwdArgs a) {
+    const Latent3Args& f = a.f;
+    const int n = f.B * f.D, D2 = 2 * f.D;
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    const int b = i / f.D, d = i - b * f.D;
+    const float im0 = f.img_out[(size_t)b * D2 + d], il0 = f.img_out[(size_t)b * D2 + f.D + d];
+    const float im1 = f.img_out[(size_t)(f.B + b) * D2 + d], il1 = f.img_out[(size_t)(f.B + b) * D2 + f.D + d];
+    const float tm = f.txt_out[(size_t)b * D2 + d], tl = f.txt_out[(size_t)b * D2 + f.D + d];
+    float gmu[3], glv[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const size_t e = (size_t)k * n + i;
+        float dz = 0.f;
+        if (a.dz_a) dz += a.dz_a[e];
+        if (a.dz_b) dz += a.dz_b[e];
+        const float mu = f.mu[e], lv = f.logvar[e];
+        gmu[k] = dz + a.kl_coef[k] * mu;
+        glv[k] = -0.5f * a.kl_coef[k] * (1.0f - expf(lv));
+        if (f.training) glv[k] += dz * f.eps[e] * 0.5f * expf(0.5f * lv);
+    }
+    float d_im0, d_il0, d_im1, d_il1, d_tm = 0.f, d_tl = 0.f;
+    {
+        float m[2] = {im0, tm}, l[2] = {il0, tl}, dm[2], dl[2];
+        poe_bwd_m<2>(m, l, gmu[0], glv[0], dm, dl);
+        d_im0 = dm[0]; d_il0 = dl[0]; d_tm += dm[1]; d_tl += dl[1];
+    }
+    {
+        float m[1] = {im1}, l[1] = {il1}, dm[1], dl[1];
+        poe_bwd_m<1>(m, l, gmu[1], glv[1], dm, dl);
+        d_im1 = dm[0]; d_il1 = dl[0];
+    }
+    {
+        float m[1] = {tm}, l[1] = {tl}, dm[1], dl[1];
+        poe_bwd_m<1>(m, l, gmu[2], glv[2], dm, dl);
+        d_tm += dm[0]; d_tl += dl[0];
+    }
+    a.d_img_out_bf[(size_t)b * D2 + d] = (bf16)d_im0;
+    a.d_img_out_bf[(size_t)b * D2 + f.D + d] = (bf16)d_il0;
+    a.d_img_out_bf[(size_t)(f.B + b) * D2 + d] = (bf16)d_im1;
+    a.d_img_out_bf[(size_t)(f.B + b) * D2 + f.D + d] = (bf16)d_il1;
+    a.d_txt_out[(size_t)b * D2 + d] = d_tm;
+    a.d_txt_out[(size_t)b * D2 + f.D + d] = d_tl;
+    if (a.d_img_bias) {
+        atomicAdd(a.d_img_bias + d, d_im0 + d_im1);
+        atomicAdd(a.d_img_bias + f.D + d, d_il0 + d_il1);
+    }
+}
+
+// ------------------------------------------------------------------ Adam (torch.optim.Adam defaults)
+__global__ __launch_bounds__(TPB) void adam_kernel(const AdamArgs a, unsigned* done) {
+    const long long t = *a.step + 1;
+    const float bc1 = 1.0f - powf(a.b1, (float)t);
+    const float bc2 = 1.0f - powf(a.b2, (float)t);
+    const float step_size = a.lr / bc1;
+    const float inv_sqrt_bc2 = rsqrtf(bc2);
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i * 4 < a.n; i += (long long)gridDim.x * TPB) {
+        const long long e = i * 4;
+        if (e + 4 <= a.n) {
+            f32x4 g = *reinterpret_cast<const f32x4*>(a.g + e);
+            f32x4 m = *reinterpret_cast<const f32x4*>(a.m + e);
+            f32x4 v = *reinterpret_cast<const f32x4*>(a.v + e);
+            f32x4 p = *reinterpret_cast<const f32x4*>(a.p + e);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float gj = g[j] * a.grad_scale;
+                m[j] = a.b1 * m[j] + (1.f - a.b1) * gj;
+                v[j] = a.b2 * v[j] + (1.f - a.b2) * gj * gj;
+                p[j] -= step_size * m[j] / (sqrtf(v[j]) * inv_sqrt_bc2 + a.eps);
+            }
+            *reinterpret_cast<f32x4*>(a.m + e) = m;
+            *reinterpret_cast<f32x4*>(a.v + e) = v;
+            *reinterpret_cast<f32x4*>(a.p + e) = p;
+        } else {
+            for (long long q = e; q < a.n; ++q) {
+                float gj = a.g[q] * a.grad_scale;
+                float m = a.b1 * a.m[q] + (1.f - a.b1) * gj;
+                float v = a.b2 * a.v[q] + (1.f - a.b2) * gj * gj;
+                a.m[q] = m; a.v[q] = v;
+                a.p[q] -= step_size * m / (sqrtf(v) * inv_sqrt_bc2 + a.eps);
+            }
+        }
+    }
+    // the last block to finish advances the step counter (every block has read it by then)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned ticket = atomicAdd(done, 1u);
+        if (ticket == gridDim.x - 1) {
+            *done = 0u;
+            *a.step = t;
+            __threadfence();
+        }
+    }
+}
+
+}  // namespace
+
+int launch_pack(const PackDesc* table_dev, const PackDesc* table_host, int nd, const float* params, bf16* packed_bf,
+                float* packed_f32, hipStream_t s) {
+    MMVAE_REQUIRE(nd > 0, "pack: empty table");
+    hipLaunchKernelGGL(pack_kernel, dim3(table_blocks(table_host, nd)), dim3(TPB), 0, s, table_dev, nd, params, packed_bf, packed_f32);
+    return mmvae_check_launch("pack");
+}
+int launch_unpack_grads(const PackDesc* table_dev, const PackDesc* table_host, int nd, const float* gmat, const float* gvec,
+                        float* grads, hipStream_t s) {
+    MMVAE_REQUIRE(nd > 0, "unpack: empty table");
+    hipLaunchKernelGGL(unpack_kernel, dim3(table_blocks(table_host, nd)), dim3(TPB), 0, s, table_dev, nd, gmat, gvec, grads);
+    return mmvae_check_launch("unpack_grads");
+}
+int launch_im2col_small(const float* src, int Nimg, int Cin, int H, int W, int KH, int KW, int stride, int pad, int OH, int OW,
+                        bf16* dst, int ld, hipStream_t s) {
+    MMVAE_REQUIRE(ld % 8 == 0 && ld >= KH * KW * Cin, "im2col: ld=%d", ld);
+    long long nvec = (long long)Nimg * OH * OW * (ld / 8);
+    hipLaunchKernelGGL(im2col_small_kernel, dim3(nblocks(nvec)), dim3(TPB), 0, s, src, Nimg, Cin, H, W, KH, KW, stride, pad, OH, OW, dst, ld);
+    return mmvae_check_launch("im2col_small");
+}
+int launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s) {
+    MMVAE_REQUIRE(!a.training || a.count > 1.f, "Expected more than 1 value per channel when training");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(a.C, 64)), dim3(64), 0, s, a);
+    return mmvae_check_launch("bn_finalize");
+}
+int launch_bn_bwd_apply(const BnBwdApplyArgs& a, hipStream_t s) {
+    MMVAE_REQUIRE(a.C % 8 == 0 && a.ld % 8 == 0, "bn_bwd_apply: C=%d ld=%d", a.C, a.ld);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblocks((long long)a.rows * a.C / 8)), dim3(TPB), 0, s, a);
+    return mmvae_check_launch("bn_bwd_apply");
+}
+int launch_sigmoid_bce(const BceArgs& a, hipStream_t s) {
+    MMVAE_REQUIRE(a.G >= 1 && a.G <= 4, "bce: G=%d", a.G);
+    long long per_group = (long long)a.B * a.C * a.H * a.W;
+    hipLaunchKernelGGL(sigmoid_bce_kernel, dim3(nblocks(per_group, TPB * 4, 1024), a.G), dim3(TPB), 0, s, a);
+    return mmvae_check_launch("sigmoid_bce");
+}
+int launch_poe_fwd(const float* mu, const float* lv, int M, int n, float* omu, float* olv, hipStream_t s) {
+    hipLaunchKernelGGL(poe_fwd_kernel, dim3(ceil_div(n, TPB)), dim3(TPB), 0, s, mu, lv, M, n, omu, olv);
+    return mmvae_check_launch("poe_fwd");
+}
+int launch_poe_bwd(const float* mu, const float* lv, int M, int n, const float* gmu, const float* glv, float* dmu, float* dlv, hipStream_t s) {
+    hipLaunchKernelGGL(poe_bwd_kernel, dim3(ceil_div(n, TPB)), dim3(TPB), 0, s, mu, lv, M, n, gmu, glv, dmu, dlv);
+    return mmvae_check_launch("poe_bwd");
+}
+int launch_reparam_fwd(const float* mu, const float* lv, const float* eps, int n, float* z, hipStream_t s) {
+    hipLaunchKernelGGL(reparam_fwd_kernel, dim3(ceil_div(n, TPB)), dim3(TPB), 0, s, mu, lv, eps, n, z);
+    return mmvae_check_launch("reparam_fwd");
+}
+int launch_reparam_bwd(const float* lv, const float* eps, const float* dz, int n, float* dmu, float* dlv, hipStream_t s) {
+    hipLaunchKernelGGL(reparam_bwd_kernel, dim3(ceil_div(n, TPB)), dim3(TPB), 0, s, lv, eps, dz, n, dmu, dlv);
+    return mmvae_check_launch("reparam_bwd");
+}
+int launch_kl_fwd(const float* mu, const float* lv, int n, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(kl_fwd_kernel, dim3(nblocks(n, TPB, 64)), dim3(TPB), 0, s, mu, lv, n, out);
+    return mmvae_check_launch("kl_fwd");
+}
+int launch_kl_bwd(const float* mu, const float* lv, int n, float coef, float* dmu, float* dlv, hipStream_t s) {
+    hipLaunchKernelGGL(kl_bwd_kernel, dim3(ceil_div(n, TPB)), dim3(TPB), 0, s, mu, lv, n, coef, dmu, dlv);
+    return mmvae_check_launch("kl_bwd");
+}
+int launch_normal(float* out, long long n, unsigned long long seed, const long long* step, unsigned stream_id, hipStream_t s) {
+    hipLaunchKernelGGL(normal_kernel, dim3(nblocks((n + 3) / 4, TPB, 512)), dim3(TPB), 0, s, out, n, seed, step, stream_id);
+    return mmvae_check_launch("normal");
+}
+int launch_keep_mask(uint8_t* out, long long n, float p, unsigned long long seed, const long long* step, unsigned stream_id, hipStream_t s) {
+    hipLaunchKernelGGL(keep_mask_kernel, dim3(nblocks((n + 3) / 4, TPB, 512)), dim3(TPB), 0, s, out, n, p, seed, step, stream_id);
+    return mmvae_check_launch("keep_mask");
+}
+int launch_latent3_fwd(const Latent3Args& a, hipStream_t s) {
+    MMVAE_REQUIRE(a.ldz >= a.D && a.ldz % 8 == 0, "latent3: ldz=%d", a.ldz);
+    hipLaunchKernelGGL(latent3_fwd_kernel, dim3(nblocks((long long)a.B * a.ldz, TPB, 256)), dim3(TPB), 0, s, a);
+    return mmvae_check_launch("latent3_fwd");
+}
+int launch_latent3_bwd(const Latent3BwdArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(latent3_bwd_kernel, dim3(ceil_div(a.f.B * a.f.D, TPB)), dim3(TPB), 0, s, a);
+    return mmvae_check_launch("latent3_bwd");
+}
+int launch_adam(const AdamArgs& a, hipStream_t s) {
+    MMVAE_REQUIRE(a.step != nullptr, "adam: step counter is null");
+    // the word after the step counter is the block ticket (both live in the caller's 16-byte state block)
+    unsigned* done = reinterpret_cast<unsigned*>(a.step + 1);
+    hipLaunchKernelGGL(adam_kernel, dim3(nblocks((a.n + 3) / 4, TPB, 2048)), dim3(TPB), 0, s, a, done);
+    return mmvae_check_launch("adam");
+}
+int launch_fill_zero(void* p, size_t bytes, hipStream_t s) {
+    if (hipMemsetAsync(p, 0, bytes, s) != hipSuccess) {
+        mmvae_set_error("hipMemsetAsync failed");
+        return MMVAE_EHIP;
+    }
+    return MMVAE_OK;
+}
+
+int launch_bce_fwd(const float* p, const float* t, long long n, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(bce_fwd_kernel, dim3(nblocks(n, TPB * 4, 1024)), dim3(TPB), 0, s, p, t, n, out);
+    return mmvae_check_launch("bce_fwd");
+}
+int launch_bce_bwd(const float* p, const float* t, long long n, float coef, float* dp, hipStream_t s) {
+    hipLaunchKernelGGL(bce_bwd_kernel, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, s, p, t, n, coef, dp);
+    return mmvae_check_launch("bce_bwd");
+}
+int launch_nll_fwd(const float* lp, const long long* tg, int rows, int classes, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(nll_fwd_kernel, dim3(nblocks(rows, TPB, 64)), dim3(TPB), 0, s, lp, tg, rows, classes, out);
+    return mmvae_check_launch("nll_fwd");
+}
+int launch_nll_bwd(const long long* tg, int rows, int classes, float coef, float* dlp, hipStream_t s) {
+    hipLaunchKernelGGL(nll_bwd_kernel, dim3(ceil_div(rows * classes, TPB)), dim3(TPB), 0, s, tg, rows, classes, coef, dlp);
+    return mmvae_check_launch("nll_bwd");
+}

@@ -1,0 +1,73 @@
+// Parameter blocks of the two MFMA workhorse kernels (gemm.hip):
+//   gemm_gather : C[rows][N] = act(A_gathered)[rows][K] * Wp[N][K]^T   (conv fwd / conv dgrad / convT / Linear)
+//   wgrad       : dWp[N][K] += P[rows][N]^T * act(G_gathered)[rows][K]  (all weight gradients)
+// "rows" are pixels (n, oy, ox) of a row grid; the gathered operand is an NHWC bf16 tensor whose pixel for
+// row (n,oy,ox) and tap (ty,tx) is (n, oy*sy+offy+ty*dy, ox*sx+offx+tx*dx); K = TH*TW*C with c fastest.
+#pragma once
+#include "common.h"
+
+#define MMVAE_MAX_CLASSES 4
+
+struct GatherClass {        // one stride-parity class (conv fwd and Linear have exactly one)
+    int OY, OX;             // row grid per image
+    int rows_per_group;     // group_n*OY*OX
+    int TH, TW;             // taps
+    int offy, offx;         // gather offsets
+    int ooy, oox;           // position of row (oy,ox) in the "row tensor": (oy*osy+ooy, ox*osx+oox)
+    int K;                  // TH*TW*C
+    int Kpad;               // packed weight row stride (multiple of 64)
+    const bf16* Wp;         // gemm: packed weights [Npad][Kpad]
+    float* dWp;             // wgrad: packed fp32 gradient [Npad][Kpad]
+};
+
+struct GatherCommon {
+    int groups, group_n;    // BN groups (passes) and images per group
+    // gathered tensor [Nimg][AH][AW][Ald] bf16
+    const bf16* A;
+    int AH, AW, Ald, C;
+    int sy, sx, dy, dx;
+    const float2* a_affine; // [groups][C] (scale, shift) applied before a_act; may be null
+    int a_act;
+    const uint8_t* a_mask;  // keep flags [rows][C] (single-tap dense operands only); may be null
+    float a_mask_scale;
+    int a_bcast_n;          // >0: the gathered tensor holds only a_bcast_n images shared by every row block
+                            // (image = row_image % a_bcast_n, affine group 0): encoder features reused by 2 passes
+    // row tensor geometry [Nimg][OH][OW][ld]: gemm output / wgrad plain operand
+    int OH, OW, osy, osx;
+    int N;                  // valid columns
+    int nclasses;
+};
+
+struct GemmParams {
+    GatherCommon c;
+    GatherClass cls[MMVAE_MAX_CLASSES];
+    const float* bias;      // [N] or null
+    bf16* out_bf;           // [Nimg][OH][OW][ldo] or null
+    float* out_f;           // same geometry, fp32, or null
+    int ldo;
+    float2* colstats;       // [groups][N] += (sum v, sum v^2) or null
+    // d-activation epilogue: v *= act'(affine(r)) [* keep*scale], r has the output geometry (ld = d_ld)
+    const bf16* d_r;
+    int d_ld;
+    int d_bcast_n;          // >0: d_r holds d_bcast_n images (image = row_image % d_bcast_n)
+    const float2* d_affine; // [groups][N] or null
+    int d_act;
+    const uint8_t* d_mask;  // [rows][N] keep flags or null
+    float d_mask_scale;
+    const float2* d_meanrstd;  // [groups][N] for xhat=(r-mean)*rstd, with d_red
+    float2* d_red;             // [groups][N] += (sum v, sum v*xhat) or null
+    float* d_colsum;           // [N] += sum v over all rows (bias gradient of the producer Linear) or null
+};
+
+struct WgradParams {
+    GatherCommon c;
+    GatherClass cls[MMVAE_MAX_CLASSES];
+    const bf16* P;          // plain operand, row tensor geometry, ld = ldp
+    int ldp;
+    const float2* p_affine; // optional transform of the plain operand [groups][N]
+    int p_act;
+    int rows_per_block;     // multiple of 64
+};
+
+int launch_gemm_gather(const GemmParams& p, hipStream_t stream);
+int launch_wgrad(const WgradParams& p, hipStream_t stream);

@@ -1,0 +1,439 @@
+// MFMA implicit-GEMM kernels for gfx950 (wave64, v_mfma_f32_16x16x32_bf16, fp32 accumulate).
+//
+// gemm_gather_kernel<NT>: block = 4 waves stacked along M (BM=128), BN = 16*NT, BK = 64.
+//   Operand A is gathered pixel rows of an NHWC bf16 tensor (register staged so the BatchNorm affine +
+//   Swish/ReLU (+dropout keep-mask) of the PRODUCER layer is applied while staging: activated tensors are
+//   never materialised in HBM).  Operand B is a pre-packed bf16 weight matrix [Npad][Kpad].
+//   LDS rows are padded by one 16-B slot (stride 144 B) -> conflict-free ds_read_b128 fragments.
+//   Epilogue options: bias, bf16/fp32 store to a strided pixel grid, per-(group,column) BatchNorm statistics,
+//   and the "d-activation" form used by backward (multiply by act'(.) of the consumer-side saved tensor and
+//   reduce the two BatchNorm-backward sums).
+// wgrad_kernel: dW[N][K] += P^T G over pixel rows, both operands transposed on the fly with
+//   ds_read_b64_tr_b16 (LDS row stride 160 B makes the 8-row transposed reads conflict-free),
+//   split over row chunks with fp32 atomics into a packed gradient matrix.
+#include "gemm.h"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BK = 64;
+constexpr int LDA = BK + 8;    // bf16 elements per LDS row (144 B)
+
+struct RowCoord {
+    int pix;    // n*AH*AW (gather base) -- or -1 when the row is out of range
+    int y, x;   // oy*sy+offy, ox*sx+offx
+};
+
+__device__ __forceinline__ bf16x8 zero8() {
+    bf16x8 z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = (bf16)0.0f;
+    return z;
+}
+
+// applies (affine, act, keep-mask) to 8 gathered channels
+__device__ __forceinline__ bf16x8 transform8(bf16x8 v, const float2* aff, int act, const uint8_t* mask, float mscale) {
+    bf16x8 o;
+    uint64_t mbits = 0;
+    if (mask) mbits = *reinterpret_cast<const uint64_t*>(mask);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float f = (float)v[j];
+        if (aff) f = f * aff[j].x + aff[j].y;
+        f = act_fwd(act, f);
+        if (mask) f = ((mbits >> (8 * j)) & 0xff) ? f * mscale : 0.f;
+        o[j] = (bf16)f;
+    }
+    return o;
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void gemm_gather_kernel(const GemmParams p) {
+    constexpr int BN = NT * 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* As = reinterpret_cast<bf16*>(smem);                 // [2][BM][LDA]
+    bf16* Bs = As + 2 * BM * LDA;                             // [2][BN][LDA]
+    float2* aff_s = reinterpret_cast<float2*>(Bs + 2 * BN * LDA);   // [groups*C] when a_affine
+
+    const GatherCommon& c = p.c;
+    const GatherClass& k = p.cls[blockIdx.z];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_per_group = (k.rows_per_group + BM - 1) / BM;
+    if ((int)blockIdx.x >= tiles_per_group * c.groups) return;
+    const int g = blockIdx.x / tiles_per_group;
+    const int row0 = (blockIdx.x - g * tiles_per_group) * BM;
+    const int n0 = blockIdx.y * BN;
+    const int K = k.K;
+    const int nk = (K + BK - 1) / BK;
+    const int pix_per_img = k.OY * k.OX;
+    const bool has_tf = (c.a_affine != nullptr) || (c.a_act != ACT_NONE) || (c.a_mask != nullptr);
+
+    if (c.a_affine) {
+        const int ag = c.a_bcast_n > 0 ? 0 : g;
+        for (int i = tid; i < c.C; i += 256) aff_s[i] = c.a_affine[ag * c.C + i];
+    }
+
+    // ---- per-thread staging coordinates: 4 A rows, vector column kv ----
+    const int kv = tid & 7;
+    RowCoord rc[4];
+    int grow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int r = row0 + (tid >> 3) + 32 * i;
+        if (r < k.rows_per_group) {
+            int img = r / pix_per_img;
+            int rem = r - img * pix_per_img;
+            int oy = rem / k.OX;
+            int ox = rem - oy * k.OX;
+            int aimg = g * c.group_n + img;
+            if (c.a_bcast_n > 0) aimg %= c.a_bcast_n;
+            rc[i].pix = aimg * c.AH * c.AW;
+            rc[i].y = oy * c.sy + k.offy;
+            rc[i].x = ox * c.sx + k.offx;
+        } else {
+            rc[i].pix = -1; rc[i].y = 0; rc[i].x = 0;
+        }
+        grow[i] = g * k.rows_per_group + r;
+    }
+
+    bf16x8 areg[4];
+    unsigned avalid = 0;
+    int a_c = 0;
+    constexpr int NB = (BN * 8 + 255) / 256;       // B vectors per thread
+    bf16x8 breg[NB];
+
+    auto load_tile = [&](int kt) {
+        const int kk = kt * BK + kv * 8;
+        avalid = 0;
+        int ty = 0, tx = 0;
+        a_c = 0;
+        const bool kin = kk < K;
+        if (kin) {
+            int tap = kk / c.C;
+            a_c = kk - tap * c.C;
+            ty = tap / k.TW;
+            tx = tap - ty * k.TW;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int y = rc[i].y + ty * c.dy, x = rc[i].x + tx * c.dx;
+            bool ok = kin && rc[i].pix >= 0 && (unsigned)y < (unsigned)c.AH && (unsigned)x < (unsigned)c.AW;
+            if (ok) {
+                const bf16* src = c.A + (size_t)(rc[i].pix + y * c.AW + x) * c.Ald + a_c;
+                areg[i] = *reinterpret_cast<const bf16x8*>(src);
+                avalid |= 1u << i;
+            } else {
+                areg[i] = zero8();
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            int v = tid + 256 * i;
+            if (v < BN * 8) {
+                const bf16* src = k.Wp + (size_t)(n0 + (v >> 3)) * k.Kpad + kt * BK + (v & 7) * 8;
+                breg[i] = *reinterpret_cast<const bf16x8*>(src);
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+        bf16* a_dst = As + buf * BM * LDA;
+        bf16* b_dst = Bs + buf * BN * LDA;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bf16x8 v = areg[i];
+            if (has_tf && ((avalid >> i) & 1)) {
+                const uint8_t* m = c.a_mask ? c.a_mask + (size_t)grow[i] * c.C + a_c : nullptr;
+                v = transform8(v, c.a_affine ? aff_s + a_c : nullptr, c.a_act, m, c.a_mask_scale);
+            }
+            *reinterpret_cast<bf16x8*>(a_dst + ((tid >> 3) + 32 * i) * LDA + kv * 8) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            int v = tid + 256 * i;
+            if (v < BN * 8) *reinterpret_cast<bf16x8*>(b_dst + (v >> 3) * LDA + (v & 7) * 8) = breg[i];
+        }
+    };
+
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    load_tile(0);
+    __syncthreads();          // aff_s visible
+    store_tile(0);
+    __syncthreads();
+
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const bf16* a_src = As + buf * BM * LDA + (wave * 32 + fr) * LDA + fq * 8;
+        const bf16* b_src = Bs + buf * BN * LDA + fr * LDA + fq * 8;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a0 = *reinterpret_cast<const bf16x8*>(a_src + ks * 32);
+            bf16x8 a1 = *reinterpret_cast<const bf16x8*>(a_src + 16 * LDA + ks * 32);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                bf16x8 b = *reinterpret_cast<const bf16x8*>(b_src + nt * 16 * LDA + ks * 32);
+                acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, acc[0][nt], 0, 0, 0);
+                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, acc[1][nt], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---------------- epilogue ----------------
+    const bool want_stats = p.colstats != nullptr;
+    const bool want_red = p.d_red != nullptr || p.d_colsum != nullptr;
+    float s1[NT], s2[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.f; s2[nt] = 0.f; }
+
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = row0 + wave * 32 + mt * 16 + fq * 4 + j;
+            if (r >= k.rows_per_group) continue;
+            int img = r / pix_per_img;
+            int rem = r - img * pix_per_img;
+            int oy = rem / k.OX;
+            int ox = rem - oy * k.OX;
+            const size_t opix = (size_t)((g * c.group_n + img) * c.OH + oy * c.osy + k.ooy) * c.OW + ox * c.osx + k.oox;
+            const size_t growi = (size_t)g * k.rows_per_group + r;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int col = n0 + nt * 16 + fr;
+                if (col >= c.N) continue;
+                float v = acc[mt][nt][j];
+                if (p.bias) v += p.bias[col];
+                if (p.d_r) {
+                    size_t rpix = opix;
+                    if (p.d_bcast_n > 0)
+                        rpix = (size_t)(((g * c.group_n + img) % p.d_bcast_n) * c.OH + oy * c.osy + k.ooy) * c.OW + ox * c.osx + k.oox;
+                    float rr = (float)p.d_r[rpix * p.d_ld + col];
+                    float b = rr;
+                    if (p.d_affine) { float2 a = p.d_affine[g * c.N + col]; b = rr * a.x + a.y; }
+                    v *= act_bwd(p.d_act, b);
+                    if (p.d_mask) v = p.d_mask[growi * c.N + col] ? v * p.d_mask_scale : 0.f;
+                    if (want_red) {
+                        float2 mr = p.d_meanrstd ? p.d_meanrstd[g * c.N + col] : make_float2(0.f, 0.f);
+                        s1[nt] += v;
+                        s2[nt] += v * (rr - mr.x) * mr.y;
+                    }
+                }
+                if (want_stats) { s1[nt] += v; s2[nt] += v * v; }
+                if (p.out_bf) p.out_bf[opix * p.ldo + col] = (bf16)v;
+                if (p.out_f) p.out_f[opix * p.ldo + col] = v;
+            }
+        }
+    }
+    if (want_stats || want_red) {
+        float2* red = reinterpret_cast<float2*>(smem);       // [4][BN], staging LDS is free after the last barrier
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float a = s1[nt], b = s2[nt];
+            a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+            a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+            if (fq == 0) red[wave * BN + nt * 16 + fr] = make_float2(a, b);
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < c.N) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { a += red[w * BN + tid].x; b += red[w * BN + tid].y; }
+            float2* dst = want_stats ? p.colstats : p.d_red;
+            if (dst) {
+                atomicAdd(&dst[g * c.N + n0 + tid].x, a);
+                atomicAdd(&dst[g * c.N + n0 + tid].y, b);
+            }
+            if (p.d_colsum) atomicAdd(p.d_colsum + n0 + tid, a);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+constexpr int WT = 64;          // wgrad tile (N and K)
+constexpr int WM = 64;          // rows per iteration
+constexpr int LDW = 80;         // bf16 elements per LDS row (160 B): conflict-free ds_read_b64_tr_b16
+
+__device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int mb, int c0, int lane) {
+    // MFMA operand fragment whose k index runs over LDS rows (pixel rows), element i over columns.
+    const int g4 = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int row = mb + (g4 >> 1) * 16 + (g4 & 1) * 4 + q;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const bf16* a0 = tile + row * LDW + c0 + 4 * pp;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 8 * LDW));
+    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+    u.s.a = lo; u.s.b = hi;
+    return u.v;
+}
+
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
+    __shared__ __attribute__((aligned(16))) bf16 Ps[WM * LDW];
+    __shared__ __attribute__((aligned(16))) bf16 Gs[WM * LDW];
+    const GatherCommon& c = p.c;
+    const int ncls = c.nclasses;
+    const int cls_i = blockIdx.z % ncls;
+    const int chunk = blockIdx.z / ncls;
+    const GatherClass& k = p.cls[cls_i];
+    const int n0 = blockIdx.x * WT, k0 = blockIdx.y * WT;
+    if (k0 >= k.Kpad) return;
+    const int rows_total = c.groups * k.rows_per_group;
+    const int r_begin = chunk * p.rows_per_block;
+    if (r_begin >= rows_total) return;
+    const int r_end = min(rows_total, r_begin + p.rows_per_block);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int pix_per_img = k.OY * k.OX;
+
+    // fixed (tap, channel) of this thread's gathered vector
+    const int kv = tid & 7;
+    const int kk = k0 + kv * 8;
+    const bool kin = kk < k.K;
+    int ty = 0, tx = 0, gc = 0;
+    if (kin) {
+        int tap = kk / c.C;
+        gc = kk - tap * c.C;
+        ty = tap / k.TW;
+        tx = tap - ty * k.TW;
+    }
+    const int pcol = n0 + kv * 8;
+    const bool has_gtf = (c.a_affine != nullptr) || (c.a_act != ACT_NONE) || (c.a_mask != nullptr);
+    const bool has_ptf = (p.p_affine != nullptr) || (p.p_act != ACT_NONE);
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int rb = r_begin; rb < r_end; rb += WM) {
+        bf16x8 pv[2], gv[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = rb + (tid >> 3) + 32 * i;
+            pv[i] = zero8(); gv[i] = zero8();
+            if (r < r_end) {
+                int g = r / k.rows_per_group;
+                int rg = r - g * k.rows_per_group;
+                int img = rg / pix_per_img;
+                int rem = rg - img * pix_per_img;
+                int oy = rem / k.OX;
+                int ox = rem - oy * k.OX;
+                int n = g * c.group_n + img;
+                int an = n, ag = g;
+                if (c.a_bcast_n > 0) { an = n % c.a_bcast_n; ag = 0; }
+                if (pcol < c.N) {     // ldp >= round_up(N,8): columns >= N only feed discarded output rows
+                    const size_t ppix = (size_t)(n * c.OH + oy * c.osy + k.ooy) * c.OW + ox * c.osx + k.oox;
+                    bf16x8 v = *reinterpret_cast<const bf16x8*>(p.P + ppix * p.ldp + pcol);
+                    if (has_ptf) v = transform8(v, p.p_affine ? p.p_affine + g * c.N + pcol : nullptr, p.p_act, nullptr, 1.f);
+                    pv[i] = v;
+                }
+                int y = oy * c.sy + k.offy + ty * c.dy, x = ox * c.sx + k.offx + tx * c.dx;
+                if (kin && (unsigned)y < (unsigned)c.AH && (unsigned)x < (unsigned)c.AW) {
+                    bf16x8 v = *reinterpret_cast<const bf16x8*>(c.A + (size_t)((an * c.AH + y) * c.AW + x) * c.Ald + gc);
+                    if (has_gtf) {
+                        const uint8_t* m = c.a_mask ? c.a_mask + (size_t)r * c.C + gc : nullptr;
+                        v = transform8(v, c.a_affine ? c.a_affine + ag * c.C + gc : nullptr, c.a_act, m, c.a_mask_scale);
+                    }
+                    gv[i] = v;
+                }
+            }
+        }
+        __syncthreads();      // previous iteration's fragment reads are done
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<bf16x8*>(Ps + ((tid >> 3) + 32 * i) * LDW + kv * 8) = pv[i];
+            *reinterpret_cast<bf16x8*>(Gs + ((tid >> 3) + 32 * i) * LDW + kv * 8) = gv[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[2], bfr[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) af[a] = tr_frag(Ps, ks * 32, wn * 32 + a * 16, lane);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bfr[b] = tr_frag(Gs, ks * 32, wk * 32 + b * 16, lane);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+        }
+    }
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int n = n0 + wn * 32 + a * 16 + fq * 4 + j;
+                int kc = k0 + wk * 32 + b * 16 + fr;
+                if (n < c.N && kc < k.K) atomicAdd(k.dWp + (size_t)n * k.Kpad + kc, acc[a][b][j]);
+            }
+}
+
+template <int NT>
+int launch_gemm_nt(const GemmParams& p, hipStream_t stream) {
+    constexpr int BN = NT * 16;
+    int max_tiles = 0;
+    for (int i = 0; i < p.c.nclasses; ++i) max_tiles = max(max_tiles, ceil_div(p.cls[i].rows_per_group, BM));
+    dim3 grid(max_tiles * p.c.groups, ceil_div(p.c.N, BN), p.c.nclasses);
+    size_t lds = (size_t)2 * (BM + BN) * LDA * sizeof(bf16) + (p.c.a_affine ? (size_t)p.c.C * sizeof(float2) : 0);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_gather_kernel<NT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_gather_kernel<NT>, grid, dim3(256), lds, stream, p);
+    return mmvae_check_launch("gemm_gather");
+}
+
+}  // namespace
+
+int launch_gemm_gather(const GemmParams& p, hipStream_t stream) {
+    const GatherCommon& c = p.c;
+    MMVAE_REQUIRE(c.nclasses >= 1 && c.nclasses <= MMVAE_MAX_CLASSES, "gemm: bad class count %d", c.nclasses);
+    MMVAE_REQUIRE(c.C % 8 == 0 && c.Ald % 8 == 0, "gemm: C=%d / Ald=%d must be multiples of 8", c.C, c.Ald);
+    MMVAE_REQUIRE(c.groups >= 1 && c.group_n >= 1 && c.N >= 1, "gemm: empty problem");
+    MMVAE_REQUIRE(c.C <= 1024, "gemm: C=%d too large for the LDS affine table", c.C);
+    for (int i = 0; i < c.nclasses; ++i) {
+        const GatherClass& k = p.cls[i];
+        MMVAE_REQUIRE(k.Kpad % BK == 0 && k.Kpad >= k.K && k.K == k.TH * k.TW * c.C, "gemm: class %d K=%d Kpad=%d", i, k.K, k.Kpad);
+        MMVAE_REQUIRE(k.rows_per_group == c.group_n * k.OY * k.OX && k.rows_per_group > 0, "gemm: class %d rows", i);
+        MMVAE_REQUIRE(k.Wp != nullptr, "gemm: class %d has no weights", i);
+        MMVAE_REQUIRE((k.OY - 1) * c.osy + k.ooy < c.OH && (k.OX - 1) * c.osx + k.oox < c.OW, "gemm: class %d output grid", i);
+    }
+    MMVAE_REQUIRE(c.a_mask == nullptr || (c.nclasses == 1 && p.cls[0].TH * p.cls[0].TW == 1), "gemm: mask needs a dense operand");
+    if (c.N <= 16) return launch_gemm_nt<1>(p, stream);
+    if (c.N <= 32) return launch_gemm_nt<2>(p, stream);
+    if (c.N <= 64) return launch_gemm_nt<4>(p, stream);
+    return launch_gemm_nt<8>(p, stream);
+}
+
+int launch_wgrad(const WgradParams& p, hipStream_t stream) {
+    const GatherCommon& c = p.c;
+    MMVAE_REQUIRE(c.nclasses >= 1 && c.nclasses <= MMVAE_MAX_CLASSES, "wgrad: bad class count %d", c.nclasses);
+    MMVAE_REQUIRE(c.C % 8 == 0 && c.Ald % 8 == 0 && p.ldp % 8 == 0 && p.ldp >= round_up(c.N, 8),
+                  "wgrad: C/Ald/ldp must be multiples of 8 and ldp >= round_up(N,8)");
+    MMVAE_REQUIRE(p.rows_per_block > 0 && p.rows_per_block % WM == 0, "wgrad: rows_per_block=%d", p.rows_per_block);
+    int max_rows = 0, max_kpad = 0;
+    for (int i = 0; i < c.nclasses; ++i) {
+        const GatherClass& k = p.cls[i];
+        MMVAE_REQUIRE(k.Kpad % WT == 0 && k.Kpad >= k.K && k.K == k.TH * k.TW * c.C, "wgrad: class %d K=%d Kpad=%d", i, k.K, k.Kpad);
+        MMVAE_REQUIRE(k.rows_per_group == c.group_n * k.OY * k.OX && k.dWp != nullptr, "wgrad: class %d", i);
+        max_rows = max(max_rows, c.groups * k.rows_per_group);
+        max_kpad = max(max_kpad, k.Kpad);
+    }
+    dim3 grid(ceil_div(c.N, WT), max_kpad / WT, ceil_div(max_rows, p.rows_per_block) * c.nclasses);
+    hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, stream, p);
+    return mmvae_check_launch("wgrad");
+}

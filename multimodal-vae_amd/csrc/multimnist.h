@@ -1,0 +1,79 @@
+// MultiMNIST MMVAE plan (multimnist/model.py:21-93,150-307 ; multimnist/train.py:69-87,146-173).
+#pragma once
+#include "layers.h"
+#include "text.h"
+
+struct MMBuffers {          // caller-owned device memory bound to a plan
+    float* params = nullptr;        // flat fp32 parameters, state_dict order
+    float* grads = nullptr;         // flat fp32 gradients (accumulated)
+    float* bn_stats = nullptr;      // running_mean | running_var of the 6 BatchNorms, state_dict order
+    long long* bn_nbt = nullptr;    // num_batches_tracked [6]
+    bf16* packed = nullptr;         // bf16 GEMM-layout weights
+    float* packed_vec = nullptr;    // fp32 packed vectors (permuted biases)
+    float* gpk = nullptr;           // fp32 packed weight gradients
+    float* gpk_vec = nullptr;
+    PackDesc* desc_dev = nullptr;   // device copies of the descriptor tables
+    PackDesc* gdesc_dev = nullptr;
+};
+
+struct MMStepIO {
+    void* ws = nullptr; size_t ws_bytes = 0;   // caller-owned scratch (mm_workspace_bytes)
+    const long long* step_ctr = nullptr;       // device step counter keying the Philox streams (may be null)
+    const float* image = nullptr;       // [B][1][50][50] fp32
+    const long long* text = nullptr;    // [B][4] int64
+    const float* eps = nullptr;         // [3][B][D] injected N(0,1) draws, or null -> Philox
+    const uint8_t* enc_mask1 = nullptr; // [2][B][400] keep flags (null -> Philox, p=0.1)
+    const uint8_t* enc_mask2 = nullptr; // [2][B][200]
+    const uint8_t* gru_keep = nullptr;  // [4][3B][100]
+    int enc_dropout = 1;                // 0 disables the classifier dropout (fixtures with p=0)
+    int gru_dropout = 1;
+    const long long* force_tokens = nullptr;   // [3B][4] test hook
+    float kl_lambda = 1e-3f;
+    float lambda_xy[3] = {1.f, 1.f, 0.f};      // multimnist/train.py:158-166
+    float lambda_yx[3] = {1.f, 0.5f, 1.f};
+    unsigned long long seed = 0x243F6A8885A308D3ull;
+    // outputs
+    float* sums = nullptr;              // [16]: bce_sum[0..2], nll_sum[4..6], kl_sum[8..10]
+    float* recon_image = nullptr;       // [3][B][2500] or null
+    float* recon_text = nullptr;        // [3][B][4][12] or null
+    float* mu = nullptr; float* logvar = nullptr;   // [3][B][D] or null
+    long long* tokens = nullptr;        // [3][B][4] or null
+};
+
+struct MMPlan;
+MMPlan* mm_create(int D, int B);
+void mm_destroy(MMPlan*);
+int mm_D(const MMPlan*);
+int mm_B(const MMPlan*);
+const std::vector<ParamInfo>& mm_params(const MMPlan*);
+long long mm_param_count(const MMPlan*);
+long long mm_packed_elems(const MMPlan*);
+long long mm_packed_vec_elems(const MMPlan*);
+long long mm_gpk_elems(const MMPlan*);
+long long mm_gpk_vec_elems(const MMPlan*);
+int mm_ndesc(const MMPlan*); const PackDesc* mm_desc_host(const MMPlan*);
+int mm_ngdesc(const MMPlan*); const PackDesc* mm_gdesc_host(const MMPlan*);
+size_t mm_workspace_bytes(const MMPlan*);
+int mm_bind(MMPlan*, const MMBuffers&);
+int mm_pack_weights(MMPlan*, hipStream_t);
+// forward (3 passes) + losses; training!=0 also runs backward into `grads` (which the caller zeroed)
+int mm_step_fwd_bwd(MMPlan*, const MMStepIO&, int training, int do_backward, hipStream_t);
+// granular module entry points (drop-in modules); every call brings its own workspace
+int mm_image_encoder_fwd(MMPlan*, void* ws, size_t wsb, const float* image, const uint8_t* m1, const uint8_t* m2,
+                         int training, float* out, hipStream_t);
+int mm_image_encoder_bwd(MMPlan*, void* ws, size_t wsb, const float* d_out, const uint8_t* m1, const uint8_t* m2, hipStream_t);
+int mm_image_decoder_fwd(MMPlan*, void* ws, size_t wsb, const float* z, int training, float* recon, hipStream_t);
+int mm_image_decoder_bwd(MMPlan*, void* ws, size_t wsb, const float* d_recon, const float* recon, float* dz, hipStream_t);
+int mm_text_encoder_fwd(MMPlan*, void* ws, size_t wsb, const long long* text, float* out, hipStream_t);
+int mm_text_encoder_bwd(MMPlan*, void* ws, size_t wsb, const long long* text, const float* d_out, hipStream_t);
+int mm_text_decoder_fwd(MMPlan*, void* ws, size_t wsb, const float* z, int training, const uint8_t* keep,
+                        const long long* force_tokens, float* words, long long* tokens, hipStream_t);
+int mm_text_decoder_bwd(MMPlan*, void* ws, size_t wsb, const float* z, const uint8_t* keep, const long long* force_tokens,
+                        const float* words, const long long* tokens, const float* d_words, float* dz, hipStream_t);
+int mm_unpack_grads(MMPlan*, hipStream_t);
+int mm_bench_layer(MMPlan*, void* ws, size_t wsb, const char* layer, int iters, hipStream_t);
+double mm_layer_flops(const MMPlan*, const char* layer);
+int mm_num_bn(const MMPlan*);
+int mm_bn_info(const MMPlan*, int i, std::string& prefix, int& C, long long& offset);
+long long mm_bn_floats(const MMPlan*);
+long long mm_debug_offset(MMPlan*, const char* name);

@@ -1,0 +1,986 @@
+// MultiMNIST MMVAE: layer plans, weight-pack tables and the kernel sequences of the ELBO step.
+// Reference: multimnist/model.py:21-93 (MultimodalVAE), :150-216 (image enc/dec), :219-307 (text enc/dec),
+//            multimnist/train.py:69-87 (loss_function), :146-173 (3-pass step).
+#include "multimnist.h"
+#include <map>
+#include <cstring>
+
+namespace {
+constexpr int IMG = 50, NPIX = 2500;
+constexpr float BN_EPS = 1e-5f, BN_MOM = 0.1f, DROP_P = 0.1f;
+}
+
+struct ConvL {
+    ConvGeom g;
+    long long w_off;
+    int bn;                       // index into bn tables or -1
+    GatherPlan fwd, dgrad;        // geometry templates (groups/pointers filled per call)
+    int pk_fwd[4], pk_dgrad[4], gk[4];
+};
+struct LinL {
+    long long w_off, b_off;
+    int N, K;
+    int pk_fwd, pk_dgrad, gk;
+    int pk_dgrad4[4];             // classifier.0 only: one dgrad matrix per pixel of the 2x2 feature map
+};
+struct BnL { long long w_off, b_off; int C; long long stat_off; int idx; };
+
+struct MMPlan {
+    int D, B;
+    int ldz, kx, kz;
+    std::vector<ParamInfo> params;
+    std::map<std::string, int> pidx;
+    long long nparams = 0;
+    PackList pk, gk;
+    ConvL conv[4], convT[4];
+    LinL fc[3], up;
+    BnL bn[6];
+    // text packs
+    struct GruIdx { int wih, whh, wihT, whhT, g_wih, g_whh; long long bih, bhh; } te_f, te_r, td0, td1;
+    int te_h2p, te_h2pT, g_te_h2p, td_z2h, td_z2hT, g_td_z2h, td_h2o, td_h2oT, g_td_h2o;
+    MMBuffers buf;
+    bool bound = false;
+    // ---- workspace pointers
+    struct W {
+        char* zero_begin; size_t zero_bytes;
+        float2 *st_e[3], *red_e[3], *st_d[3], *red_d[3];
+        float* sums; float* dz_img; float* dz_txt;
+        float2 *aff_e[3], *mr_e[3], *aff_d[3], *mr_d[3];
+        bf16 *patches1, *r1, *r2, *r3, *r4, *y1, *y2;
+        float* encout; uint8_t *m1, *m2, *gkeep;
+        float *txtout, *te_gates_f, *te_gates_r; bf16 *te_x, *te_hprev, *te_hsum;
+        float *eps, *mu, *logvar, *z_f32; bf16* z_bf;
+        bf16 *u, *q1, *q2, *q3; float *logits, *recon, *dlogit;
+        float *words, *dwords, *td_gates; long long* tokens;
+        bf16 *td_x0, *td_h0p, *td_mid, *td_h1p, *td_hz, *td_zbf;
+        bf16 *dgi0, *dgh0, *dgi1, *dgh1, *dlogit_bf, *dhinit;
+        bf16 *patches4, *d3, *d2, *d1, *du;
+        bf16 *d_encout; float* d_txtout; bf16* te_dout_bf; bf16 *te_dgi_f, *te_dgh_f, *te_dgi_r;
+        bf16 *dy2, *dy1, *db4, *dr4, *d3e, *d2e, *d1e;
+        float* tmp_f32;
+    } w;
+    size_t ws_bytes = 0;
+};
+
+namespace {
+
+void add_param(MMPlan& P, const std::string& name, std::initializer_list<int> shape) {
+    ParamInfo pi{};
+    pi.name = name; pi.ndim = (int)shape.size(); pi.numel = 1;
+    int i = 0;
+    for (int s : shape) { pi.shape[i++] = s; pi.numel *= s; }
+    pi.offset = P.nparams;
+    P.nparams += pi.numel;
+    P.pidx[name] = (int)P.params.size();
+    P.params.push_back(pi);
+}
+long long off(const MMPlan& P, const std::string& n) { return P.params[P.pidx.at(n)].offset; }
+
+void build_params(MMPlan& P) {
+    const int D = P.D;
+    auto bn = [&](const std::string& n, int c) { add_param(P, n + ".weight", {c}); add_param(P, n + ".bias", {c}); };
+    auto gru = [&](const std::string& n, int inp, const char* sfx) {
+        add_param(P, n + ".weight_ih_" + sfx, {300, inp}); add_param(P, n + ".weight_hh_" + sfx, {300, 100});
+        add_param(P, n + ".bias_ih_" + sfx, {300}); add_param(P, n + ".bias_hh_" + sfx, {300});
+    };
+    add_param(P, "image_encoder.features.0.weight", {32, 1, 4, 4});
+    add_param(P, "image_encoder.features.2.weight", {64, 32, 4, 4}); bn("image_encoder.features.3", 64);
+    add_param(P, "image_encoder.features.5.weight", {128, 64, 4, 4}); bn("image_encoder.features.6", 128);
+    add_param(P, "image_encoder.features.8.weight", {256, 128, 4, 4}); bn("image_encoder.features.9", 256);
+    add_param(P, "image_encoder.classifier.0.weight", {400, 1024}); add_param(P, "image_encoder.classifier.0.bias", {400});
+    add_param(P, "image_encoder.classifier.3.weight", {200, 400}); add_param(P, "image_encoder.classifier.3.bias", {200});
+    add_param(P, "image_encoder.classifier.6.weight", {2 * D, 200}); add_param(P, "image_encoder.classifier.6.bias", {2 * D});
+    add_param(P, "image_decoder.upsample.0.weight", {1024, D}); add_param(P, "image_decoder.upsample.0.bias", {1024});
+    add_param(P, "image_decoder.hallucinate.0.weight", {256, 128, 4, 4}); bn("image_decoder.hallucinate.1", 128);
+    add_param(P, "image_decoder.hallucinate.3.weight", {128, 64, 4, 4}); bn("image_decoder.hallucinate.4", 64);
+    add_param(P, "image_decoder.hallucinate.6.weight", {64, 32, 5, 5}); bn("image_decoder.hallucinate.7", 32);
+    add_param(P, "image_decoder.hallucinate.9.weight", {32, 1, 4, 4});
+    add_param(P, "text_encoder.embed.weight", {12, 100});
+    gru("text_encoder.gru", 100, "l0"); gru("text_encoder.gru", 100, "l0_reverse");
+    add_param(P, "text_encoder.h2p.weight", {2 * D, 100}); add_param(P, "text_encoder.h2p.bias", {2 * D});
+    add_param(P, "text_decoder.embed.weight", {12, 100});
+    add_param(P, "text_decoder.z2h.weight", {100, D}); add_param(P, "text_decoder.z2h.bias", {100});
+    gru("text_decoder.gru", 100 + D, "l0"); gru("text_decoder.gru", 100, "l1");
+    add_param(P, "text_decoder.h2o.weight", {12, 100 + D}); add_param(P, "text_decoder.h2o.bias", {12});
+}
+
+// ---- conv-like layer: builds both gather plans and the pack descriptors
+void build_conv(MMPlan& P, ConvL& L, const std::string& wname, ConvGeom g, int bn_idx, bool need_dgrad, bool thin_in, bool thin_out) {
+    L.g = g; L.w_off = off(P, wname); L.bn = bn_idx;
+    const int kk = g.KH * g.KW;
+    for (int i = 0; i < 4; ++i) { L.pk_fwd[i] = L.pk_dgrad[i] = L.gk[i] = -1; }
+    if (!g.transposed) {
+        // Conv2d weight (Cout, Cin, KH, KW)
+        if (thin_in) {      // dense over im2col patches: K = kk*Cin
+            const int K = kk * g.Cin, ld = round_up(K, 8);
+            L.fwd = plan_dense(1, ld, ld, g.Cout);
+            PackDesc d = pack_dense(L.w_off, g.Cout, K, npad_for(g.Cout), L.fwd.cls[0].Kpad, g.Cin * kk, 1);
+            // patches order k = (kh*KW+kw)*Cin + ci ; weight order ci*kk + kh*KW + kw
+            d.TW = g.KW; d.C = g.Cin; d.s_ty = g.KW; d.s_tx = 1; d.s_c = kk;
+            L.pk_fwd[0] = P.pk.add(d);
+            PackDesc gd = d; gd.Npad = round_up(g.Cout, 64);
+            L.gk[0] = P.gk.add(gd);
+        } else {
+            L.fwd = plan_fwdform(g.IH, g.IW, g.OH, g.OW, g.Cin, g.KH, g.KW, g.stride, g.pad, g.Cout, 1, 1);
+            PackDesc d = pack_conv(L.w_off, L.fwd.c, L.fwd.cls[0], npad_for(g.Cout), g.Cin * kk, kk, g.KW, 0, 0, 1);
+            L.pk_fwd[0] = P.pk.add(d);
+            PackDesc gd = d; gd.Npad = round_up(g.Cout, 64);
+            L.gk[0] = P.gk.add(gd);
+        }
+        if (need_dgrad) {   // rows over the input (big) side, gathers dr (small side, Cout channels)
+            L.dgrad = plan_classform(g.IH, g.IW, g.OH, g.OW, g.Cout, g.KH, g.KW, g.stride, g.pad, g.Cin, 1, 1);
+            for (int ci = 0; ci < L.dgrad.c.nclasses; ++ci) {
+                const int ph = ci / g.stride, pw = ci % g.stride;
+                PackDesc d = pack_conv(L.w_off, L.dgrad.c, L.dgrad.cls[ci], npad_for(g.Cin), kk, g.Cin * kk, g.KW,
+                                       (ph + g.pad) % g.stride, (pw + g.pad) % g.stride, g.stride);
+                L.pk_dgrad[ci] = P.pk.add(d);
+            }
+        }
+    } else {
+        // ConvTranspose2d weight (Cin, Cout, KH, KW); forward rows over the output (big) side
+        if (!thin_out) {
+            L.fwd = plan_classform(g.OH, g.OW, g.IH, g.IW, g.Cin, g.KH, g.KW, g.stride, g.pad, g.Cout, 1, 1);
+            for (int ci = 0; ci < L.fwd.c.nclasses; ++ci) {
+                const int ph = ci / g.stride, pw = ci % g.stride;
+                PackDesc d = pack_conv(L.w_off, L.fwd.c, L.fwd.cls[ci], npad_for(g.Cout), kk, g.Cout * kk, g.KW,
+                                       (ph + g.pad) % g.stride, (pw + g.pad) % g.stride, g.stride);
+                L.pk_fwd[ci] = P.pk.add(d);
+                PackDesc gd = d; gd.Npad = round_up(g.Cout, 64);
+                L.gk[ci] = P.gk.add(gd);
+            }
+            if (need_dgrad) {
+                L.dgrad = plan_fwdform(g.OH, g.OW, g.IH, g.IW, g.Cout, g.KH, g.KW, g.stride, g.pad, g.Cin, 1, 1);
+                PackDesc d = pack_conv(L.w_off, L.dgrad.c, L.dgrad.cls[0], npad_for(g.Cin), g.Cout * kk, kk, g.KW, 0, 0, 1);
+                L.pk_dgrad[0] = P.pk.add(d);
+            }
+        } else {
+            // thin output (Cout small): forward still class-form (N = Cout padded to 16); backward goes through
+            // im2col patches of dlogit: dgrad = dense [rows][kk*Cout] x W_D[Cin][kk*Cout], wgrad in the same layout
+            L.fwd = plan_classform(g.OH, g.OW, g.IH, g.IW, g.Cin, g.KH, g.KW, g.stride, g.pad, g.Cout, 1, 1);
+            for (int ci = 0; ci < L.fwd.c.nclasses; ++ci) {
+                const int ph = ci / g.stride, pw = ci % g.stride;
+                PackDesc d = pack_conv(L.w_off, L.fwd.c, L.fwd.cls[ci], npad_for(g.Cout), kk, g.Cout * kk, g.KW,
+                                       (ph + g.pad) % g.stride, (pw + g.pad) % g.stride, g.stride);
+                L.pk_fwd[ci] = P.pk.add(d);
+            }
+            const int K = kk * g.Cout, ld = round_up(K, 8);
+            L.dgrad = plan_dense(1, ld, ld, g.Cin);
+            PackDesc d = pack_dense(L.w_off, g.Cin, K, npad_for(g.Cin), L.dgrad.cls[0].Kpad, g.Cout * kk, 1);
+            d.TW = g.KW; d.C = g.Cout; d.s_ty = g.KW; d.s_tx = 1; d.s_c = kk;   // k = (kh*KW+kw)*Cout + co
+            L.pk_dgrad[0] = P.pk.add(d);
+            PackDesc gd = d; gd.Npad = round_up(g.Cin, 64);
+            L.gk[0] = P.gk.add(gd);
+        }
+    }
+}
+
+void build_plan(MMPlan& P) {
+    const int D = P.D;
+    P.ldz = round_up(D + 1, 8); P.kz = round_up(D, 32); P.kx = round_up(100 + D, 32);
+    build_params(P);
+    // BatchNorm tables (state_dict order)
+    const char* bnn[6] = {"image_encoder.features.3", "image_encoder.features.6", "image_encoder.features.9",
+                          "image_decoder.hallucinate.1", "image_decoder.hallucinate.4", "image_decoder.hallucinate.7"};
+    const int bnc[6] = {64, 128, 256, 128, 64, 32};
+    long long so = 0;
+    for (int i = 0; i < 6; ++i) {
+        P.bn[i] = BnL{off(P, std::string(bnn[i]) + ".weight"), off(P, std::string(bnn[i]) + ".bias"), bnc[i], so, i};
+        so += 2 * bnc[i];
+    }
+    // encoder convs (multimnist/model.py:160-169)
+    build_conv(P, P.conv[0], "image_encoder.features.0.weight", ConvGeom{1, 32, 4, 4, 2, 1, 50, 50, 25, 25, false}, -1, false, true, false);
+    build_conv(P, P.conv[1], "image_encoder.features.2.weight", ConvGeom{32, 64, 4, 4, 2, 1, 25, 25, 12, 12, false}, 0, true, false, false);
+    build_conv(P, P.conv[2], "image_encoder.features.5.weight", ConvGeom{64, 128, 4, 4, 2, 1, 12, 12, 6, 6, false}, 1, true, false, false);
+    build_conv(P, P.conv[3], "image_encoder.features.8.weight", ConvGeom{128, 256, 4, 4, 2, 0, 6, 6, 2, 2, false}, 2, true, false, false);
+    // decoder transposed convs (multimnist/model.py:199-208)
+    build_conv(P, P.convT[0], "image_decoder.hallucinate.0.weight", ConvGeom{256, 128, 4, 4, 2, 0, 2, 2, 6, 6, true}, 3, true, false, false);
+    build_conv(P, P.convT[1], "image_decoder.hallucinate.3.weight", ConvGeom{128, 64, 4, 4, 2, 1, 6, 6, 12, 12, true}, 4, true, false, false);
+    build_conv(P, P.convT[2], "image_decoder.hallucinate.6.weight", ConvGeom{64, 32, 5, 5, 2, 1, 12, 12, 25, 25, true}, 5, true, false, false);
+    build_conv(P, P.convT[3], "image_decoder.hallucinate.9.weight", ConvGeom{32, 1, 4, 4, 2, 1, 25, 25, 50, 50, true}, -1, true, false, true);
+
+    // classifier (multimnist/model.py:173-179). fc1 consumes the NCHW flatten c*4+y*2+x of a (256,2,2) map that
+    // lives here as NHWC [2][2][256]: a 2x2-tap gather with k = (y*2+x)*256 + c.
+    {
+        LinL& f = P.fc[0];
+        f.w_off = off(P, "image_encoder.classifier.0.weight"); f.b_off = off(P, "image_encoder.classifier.0.bias");
+        f.N = 400; f.K = 1024; f.pk_dgrad = -1;
+        PackDesc d = pack_dense(f.w_off, 400, 1024, npad_for(400), 1024, 1024, 0);
+        d.TW = 2; d.C = 256; d.s_ty = 2; d.s_tx = 1; d.s_c = 4;
+        f.pk_fwd = P.pk.add(d);
+        PackDesc gd = d; gd.Npad = round_up(400, 64);
+        f.gk = P.gk.add(gd);
+        // dgrad: one class per pixel s of the 2x2 map: da[n][s][c] = sum_j dy[n][j] * W[j][c*4+s]
+        for (int sidx = 0; sidx < 4; ++sidx)
+            f.pk_dgrad4[sidx] = P.pk.add(pack_dense(f.w_off + sidx, 256, 400, npad_for(256), round_up(400, 64), 4, 1024));
+    }
+    auto lin = [&](LinL& f, const std::string& n, int N, int K) {
+        f.w_off = off(P, n + ".weight"); f.b_off = off(P, n + ".bias"); f.N = N; f.K = K;
+        f.pk_fwd = P.pk.add(pack_dense(f.w_off, N, K, npad_for(N), round_up(round_up(K, 8), 64), K, 1));
+        f.gk = P.gk.add(pack_dense(f.w_off, N, K, round_up(N, 64), round_up(round_up(K, 8), 64), K, 1));
+        f.pk_dgrad = P.pk.add(pack_dense(f.w_off, K, N, npad_for(K), round_up(round_up(N, 8), 64), 1, K));
+    };
+    lin(P.fc[1], "image_encoder.classifier.3", 200, 400);
+    lin(P.fc[2], "image_encoder.classifier.6", 2 * D, 200);
+    {   // upsample Linear(D, 1024): output columns permuted to NHWC n' = s*256 + c  <->  row c*4 + s
+        LinL& f = P.up;
+        f.w_off = off(P, "image_decoder.upsample.0.weight"); f.b_off = off(P, "image_decoder.upsample.0.bias");
+        f.N = 1024; f.K = D;
+        // the bias rides in packed column D (the operand z carries a 1.0 there), so its permutation and its
+        // gradient (column D of the packed weight gradient) come for free
+        PackDesc d = pack_dense(f.w_off, 1024, D, npad_for(1024), round_up(P.ldz, 64), 0, 1);
+        d.NL = 256; d.s_nhi = D; d.s_nlo = 4 * D;
+        d.bias_off = f.b_off; d.b_nhi = 1; d.b_nlo = 4;
+        f.pk_fwd = P.pk.add(d);
+        PackDesc gd = d; f.gk = P.gk.add(gd);
+        // dgrad: dz[rows][D] = du[rows][1024 NHWC] x W_D[D][1024]
+        PackDesc t = pack_dense(f.w_off, D, 1024, npad_for(D), 1024, 1, 0);
+        t.TW = 4; t.C = 256; t.s_ty = 0; t.s_tx = D; t.s_c = 4 * D;
+        f.pk_dgrad = P.pk.add(t);
+    }
+    // ---- text packs (row-tile kernels): [round16(N)][round32(K)] bf16, plus transposed copies for backward
+    auto rt = [&](long long w, int N, int K, bool transpose) {
+        if (!transpose) return P.pk.add(pack_dense(w, N, K, round_up(N, 16), round_up(K, 32), K, 1));
+        return P.pk.add(pack_dense(w, K, N, round_up(K, 16), round_up(N, 32), 1, K));
+    };
+    auto gw = [&](long long w, int N, int K, int Kc) {   // wgrad target: [round64(N)][round64(Kc)] with K valid columns
+        return P.gk.add(pack_dense(w, N, K, round_up(N, 64), round_up(Kc, 64), K, 1));
+    };
+    auto grui = [&](MMPlan::GruIdx& g, const std::string& n, const char* sfx, int inp, int inp_k, bool need_hh) {
+        const long long wih = off(P, n + ".weight_ih_" + sfx), whh = off(P, n + ".weight_hh_" + sfx);
+        g.bih = off(P, n + ".bias_ih_" + sfx); g.bhh = off(P, n + ".bias_hh_" + sfx);
+        g.wih = rt(wih, 300, inp, false); g.wihT = rt(wih, 300, inp, true);
+        g.whh = rt(whh, 300, 100, false); g.whhT = rt(whh, 300, 100, true);
+        g.g_wih = gw(wih, 300, inp, inp_k);
+        g.g_whh = need_hh ? gw(whh, 300, 100, TXT_HP) : -1;
+    };
+    grui(P.te_f, "text_encoder.gru", "l0", 100, TXT_HP, true);
+    grui(P.te_r, "text_encoder.gru", "l0_reverse", 100, TXT_HP, false);
+    {
+        const long long w = off(P, "text_encoder.h2p.weight");
+        P.te_h2p = rt(w, 2 * D, 100, false); P.te_h2pT = rt(w, 2 * D, 100, true); P.g_te_h2p = gw(w, 2 * D, 100, TXT_HP);
+    }
+    {
+        const long long w = off(P, "text_decoder.z2h.weight");
+        P.td_z2h = rt(w, 100, D, false); P.td_z2hT = rt(w, 100, D, true); P.g_td_z2h = gw(w, 100, D, P.kz);
+    }
+    grui(P.td0, "text_decoder.gru", "l0", 100 + D, P.kx, true);
+    grui(P.td1, "text_decoder.gru", "l1", 100, TXT_HP, true);
+    {
+        const long long w = off(P, "text_decoder.h2o.weight");
+        P.td_h2o = rt(w, 12, 100 + D, false); P.td_h2oT = rt(w, 12, 100 + D, true); P.g_td_h2o = gw(w, 12, 100 + D, P.kx);
+    }
+}
+
+// ------------------------------------------------------------------ workspace
+void carve(MMPlan& P, Workspace& ws) {
+    MMPlan::W& w = P.w;
+    const size_t B = P.B, D = P.D, B3 = 3 * B, B2 = 2 * B;
+    char* z0 = ws.take<char>(0);
+    const int ec[3] = {64, 128, 256}, dc[3] = {128, 64, 32};
+    for (int i = 0; i < 3; ++i) { w.st_e[i] = ws.take<float2>(ec[i]); w.red_e[i] = ws.take<float2>(ec[i]); }
+    for (int i = 0; i < 3; ++i) { w.st_d[i] = ws.take<float2>(3 * dc[i]); w.red_d[i] = ws.take<float2>(3 * dc[i]); }
+    w.sums = ws.take<float>(16);
+    w.dz_img = ws.take<float>(B3 * D);
+    w.dz_txt = ws.take<float>(B3 * D);
+    char* z1 = ws.take<char>(0);
+    w.zero_begin = z0; w.zero_bytes = (size_t)(z1 - z0);
+    for (int i = 0; i < 3; ++i) { w.aff_e[i] = ws.take<float2>(ec[i]); w.mr_e[i] = ws.take<float2>(ec[i]); }
+    for (int i = 0; i < 3; ++i) { w.aff_d[i] = ws.take<float2>(3 * dc[i]); w.mr_d[i] = ws.take<float2>(3 * dc[i]); }
+    w.patches1 = ws.take<bf16>(B * 625 * 16);
+    w.r1 = ws.take<bf16>(B * 625 * 32); w.r2 = ws.take<bf16>(B * 144 * 64); w.r3 = ws.take<bf16>(B * 36 * 128);
+    w.r4 = ws.take<bf16>(B * 4 * 256);
+    w.y1 = ws.take<bf16>(B2 * 400); w.y2 = ws.take<bf16>(B2 * 200);
+    w.encout = ws.take<float>(B2 * 2 * D);
+    w.m1 = ws.take<uint8_t>(B2 * 400); w.m2 = ws.take<uint8_t>(B2 * 200); w.gkeep = ws.take<uint8_t>(4 * B3 * 100);
+    w.txtout = ws.take<float>(B * 2 * D);
+    w.te_gates_f = ws.take<float>(4 * 5 * B * 100); w.te_gates_r = ws.take<float>(5 * B * 100);
+    w.te_x = ws.take<bf16>(4 * B * 128); w.te_hprev = ws.take<bf16>(4 * B * 128); w.te_hsum = ws.take<bf16>(B * 128);
+    w.eps = ws.take<float>(B3 * D); w.mu = ws.take<float>(B3 * D); w.logvar = ws.take<float>(B3 * D);
+    w.z_f32 = ws.take<float>(B3 * D); w.z_bf = ws.take<bf16>(B3 * P.ldz);
+    w.u = ws.take<bf16>(B3 * 1024); w.q1 = ws.take<bf16>(B3 * 36 * 128); w.q2 = ws.take<bf16>(B3 * 144 * 64);
+    w.q3 = ws.take<bf16>(B3 * 625 * 32);
+    w.logits = ws.take<float>(B3 * NPIX); w.recon = ws.take<float>(B3 * NPIX); w.dlogit = ws.take<float>(B3 * NPIX);
+    w.words = ws.take<float>(B3 * 48); w.dwords = ws.take<float>(B3 * 48); w.tokens = ws.take<long long>(B3 * 4);
+    w.td_gates = ws.take<float>(4 * 2 * 5 * B3 * 100);
+    w.td_x0 = ws.take<bf16>(4 * B3 * P.kx); w.td_hz = ws.take<bf16>(4 * B3 * P.kx);
+    w.td_h0p = ws.take<bf16>(4 * B3 * 128); w.td_mid = ws.take<bf16>(4 * B3 * 128); w.td_h1p = ws.take<bf16>(4 * B3 * 128);
+    w.td_zbf = ws.take<bf16>(B3 * P.kz);
+    w.dgi0 = ws.take<bf16>(4 * B3 * 304); w.dgh0 = ws.take<bf16>(4 * B3 * 304);
+    w.dgi1 = ws.take<bf16>(4 * B3 * 304); w.dgh1 = ws.take<bf16>(4 * B3 * 304);
+    w.dlogit_bf = ws.take<bf16>(4 * B3 * 16); w.dhinit = ws.take<bf16>(B3 * 112);
+    w.patches4 = ws.take<bf16>(B3 * 625 * 16);
+    w.d3 = ws.take<bf16>(B3 * 625 * 32); w.d2 = ws.take<bf16>(B3 * 144 * 64); w.d1 = ws.take<bf16>(B3 * 36 * 128);
+    w.du = ws.take<bf16>(B3 * 1024);
+    w.d_encout = ws.take<bf16>(B2 * 2 * D); w.d_txtout = ws.take<float>(B * 2 * D);
+    w.te_dout_bf = ws.take<bf16>(B * round_up(2 * (int)D, 8));
+    w.te_dgi_f = ws.take<bf16>(4 * B * 304); w.te_dgh_f = ws.take<bf16>(4 * B * 304); w.te_dgi_r = ws.take<bf16>(B * 304);
+    w.dy2 = ws.take<bf16>(B2 * 200); w.dy1 = ws.take<bf16>(B2 * 400);
+    w.db4 = ws.take<bf16>(B2 * 1024); w.dr4 = ws.take<bf16>(B * 1024);
+    w.d3e = ws.take<bf16>(B * 36 * 128); w.d2e = ws.take<bf16>(B * 144 * 64); w.d1e = ws.take<bf16>(B * 625 * 32);
+    w.tmp_f32 = ws.take<float>(B3 * NPIX);
+}
+
+// ------------------------------------------------------------------ launch helpers
+GemmParams gemm_of(const MMPlan& P, const GatherPlan& pl, const int* pk, int groups, int group_n) {
+    GemmParams g{};
+    g.c = pl.c; g.c.groups = groups; g.c.group_n = group_n;
+    for (int i = 0; i < pl.c.nclasses; ++i) {
+        g.cls[i] = pl.cls[i];
+        g.cls[i].rows_per_group = group_n * pl.cls[i].OY * pl.cls[i].OX;
+        g.cls[i].Wp = P.buf.packed + P.pk.d[pk[i]].dst_off;
+    }
+    return g;
+}
+WgradParams wgrad_of(const MMPlan& P, const GatherPlan& pl, const int* gk, int groups, int group_n) {
+    WgradParams g{};
+    g.c = pl.c; g.c.groups = groups; g.c.group_n = group_n;
+    int max_rows = 0, max_kpad = 0;
+    for (int i = 0; i < pl.c.nclasses; ++i) {
+        g.cls[i] = pl.cls[i];
+        g.cls[i].rows_per_group = group_n * pl.cls[i].OY * pl.cls[i].OX;
+        g.cls[i].dWp = P.buf.gpk + P.gk.d[gk[i]].dst_off;
+        g.cls[i].Kpad = P.gk.d[gk[i]].Kpad;
+        max_rows = max(max_rows, groups * g.cls[i].rows_per_group);
+        max_kpad = max(max_kpad, g.cls[i].Kpad);
+    }
+    const int tiles = ceil_div(pl.c.N, 64) * (max_kpad / 64) * pl.c.nclasses;
+    int chunks = max(1, min(ceil_div(max_rows, 64), 768 / max(tiles, 1)));
+    g.rows_per_block = round_up(ceil_div(max_rows, chunks), 64);
+    return g;
+}
+GatherPlan dense_plan(int rows, int C, int ld, int N) { return plan_dense(rows, C, ld, N); }
+
+int bn_fin(MMPlan& P, const BnL& b, const float2* stats, int G, float count, int updates, float2* aff, float2* mr, int training, hipStream_t s) {
+    BnFinalizeArgs a{};
+    a.stats = stats; a.G = G; a.C = b.C; a.count = count;
+    a.gamma = P.buf.params + b.w_off; a.beta = P.buf.params + b.b_off;
+    a.running_mean = P.buf.bn_stats + b.stat_off; a.running_var = P.buf.bn_stats + b.stat_off + b.C;
+    a.num_batches_tracked = P.buf.bn_nbt + b.idx;
+    a.updates_per_group = updates; a.affine = aff; a.meanrstd = mr; a.eps = BN_EPS; a.momentum = BN_MOM; a.training = training;
+    return launch_bn_finalize(a, s);
+}
+
+// ================================================================== image encoder
+// convs once on B images; classifier on variants*B rows (different dropout masks): multimnist/model.py:183-188
+int enc_fwd(MMPlan& P, const float* image, int variants, const uint8_t* m1, const uint8_t* m2, int dropout, int training,
+            int bn_updates, float* out, hipStream_t s) {
+    MMPlan::W& w = P.w;
+    const int B = P.B;
+    MMVAE_TRY(launch_im2col_small(image, B, 1, IMG, IMG, 4, 4, 2, 1, 25, 25, w.patches1, 16, s));
+    {   // conv1 (+Swish applied by consumers)
+        GatherPlan pl = dense_plan(B * 625, 16, 16, 32);
+        GemmParams g = gemm_of(P, pl, P.conv[0].pk_fwd, 1, B * 625);
+        g.c.A = w.patches1; g.out_bf = w.r1; g.ldo = 32;
+        MMVAE_TRY(launch_gemm_gather(g, s));
+    }
+    bf16* r[4] = {w.r1, w.r2, w.r3, w.r4};
+    for (int l = 1; l < 4; ++l) {
+        const ConvL& L = P.conv[l];
+        GemmParams g = gemm_of(P, L.fwd, L.pk_fwd, 1, B);
+        g.c.A = r[l - 1]; g.c.a_act = ACT_SWISH;
+        g.c.a_affine = l > 1 ? w.aff_e[l - 2] : nullptr;
+        g.out_bf = r[l]; g.ldo = L.g.Cout;
+        g.colstats = training ? w.st_e[l - 1] : nullptr;
+        MMVAE_TRY(launch_gemm_gather(g, s));
+        MMVAE_TRY(bn_fin(P, P.bn[L.bn], w.st_e[l - 1], 1, (float)(B * L.g.OH * L.g.OW), bn_updates, w.aff_e[l - 1], w.mr_e[l - 1], training, s));
+    }
+    const int rows = variants * B;
+    const bool drop = training && dropout;
+    {   // fc1 over the NHWC 2x2x256 map
+        GatherPlan pl = plan_fwdform(2, 2, 1, 1, 256, 2, 2, 1, 0, 400, 1, rows);
+        GemmParams g = gemm_of(P, pl, &P.fc[0].pk_fwd, 1, rows);
+        g.c.A = w.r4; g.c.a_act = ACT_SWISH; g.c.a_affine = w.aff_e[2]; g.c.a_bcast_n = B;
+        g.bias = P.buf.params + P.fc[0].b_off; g.out_bf = w.y1; g.ldo = 400;
+        MMVAE_TRY(launch_gemm_gather(g, s));
+    }
+    {
+        GatherPlan pl = dense_plan(rows, 400, 400, 200);
+        GemmParams g = gemm_of(P, pl, &P.fc[1].pk_fwd, 1, rows);
+        g.c.A = w.y1; g.c.a_act = ACT_SWISH;
+        if (drop) { g.c.a_mask = m1; g.c.a_mask_scale = 1.f / (1.f - DROP_P); }
+        g.bias = P.buf.params + P.fc[1].b_off; g.out_bf = w.y2; g.ldo = 200;
+        MMVAE_TRY(launch_gemm_gather(g, s));
+    }
+    {
+        GatherPlan pl = dense_plan(rows, 200, 200, 2 * P.D);
+        GemmParams g = gemm_of(P, pl, &P.fc[2].pk_fwd, 1, rows);
+        g.c.A = w.y2; g.c.a_act = ACT_SWISH;
+        if (drop) { g.c.a_mask = m2; g.c.a_mask_scale = 1.f / (1.f - DROP_P); }
+        g.bias = P.buf.params + P.fc[2].b_off; g.out_f = out; g.ldo = 2 * P.D;
+        MMVAE_TRY(launch_gemm_gather(g, s));
+    }
+    return MMVAE_OK;
+}
+
+// d_out: bf16 [variants*B][2D]; the bias gradient of classifier.6 must already be accumulated by the caller
+int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const uint8_t* m2, int dropout, hipStream_t s) {
+    MMPlan::W& w = P.w;
+    const int B = P.B, rows = variants * B, D2 = 2 * P.D;
+    const float ms = 1.f / (1.f - DROP_P);
+    {   // fc3
+        GatherPlan pl = dense_plan(rows, 200, 200, D2);
+        WgradParams g = wgrad_of(P, pl, &P.fc[2].gk, 1, rows);
+        g.c.A = w.y2; g.c.a_act = ACT_SWISH; if (dropout) { g.c.a_mask = m2; g.c.a_mask_scale = ms; }
+        g.P = d_out; g.ldp = D2;
+        MMVAE_TRY(launch_wgrad(g, s));
+        GatherPlan pd = dense_plan(rows, D2, D2, 200);
+        GemmParams d = gemm_of(P, pd, &P.fc[2].pk_dgrad, 1, rows);
+        d.c.A = d_out; d.out_bf = w.dy2; d.ldo = 200;
+        d.d_r = w.y2; d.d_ld = 200; d.d_act = ACT_SWISH; if (dropout) { d.d_mask = m2; d.d_mask_scale = ms; }
+        d.d_colsum = P.buf.grads + P.fc[1].b_off;
+        MMVAE_TRY(launch_gemm_gather(d, s));
+    }
+    {   // fc2
+        GatherPlan pl = dense_plan(rows, 400, 400, 200);
+        WgradParams g = wgrad_of(P, pl, &P.fc[1].gk, 1, rows);
+        g.c.A = w.y1; g.c.a_act = ACT_SWISH; if (dropout) { g.c.a_mask = m1; g.c.a_mask_scale = ms; }
+        g.P = w.dy2; g.ldp = 200;
+        MMVAE_TRY(launch_wgrad(g, s));
+        GatherPlan pd = dense_plan(rows, 200, 200, 400);
+        GemmParams d = gemm_of(P, pd, &P.fc[1].pk_dgrad, 1, rows);
+        d.c.A = w.dy2; d.out_bf = w.dy1; d.ldo = 400;
+        d.d_r = w.y1; d.d_ld = 400; d.d_act = ACT_SWISH; if (dropout) { d.d_mask = m1; d.d_mask_scale = ms; }
+        d.d_colsum = P.buf.grads + P.fc[0].b_off;
+        MMVAE_TRY(launch_gemm_gather(d, s));
+    }
+    {   // fc1: wgrad gathers the shared 2x2x256 map; dgrad emits NHWC gradients for `rows` samples
+        GatherPlan pl = plan_fwdform(2, 2, 1, 1, 256, 2, 2, 1, 0, 400, 1, rows);
+        WgradParams g = wgrad_of(P, pl, &P.fc[0].gk, 1, rows);
+        g.c.A = w.r4; g.c.a_act = ACT_SWISH; g.c.a_affine = w.aff_e[2]; g.c.a_bcast_n = B;
+        g.P = w.dy1; g.ldp = 400;
+        MMVAE_TRY(launch_wgrad(g, s));
+        // dgrad: 4 classes = the 4 pixels of the 2x2 map, each with its own [256][400] matrix
+        GatherPlan pd{};
+        pd.c.AH = 1; pd.c.AW = 1; pd.c.Ald = 400; pd.c.C = 400; pd.c.sy = pd.c.sx = 1; pd.c.dy = pd.c.dx = 1;
+        pd.c.OH = 2; pd.c.OW = 2; pd.c.osy = pd.c.osx = 1; pd.c.N = 256; pd.c.nclasses = 4;
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            GatherClass& k = pd.cls[sidx];
+            k.OY = 1; k.OX = 1; k.TH = 1; k.TW = 1; k.offy = 0; k.offx = 0; k.ooy = sidx / 2; k.oox = sidx % 2;
+            k.K = 400; k.Kpad = round_up(400, 64);
+        }
+        GemmParams d = gemm_of(P, pd, P.fc[0].pk_dgrad4, 1, rows);
+        d.c.A = w.dy1; d.out_bf = w.db4; d.ldo = 256;
+        d.d_r = w.r4; d.d_ld = 256; d.d_bcast_n = B; d.d_act = ACT_SWISH;
+        d.d_affine = w.aff_e[2]; d.d_meanrstd = w.mr_e[2]; d.d_red = w.red_e[2];
+        MMVAE_TRY(launch_gemm_gather(d, s));
+    }
+    // ---- conv stack (features shared by all variants: gradients of the variants add up)
+    bf16* r[4] = {w.r1, w.r2, w.r3, w.r4};
+    bf16* dr[4] = {w.d1e, w.d2e, w.d3e, w.dr4};
+    for (int l = 3; l >= 1; --l) {
+        const ConvL& L = P.conv[l];
+        const BnL& b = P.bn[L.bn];
+        const int pix = L.g.OH * L.g.OW;
+        BnBwdApplyArgs a{};
+        a.db = (l == 3) ? w.db4 : dr[l];
+        a.db2 = (l == 3 && variants == 2) ? w.db4 + (size_t)B * 1024 : nullptr;
+        a.r = r[l]; a.dr = dr[l]; a.rows = B * pix; a.C = L.g.Cout; a.ld = L.g.Cout; a.rows_per_group = B * pix; a.G = 1;
+        a.red = w.red_e[l - 1]; a.meanrstd = w.mr_e[l - 1]; a.gamma = P.buf.params + b.w_off;
+        a.dgamma = P.buf.grads + b.w_off; a.dbeta = P.buf.grads + b.b_off;
+        MMVAE_TRY(launch_bn_bwd_apply(a, s));
+        {   // wgrad: P = dr[l] (rows over the output grid), G = activated input gathered in forward form
+            WgradParams g = wgrad_of(P, L.fwd, L.gk, 1, B);
+            g.c.A = r[l - 1]; g.c.a_act = ACT_SWISH; g.c.a_affine = l > 1 ? w.aff_e[l - 2] : nullptr;
+            g.P = dr[l]; g.ldp = L.g.Cout;
+            MMVAE_TRY(launch_wgrad(g, s));
+        }
+        {   // dgrad (class form) with the d-activation of the producer layer fused in the epilogue
+            GemmParams d = gemm_of(P, L.dgrad, L.pk_dgrad, 1, B);
+            d.c.A = dr[l]; d.out_bf = dr[l - 1]; d.ldo = L.g.Cin;
+            d.d_r = r[l - 1]; d.d_ld = L.g.Cin; d.d_act = ACT_SWISH;
+            if (l > 1) { d.d_affine = w.aff_e[l - 2]; d.d_meanrstd = w.mr_e[l - 2]; d.d_red = w.red_e[l - 2]; }
+            MMVAE_TRY(launch_gemm_gather(d, s));
+        }
+    }
+    {   // conv1 wgrad over the im2col patches
+        GatherPlan pl = dense_plan(B * 625, 16, 16, 32);
+        WgradParams g = wgrad_of(P, pl, P.conv[0].gk, 1, B * 625);
+        g.c.A = w.patches1; g.P = w.d1e; g.ldp = 32;
+        MMVAE_TRY(launch_wgrad(g, s));
+    }
+    return MMVAE_OK;
+}
+
+// ================================================================== image decoder (multimnist/model.py:211-216)
+// z_bf: [groups*B][ldz] with column D == 1.0 (folded bias).  Leaves logits (fp32, [groups*B][2500]) in w.logits.
+int dec_fwd(MMPlan& P, int groups, int training, hipStream_t s) {
+    MMPlan::W& w = P.w;
+    const int B = P.B, rows = groups * B;
+    {
+        GatherPlan pl = dense_plan(rows, P.ldz, P.ldz, 1024);
+        GemmParams g = gemm_of(P, pl, &P.up.pk_fwd, 1, rows);
+        g.c.A = w.z_bf; g.out_bf = w.u; g.ldo = 1024;
+        MMVAE_TRY(launch_gemm_gather(g, s));
+    }
+    bf16* q[4] = {w.u, w.q1, w.q2, w.q3};
+    for (int l = 0; l < 3; ++l) {
+        const ConvL& L = P.convT[l];
+        GemmParams g = gemm_of(P, L.fwd, L.pk_fwd, groups, B);
+        g.c.A = q[l]; g.c.a_act = ACT_SWISH; g.c.a_affine = l > 0 ? w.aff_d[l - 1] : nullptr;
+        g.out_bf = q[l + 1]; g.ldo = L.g.Cout;
+        g.colstats = training ? w.st_d[l] : nullptr;
+        MMVAE_TRY(launch_gemm_gather(g, s));
+        MMVAE_TRY(bn_fin(P, P.bn[L.bn], w.st_d[l], groups, (float)(B * L.g.OH * L.g.OW), 1, w.aff_d[l], w.mr_d[l], training, s));
+    }
+    {
+        const ConvL& L = P.convT[3];
+        GemmParams g = gemm_of(P, L.fwd, L.pk_fwd, groups, B);
+        g.c.A = w.q3; g.c.a_act = ACT_SWISH; g.c.a_affine = w.aff_d[2];
+        g.out_f = w.logits; g.ldo = 1;
+        MMVAE_TRY(launch_gemm_gather(g, s));
+    }
+    return MMVAE_OK;
+}
+
+// dlogit: fp32 NCHW [groups*B][1][50][50] (grad wrt the pre-sigmoid logits). Writes dz (fp32 [groups*B][D]).
+int dec_bwd(MMPlan& P, const float* dlogit, int groups, float* dz, hipStream_t s) {
+    MMPlan::W& w = P.w;
+    const int B = P.B, rows = groups * B;
+    MMVAE_TRY(launch_im2col_small(dlogit, rows, 1, IMG, IMG, 4, 4, 2, 1, 25, 25, w.patches4, 16, s));
+    bf16* q[4] = {w.u, w.q1, w.q2, w.q3};
+    bf16* dq[4] = {w.du, w.d1, w.d2, w.d3};
+    {   // last transposed conv (32 -> 1) through the patches of dlogit
+        const ConvL& L = P.convT[3];
+        GatherPlan pl = plan_fwdform(1, 1, 25, 25, 16, 1, 1, 1, 0, 32, groups, B);   // rows (n, iy, ix), dense K=16
+        GemmParams d = gemm_of(P, pl, L.pk_dgrad, groups, B);
+        d.c.A = w.patches4; d.c.AH = 25; d.c.AW = 25;         // patches are indexed by the same (n, iy, ix)
+        d.c.sy = d.c.sx = 1;
+        d.out_bf = w.d3; d.ldo = 32;
+        d.d_r = w.q3; d.d_ld = 32; d.d_act = ACT_SWISH; d.d_affine = w.aff_d[2]; d.d_meanrstd = w.mr_d[2]; d.d_red = w.red_d[2];
+        MMVAE_TRY(launch_gemm_gather(d, s));
+        WgradParams g = wgrad_of(P, pl, L.gk, groups, B);
+        g.c.A = w.patches4; g.c.AH = 25; g.c.AW = 25; g.c.sy = g.c.sx = 1;
+        g.P = w.q3; g.ldp = 32; g.p_act = ACT_SWISH; g.p_affine = w.aff_d[2];
+        MMVAE_TRY(launch_wgrad(g, s));
+    }
+    for (int l = 2; l >= 0; --l) {
+        const ConvL& L = P.convT[l];
+        const BnL& b = P.bn[L.bn];
+        const int pix = L.g.OH * L.g.OW;
+        BnBwdApplyArgs a{};
+        a.db = dq[l + 1]; a.r = q[l + 1]; a.dr = dq[l + 1]; a.rows = rows * pix; a.C = L.g.Cout; a.ld = L.g.Cout;
+        a.rows_per_group = B * pix; a.G = groups;
+        a.red = w.red_d[l]; a.meanrstd = w.mr_d[l]; a.gamma = P.buf.params + b.w_off;
+        a.dgamma = P.buf.grads + b.w_off; a.dbeta = P.buf.grads + b.b_off;
+        MMVAE_TRY(launch_bn_bwd_apply(a, s));
+        {
+            WgradParams g = wgrad_of(P, L.fwd, L.gk, groups, B);
+            g.c.A = q[l]; g.c.a_act = ACT_SWISH; g.c.a_affine = l > 0 ? w.aff_d[l - 1] : nullptr;
+            g.P = dq[l + 1]; g.ldp = L.g.Cout;
+            MMVAE_TRY(launch_wgrad(g, s));
+        }
+        {
+            GemmParams d = gemm_of(P, L.dgrad, L.pk_dgrad, groups, B);
+            d.c.A = dq[l + 1]; d.out_bf = dq[l]; d.ldo = L.g.Cin;
+            d.d_r = q[l]; d.d_ld = L.g.Cin; d.d_act = ACT_SWISH;
+            if (l > 0) { d.d_affine = w.aff_d[l - 1]; d.d_meanrstd = w.mr_d[l - 1]; d.d_red = w.red_d[l - 1]; }
+            MMVAE_TRY(launch_gemm_gather(d, s));
+        }
+    }
+    {   // upsample Linear: weight (+ folded bias) gradient and dz
+        GatherPlan pl = dense_plan(rows, P.ldz, P.ldz, 1024);
+        WgradParams g = wgrad_of(P, pl, &P.up.gk, 1, rows);
+        g.c.A = w.z_bf; g.P = w.du; g.ldp = 1024;
+        MMVAE_TRY(launch_wgrad(g, s));
+        GatherPlan pd = dense_plan(rows, 1024, 1024, P.D);
+        GemmParams d = gemm_of(P, pd, &P.up.pk_dgrad, 1, rows);
+        d.c.A = w.du; d.out_f = dz; d.ldo = P.D;
+        MMVAE_TRY(launch_gemm_gather(d, s));
+    }
+    return MMVAE_OK;
+}
+
+// ================================================================== text modules
+GruPacked gru_of(const MMPlan& P, const MMPlan::GruIdx& g) {
+    GruPacked r{};
+    r.wih = P.buf.packed + P.pk.d[g.wih].dst_off; r.kih = P.pk.d[g.wih].Kpad;
+    r.whh = P.buf.packed + P.pk.d[g.whh].dst_off;
+    r.wihT = P.buf.packed + P.pk.d[g.wihT].dst_off; r.nih = P.pk.d[g.wihT].Npad;
+    r.whhT = P.buf.packed + P.pk.d[g.whhT].dst_off;
+    r.bih = P.buf.params + g.bih; r.bhh = P.buf.params + g.bhh;
+    return r;
+}
+TextEncArgs te_args(MMPlan& P, const long long* text, float* out, bool save) {
+    MMPlan::W& w = P.w;
+    TextEncArgs a{};
+    a.B = P.B; a.D = P.D; a.tokens = text; a.embed = P.buf.params + off(P, "text_encoder.embed.weight");
+    a.fwd = gru_of(P, P.te_f); a.rev = gru_of(P, P.te_r);
+    a.h2p = P.buf.packed + P.pk.d[P.te_h2p].dst_off; a.nh2p = P.pk.d[P.te_h2p].Npad;
+    a.h2pT = P.buf.packed + P.pk.d[P.te_h2pT].dst_off;
+    a.h2p_bias = P.buf.params + off(P, "text_encoder.h2p.bias");
+    a.out = out;
+    if (save) { a.gates_f = w.te_gates_f; a.gates_r = w.te_gates_r; a.x_bf = w.te_x; a.hprev_bf = w.te_hprev; a.hsum_bf = w.te_hsum; }
+    return a;
+}
+int txt_enc_bwd(MMPlan& P, const long long* text, const float* d_out, hipStream_t s) {
+    MMPlan::W& w = P.w;
+    const int B = P.B, D2 = 2 * P.D;
+    TextEncBwdArgs a{};
+    a.f = te_args(P, text, nullptr, true);
+    a.d_out = d_out; a.d_out_bf = w.te_dout_bf;
+    a.dgi_f = w.te_dgi_f; a.dgh_f = w.te_dgh_f; a.dgi_r = w.te_dgi_r;
+    float* G = P.buf.grads;
+    a.g_embed = G + off(P, "text_encoder.embed.weight");
+    a.g_bih_f = G + P.te_f.bih; a.g_bhh_f = G + P.te_f.bhh; a.g_bih_r = G + P.te_r.bih; a.g_bhh_r = G + P.te_r.bhh;
+    a.g_h2p_bias = G + off(P, "text_encoder.h2p.bias");
+    MMVAE_TRY(launch_text_encoder_bwd(a, s));
+    auto wg = [&](int gidx, const bf16* Pm, int N, int ldp, const bf16* Gm, int C, int rows) -> int {
+        GatherPlan pl = dense_plan(rows, C, C, N);
+        WgradParams g = wgrad_of(P, pl, &gidx, 1, rows);
+        g.c.A = Gm; g.P = Pm; g.ldp = ldp;
+        return launch_wgrad(g, s);
+    };
+    MMVAE_TRY(wg(P.te_f.g_wih, w.te_dgi_f, 300, 304, w.te_x, TXT_HP, 4 * B));
+    MMVAE_TRY(wg(P.te_f.g_whh, w.te_dgh_f, 300, 304, w.te_hprev, TXT_HP, 4 * B));
+    MMVAE_TRY(wg(P.te_r.g_wih, w.te_dgi_r, 300, 304, w.te_x + (size_t)3 * B * TXT_HP, TXT_HP, B));
+    MMVAE_TRY(wg(P.g_te_h2p, w.te_dout_bf, D2, round_up(D2, 8), w.te_hsum, TXT_HP, B));
+    return MMVAE_OK;
+}
+TextDecArgs td_args(MMPlan& P, const float* z, int groups, bool save) {
+    MMPlan::W& w = P.w;
+    TextDecArgs a{};
+    a.R = groups * P.B; a.D = P.D; a.rows_per_pass = P.B; a.z = z;
+    a.embed = P.buf.params + off(P, "text_decoder.embed.weight");
+    a.z2h = P.buf.packed + P.pk.d[P.td_z2h].dst_off; a.kz = P.kz;
+    a.z2hT = P.buf.packed + P.pk.d[P.td_z2hT].dst_off;
+    a.z2h_bias = P.buf.params + off(P, "text_decoder.z2h.bias");
+    a.l0 = gru_of(P, P.td0); a.l1 = gru_of(P, P.td1);
+    a.h2o = P.buf.packed + P.pk.d[P.td_h2o].dst_off; a.kx = P.kx;
+    a.h2oT = P.buf.packed + P.pk.d[P.td_h2oT].dst_off;
+    a.h2o_bias = P.buf.params + off(P, "text_decoder.h2o.bias");
+    a.words = w.words; a.tokens_out = w.tokens;
+    if (save) {
+        a.gates = w.td_gates; a.x0_bf = w.td_x0; a.h0p_bf = w.td_h0p; a.mid_bf = w.td_mid; a.h1p_bf = w.td_h1p;
+        a.hz_bf = w.td_hz; a.z_bf = w.td_zbf;
+    }
+    return a;
+}
+int txt_dec_bwd(MMPlan& P, const TextDecArgs& f, const float* dwords, float* dz, hipStream_t s) {
+    MMPlan::W& w = P.w;
+    const int R = f.R, XI = 100 + P.D;
+    TextDecBwdArgs a{};
+    a.f = f; a.dwords = dwords; a.R_active = R; a.dz = dz;
+    a.dgi0 = w.dgi0; a.dgh0 = w.dgh0; a.dgi1 = w.dgi1; a.dgh1 = w.dgh1; a.dlogit_bf = w.dlogit_bf; a.dhinit_bf = w.dhinit;
+    float* G = P.buf.grads;
+    a.g_embed = G + off(P, "text_decoder.embed.weight");
+    a.g_b[0] = G + P.td0.bih; a.g_b[1] = G + P.td0.bhh; a.g_b[2] = G + P.td1.bih; a.g_b[3] = G + P.td1.bhh;
+    a.g_h2o_bias = G + off(P, "text_decoder.h2o.bias"); a.g_z2h_bias = G + off(P, "text_decoder.z2h.bias");
+    MMVAE_TRY(launch_text_decoder_bwd(a, s));
+    auto wg = [&](int gidx, const bf16* Pm, int N, int ldp, const bf16* Gm, int C, int rows) -> int {
+        GatherPlan pl = dense_plan(rows, C, C, N);
+        WgradParams g = wgrad_of(P, pl, &gidx, 1, rows);
+        g.c.A = Gm; g.P = Pm; g.ldp = ldp;
+        return launch_wgrad(g, s);
+    };
+    (void)XI;
+    MMVAE_TRY(wg(P.td0.g_wih, w.dgi0, 300, 304, w.td_x0, P.kx, 4 * R));
+    MMVAE_TRY(wg(P.td0.g_whh, w.dgh0, 300, 304, w.td_h0p, TXT_HP, 4 * R));
+    MMVAE_TRY(wg(P.td1.g_wih, w.dgi1, 300, 304, w.td_mid, TXT_HP, 4 * R));
+    MMVAE_TRY(wg(P.td1.g_whh, w.dgh1, 300, 304, w.td_h1p, TXT_HP, 4 * R));
+    MMVAE_TRY(wg(P.g_td_h2o, w.dlogit_bf, 12, 16, w.td_hz, P.kx, 4 * R));
+    MMVAE_TRY(wg(P.g_td_z2h, w.dhinit, 100, 112, w.td_zbf, P.kz, R));
+    return MMVAE_OK;
+}
+
+__global__ void cast_z_kernel(const float* z, int rows, int D, bf16* out, int ldz) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * ldz) return;
+    int r = i / ldz, d = i - r * ldz;
+    float v = d < D ? z[(size_t)r * D + d] : (d == D ? 1.0f : 0.0f);
+    out[i] = (bf16)v;
+}
+__global__ void cast_bf_kernel(const float* x, long long n, bf16* out) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (bf16)x[i];
+}
+__global__ void colsum_kernel(const float* x, int rows, int cols, float* out) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += x[(size_t)r * cols + c];
+    out[c] += s;
+}
+// dlogit = d_recon * p * (1 - p)   (sigmoid backward for the drop-in decoder module)
+__global__ void sigmoid_bwd_kernel(const float* d_recon, const float* recon, long long n, float* dlogit) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { float p = recon[i]; dlogit[i] = d_recon[i] * p * (1.0f - p); }
+}
+__global__ void sigmoid_kernel(const float* logits, long long n, float* out) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = 1.0f / (1.0f + expf(-logits[i]));
+}
+
+int check_bound(const MMPlan* P) {
+    MMVAE_REQUIRE(P && P->bound, "plan has no buffers bound (mmvae_mm_bind)");
+    return MMVAE_OK;
+}
+
+}  // namespace
+
+// ================================================================== public (internal C++) API
+MMPlan* mm_create(int D, int B) {
+    if (D < 1 || D > 127 || B < 1) { mmvae_set_error("mm_create: need 1 <= n_latents <= 127 and batch >= 1"); return nullptr; }
+    MMPlan* P = new MMPlan();
+    P->D = D; P->B = B;
+    build_plan(*P);
+    Workspace ws(nullptr, 0);
+    carve(*P, ws);
+    P->ws_bytes = ws.used();
+    return P;
+}
+void mm_destroy(MMPlan* P) { delete P; }
+int mm_D(const MMPlan* P) { return P->D; }
+int mm_B(const MMPlan* P) { return P->B; }
+const std::vector<ParamInfo>& mm_params(const MMPlan* P) { return P->params; }
+long long mm_param_count(const MMPlan* P) { return P->nparams; }
+long long mm_packed_elems(const MMPlan* P) { return P->pk.mat_elems; }
+long long mm_packed_vec_elems(const MMPlan* P) { return P->pk.vec_elems > 0 ? P->pk.vec_elems : 64; }
+long long mm_gpk_elems(const MMPlan* P) { return P->gk.mat_elems; }
+long long mm_gpk_vec_elems(const MMPlan* P) { return P->gk.vec_elems > 0 ? P->gk.vec_elems : 64; }
+int mm_ndesc(const MMPlan* P) { return (int)P->pk.d.size(); }
+const PackDesc* mm_desc_host(const MMPlan* P) { return P->pk.d.data(); }
+int mm_ngdesc(const MMPlan* P) { return (int)P->gk.d.size(); }
+const PackDesc* mm_gdesc_host(const MMPlan* P) { return P->gk.d.data(); }
+size_t mm_workspace_bytes(const MMPlan* P) { return P->ws_bytes; }
+
+int mm_bind(MMPlan* P, const MMBuffers& b) {
+    MMVAE_REQUIRE(b.params && b.grads && b.bn_stats && b.bn_nbt && b.packed && b.packed_vec && b.gpk && b.gpk_vec &&
+                  b.desc_dev && b.gdesc_dev, "mm_bind: null buffer");
+    P->buf = b;
+    P->bound = true;
+    return MMVAE_OK;
+}
+static int use_ws(MMPlan* P, void* ws, size_t bytes) {
+    MMVAE_TRY(check_bound(P));
+    MMVAE_REQUIRE(ws != nullptr && bytes >= P->ws_bytes, "workspace too small (%zu < %zu)", bytes, P->ws_bytes);
+    Workspace w(ws, bytes);
+    carve(*P, w);
+    return MMVAE_OK;
+}
+
+int mm_pack_weights(MMPlan* P, hipStream_t s) {
+    MMVAE_TRY(check_bound(P));
+    return launch_pack(P->buf.desc_dev, P->pk.d.data(), (int)P->pk.d.size(), P->buf.params, P->buf.packed, P->buf.packed_vec, s);
+}
+int mm_unpack_grads(MMPlan* P, hipStream_t s) {
+    MMVAE_TRY(check_bound(P));
+    return launch_unpack_grads(P->buf.gdesc_dev, P->gk.d.data(), (int)P->gk.d.size(), P->buf.gpk, P->buf.gpk_vec, P->buf.grads, s);
+}
+static int zero_gpk(MMPlan* P, hipStream_t s) {
+    return launch_fill_zero(P->buf.gpk, (size_t)P->gk.mat_elems * sizeof(float), s);
+}
+
+int mm_step_fwd_bwd(MMPlan* Pp, const MMStepIO& io, int training, int do_backward, hipStream_t s) {
+    MMVAE_TRY(use_ws(Pp, io.ws, io.ws_bytes));
+    MMPlan& P = *Pp;
+    MMPlan::W& w = P.w;
+    const int B = P.B, D = P.D, B3 = 3 * B;
+    MMVAE_REQUIRE(io.image && io.text && io.sums, "step: image/text/sums must be given");
+    MMVAE_TRY(launch_fill_zero(w.zero_begin, w.zero_bytes, s));
+    if (do_backward) MMVAE_TRY(zero_gpk(Pp, s));
+    // ---- stochastic inputs (injected, or Philox keyed by the device step counter)
+    const float* eps = io.eps;
+    if (training && !eps) { MMVAE_TRY(launch_normal(w.eps, (long long)B3 * D, io.seed, io.step_ctr, 1, s)); eps = w.eps; }
+    const uint8_t *m1 = io.enc_mask1, *m2 = io.enc_mask2, *gk = io.gru_keep;
+    if (training && io.enc_dropout && !m1) { MMVAE_TRY(launch_keep_mask(w.m1, (long long)2 * B * 400, DROP_P, io.seed, io.step_ctr, 2, s)); m1 = w.m1; }
+    if (training && io.enc_dropout && !m2) { MMVAE_TRY(launch_keep_mask(w.m2, (long long)2 * B * 200, DROP_P, io.seed, io.step_ctr, 3, s)); m2 = w.m2; }
+    if (training && io.gru_dropout && !gk) { MMVAE_TRY(launch_keep_mask(w.gkeep, (long long)4 * B3 * 100, DROP_P, io.seed, io.step_ctr, 4, s)); gk = w.gkeep; }
+    const int enc_drop = training && io.enc_dropout;
+    // ---- encoders (image features computed once for passes 1 and 2; text encoder once for passes 1 and 3)
+    MMVAE_TRY(enc_fwd(P, io.image, 2, m1, m2, enc_drop, training, 2, w.encout, s));
+    {
+        TextEncArgs a = te_args(P, io.text, w.txtout, do_backward);
+        MMVAE_TRY(launch_text_encoder_fwd(a, s));
+    }
+    // ---- product of experts + reparametrisation + KL for the three passes
+    Latent3Args la{};
+    la.B = B; la.D = D; la.img_out = w.encout; la.txt_out = w.txtout; la.eps = eps;
+    la.mu = io.mu ? io.mu : w.mu; la.logvar = io.logvar ? io.logvar : w.logvar;
+    la.z_f32 = w.z_f32; la.z_bf = w.z_bf; la.ldz = P.ldz; la.kl_sum = w.sums + 8; la.training = training;
+    MMVAE_TRY(launch_latent3_fwd(la, s));
+    // ---- decoders on 3B rows, BatchNorm statistics per pass
+    MMVAE_TRY(dec_fwd(P, 3, training, s));
+    BceArgs bc{};
+    bc.logits = w.logits; bc.ldl = 1; bc.target = io.image; bc.G = 3; bc.B = B; bc.C = 1; bc.H = IMG; bc.W = IMG;
+    bc.recon = io.recon_image; bc.dlogit = do_backward ? w.dlogit : nullptr; bc.loss_sum = w.sums;
+    for (int k = 0; k < 3; ++k) bc.coef[k] = io.lambda_xy[k] / (float)(B * NPIX);
+    MMVAE_TRY(launch_sigmoid_bce(bc, s));
+    TextDecArgs td = td_args(P, w.z_f32, 3, do_backward);
+    td.keep = (training && io.gru_dropout) ? gk : nullptr; td.keep_scale = 1.f / (1.f - DROP_P);
+    td.force_tokens = io.force_tokens;
+    if (io.recon_text) td.words = io.recon_text;
+    if (io.tokens) td.tokens_out = io.tokens;
+    td.target = io.text; td.nll_sum = w.sums + 4; td.dwords = do_backward ? w.dwords : nullptr;
+    for (int k = 0; k < 3; ++k) td.nll_coef[k] = io.lambda_yx[k] / (float)(B * TXT_T);
+    MMVAE_TRY(launch_text_decoder_fwd(td, s));
+    if (hipMemcpyAsync(io.sums, w.sums, 16 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+        mmvae_set_error("step: copy of the loss sums failed");
+        return MMVAE_EHIP;
+    }
+    if (!do_backward) return MMVAE_OK;
+
+    // =============================== backward ===============================
+    MMVAE_TRY(txt_dec_bwd(P, td, w.dwords, w.dz_txt, s));
+    // image decoder: a pass with lambda_xy = 0 (text-only) has exactly zero gradient: only the leading groups run
+    int img_groups = 3;
+    while (img_groups > 0 && io.lambda_xy[img_groups - 1] == 0.f) --img_groups;
+    if (img_groups > 0) MMVAE_TRY(dec_bwd(P, w.dlogit, img_groups, w.dz_img, s));
+    Latent3BwdArgs lb{};
+    lb.f = la; lb.dz_a = w.dz_img; lb.dz_b = w.dz_txt;
+    for (int k = 0; k < 3; ++k) lb.kl_coef[k] = io.kl_lambda / (float)B;
+    lb.d_img_out_bf = w.d_encout; lb.d_img_bias = P.buf.grads + P.fc[2].b_off; lb.d_txt_out = w.d_txtout;
+    MMVAE_TRY(launch_latent3_bwd(lb, s));
+    MMVAE_TRY(txt_enc_bwd(P, io.text, w.d_txtout, s));
+    MMVAE_TRY(enc_bwd(P, w.d_encout, 2, m1, m2, enc_drop, s));
+    MMVAE_TRY(mm_unpack_grads(Pp, s));
+    return MMVAE_OK;
+}
+
+// ---------------------------------------------------------------- granular module entry points (drop-in modules)
+// Every call gets its own workspace (saved activations live there until the matching backward).
+int mm_image_encoder_fwd(MMPlan* P, void* ws, size_t wsb, const float* image, const uint8_t* m1, const uint8_t* m2,
+                         int training, float* out, hipStream_t s) {
+    MMVAE_TRY(use_ws(P, ws, wsb));
+    MMPlan::W& w = P->w;
+    MMVAE_TRY(launch_fill_zero(w.zero_begin, w.zero_bytes, s));
+    return enc_fwd(*P, image, 1, m1, m2, training && m1 != nullptr, training, 1, out, s);
+}
+int mm_image_encoder_bwd(MMPlan* P, void* ws, size_t wsb, const float* d_out, const uint8_t* m1, const uint8_t* m2, hipStream_t s) {
+    MMVAE_TRY(use_ws(P, ws, wsb));
+    MMPlan::W& w = P->w;
+    const int rows = P->B, D2 = 2 * P->D;
+    MMVAE_TRY(zero_gpk(P, s));
+    hipLaunchKernelGGL(cast_bf_kernel, dim3(ceil_div(rows * D2, 256)), dim3(256), 0, s, d_out, (long long)rows * D2, w.d_encout);
+    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(D2, 64)), dim3(64), 0, s, d_out, rows, D2, P->buf.grads + P->fc[2].b_off);
+    MMVAE_TRY(mmvae_check_launch("image encoder bwd prologue"));
+    MMVAE_TRY(enc_bwd(*P, w.d_encout, 1, m1, m2, m1 != nullptr, s));
+    return mm_unpack_grads(P, s);
+}
+int mm_image_decoder_fwd(MMPlan* P, void* ws, size_t wsb, const float* z, int training, float* recon, hipStream_t s) {
+    MMVAE_TRY(use_ws(P, ws, wsb));
+    MMPlan::W& w = P->w;
+    const int rows = P->B;
+    MMVAE_TRY(launch_fill_zero(w.zero_begin, w.zero_bytes, s));
+    hipLaunchKernelGGL(cast_z_kernel, dim3(ceil_div(rows * P->ldz, 256)), dim3(256), 0, s, z, rows, P->D, w.z_bf, P->ldz);
+    MMVAE_TRY(mmvae_check_launch("cast_z"));
+    MMVAE_TRY(dec_fwd(*P, 1, training, s));
+    hipLaunchKernelGGL(sigmoid_kernel, dim3(ceil_div(rows * NPIX, 256)), dim3(256), 0, s, w.logits, (long long)rows * NPIX, recon);
+    return mmvae_check_launch("sigmoid");
+}
+int mm_image_decoder_bwd(MMPlan* P, void* ws, size_t wsb, const float* d_recon, const float* recon, float* dz, hipStream_t s) {
+    MMVAE_TRY(use_ws(P, ws, wsb));
+    MMPlan::W& w = P->w;
+    const int rows = P->B;
+    MMVAE_TRY(zero_gpk(P, s));
+    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(ceil_div(rows * NPIX, 256)), dim3(256), 0, s, d_recon, recon, (long long)rows * NPIX, w.dlogit);
+    MMVAE_TRY(mmvae_check_launch("sigmoid_bwd"));
+    MMVAE_TRY(dec_bwd(*P, w.dlogit, 1, dz, s));
+    return mm_unpack_grads(P, s);
+}
+int mm_text_encoder_fwd(MMPlan* P, void* ws, size_t wsb, const long long* text, float* out, hipStream_t s) {
+    MMVAE_TRY(use_ws(P, ws, wsb));
+    TextEncArgs a = te_args(*P, text, out, true);
+    return launch_text_encoder_fwd(a, s);
+}
+int mm_text_encoder_bwd(MMPlan* P, void* ws, size_t wsb, const long long* text, const float* d_out, hipStream_t s) {
+    MMVAE_TRY(use_ws(P, ws, wsb));
+    MMVAE_TRY(zero_gpk(P, s));
+    MMVAE_TRY(txt_enc_bwd(*P, text, d_out, s));
+    return mm_unpack_grads(P, s);
+}
+int mm_text_decoder_fwd(MMPlan* P, void* ws, size_t wsb, const float* z, int training, const uint8_t* keep,
+                        const long long* force_tokens, float* words, long long* tokens, hipStream_t s) {
+    MMVAE_TRY(use_ws(P, ws, wsb));
+    TextDecArgs a = td_args(*P, z, 1, true);
+    a.keep = training ? keep : nullptr; a.keep_scale = 1.f / (1.f - DROP_P);
+    a.force_tokens = force_tokens; a.words = words; a.tokens_out = tokens;
+    return launch_text_decoder_fwd(a, s);
+}
+int mm_text_decoder_bwd(MMPlan* P, void* ws, size_t wsb, const float* z, const uint8_t* keep, const long long* force_tokens,
+                        const float* words, const long long* tokens, const float* d_words, float* dz, hipStream_t s) {
+    MMVAE_TRY(use_ws(P, ws, wsb));
+    MMVAE_TRY(zero_gpk(P, s));
+    TextDecArgs a = td_args(*P, z, 1, true);
+    a.keep = keep; a.keep_scale = 1.f / (1.f - DROP_P);
+    a.force_tokens = force_tokens; a.words = const_cast<float*>(words); a.tokens_out = const_cast<long long*>(tokens);
+    MMVAE_TRY(txt_dec_bwd(*P, a, d_words, dz, s));
+    return mm_unpack_grads(P, s);
+}
+
+// ---------------------------------------------------------------- profiling aid: replay one GEMM of the step
+static bool layer_gemm(MMPlan& P, const std::string& name, GemmParams& g) {
+    MMPlan::W& w = P.w;
+    const int B = P.B;
+    bf16* r[4] = {w.r1, w.r2, w.r3, w.r4};
+    bf16* q[4] = {w.u, w.q1, w.q2, w.q3};
+    bf16* dq[4] = {w.du, w.d1, w.d2, w.d3};
+    for (int l = 1; l < 4; ++l)
+        if (name == "enc_conv" + std::to_string(l + 1)) {
+            const ConvL& L = P.conv[l];
+            g = gemm_of(P, L.fwd, L.pk_fwd, 1, B);
+            g.c.A = r[l - 1]; g.c.a_act = ACT_SWISH; g.c.a_affine = l > 1 ? w.aff_e[l - 2] : nullptr;
+            g.out_bf = r[l]; g.ldo = L.g.Cout;
+            return true;
+        }
+    for (int l = 0; l < 3; ++l) {
+        const ConvL& L = P.convT[l];
+        if (name == "dec_convT" + std::to_string(l + 1)) {
+            g = gemm_of(P, L.fwd, L.pk_fwd, 3, B);
+            g.c.A = q[l]; g.c.a_act = ACT_SWISH; g.c.a_affine = l > 0 ? w.aff_d[l - 1] : nullptr;
+            g.out_bf = q[l + 1]; g.ldo = L.g.Cout;
+            return true;
+        }
+        if (name == "dec_convT" + std::to_string(l + 1) + "_dgrad") {
+            g = gemm_of(P, L.dgrad, L.pk_dgrad, 2, B);
+            g.c.A = dq[l + 1]; g.out_bf = dq[l]; g.ldo = L.g.Cin;
+            return true;
+        }
+    }
+    return false;
+}
+static double gemm_flops(const GemmParams& g) {
+    double f = 0;
+    for (int i = 0; i < g.c.nclasses; ++i) f += 2.0 * g.c.groups * g.cls[i].rows_per_group * (double)g.c.N * g.cls[i].K;
+    return f;
+}
+int mm_bench_layer(MMPlan* P, void* ws, size_t wsb, const char* layer, int iters, hipStream_t s) {
+    MMVAE_TRY(use_ws(P, ws, wsb));
+    GemmParams g{};
+    MMVAE_REQUIRE(layer_gemm(*P, layer, g), "bench_layer: unknown layer '%s'", layer);
+    for (int i = 0; i < iters; ++i) MMVAE_TRY(launch_gemm_gather(g, s));
+    return MMVAE_OK;
+}
+double mm_layer_flops(const MMPlan* Pc, const char* layer) {
+    MMPlan& P = *const_cast<MMPlan*>(Pc);
+    GemmParams g{};
+    if (!P.bound || !layer_gemm(P, layer, g)) return -1.0;
+    return gemm_flops(g);
+}
+int mm_num_bn(const MMPlan*) { return 6; }
+int mm_bn_info(const MMPlan* P, int i, std::string& prefix, int& C, long long& offset) {
+    if (i < 0 || i >= 6) return MMVAE_EINVAL;
+    const char* bnn[6] = {"image_encoder.features.3", "image_encoder.features.6", "image_encoder.features.9",
+                          "image_decoder.hallucinate.1", "image_decoder.hallucinate.4", "image_decoder.hallucinate.7"};
+    prefix = bnn[i]; C = P->bn[i].C; offset = P->bn[i].stat_off;
+    return MMVAE_OK;
+}
+long long mm_bn_floats(const MMPlan* P) { return P->bn[5].stat_off + 2 * P->bn[5].C; }
+
+// ---------------------------------------------------------------- test aid: byte offset of a named workspace buffer
+long long mm_debug_offset(MMPlan* P, const char* name) {
+    Workspace ws((void*)0x1000, (size_t)1 << 40);
+    carve(*P, ws);
+    MMPlan::W& w = P->w;
+    std::map<std::string, const void*> m = {
+        {"patches1", w.patches1}, {"r1", w.r1}, {"r2", w.r2}, {"r3", w.r3}, {"r4", w.r4}, {"y1", w.y1}, {"y2", w.y2},
+        {"encout", w.encout}, {"txtout", w.txtout}, {"z_bf", w.z_bf}, {"z_f32", w.z_f32}, {"u", w.u}, {"q1", w.q1}, {"q2", w.q2},
+        {"q3", w.q3}, {"logits", w.logits}, {"dlogit", w.dlogit}, {"d3", w.d3}, {"d2", w.d2}, {"d1", w.d1}, {"du", w.du},
+        {"dz_img", w.dz_img}, {"dz_txt", w.dz_txt}, {"d_encout", w.d_encout}, {"d_txtout", w.d_txtout}, {"dy2", w.dy2},
+        {"dy1", w.dy1}, {"db4", w.db4}, {"dr4", w.dr4}, {"d3e", w.d3e}, {"d2e", w.d2e}, {"d1e", w.d1e},
+        {"aff_d0", w.aff_d[0]}, {"aff_d1", w.aff_d[1]}, {"aff_d2", w.aff_d[2]}, {"st_d0", w.st_d[0]}, {"patches4", w.patches4},
+        {"aff_e0", w.aff_e[0]}, {"aff_e1", w.aff_e[1]}, {"aff_e2", w.aff_e[2]},
+    };
+    auto it = m.find(name);
+    if (it == m.end()) return -1;
+    return (long long)((const char*)it->second - (const char*)0x1000);
+}

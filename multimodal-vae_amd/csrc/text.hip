@@ -1,0 +1,552 @@
+// Persistent row-tile kernels of the MultiMNIST text encoder / decoder (fwd + bwd).
+// One workgroup = 4 waves = 16 batch rows for the whole recurrence.  Matmuls: 16 x N x K MFMA tiles
+// (v_mfma_f32_16x16x32_bf16), A fragments from LDS (row stride K+8 elements: conflict-free ds_read_b128),
+// B fragments straight from the packed bf16 weights in L2 (each 16-lane group reads 64 contiguous bytes per row).
+// Gate math, softmax, NLL and all state are fp32.
+#include "text.h"
+#include <math.h>
+
+namespace {
+
+constexpr int TR = 16;       // rows per workgroup
+constexpr int NW = 4;        // waves per workgroup
+constexpr int NTHR = NW * 64;
+constexpr int H = TXT_H;
+constexpr int HP = TXT_HP;
+constexpr int GL = TXT_G3P;  // fp32 gate buffer row stride (304)
+constexpr int GK = TXT_G3K;  // 320
+constexpr int MAXKS = 10;
+
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// out[16][ldo] = A[16][32*ksteps] * Wp[16*ntiles][kpad]^T
+__device__ __forceinline__ void rowtile_gemm(const bf16* A, int lda, int ksteps, const bf16* __restrict__ Wp, int kpad, int ntiles,
+                                             float* out, int ldo, int wave, int lane) {
+    const int fr = lane & 15, fq = lane >> 4;
+    bf16x8 af[MAXKS];
+#pragma unroll
+    for (int ks = 0; ks < MAXKS; ++ks)
+        if (ks < ksteps) af[ks] = *reinterpret_cast<const bf16x8*>(A + fr * lda + ks * 32 + fq * 8);
+    for (int nt = wave; nt < ntiles; nt += NW) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const bf16* w = Wp + (size_t)(nt * 16 + fr) * kpad + fq * 8;
+#pragma unroll
+        for (int ks = 0; ks < MAXKS; ++ks)
+            if (ks < ksteps) {
+                bf16x8 b = *reinterpret_cast<const bf16x8*>(w + ks * 32);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], b, acc, 0, 0, 0);
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[(fq * 4 + j) * ldo + nt * 16 + fr] = acc[j];
+    }
+}
+
+// GRU gate math for 16 rows (PyTorch gate order r,z,n). hf: fp32 state in/out, hb: bf16 copy for the next MFMA.
+// save: [5][R][100] (r, z, n, W_hn h + b_hn, h_prev) or null.
+__device__ __forceinline__ void gru_gates(const float* gi, const float* gh, const float* __restrict__ bih,
+                                          const float* __restrict__ bhh, float* hf, bf16* hb, int ldh, int r0, int R,
+                                          float* save, int tid) {
+    for (int idx = tid; idx < TR * H; idx += NTHR) {
+        const int row = idx / H, j = idx - row * H;
+        const float* a = gi + row * GL;
+        const float* b = gh + row * GL;
+        float r = sigm(a[j] + bih[j] + b[j] + bhh[j]);
+        float z = sigm(a[H + j] + bih[H + j] + b[H + j] + bhh[H + j]);
+        float ghn = b[2 * H + j] + bhh[2 * H + j];
+        float n = tanhf(a[2 * H + j] + bih[2 * H + j] + r * ghn);
+        float hp = hf[row * H + j];
+        float hn = (1.0f - z) * n + z * hp;
+        hf[row * H + j] = hn;
+        hb[row * ldh + j] = (bf16)hn;
+        if (save && r0 + row < R) {
+            const size_t o = (size_t)(r0 + row) * H + j, pl = (size_t)R * H;
+            save[o] = r; save[pl + o] = z; save[2 * pl + o] = n; save[3 * pl + o] = ghn; save[4 * pl + o] = hp;
+        }
+    }
+}
+
+// backward of gru_gates: dh (fp32 [16][100], grad wrt h_new) -> dgi/dgh (bf16 LDS [16][ldg] + global), dh_direct = dh*z
+__device__ __forceinline__ void gru_gates_bwd(const float* save, int r0, int R, const float* dh, bf16* dgi_s, bf16* dgh_s, int ldg,
+                                              float* dh_direct, bf16* dgi_g, bf16* dgh_g, int tid) {
+    for (int idx = tid; idx < TR * H; idx += NTHR) {
+        const int row = idx / H, j = idx - row * H;
+        float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f, dd = 0.f;
+        if (r0 + row < R) {
+            const size_t o = (size_t)(r0 + row) * H + j, pl = (size_t)R * H;
+            const float r = save[o], z = save[pl + o], n = save[2 * pl + o], ghn = save[3 * pl + o], hp = save[4 * pl + o];
+            const float d = dh[row * H + j];
+            dn = d * (1.0f - z) * (1.0f - n * n);
+            dz = d * (hp - n) * z * (1.0f - z);
+            dr = dn * ghn * r * (1.0f - r);
+            dnr = dn * r;
+            dd = d * z;
+        }
+        dh_direct[row * H + j] = dd;
+        dgi_s[row * ldg + j] = (bf16)dr; dgi_s[row * ldg + H + j] = (bf16)dz; dgi_s[row * ldg + 2 * H + j] = (bf16)dn;
+        dgh_s[row * ldg + j] = (bf16)dr; dgh_s[row * ldg + H + j] = (bf16)dz; dgh_s[row * ldg + 2 * H + j] = (bf16)dnr;
+        if (r0 + row < R) {
+            const size_t g = (size_t)(r0 + row) * GL;
+            if (dgi_g) { dgi_g[g + j] = (bf16)dr; dgi_g[g + H + j] = (bf16)dz; dgi_g[g + 2 * H + j] = (bf16)dn; }
+            if (dgh_g) { dgh_g[g + j] = (bf16)dr; dgh_g[g + H + j] = (bf16)dz; dgh_g[g + 2 * H + j] = (bf16)dnr; }
+        }
+    }
+}
+
+// per-thread column sums of a bf16 LDS gate-gradient tile (thread j < 300 owns column j)
+__device__ __forceinline__ float colsum16(const bf16* t, int ld, int col) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < TR; ++r) s += (float)t[r * ld + col];
+    return s;
+}
+
+__device__ __forceinline__ void zero_bf(bf16* p, int n, int tid) {
+    for (int i = tid; i < n; i += NTHR) p[i] = (bf16)0.f;
+}
+__device__ __forceinline__ void zero_f(float* p, int n, int tid) {
+    for (int i = tid; i < n; i += NTHR) p[i] = 0.f;
+}
+// copy LDS bf16 tile rows [16][ld] (first `w` columns) to global [R][gld]
+__device__ __forceinline__ void save_tile(const bf16* t, int ld, int w, bf16* g, int gld, int r0, int R, int tid) {
+    if (!g) return;
+    for (int idx = tid; idx < TR * w; idx += NTHR) {
+        int row = idx / w, c = idx - row * w;
+        if (r0 + row < R) g[(size_t)(r0 + row) * gld + c] = t[row * ld + c];
+    }
+}
+
+// ============================================================== text encoder forward
+__global__ __launch_bounds__(NTHR) void text_encoder_fwd_kernel(const TextEncArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int LH = HP + 8;
+    float* gi = reinterpret_cast<float*>(smem);              // [16][304]
+    float* gh = gi + TR * GL;                                // [16][304]
+    float* hf = gh + TR * GL;                                // [16][100]
+    float* hr = hf + TR * H;                                 // [16][100] reverse-direction state
+    bf16* xb = reinterpret_cast<bf16*>(hr + TR * H);         // [16][136]
+    bf16* hb = xb + TR * LH;                                 // [16][136]
+    bf16* hrb = hb + TR * LH;                                // [16][136]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = blockIdx.x * TR, R = a.B;
+    zero_bf(xb, 3 * TR * LH, tid);
+    zero_f(hf, 2 * TR * H, tid);
+    __syncthreads();
+    const size_t plane = (size_t)R * HP;
+    for (int t = 0; t < TXT_T; ++t) {
+        for (int idx = tid; idx < TR * H; idx += NTHR) {
+            int row = idx / H, j = idx - row * H;
+            int tok = (r0 + row < R) ? (int)a.tokens[(size_t)(r0 + row) * TXT_T + t] : 0;
+            xb[row * LH + j] = (bf16)a.embed[tok * H + j];
+        }
+        __syncthreads();
+        save_tile(xb, LH, HP, a.x_bf ? a.x_bf + t * plane : nullptr, HP, r0, R, tid);
+        save_tile(hb, LH, HP, a.hprev_bf ? a.hprev_bf + t * plane : nullptr, HP, r0, R, tid);
+        rowtile_gemm(xb, LH, HP / 32, a.fwd.wih, a.fwd.kih, GL / 16, gi, GL, wave, lane);
+        rowtile_gemm(hb, LH, HP / 32, a.fwd.whh, HP, GL / 16, gh, GL, wave, lane);
+        __syncthreads();
+        gru_gates(gi, gh, a.fwd.bih, a.fwd.bhh, hf, hb, LH, r0, R, a.gates_f ? a.gates_f + (size_t)t * 5 * R * H : nullptr, tid);
+        __syncthreads();
+    }
+    // reverse direction at the last time step: one step from h = 0 on token T-1 (xb still holds it)
+    rowtile_gemm(xb, LH, HP / 32, a.rev.wih, a.rev.kih, GL / 16, gi, GL, wave, lane);
+    zero_f(gh, TR * GL, tid);       // W_hh * 0
+    __syncthreads();
+    gru_gates(gi, gh, a.rev.bih, a.rev.bhh, hr, hrb, LH, r0, R, a.gates_r, tid);
+    __syncthreads();
+    for (int idx = tid; idx < TR * H; idx += NTHR) {
+        int row = idx / H, j = idx - row * H;
+        xb[row * LH + j] = (bf16)(hf[row * H + j] + hr[row * H + j]);    // x[:, :H] + x[:, H:]  (model.py:245)
+    }
+    __syncthreads();
+    save_tile(xb, LH, HP, a.hsum_bf, HP, r0, R, tid);
+    const int D2 = 2 * a.D;
+    rowtile_gemm(xb, LH, HP / 32, a.h2p, HP, a.nh2p / 16, gi, GL, wave, lane);
+    __syncthreads();
+    for (int idx = tid; idx < TR * D2; idx += NTHR) {
+        int row = idx / D2, j = idx - row * D2;
+        if (r0 + row < R) a.out[(size_t)(r0 + row) * D2 + j] = gi[row * GL + j] + a.h2p_bias[j];
+    }
+}
+
+// ============================================================== text encoder backward
+__global__ __launch_bounds__(NTHR) void text_encoder_bwd_kernel(const TextEncBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const TextEncArgs& f = a.f;
+    constexpr int LG = GK + 8;                                // 328
+    const int D2 = 2 * f.D, K2 = round_up(D2, 32), LD2 = K2 + 8;
+    float* o1 = reinterpret_cast<float*>(smem);              // [16][128] gemm output
+    float* dh = o1 + TR * HP;                                // [16][100]
+    float* dhd = dh + TR * H;                                // [16][100] direct term dh*z
+    float* demb = dhd + TR * H;                              // [12][100]
+    bf16* dgi = reinterpret_cast<bf16*>(demb + TXT_V * H);   // [16][328]
+    bf16* dgh = dgi + TR * LG;                               // [16][328]
+    bf16* dob = dgh + TR * LG;                               // [16][LD2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = blockIdx.x * TR, R = f.B;
+    zero_bf(dgi, 2 * TR * LG + TR * LD2, tid);
+    zero_f(demb, TXT_V * H, tid);
+    __syncthreads();
+    float bsum = 0.f;      // h2p bias gradient (thread j < 2D)
+    for (int idx = tid; idx < TR * D2; idx += NTHR) {
+        int row = idx / D2, j = idx - row * D2;
+        float v = (r0 + row < R) ? a.d_out[(size_t)(r0 + row) * D2 + j] : 0.f;
+        dob[row * LD2 + j] = (bf16)v;
+        if (a.d_out_bf && r0 + row < R) a.d_out_bf[(size_t)(r0 + row) * round_up(D2, 8) + j] = (bf16)v;
+    }
+    __syncthreads();
+    if (tid < D2) {
+        for (int r = 0; r < TR; ++r) bsum += (float)dob[r * LD2 + tid];
+        atomicAdd(a.g_h2p_bias + tid, bsum);
+    }
+    // d(hf + hr) = d_out * W_h2p
+    rowtile_gemm(dob, LD2, K2 / 32, f.h2pT, K2, 7, o1, HP, wave, lane);
+    __syncthreads();
+    for (int idx = tid; idx < TR * H; idx += NTHR) dh[idx] = o1[(idx / H) * HP + idx % H];
+    __syncthreads();
+    // ---- reverse direction (single step from h=0 on token T-1)
+    float gb[4][2] = {};                  // bih_f, bhh_f, bih_r, bhh_r partial sums (thread owns columns tid, tid+256)
+    gru_gates_bwd(f.gates_r, r0, R, dh, dgi, dgh, LG, dhd, a.dgi_r, nullptr, tid);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+        if (tid + q * NTHR < TXT_G3) { gb[2][q] += colsum16(dgi, LG, tid + q * NTHR); gb[3][q] += colsum16(dgh, LG, tid + q * NTHR); }
+    rowtile_gemm(dgi, LG, GK / 32, f.rev.wihT, GK, 7, o1, HP, wave, lane);
+    __syncthreads();
+    for (int idx = tid; idx < TR * H; idx += NTHR) {
+        int row = idx / H, j = idx - row * H;
+        if (r0 + row < R) atomicAdd(demb + (int)f.tokens[(size_t)(r0 + row) * TXT_T + TXT_T - 1] * H + j, o1[row * HP + j]);
+    }
+    __syncthreads();
+    // ---- forward direction BPTT
+    for (int t = TXT_T - 1; t >= 0; --t) {
+        gru_gates_bwd(f.gates_f + (size_t)t * 5 * R * H, r0, R, dh, dgi, dgh, LG, dhd,
+                      a.dgi_f + (size_t)t * R * GL, a.dgh_f + (size_t)t * R * GL, tid);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (tid + q * NTHR < TXT_G3) { gb[0][q] += colsum16(dgi, LG, tid + q * NTHR); gb[1][q] += colsum16(dgh, LG, tid + q * NTHR); }
+        rowtile_gemm(dgi, LG, GK / 32, f.fwd.wihT, GK, 7, o1, HP, wave, lane);
+        __syncthreads();
+        for (int idx = tid; idx < TR * H; idx += NTHR) {
+            int row = idx / H, j = idx - row * H;
+            if (r0 + row < R) atomicAdd(demb + (int)f.tokens[(size_t)(r0 + row) * TXT_T + t] * H + j, o1[row * HP + j]);
+        }
+        __syncthreads();
+        rowtile_gemm(dgh, LG, GK / 32, f.fwd.whhT, GK, 7, o1, HP, wave, lane);
+        __syncthreads();
+        for (int idx = tid; idx < TR * H; idx += NTHR) dh[idx] = dhd[idx] + o1[(idx / H) * HP + idx % H];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+        if (tid + q * NTHR < TXT_G3) {
+            const int c = tid + q * NTHR;
+            atomicAdd(a.g_bih_f + c, gb[0][q]); atomicAdd(a.g_bhh_f + c, gb[1][q]);
+            atomicAdd(a.g_bih_r + c, gb[2][q]); atomicAdd(a.g_bhh_r + c, gb[3][q]);
+        }
+    for (int idx = tid; idx < TXT_V * H; idx += NTHR)
+        if (demb[idx] != 0.f) atomicAdd(a.g_embed + idx, demb[idx]);
+}
+
+// ============================================================== text decoder forward
+struct DecLds {
+    float *gi, *gh, *h0f, *h1f, *zf, *lg;
+    bf16 *x0b, *zb, *h0b, *midb, *h1b, *hzb;
+    int LX, LZ;
+};
+__device__ __forceinline__ DecLds dec_lds(char* smem, int kx, int kz) {
+    DecLds L;
+    L.LX = kx + 8; L.LZ = kz + 8;
+    L.gi = reinterpret_cast<float*>(smem);
+    L.gh = L.gi + TR * GL;
+    L.h0f = L.gh + TR * GL;
+    L.h1f = L.h0f + TR * H;
+    L.zf = L.h1f + TR * H;               // [16][128]
+    L.lg = L.zf + TR * 128;              // [16][16]
+    L.x0b = reinterpret_cast<bf16*>(L.lg + TR * 16);
+    L.hzb = L.x0b + TR * L.LX;
+    L.zb = L.hzb + TR * L.LX;
+    L.h0b = L.zb + TR * L.LZ;
+    L.midb = L.h0b + TR * (HP + 8);
+    L.h1b = L.midb + TR * (HP + 8);
+    return L;
+}
+inline size_t dec_lds_bytes(int kx, int kz) {
+    return (size_t)(2 * TR * GL + 2 * TR * H + TR * 128 + TR * 16) * 4 +
+           (size_t)(2 * TR * (kx + 8) + TR * (kz + 8) + 3 * TR * (HP + 8)) * 2;
+}
+
+__global__ __launch_bounds__(NTHR) void text_decoder_fwd_kernel(const TextDecArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int ctok[TR];
+    DecLds L = dec_lds(smem, a.kx, a.kz);
+    constexpr int LH = HP + 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = blockIdx.x * TR, R = a.R, D = a.D;
+    zero_bf(L.x0b, 2 * TR * L.LX + TR * L.LZ + 3 * TR * LH, tid);
+    if (tid < TR) ctok[tid] = 10;     // SOS (multimnist/utils.py:17)
+    __syncthreads();
+    for (int idx = tid; idx < TR * D; idx += NTHR) {
+        int row = idx / D, j = idx - row * D;
+        float z = (r0 + row < R) ? a.z[(size_t)(r0 + row) * D + j] : 0.f;
+        L.zf[row * 128 + j] = z;
+        bf16 zb = (bf16)z;
+        L.zb[row * L.LZ + j] = zb;
+        L.x0b[row * L.LX + H + j] = zb;
+        L.hzb[row * L.LX + H + j] = zb;
+    }
+    __syncthreads();
+    save_tile(L.zb, L.LZ, a.kz, a.z_bf, a.kz, r0, R, tid);
+    // h = z2h(z) replicated into both layers (model.py:280)
+    rowtile_gemm(L.zb, L.LZ, a.kz / 32, a.z2h, a.kz, 7, L.gi, GL, wave, lane);
+    __syncthreads();
+    for (int idx = tid; idx < TR * H; idx += NTHR) {
+        int row = idx / H, j = idx - row * H;
+        float h = L.gi[row * GL + j] + a.z2h_bias[j];
+        L.h0f[idx] = h; L.h1f[idx] = h;
+        L.h0b[row * LH + j] = (bf16)h; L.h1b[row * LH + j] = (bf16)h;
+    }
+    __syncthreads();
+    float nll[4] = {0.f, 0.f, 0.f, 0.f};
+    const size_t pl128 = (size_t)R * HP, plx = (size_t)R * a.kx;
+    for (int i = 0; i < TXT_T; ++i) {
+        // c_in = swish(embed(c_in)) ; x0 = [c_in | z]   (model.py:299-300)
+        for (int idx = tid; idx < TR * H; idx += NTHR) {
+            int row = idx / H, j = idx - row * H;
+            float e = a.embed[ctok[row] * H + j];
+            L.x0b[row * L.LX + j] = (bf16)(e / (1.0f + expf(-e)));
+        }
+        __syncthreads();
+        save_tile(L.x0b, L.LX, a.kx, a.x0_bf ? a.x0_bf + i * plx : nullptr, a.kx, r0, R, tid);
+        save_tile(L.h0b, LH, HP, a.h0p_bf ? a.h0p_bf + i * pl128 : nullptr, HP, r0, R, tid);
+        save_tile(L.h1b, LH, HP, a.h1p_bf ? a.h1p_bf + i * pl128 : nullptr, HP, r0, R, tid);
+        rowtile_gemm(L.x0b, L.LX, a.kx / 32, a.l0.wih, a.l0.kih, GL / 16, L.gi, GL, wave, lane);
+        rowtile_gemm(L.h0b, LH, HP / 32, a.l0.whh, HP, GL / 16, L.gh, GL, wave, lane);
+        __syncthreads();
+        gru_gates(L.gi, L.gh, a.l0.bih, a.l0.bhh, L.h0f, L.h0b, LH, r0, R,
+                  a.gates ? a.gates + (size_t)(i * 2 + 0) * 5 * R * H : nullptr, tid);
+        __syncthreads();
+        // inter-layer dropout (nn.GRU dropout=0.1, train only)
+        for (int idx = tid; idx < TR * H; idx += NTHR) {
+            int row = idx / H, j = idx - row * H;
+            float v = L.h0f[idx];
+            if (a.keep && r0 + row < R) v = a.keep[((size_t)i * R + r0 + row) * H + j] ? v * a.keep_scale : 0.f;
+            L.midb[row * LH + j] = (bf16)v;
+        }
+        __syncthreads();
+        save_tile(L.midb, LH, HP, a.mid_bf ? a.mid_bf + i * pl128 : nullptr, HP, r0, R, tid);
+        rowtile_gemm(L.midb, LH, HP / 32, a.l1.wih, a.l1.kih, GL / 16, L.gi, GL, wave, lane);
+        rowtile_gemm(L.h1b, LH, HP / 32, a.l1.whh, HP, GL / 16, L.gh, GL, wave, lane);
+        __syncthreads();
+        gru_gates(L.gi, L.gh, a.l1.bih, a.l1.bhh, L.h1f, L.h1b, LH, r0, R,
+                  a.gates ? a.gates + (size_t)(i * 2 + 1) * 5 * R * H : nullptr, tid);
+        __syncthreads();
+        for (int idx = tid; idx < TR * H; idx += NTHR) {
+            int row = idx / H, j = idx - row * H;
+            L.hzb[row * L.LX + j] = L.h1b[row * LH + j];
+        }
+        __syncthreads();
+        save_tile(L.hzb, L.LX, a.kx, a.hz_bf ? a.hz_bf + i * plx : nullptr, a.kx, r0, R, tid);
+        rowtile_gemm(L.hzb, L.LX, a.kx / 32, a.h2o, a.kx, 1, L.lg, 16, wave, lane);
+        __syncthreads();
+        if (tid < TR) {
+            const int row = tid;
+            float v[TXT_V], mx = -INFINITY;
+            for (int c = 0; c < TXT_V; ++c) { v[c] = L.lg[row * 16 + c] + a.h2o_bias[c]; mx = fmaxf(mx, v[c]); }
+            float se = 0.f;
+            for (int c = 0; c < TXT_V; ++c) se += expf(v[c] - mx);
+            const float lse = mx + logf(se);
+            int best = 0; float bv = -INFINITY;
+            for (int c = 0; c < TXT_V; ++c) { v[c] -= lse; if (v[c] > bv) { bv = v[c]; best = c; } }   // first max, like torch.max
+            if (r0 + row < R) {
+                const size_t o = ((size_t)(r0 + row) * TXT_T + i) * TXT_V;
+                for (int c = 0; c < TXT_V; ++c) a.words[o + c] = v[c];
+                if (a.tokens_out) a.tokens_out[(size_t)(r0 + row) * TXT_T + i] = best;
+                if (a.target) {
+                    const int pass = (r0 + row) / a.rows_per_pass, b = (r0 + row) - pass * a.rows_per_pass;
+                    const int tg = (int)a.target[(size_t)b * TXT_T + i];
+                    float vt = 0.f;
+#pragma unroll
+                    for (int c = 0; c < TXT_V; ++c) vt = (c == tg) ? v[c] : vt;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) nll[p] += (p == (pass & 3)) ? -vt : 0.f;
+                    if (a.dwords)
+                        for (int c = 0; c < TXT_V; ++c) a.dwords[o + c] = (c == tg) ? -a.nll_coef[pass & 3] : 0.f;
+                }
+                ctok[row] = a.force_tokens ? (int)a.force_tokens[(size_t)(r0 + row) * TXT_T + i] : best;
+            }
+        }
+        __syncthreads();
+    }
+    if (a.target && a.nll_sum && tid < TR) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            if (nll[p] != 0.f) atomicAdd(a.nll_sum + p, nll[p]);
+    }
+}
+
+// ============================================================== text decoder backward
+__global__ __launch_bounds__(NTHR) void text_decoder_bwd_kernel(const TextDecBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const TextDecArgs& f = a.f;
+    constexpr int LG = GK + 8, LO = 256;
+    float* o1 = reinterpret_cast<float*>(smem);              // [16][256] gemm output
+    float* dh0 = o1 + TR * LO;                               // [16][100] grad wrt layer-0 state
+    float* dh1 = dh0 + TR * H;                               // [16][100]
+    float* dhd = dh1 + TR * H;                               // [16][100]
+    float* dzacc = dhd + TR * H;                             // [16][128]
+    float* demb = dzacc + TR * 128;                          // [12][100]
+    bf16* dgi = reinterpret_cast<bf16*>(demb + TXT_V * H);   // [16][328]
+    bf16* dgh = dgi + TR * LG;                               // [16][328]
+    bf16* dlg = dgh + TR * LG;                               // [16][40]
+    bf16* dhb = dlg + TR * 40;                               // [16][136]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = blockIdx.x * TR, R = f.R, D = f.D, XI = H + D;
+    const int nxt = round_up(XI, 16) / 16, ndt = round_up(D, 16) / 16;
+    zero_bf(dgi, 2 * TR * LG + TR * 40 + TR * 136, tid);
+    zero_f(dh0, 3 * TR * H + TR * 128 + TXT_V * H, tid);
+    __syncthreads();
+    float gb[4][2] = {};
+    float gho = 0.f;
+    for (int i = TXT_T - 1; i >= 0; --i) {
+        // dlogit = dlp - softmax * sum(dlp)   (log_softmax backward)
+        if (tid < TR) {
+            const int row = tid;
+            float d[TXT_V], s = 0.f;
+            const bool ok = r0 + row < R && r0 + row < a.R_active;
+            const size_t o = ((size_t)(r0 + row) * TXT_T + i) * TXT_V;
+            for (int c = 0; c < TXT_V; ++c) { d[c] = ok ? a.dwords[o + c] : 0.f; s += d[c]; }
+            for (int c = 0; c < TXT_V; ++c) {
+                float v = ok ? d[c] - expf(f.words[o + c]) * s : 0.f;
+                dlg[row * 40 + c] = (bf16)v;
+                if (r0 + row < R) a.dlogit_bf[((size_t)i * R + r0 + row) * 16 + c] = (bf16)v;
+            }
+            if (r0 + row < R)
+                for (int c = TXT_V; c < 16; ++c) a.dlogit_bf[((size_t)i * R + r0 + row) * 16 + c] = (bf16)0.f;
+        }
+        __syncthreads();
+        if (tid < TXT_V) gho += colsum16(dlg, 40, tid);
+        // d[h1 | z] = dlogit * W_h2o
+        rowtile_gemm(dlg, 40, 1, f.h2oT, 32, nxt, o1, LO, wave, lane);
+        __syncthreads();
+        for (int idx = tid; idx < TR * XI; idx += NTHR) {
+            int row = idx / XI, j = idx - row * XI;
+            if (j < H) dh1[row * H + j] += o1[row * LO + j];
+            else dzacc[row * 128 + j - H] += o1[row * LO + j];
+        }
+        __syncthreads();
+        // ---- layer 1
+        gru_gates_bwd(f.gates + (size_t)(i * 2 + 1) * 5 * R * H, r0, R, dh1, dgi, dgh, LG, dhd,
+                      a.dgi1 + (size_t)i * R * GL, a.dgh1 + (size_t)i * R * GL, tid);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (tid + q * NTHR < TXT_G3) { gb[2][q] += colsum16(dgi, LG, tid + q * NTHR); gb[3][q] += colsum16(dgh, LG, tid + q * NTHR); }
+        rowtile_gemm(dgh, LG, GK / 32, f.l1.whhT, GK, 7, o1, LO, wave, lane);
+        __syncthreads();
+        for (int idx = tid; idx < TR * H; idx += NTHR) dh1[idx] = dhd[idx] + o1[(idx / H) * LO + idx % H];
+        __syncthreads();
+        rowtile_gemm(dgi, LG, GK / 32, f.l1.wihT, GK, 7, o1, LO, wave, lane);     // d mid
+        __syncthreads();
+        for (int idx = tid; idx < TR * H; idx += NTHR) {
+            int row = idx / H, j = idx - row * H;
+            float v = o1[row * LO + j];
+            if (f.keep && r0 + row < R) v = f.keep[((size_t)i * R + r0 + row) * H + j] ? v * f.keep_scale : 0.f;
+            dh0[idx] += v;
+        }
+        __syncthreads();
+        // ---- layer 0
+        gru_gates_bwd(f.gates + (size_t)(i * 2 + 0) * 5 * R * H, r0, R, dh0, dgi, dgh, LG, dhd,
+                      a.dgi0 + (size_t)i * R * GL, a.dgh0 + (size_t)i * R * GL, tid);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (tid + q * NTHR < TXT_G3) { gb[0][q] += colsum16(dgi, LG, tid + q * NTHR); gb[1][q] += colsum16(dgh, LG, tid + q * NTHR); }
+        rowtile_gemm(dgh, LG, GK / 32, f.l0.whhT, GK, 7, o1, LO, wave, lane);
+        __syncthreads();
+        for (int idx = tid; idx < TR * H; idx += NTHR) dh0[idx] = dhd[idx] + o1[(idx / H) * LO + idx % H];
+        __syncthreads();
+        rowtile_gemm(dgi, LG, GK / 32, f.l0.wihT, GK, nxt, o1, LO, wave, lane);   // d[x_embed | z]
+        __syncthreads();
+        for (int idx = tid; idx < TR * XI; idx += NTHR) {
+            int row = idx / XI, j = idx - row * XI;
+            if (r0 + row >= R) continue;
+            if (j < H) {
+                // input token of step i: SOS for i == 0, else the fed-back token of step i-1
+                int tok = 10;
+                if (i > 0) tok = f.force_tokens ? (int)f.force_tokens[(size_t)(r0 + row) * TXT_T + i - 1]
+                                                : (int)f.tokens_out[(size_t)(r0 + row) * TXT_T + i - 1];
+                float e = f.embed[tok * H + j];
+                float sg = 1.0f / (1.0f + expf(-e));
+                atomicAdd(demb + tok * H + j, o1[row * LO + j] * sg * (1.0f + e * (1.0f - sg)));
+            } else {
+                dzacc[row * 128 + j - H] += o1[row * LO + j];
+            }
+        }
+        __syncthreads();
+    }
+    // initial hidden state of both layers = z2h(z)
+    for (int idx = tid; idx < TR * H; idx += NTHR) {
+        int row = idx / H, j = idx - row * H;
+        float v = dh0[idx] + dh1[idx];
+        dhb[row * 136 + j] = (bf16)v;
+        if (r0 + row < R) a.dhinit_bf[(size_t)(r0 + row) * 112 + j] = (bf16)v;
+    }
+    __syncthreads();
+    if (tid < H) atomicAdd(a.g_z2h_bias + tid, colsum16(dhb, 136, tid));
+    rowtile_gemm(dhb, 136, HP / 32, f.z2hT, HP, ndt, o1, LO, wave, lane);
+    __syncthreads();
+    for (int idx = tid; idx < TR * D; idx += NTHR) {
+        int row = idx / D, j = idx - row * D;
+        if (r0 + row < R) a.dz[(size_t)(r0 + row) * D + j] = dzacc[row * 128 + j] + o1[row * LO + j];
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+        if (tid + q * NTHR < TXT_G3) {
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) atomicAdd(a.g_b[k4] + tid + q * NTHR, gb[k4][q]);
+        }
+    if (tid < TXT_V) atomicAdd(a.g_h2o_bias + tid, gho);
+    for (int idx = tid; idx < TXT_V * H; idx += NTHR)
+        if (demb[idx] != 0.f) atomicAdd(a.g_embed + idx, demb[idx]);
+}
+
+template <typename K>
+void set_lds_attr(K kernel) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+}
+
+}  // namespace
+
+int launch_text_encoder_fwd(const TextEncArgs& a, hipStream_t s) {
+    MMVAE_REQUIRE(a.B >= 1 && 2 * a.D <= 256 && a.nh2p % 16 == 0, "text encoder: B=%d D=%d", a.B, a.D);
+    size_t lds = (size_t)(2 * TR * GL + 2 * TR * H) * 4 + (size_t)3 * TR * (HP + 8) * 2;
+    static bool once = false;
+    if (!once) { set_lds_attr(text_encoder_fwd_kernel); once = true; }
+    hipLaunchKernelGGL(text_encoder_fwd_kernel, dim3(ceil_div(a.B, TR)), dim3(NTHR), lds, s, a);
+    return mmvae_check_launch("text_encoder_fwd");
+}
+int launch_text_encoder_bwd(const TextEncBwdArgs& a, hipStream_t s) {
+    const int K2 = round_up(2 * a.f.D, 32);
+    size_t lds = (size_t)(TR * HP + 2 * TR * H + TXT_V * H) * 4 + (size_t)(2 * TR * (GK + 8) + TR * (K2 + 8)) * 2;
+    static bool once = false;
+    if (!once) { set_lds_attr(text_encoder_bwd_kernel); once = true; }
+    hipLaunchKernelGGL(text_encoder_bwd_kernel, dim3(ceil_div(a.f.B, TR)), dim3(NTHR), lds, s, a);
+    return mmvae_check_launch("text_encoder_bwd");
+}
+int launch_text_decoder_fwd(const TextDecArgs& a, hipStream_t s) {
+    MMVAE_REQUIRE(a.R >= 1 && a.D >= 1 && a.D <= 128 && a.kx == round_up(H + a.D, 32) && a.kz == round_up(a.D, 32) && a.kx <= 256,
+                  "text decoder: R=%d D=%d kx=%d kz=%d", a.R, a.D, a.kx, a.kz);
+    static bool once = false;
+    if (!once) { set_lds_attr(text_decoder_fwd_kernel); once = true; }
+    hipLaunchKernelGGL(text_decoder_fwd_kernel, dim3(ceil_div(a.R, TR)), dim3(NTHR), dec_lds_bytes(a.kx, a.kz), s, a);
+    return mmvae_check_launch("text_decoder_fwd");
+}
+int launch_text_decoder_bwd(const TextDecBwdArgs& a, hipStream_t s) {
+    MMVAE_REQUIRE(a.f.tokens_out != nullptr || a.f.force_tokens != nullptr, "text decoder bwd needs the token path");
+    size_t lds = (size_t)(TR * 256 + 3 * TR * H + TR * 128 + TXT_V * H) * 4 + (size_t)(2 * TR * (GK + 8) + TR * 40 + TR * 136) * 2;
+    static bool once = false;
+    if (!once) { set_lds_attr(text_decoder_bwd_kernel); once = true; }
+    hipLaunchKernelGGL(text_decoder_bwd_kernel, dim3(ceil_div(a.f.R, TR)), dim3(NTHR), lds, s, a);
+    return mmvae_check_launch("text_decoder_bwd");
+}

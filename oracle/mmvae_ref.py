@@ -495,30 +495,42 @@ def bn_layers(model: str, D: int) -> List[Tuple[str, int]]:
     return out
 
 
+def _hash_uniform(n: int, salt: int) -> Tensor:
+    """Exact-integer hash -> uniform(-1, 1) float64 (bitwise reproducible on every machine, no RNG state)."""
+    x = (torch.arange(n, dtype=torch.int64) * 2654435761 + salt * 40503 + 12345) & 0xFFFFFFFF
+    x = (x ^ (x >> 15)) * 2246822519 & 0xFFFFFFFF
+    x = (x ^ (x >> 13)) * 3266489917 & 0xFFFFFFFF
+    x = x ^ (x >> 16)
+    return (x.to(torch.float64) + 0.5) / 2147483648.0 - 1.0
+
+
 def formula_params(model: str, D: int, requires_grad: bool = False) -> Params:
-    """Closed-form, RNG-free initialisation shared by the golden generator, the
-    oracle and the HIP tests:  w_k[i] = s_k * sin(0.37*i + k) with
-    s_k = 1/sqrt(fan_in); BN weight 1 + 0.1*sin(.), BN/Linear bias 0.05*sin(.);
-    embeddings 0.5*sin(.).  Fresh BN buffers (mean 0, var 1, count 0)."""
+    """RNG-free initialisation shared by the golden generator, the oracle and the HIP tests.  It mimics the
+    reference's default PyTorch init in distribution (Linear/Conv/GRU: U(+-1/sqrt(fan_in)), Embedding ~unit
+    scale, BN weight near 1) but comes from an exact integer hash, so both sides regenerate identical tensors.
+    Fresh BN buffers (mean 0, var 1, count 0)."""
     p: Params = {}
     bn = dict(bn_layers(model, D))
     for k, (name, shape) in enumerate(param_table(model, D)):
-        n = int(torch.tensor(shape).prod())
-        i = torch.arange(n, dtype=torch.float64)
-        base = torch.sin(0.37 * i + k)
+        n = 1
+        for s_ in shape:
+            n *= s_
+        u = _hash_uniform(n, k + 1)
         prefix = name.rsplit(".", 1)[0]
         if prefix in bn and len(shape) == 1:
-            v = 1.0 + 0.1 * base if name.endswith(".weight") else 0.05 * base
+            v = 1.0 + 0.1 * u if name.endswith(".weight") else 0.1 * u
         elif "embed" in name or (model == "mnist" and name == "text_encoder.net.0.weight"):
-            v = 0.5 * base
+            v = 1.7 * u                                          # ~unit variance like N(0,1)
+        elif "gru" in name:
+            v = u * 0.1                                          # U(+-1/sqrt(hidden=100))
         elif len(shape) == 1:
-            v = 0.05 * base
+            v = 0.05 * u
         else:
-            if len(shape) == 4 and "hallucinate" in name:      # ConvTranspose (Cin, Cout, kh, kw)
-                fan_in = shape[0] * shape[2] * shape[3] / 4.0   # ~taps that hit one output pixel at stride 2
+            if len(shape) == 4 and "hallucinate" in name:       # ConvTranspose (Cin, Cout, kh, kw): fan_in = Cout*kh*kw
+                fan_in = shape[1] * shape[2] * shape[3]
             else:
                 fan_in = n // shape[0]
-            v = base * (1.7 / math.sqrt(fan_in))
+            v = u / math.sqrt(fan_in)
         p[name] = v.to(torch.float32).reshape(shape).clone().requires_grad_(requires_grad)
     for prefix, c in bn.items():
         p[prefix + ".running_mean"] = torch.zeros(c)
