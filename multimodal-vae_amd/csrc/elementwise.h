@@ -42,6 +42,18 @@ struct BnFinalizeArgs {
 };
 int launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s);
 
+// Fused BatchNorm finalize + normalise + activation: a = act(gamma*(r-mean)*rstd+beta) materialised ONCE per layer
+// (the GEMM operand staging is then a pure copy).  Also emits the per-(group,channel) tables backward needs and
+// updates the running statistics.  In eval mode the statistics come from the running buffers.
+struct BnActArgs {
+    const bf16* r;           // [rows][ld] raw conv/linear output
+    bf16* a;                 // [rows][ld] activated output
+    int rows, C, ld, rows_per_group, G;
+    int act;
+    BnFinalizeArgs fin;      // stats, gamma/beta, running buffers, tables (count = elements per channel per group)
+};
+int launch_bn_act(const BnActArgs& a, hipStream_t s);
+
 struct BnBwdApplyArgs {
     const bf16* db;          // [rows][ld] grad wrt BN output (after d-activation)
     const bf16* db2;         // optional second contribution for the same rows (encoder features shared by 2 passes)

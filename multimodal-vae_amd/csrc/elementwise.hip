@@ -133,6 +133,68 @@ __global__ void bn_finalize_kernel(const BnFinalizeArgs a) {
     if (c == 0 && a.num_batches_tracked) *a.num_batches_tracked += (long long)a.G * a.updates_per_group;
 }
 
+// ------------------------------------------------------------------ BatchNorm finalize + normalise + activation
+__device__ __forceinline__ void bn_channel_tables(const BnFinalizeArgs& a, int g, int c, float2& aff, float2& mr) {
+    const float gamma = a.gamma[c], beta = a.beta[c];
+    float mean, rstd;
+    if (a.training) {
+        float2 s = a.stats[g * a.C + c];
+        mean = s.x / a.count;
+        float var = fmaxf(s.y / a.count - mean * mean, 0.f);
+        rstd = rsqrtf(var + a.eps);
+    } else {
+        mean = a.running_mean[c];
+        rstd = rsqrtf(a.running_var[c] + a.eps);
+    }
+    aff = make_float2(gamma * rstd, beta - mean * gamma * rstd);
+    mr = make_float2(mean, rstd);
+}
+
+__global__ __launch_bounds__(TPB) void bn_act_kernel(const BnActArgs a) {
+    extern __shared__ float2 aff_s[];        // [G][C]
+    const BnFinalizeArgs& f = a.fin;
+    for (int i = threadIdx.x; i < a.G * a.C; i += TPB) {
+        float2 aff, mr;
+        bn_channel_tables(f, i / a.C, i % a.C, aff, mr);
+        aff_s[i] = aff;
+        if (blockIdx.x == 0) { f.affine[i] = aff; f.meanrstd[i] = mr; }
+    }
+    if (blockIdx.x == 0 && f.training && f.running_mean) {
+        // running statistics: momentum update once per forward call, groups in pass order
+        for (int c = threadIdx.x; c < a.C; c += TPB) {
+            float rm = f.running_mean[c], rv = f.running_var[c];
+            for (int g = 0; g < a.G; ++g) {
+                float2 s = f.stats[g * a.C + c];
+                float mean = s.x / f.count;
+                float var = fmaxf(s.y / f.count - mean * mean, 0.f);
+                float unbiased = var * f.count / (f.count - 1.f);
+                for (int u = 0; u < f.updates_per_group; ++u) {
+                    rm = (1.f - f.momentum) * rm + f.momentum * mean;
+                    rv = (1.f - f.momentum) * rv + f.momentum * unbiased;
+                }
+            }
+            f.running_mean[c] = rm; f.running_var[c] = rv;
+        }
+        if (threadIdx.x == 0 && f.num_batches_tracked) *f.num_batches_tracked += (long long)a.G * f.updates_per_group;
+    }
+    __syncthreads();
+    const int vpr = a.C / 8;
+    const long long nvec = (long long)a.rows * vpr;
+    for (long long v = (long long)blockIdx.x * TPB + threadIdx.x; v < nvec; v += (long long)gridDim.x * TPB) {
+        const long long row = v / vpr;
+        const int c0 = (int)(v - row * vpr) * 8;
+        const int g = (int)(row / a.rows_per_group);
+        bf16x8 rv = *reinterpret_cast<const bf16x8*>(a.r + row * a.ld + c0);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float2 af = aff_s[g * a.C + c0 + j];
+            o[j] = (bf16)act_fwd(a.act, (float)rv[j] * af.x + af.y);
+        }
+        *reinterpret_cast<bf16x8*>(a.a + row * a.ld + c0) = o;
+    }
+}
+
 // ------------------------------------------------------------------ BatchNorm backward apply
 __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const BnBwdApplyArgs a) {
     const int vpr = a.C / 8;
@@ -499,6 +561,13 @@ int launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s) {
     MMVAE_REQUIRE(!a.training || a.count > 1.f, "Expected more than 1 value per channel when training");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(a.C, 64)), dim3(64), 0, s, a);
     return mmvae_check_launch("bn_finalize");
+}
+int launch_bn_act(const BnActArgs& a, hipStream_t s) {
+    MMVAE_REQUIRE(a.C % 8 == 0 && a.ld % 8 == 0 && a.G * a.C <= 4096, "bn_act: C=%d ld=%d G=%d", a.C, a.ld, a.G);
+    MMVAE_REQUIRE(!a.fin.training || a.fin.count > 1.f, "Expected more than 1 value per channel when training");
+    hipLaunchKernelGGL(bn_act_kernel, dim3(nblocks((long long)a.rows * a.C / 8, TPB, 2048)), dim3(TPB),
+                       (size_t)a.G * a.C * sizeof(float2), s, a);
+    return mmvae_check_launch("bn_act");
 }
 int launch_bn_bwd_apply(const BnBwdApplyArgs& a, hipStream_t s) {
     MMVAE_REQUIRE(a.C % 8 == 0 && a.ld % 8 == 0, "bn_bwd_apply: C=%d ld=%d", a.C, a.ld);

@@ -45,6 +45,10 @@ struct GemmParams {
     bf16* out_bf;           // [Nimg][OH][OW][ldo] or null
     float* out_f;           // same geometry, fp32, or null
     int ldo;
+    bf16* out_act_bf;       // optional second output act(v) [* keep*scale]: the next layer's operand (no BN in between)
+    int e_act;
+    const uint8_t* e_mask;  // [rows][N] keep flags or null
+    float e_mask_scale;
     float2* colstats;       // [groups][N] += (sum v, sum v^2) or null
     // d-activation epilogue: v *= act'(affine(r)) [* keep*scale], r has the output geometry (ld = d_ld)
     const bf16* d_r;

@@ -229,6 +229,11 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(const GemmParams p) {
                 if (want_stats) { s1[nt] += v; s2[nt] += v * v; }
                 if (p.out_bf) p.out_bf[opix * p.ldo + col] = (bf16)v;
                 if (p.out_f) p.out_f[opix * p.ldo + col] = v;
+                if (p.out_act_bf) {
+                    float av = act_fwd(p.e_act, v);
+                    if (p.e_mask) av = p.e_mask[growi * c.N + col] ? av * p.e_mask_scale : 0.f;
+                    p.out_act_bf[opix * p.ldo + col] = (bf16)av;
+                }
             }
         }
     }

@@ -2,6 +2,7 @@
 // Reference: multimnist/model.py:21-93 (MultimodalVAE), :150-216 (image enc/dec), :219-307 (text enc/dec),
 //            multimnist/train.py:69-87 (loss_function), :146-173 (3-pass step).
 #include "multimnist.h"
+#include "thin.h"
 #include <map>
 #include <cstring>
 
@@ -47,6 +48,7 @@ struct MMPlan {
         float* sums; float* dz_img; float* dz_txt;
         float2 *aff_e[3], *mr_e[3], *aff_d[3], *mr_d[3];
         bf16 *patches1, *r1, *r2, *r3, *r4, *y1, *y2;
+        bf16 *a1, *a2, *a3, *a4, *ay1, *ay2, *au, *aq1, *aq2, *aq3;
         float* encout; uint8_t *m1, *m2, *gkeep;
         float *txtout, *te_gates_f, *te_gates_r; bf16 *te_x, *te_hprev, *te_hsum;
         float *eps, *mu, *logvar, *z_f32; bf16* z_bf;
@@ -290,6 +292,10 @@ void carve(MMPlan& P, Workspace& ws) {
     w.r1 = ws.take<bf16>(B * 625 * 32); w.r2 = ws.take<bf16>(B * 144 * 64); w.r3 = ws.take<bf16>(B * 36 * 128);
     w.r4 = ws.take<bf16>(B * 4 * 256);
     w.y1 = ws.take<bf16>(B2 * 400); w.y2 = ws.take<bf16>(B2 * 200);
+    w.a1 = ws.take<bf16>(B * 625 * 32); w.a2 = ws.take<bf16>(B * 144 * 64); w.a3 = ws.take<bf16>(B * 36 * 128);
+    w.a4 = ws.take<bf16>(B * 4 * 256); w.ay1 = ws.take<bf16>(B2 * 400); w.ay2 = ws.take<bf16>(B2 * 200);
+    w.au = ws.take<bf16>(B3 * 1024); w.aq1 = ws.take<bf16>(B3 * 36 * 128); w.aq2 = ws.take<bf16>(B3 * 144 * 64);
+    w.aq3 = ws.take<bf16>(B3 * 625 * 32);
     w.encout = ws.take<float>(B2 * 2 * D);
     w.m1 = ws.take<uint8_t>(B2 * 400); w.m2 = ws.take<uint8_t>(B2 * 200); w.gkeep = ws.take<uint8_t>(4 * B3 * 100);
     w.txtout = ws.take<float>(B * 2 * D);
@@ -350,62 +356,69 @@ WgradParams wgrad_of(const MMPlan& P, const GatherPlan& pl, const int* gk, int g
 }
 GatherPlan dense_plan(int rows, int C, int ld, int N) { return plan_dense(rows, C, ld, N); }
 
-int bn_fin(MMPlan& P, const BnL& b, const float2* stats, int G, float count, int updates, float2* aff, float2* mr, int training, hipStream_t s) {
-    BnFinalizeArgs a{};
-    a.stats = stats; a.G = G; a.C = b.C; a.count = count;
-    a.gamma = P.buf.params + b.w_off; a.beta = P.buf.params + b.b_off;
-    a.running_mean = P.buf.bn_stats + b.stat_off; a.running_var = P.buf.bn_stats + b.stat_off + b.C;
-    a.num_batches_tracked = P.buf.bn_nbt + b.idx;
-    a.updates_per_group = updates; a.affine = aff; a.meanrstd = mr; a.eps = BN_EPS; a.momentum = BN_MOM; a.training = training;
-    return launch_bn_finalize(a, s);
+int bn_act(MMPlan& P, const BnL& b, const bf16* r, bf16* a, int rows, int rows_per_group, int G, const float2* stats,
+           int updates, float2* aff, float2* mr, int training, hipStream_t s) {
+    BnActArgs x{};
+    x.r = r; x.a = a; x.rows = rows; x.C = b.C; x.ld = b.C; x.rows_per_group = rows_per_group; x.G = G; x.act = ACT_SWISH;
+    BnFinalizeArgs& f = x.fin;
+    f.stats = stats; f.G = G; f.C = b.C; f.count = (float)rows_per_group;
+    f.gamma = P.buf.params + b.w_off; f.beta = P.buf.params + b.b_off;
+    f.running_mean = P.buf.bn_stats + b.stat_off; f.running_var = P.buf.bn_stats + b.stat_off + b.C;
+    f.num_batches_tracked = P.buf.bn_nbt + b.idx;
+    f.updates_per_group = updates; f.affine = aff; f.meanrstd = mr; f.eps = BN_EPS; f.momentum = BN_MOM; f.training = training;
+    return launch_bn_act(x, s);
 }
 
 // ================================================================== image encoder
 // convs once on B images; classifier on variants*B rows (different dropout masks): multimnist/model.py:183-188
+// Every layer output is kept twice: raw (r*, y*: backward needs the pre-activation) and activated (a*: the next
+// GEMM's operand, staged by pure copies).
 int enc_fwd(MMPlan& P, const float* image, int variants, const uint8_t* m1, const uint8_t* m2, int dropout, int training,
             int bn_updates, float* out, hipStream_t s) {
     MMPlan::W& w = P.w;
     const int B = P.B;
     MMVAE_TRY(launch_im2col_small(image, B, 1, IMG, IMG, 4, 4, 2, 1, 25, 25, w.patches1, 16, s));
-    {   // conv1 (+Swish applied by consumers)
+    {   // conv1 + Swish (no BatchNorm): the epilogue emits raw and activated
         GatherPlan pl = dense_plan(B * 625, 16, 16, 32);
         GemmParams g = gemm_of(P, pl, P.conv[0].pk_fwd, 1, B * 625);
-        g.c.A = w.patches1; g.out_bf = w.r1; g.ldo = 32;
+        g.c.A = w.patches1; g.out_bf = w.r1; g.ldo = 32; g.out_act_bf = w.a1; g.e_act = ACT_SWISH;
         MMVAE_TRY(launch_gemm_gather(g, s));
     }
     bf16* r[4] = {w.r1, w.r2, w.r3, w.r4};
+    bf16* a[4] = {w.a1, w.a2, w.a3, w.a4};
     for (int l = 1; l < 4; ++l) {
         const ConvL& L = P.conv[l];
         GemmParams g = gemm_of(P, L.fwd, L.pk_fwd, 1, B);
-        g.c.A = r[l - 1]; g.c.a_act = ACT_SWISH;
-        g.c.a_affine = l > 1 ? w.aff_e[l - 2] : nullptr;
+        g.c.A = a[l - 1];
         g.out_bf = r[l]; g.ldo = L.g.Cout;
         g.colstats = training ? w.st_e[l - 1] : nullptr;
         MMVAE_TRY(launch_gemm_gather(g, s));
-        MMVAE_TRY(bn_fin(P, P.bn[L.bn], w.st_e[l - 1], 1, (float)(B * L.g.OH * L.g.OW), bn_updates, w.aff_e[l - 1], w.mr_e[l - 1], training, s));
+        const int rows = B * L.g.OH * L.g.OW;
+        MMVAE_TRY(bn_act(P, P.bn[L.bn], r[l], a[l], rows, rows, 1, w.st_e[l - 1], bn_updates, w.aff_e[l - 1], w.mr_e[l - 1], training, s));
     }
     const int rows = variants * B;
     const bool drop = training && dropout;
-    {   // fc1 over the NHWC 2x2x256 map
+    const float ms = 1.f / (1.f - DROP_P);
+    {   // fc1 over the NHWC 2x2x256 map (shared by the variants)
         GatherPlan pl = plan_fwdform(2, 2, 1, 1, 256, 2, 2, 1, 0, 400, 1, rows);
         GemmParams g = gemm_of(P, pl, &P.fc[0].pk_fwd, 1, rows);
-        g.c.A = w.r4; g.c.a_act = ACT_SWISH; g.c.a_affine = w.aff_e[2]; g.c.a_bcast_n = B;
+        g.c.A = w.a4; g.c.a_bcast_n = B;
         g.bias = P.buf.params + P.fc[0].b_off; g.out_bf = w.y1; g.ldo = 400;
+        g.out_act_bf = w.ay1; g.e_act = ACT_SWISH; if (drop) { g.e_mask = m1; g.e_mask_scale = ms; }
         MMVAE_TRY(launch_gemm_gather(g, s));
     }
     {
         GatherPlan pl = dense_plan(rows, 400, 400, 200);
         GemmParams g = gemm_of(P, pl, &P.fc[1].pk_fwd, 1, rows);
-        g.c.A = w.y1; g.c.a_act = ACT_SWISH;
-        if (drop) { g.c.a_mask = m1; g.c.a_mask_scale = 1.f / (1.f - DROP_P); }
+        g.c.A = w.ay1;
         g.bias = P.buf.params + P.fc[1].b_off; g.out_bf = w.y2; g.ldo = 200;
+        g.out_act_bf = w.ay2; g.e_act = ACT_SWISH; if (drop) { g.e_mask = m2; g.e_mask_scale = ms; }
         MMVAE_TRY(launch_gemm_gather(g, s));
     }
     {
         GatherPlan pl = dense_plan(rows, 200, 200, 2 * P.D);
         GemmParams g = gemm_of(P, pl, &P.fc[2].pk_fwd, 1, rows);
-        g.c.A = w.y2; g.c.a_act = ACT_SWISH;
-        if (drop) { g.c.a_mask = m2; g.c.a_mask_scale = 1.f / (1.f - DROP_P); }
+        g.c.A = w.ay2;
         g.bias = P.buf.params + P.fc[2].b_off; g.out_f = out; g.ldo = 2 * P.D;
         MMVAE_TRY(launch_gemm_gather(g, s));
     }
@@ -420,8 +433,7 @@ int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const
     {   // fc3
         GatherPlan pl = dense_plan(rows, 200, 200, D2);
         WgradParams g = wgrad_of(P, pl, &P.fc[2].gk, 1, rows);
-        g.c.A = w.y2; g.c.a_act = ACT_SWISH; if (dropout) { g.c.a_mask = m2; g.c.a_mask_scale = ms; }
-        g.P = d_out; g.ldp = D2;
+        g.c.A = w.ay2; g.P = d_out; g.ldp = D2;
         MMVAE_TRY(launch_wgrad(g, s));
         GatherPlan pd = dense_plan(rows, D2, D2, 200);
         GemmParams d = gemm_of(P, pd, &P.fc[2].pk_dgrad, 1, rows);
@@ -433,8 +445,7 @@ int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const
     {   // fc2
         GatherPlan pl = dense_plan(rows, 400, 400, 200);
         WgradParams g = wgrad_of(P, pl, &P.fc[1].gk, 1, rows);
-        g.c.A = w.y1; g.c.a_act = ACT_SWISH; if (dropout) { g.c.a_mask = m1; g.c.a_mask_scale = ms; }
-        g.P = w.dy2; g.ldp = 200;
+        g.c.A = w.ay1; g.P = w.dy2; g.ldp = 200;
         MMVAE_TRY(launch_wgrad(g, s));
         GatherPlan pd = dense_plan(rows, 200, 200, 400);
         GemmParams d = gemm_of(P, pd, &P.fc[1].pk_dgrad, 1, rows);
@@ -446,7 +457,7 @@ int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const
     {   // fc1: wgrad gathers the shared 2x2x256 map; dgrad emits NHWC gradients for `rows` samples
         GatherPlan pl = plan_fwdform(2, 2, 1, 1, 256, 2, 2, 1, 0, 400, 1, rows);
         WgradParams g = wgrad_of(P, pl, &P.fc[0].gk, 1, rows);
-        g.c.A = w.r4; g.c.a_act = ACT_SWISH; g.c.a_affine = w.aff_e[2]; g.c.a_bcast_n = B;
+        g.c.A = w.a4; g.c.a_bcast_n = B;
         g.P = w.dy1; g.ldp = 400;
         MMVAE_TRY(launch_wgrad(g, s));
         // dgrad: 4 classes = the 4 pixels of the 2x2 map, each with its own [256][400] matrix
@@ -466,22 +477,22 @@ int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const
     }
     // ---- conv stack (features shared by all variants: gradients of the variants add up)
     bf16* r[4] = {w.r1, w.r2, w.r3, w.r4};
+    bf16* a[4] = {w.a1, w.a2, w.a3, w.a4};
     bf16* dr[4] = {w.d1e, w.d2e, w.d3e, w.dr4};
     for (int l = 3; l >= 1; --l) {
         const ConvL& L = P.conv[l];
         const BnL& b = P.bn[L.bn];
         const int pix = L.g.OH * L.g.OW;
-        BnBwdApplyArgs a{};
-        a.db = (l == 3) ? w.db4 : dr[l];
-        a.db2 = (l == 3 && variants == 2) ? w.db4 + (size_t)B * 1024 : nullptr;
-        a.r = r[l]; a.dr = dr[l]; a.rows = B * pix; a.C = L.g.Cout; a.ld = L.g.Cout; a.rows_per_group = B * pix; a.G = 1;
-        a.red = w.red_e[l - 1]; a.meanrstd = w.mr_e[l - 1]; a.gamma = P.buf.params + b.w_off;
-        a.dgamma = P.buf.grads + b.w_off; a.dbeta = P.buf.grads + b.b_off;
-        MMVAE_TRY(launch_bn_bwd_apply(a, s));
+        BnBwdApplyArgs x{};
+        x.db = (l == 3) ? w.db4 : dr[l];
+        x.db2 = (l == 3 && variants == 2) ? w.db4 + (size_t)B * 1024 : nullptr;
+        x.r = r[l]; x.dr = dr[l]; x.rows = B * pix; x.C = L.g.Cout; x.ld = L.g.Cout; x.rows_per_group = B * pix; x.G = 1;
+        x.red = w.red_e[l - 1]; x.meanrstd = w.mr_e[l - 1]; x.gamma = P.buf.params + b.w_off;
+        x.dgamma = P.buf.grads + b.w_off; x.dbeta = P.buf.grads + b.b_off;
+        MMVAE_TRY(launch_bn_bwd_apply(x, s));
         {   // wgrad: P = dr[l] (rows over the output grid), G = activated input gathered in forward form
             WgradParams g = wgrad_of(P, L.fwd, L.gk, 1, B);
-            g.c.A = r[l - 1]; g.c.a_act = ACT_SWISH; g.c.a_affine = l > 1 ? w.aff_e[l - 2] : nullptr;
-            g.P = dr[l]; g.ldp = L.g.Cout;
+            g.c.A = a[l - 1]; g.P = dr[l]; g.ldp = L.g.Cout;
             MMVAE_TRY(launch_wgrad(g, s));
         }
         {   // dgrad (class form) with the d-activation of the producer layer fused in the epilogue
@@ -502,71 +513,67 @@ int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const
 }
 
 // ================================================================== image decoder (multimnist/model.py:211-216)
-// z_bf: [groups*B][ldz] with column D == 1.0 (folded bias).  Leaves logits (fp32, [groups*B][2500]) in w.logits.
-int dec_fwd(MMPlan& P, int groups, int training, hipStream_t s) {
+// z_bf: [groups*B][ldz] with column D == 1.0 (folded bias).  The last layer is the fused direct kernel
+// ConvTranspose2d(32,1) + sigmoid (+ BCE and its gradient when `bce` is given).
+int dec_fwd(MMPlan& P, int groups, int training, ConvTLastFwdArgs* last, hipStream_t s) {
     MMPlan::W& w = P.w;
     const int B = P.B, rows = groups * B;
     {
         GatherPlan pl = dense_plan(rows, P.ldz, P.ldz, 1024);
         GemmParams g = gemm_of(P, pl, &P.up.pk_fwd, 1, rows);
-        g.c.A = w.z_bf; g.out_bf = w.u; g.ldo = 1024;
+        g.c.A = w.z_bf; g.out_bf = w.u; g.ldo = 1024; g.out_act_bf = w.au; g.e_act = ACT_SWISH;
         MMVAE_TRY(launch_gemm_gather(g, s));
     }
     bf16* q[4] = {w.u, w.q1, w.q2, w.q3};
+    bf16* aq[4] = {w.au, w.aq1, w.aq2, w.aq3};
     for (int l = 0; l < 3; ++l) {
         const ConvL& L = P.convT[l];
         GemmParams g = gemm_of(P, L.fwd, L.pk_fwd, groups, B);
-        g.c.A = q[l]; g.c.a_act = ACT_SWISH; g.c.a_affine = l > 0 ? w.aff_d[l - 1] : nullptr;
+        g.c.A = aq[l];
         g.out_bf = q[l + 1]; g.ldo = L.g.Cout;
         g.colstats = training ? w.st_d[l] : nullptr;
         MMVAE_TRY(launch_gemm_gather(g, s));
-        MMVAE_TRY(bn_fin(P, P.bn[L.bn], w.st_d[l], groups, (float)(B * L.g.OH * L.g.OW), 1, w.aff_d[l], w.mr_d[l], training, s));
+        const int rpg = B * L.g.OH * L.g.OW;
+        MMVAE_TRY(bn_act(P, P.bn[L.bn], q[l + 1], aq[l + 1], groups * rpg, rpg, groups, w.st_d[l], 1, w.aff_d[l], w.mr_d[l], training, s));
     }
-    {
-        const ConvL& L = P.convT[3];
-        GemmParams g = gemm_of(P, L.fwd, L.pk_fwd, groups, B);
-        g.c.A = w.q3; g.c.a_act = ACT_SWISH; g.c.a_affine = w.aff_d[2];
-        g.out_f = w.logits; g.ldo = 1;
-        MMVAE_TRY(launch_gemm_gather(g, s));
-    }
-    return MMVAE_OK;
+    ConvTLastFwdArgs x = *last;
+    x.act = w.aq3; x.w = P.buf.params + P.convT[3].w_off; x.G = groups; x.B = B; x.IH = 25; x.IW = 25; x.Cin = 32; x.Cout = 1;
+    return launch_convt_last_fwd(x, s);
 }
 
 // dlogit: fp32 NCHW [groups*B][1][50][50] (grad wrt the pre-sigmoid logits). Writes dz (fp32 [groups*B][D]).
 int dec_bwd(MMPlan& P, const float* dlogit, int groups, float* dz, hipStream_t s) {
     MMPlan::W& w = P.w;
     const int B = P.B, rows = groups * B;
-    MMVAE_TRY(launch_im2col_small(dlogit, rows, 1, IMG, IMG, 4, 4, 2, 1, 25, 25, w.patches4, 16, s));
     bf16* q[4] = {w.u, w.q1, w.q2, w.q3};
+    bf16* aq[4] = {w.au, w.aq1, w.aq2, w.aq3};
     bf16* dq[4] = {w.du, w.d1, w.d2, w.d3};
-    {   // last transposed conv (32 -> 1) through the patches of dlogit
+    {   // last transposed conv (32 -> 1): direct dgrad kernel; wgrad through im2col patches of dlogit
         const ConvL& L = P.convT[3];
+        ConvTLastDgradArgs x{};
+        x.dlogit = dlogit; x.w = P.buf.params + L.w_off; x.G = groups; x.B = B; x.IH = 25; x.IW = 25; x.Cin = 32; x.Cout = 1;
+        x.r = w.q3; x.affine = w.aff_d[2]; x.meanrstd = w.mr_d[2]; x.act = ACT_SWISH; x.db = w.d3; x.red = w.red_d[2];
+        MMVAE_TRY(launch_convt_last_dgrad(x, s));
+        MMVAE_TRY(launch_im2col_small(dlogit, rows, 1, IMG, IMG, 4, 4, 2, 1, 25, 25, w.patches4, 16, s));
         GatherPlan pl = plan_fwdform(1, 1, 25, 25, 16, 1, 1, 1, 0, 32, groups, B);   // rows (n, iy, ix), dense K=16
-        GemmParams d = gemm_of(P, pl, L.pk_dgrad, groups, B);
-        d.c.A = w.patches4; d.c.AH = 25; d.c.AW = 25;         // patches are indexed by the same (n, iy, ix)
-        d.c.sy = d.c.sx = 1;
-        d.out_bf = w.d3; d.ldo = 32;
-        d.d_r = w.q3; d.d_ld = 32; d.d_act = ACT_SWISH; d.d_affine = w.aff_d[2]; d.d_meanrstd = w.mr_d[2]; d.d_red = w.red_d[2];
-        MMVAE_TRY(launch_gemm_gather(d, s));
         WgradParams g = wgrad_of(P, pl, L.gk, groups, B);
         g.c.A = w.patches4; g.c.AH = 25; g.c.AW = 25; g.c.sy = g.c.sx = 1;
-        g.P = w.q3; g.ldp = 32; g.p_act = ACT_SWISH; g.p_affine = w.aff_d[2];
+        g.P = w.aq3; g.ldp = 32;
         MMVAE_TRY(launch_wgrad(g, s));
     }
     for (int l = 2; l >= 0; --l) {
         const ConvL& L = P.convT[l];
         const BnL& b = P.bn[L.bn];
         const int pix = L.g.OH * L.g.OW;
-        BnBwdApplyArgs a{};
-        a.db = dq[l + 1]; a.r = q[l + 1]; a.dr = dq[l + 1]; a.rows = rows * pix; a.C = L.g.Cout; a.ld = L.g.Cout;
-        a.rows_per_group = B * pix; a.G = groups;
-        a.red = w.red_d[l]; a.meanrstd = w.mr_d[l]; a.gamma = P.buf.params + b.w_off;
-        a.dgamma = P.buf.grads + b.w_off; a.dbeta = P.buf.grads + b.b_off;
-        MMVAE_TRY(launch_bn_bwd_apply(a, s));
+        BnBwdApplyArgs x{};
+        x.db = dq[l + 1]; x.r = q[l + 1]; x.dr = dq[l + 1]; x.rows = rows * pix; x.C = L.g.Cout; x.ld = L.g.Cout;
+        x.rows_per_group = B * pix; x.G = groups;
+        x.red = w.red_d[l]; x.meanrstd = w.mr_d[l]; x.gamma = P.buf.params + b.w_off;
+        x.dgamma = P.buf.grads + b.w_off; x.dbeta = P.buf.grads + b.b_off;
+        MMVAE_TRY(launch_bn_bwd_apply(x, s));
         {
             WgradParams g = wgrad_of(P, L.fwd, L.gk, groups, B);
-            g.c.A = q[l]; g.c.a_act = ACT_SWISH; g.c.a_affine = l > 0 ? w.aff_d[l - 1] : nullptr;
-            g.P = dq[l + 1]; g.ldp = L.g.Cout;
+            g.c.A = aq[l]; g.P = dq[l + 1]; g.ldp = L.g.Cout;
             MMVAE_TRY(launch_wgrad(g, s));
         }
         {
@@ -799,12 +806,10 @@ int mm_step_fwd_bwd(MMPlan* Pp, const MMStepIO& io, int training, int do_backwar
     la.z_f32 = w.z_f32; la.z_bf = w.z_bf; la.ldz = P.ldz; la.kl_sum = w.sums + 8; la.training = training;
     MMVAE_TRY(launch_latent3_fwd(la, s));
     // ---- decoders on 3B rows, BatchNorm statistics per pass
-    MMVAE_TRY(dec_fwd(P, 3, training, s));
-    BceArgs bc{};
-    bc.logits = w.logits; bc.ldl = 1; bc.target = io.image; bc.G = 3; bc.B = B; bc.C = 1; bc.H = IMG; bc.W = IMG;
-    bc.recon = io.recon_image; bc.dlogit = do_backward ? w.dlogit : nullptr; bc.loss_sum = w.sums;
-    for (int k = 0; k < 3; ++k) bc.coef[k] = io.lambda_xy[k] / (float)(B * NPIX);
-    MMVAE_TRY(launch_sigmoid_bce(bc, s));
+    ConvTLastFwdArgs last{};
+    last.target = io.image; last.recon = io.recon_image; last.dlogit = do_backward ? w.dlogit : nullptr; last.loss_sum = w.sums;
+    for (int k = 0; k < 3; ++k) last.coef[k] = io.lambda_xy[k] / (float)(B * NPIX);
+    MMVAE_TRY(dec_fwd(P, 3, training, &last, s));
     TextDecArgs td = td_args(P, w.z_f32, 3, do_backward);
     td.keep = (training && io.gru_dropout) ? gk : nullptr; td.keep_scale = 1.f / (1.f - DROP_P);
     td.force_tokens = io.force_tokens;
@@ -863,9 +868,9 @@ int mm_image_decoder_fwd(MMPlan* P, void* ws, size_t wsb, const float* z, int tr
     MMVAE_TRY(launch_fill_zero(w.zero_begin, w.zero_bytes, s));
     hipLaunchKernelGGL(cast_z_kernel, dim3(ceil_div(rows * P->ldz, 256)), dim3(256), 0, s, z, rows, P->D, w.z_bf, P->ldz);
     MMVAE_TRY(mmvae_check_launch("cast_z"));
-    MMVAE_TRY(dec_fwd(*P, 1, training, s));
-    hipLaunchKernelGGL(sigmoid_kernel, dim3(ceil_div(rows * NPIX, 256)), dim3(256), 0, s, w.logits, (long long)rows * NPIX, recon);
-    return mmvae_check_launch("sigmoid");
+    ConvTLastFwdArgs last{};
+    last.recon = recon;
+    return dec_fwd(*P, 1, training, &last, s);
 }
 int mm_image_decoder_bwd(MMPlan* P, void* ws, size_t wsb, const float* d_recon, const float* recon, float* dz, hipStream_t s) {
     MMVAE_TRY(use_ws(P, ws, wsb));
@@ -918,7 +923,8 @@ static bool layer_gemm(MMPlan& P, const std::string& name, GemmParams& g) {
         if (name == "enc_conv" + std::to_string(l + 1)) {
             const ConvL& L = P.conv[l];
             g = gemm_of(P, L.fwd, L.pk_fwd, 1, B);
-            g.c.A = r[l - 1]; g.c.a_act = ACT_SWISH; g.c.a_affine = l > 1 ? w.aff_e[l - 2] : nullptr;
+            bf16* a[4] = {w.a1, w.a2, w.a3, w.a4};
+            g.c.A = a[l - 1];
             g.out_bf = r[l]; g.ldo = L.g.Cout;
             return true;
         }
@@ -926,7 +932,8 @@ static bool layer_gemm(MMPlan& P, const std::string& name, GemmParams& g) {
         const ConvL& L = P.convT[l];
         if (name == "dec_convT" + std::to_string(l + 1)) {
             g = gemm_of(P, L.fwd, L.pk_fwd, 3, B);
-            g.c.A = q[l]; g.c.a_act = ACT_SWISH; g.c.a_affine = l > 0 ? w.aff_d[l - 1] : nullptr;
+            bf16* aq[4] = {w.au, w.aq1, w.aq2, w.aq3};
+            g.c.A = aq[l];
             g.out_bf = q[l + 1]; g.ldo = L.g.Cout;
             return true;
         }
