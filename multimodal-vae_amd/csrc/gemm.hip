@@ -53,7 +53,6 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* As = reinterpret_cast<bf16*>(smem);                 // [2][BM][LDA]
     bf16* Bs = As + 2 * BM * LDA;                             // [2][BN][LDA]
-    float2* aff_s = reinterpret_cast<float2*>(Bs + 2 * BN * LDA);   // [groups*C] when a_affine
 
     const GatherCommon& c = p.c;
     const GatherClass& k = p.cls[blockIdx.z];
@@ -66,17 +65,10 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(const GemmParams p) {
     const int K = k.K;
     const int nk = (K + BK - 1) / BK;
     const int pix_per_img = k.OY * k.OX;
-    const bool has_tf = (c.a_affine != nullptr) || (c.a_act != ACT_NONE) || (c.a_mask != nullptr);
-
-    if (c.a_affine) {
-        const int ag = c.a_bcast_n > 0 ? 0 : g;
-        for (int i = tid; i < c.C; i += 256) aff_s[i] = c.a_affine[ag * c.C + i];
-    }
 
     // ---- per-thread staging coordinates: 4 A rows, vector column kv ----
     const int kv = tid & 7;
     RowCoord rc[4];
-    int grow[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         int r = row0 + (tid >> 3) + 32 * i;
@@ -93,7 +85,6 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(const GemmParams p) {
         } else {
             rc[i].pix = -1; rc[i].y = 0; rc[i].x = 0;
         }
-        grow[i] = g * k.rows_per_group + r;
     }
 
     bf16x8 areg[4];
@@ -117,22 +108,18 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(const GemmParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int y = rc[i].y + ty * c.dy, x = rc[i].x + tx * c.dx;
-            bool ok = kin && rc[i].pix >= 0 && (unsigned)y < (unsigned)c.AH && (unsigned)x < (unsigned)c.AW;
-            if (ok) {
-                const bf16* src = c.A + (size_t)(rc[i].pix + y * c.AW + x) * c.Ald + a_c;
-                areg[i] = *reinterpret_cast<const bf16x8*>(src);
-                avalid |= 1u << i;
-            } else {
-                areg[i] = zero8();
-            }
+            const bool ok = kin && rc[i].pix >= 0 && (unsigned)y < (unsigned)c.AH && (unsigned)x < (unsigned)c.AW;
+            // unconditional load from a clamped in-bounds address (no branch around the load: the loads of a tile
+            // issue back to back and are waited for once); invalid vectors are zeroed when they are stored to LDS
+            const int pix = ok ? rc[i].pix + y * c.AW + x : 0;
+            areg[i] = *reinterpret_cast<const bf16x8*>(c.A + (size_t)pix * c.Ald + a_c);
+            avalid |= (ok ? 1u : 0u) << i;
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            int v = tid + 256 * i;
-            if (v < BN * 8) {
-                const bf16* src = k.Wp + (size_t)(n0 + (v >> 3)) * k.Kpad + kt * BK + (v & 7) * 8;
-                breg[i] = *reinterpret_cast<const bf16x8*>(src);
-            }
+            int v = (tid + 256 * i) % (BN * 8);
+            const bf16* src = k.Wp + (size_t)(n0 + (v >> 3)) * k.Kpad + kt * BK + (v & 7) * 8;
+            breg[i] = *reinterpret_cast<const bf16x8*>(src);
         }
     };
     auto store_tile = [&](int buf) {
@@ -140,11 +127,7 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(const GemmParams p) {
         bf16* b_dst = Bs + buf * BN * LDA;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            bf16x8 v = areg[i];
-            if (has_tf && ((avalid >> i) & 1)) {
-                const uint8_t* m = c.a_mask ? c.a_mask + (size_t)grow[i] * c.C + a_c : nullptr;
-                v = transform8(v, c.a_affine ? aff_s + a_c : nullptr, c.a_act, m, c.a_mask_scale);
-            }
+            bf16x8 v = ((avalid >> i) & 1) ? areg[i] : zero8();
             *reinterpret_cast<bf16x8*>(a_dst + ((tid >> 3) + 32 * i) * LDA + kv * 8) = v;
         }
 #pragma unroll
@@ -161,7 +144,6 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(const GemmParams p) {
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     load_tile(0);
-    __syncthreads();          // aff_s visible
     store_tile(0);
     __syncthreads();
 
@@ -171,86 +153,166 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(const GemmParams p) {
         if (kt + 1 < nk) load_tile(kt + 1);
         const bf16* a_src = As + buf * BM * LDA + (wave * 32 + fr) * LDA + fq * 8;
         const bf16* b_src = Bs + buf * BN * LDA + fr * LDA + fq * 8;
+        bf16x8 af[2][2], bfr[2][NT];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 a0 = *reinterpret_cast<const bf16x8*>(a_src + ks * 32);
-            bf16x8 a1 = *reinterpret_cast<const bf16x8*>(a_src + 16 * LDA + ks * 32);
+            af[ks][0] = *reinterpret_cast<const bf16x8*>(a_src + ks * 32);
+            af[ks][1] = *reinterpret_cast<const bf16x8*>(a_src + 16 * LDA + ks * 32);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bfr[ks][nt] = *reinterpret_cast<const bf16x8*>(b_src + nt * 16 * LDA + ks * 32);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                bf16x8 b = *reinterpret_cast<const bf16x8*>(b_src + nt * 16 * LDA + ks * 32);
-                acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b, acc[0][nt], 0, 0, 0);
-                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b, acc[1][nt], 0, 0, 0);
+                acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][0], bfr[ks][nt], acc[0][nt], 0, 0, 0);
+                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][1], bfr[ks][nt], acc[1][nt], 0, 0, 0);
             }
-        }
         if (kt + 1 < nk) store_tile(buf ^ 1);
         __syncthreads();
     }
 
     // ---------------- epilogue ----------------
+    // The accumulator tile goes through LDS (fp32 [BM][BN+4]; the staging buffers are free after the last barrier)
+    // so that every global access below is a 16-byte vector of 8 consecutive columns of one row: coalesced stores,
+    // one row decomposition per vector, and loads that do not depend on each other across passes.
+    constexpr int LDC = BN + 4;
+    constexpr int VPR = BN / 8;              // vectors per tile row
+    constexpr int RPP = 256 / VPR;           // tile rows per pass
+    constexpr int PASSES = BM / RPP;
+    float* ct = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                ct[(wave * 32 + mt * 16 + fq * 4 + j) * LDC + nt * 16 + fr] = acc[mt][nt][j];
+    __syncthreads();
+
     const bool want_stats = p.colstats != nullptr;
     const bool want_red = p.d_red != nullptr || p.d_colsum != nullptr;
-    float s1[NT], s2[NT];
+    const int cv = tid % VPR;
+    const int col0 = n0 + cv * 8;
+    const bool vec_ok = (col0 + 8 <= c.N) && (p.ldo % 8 == 0);
+    float s1[8], s2[8];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.f; s2[nt] = 0.f; }
-
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    float bias8[8], dsc[8], dsh[8], dmean[8], drstd[8];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int j = 0; j < 8; ++j) {
+        const int col = min(col0 + j, c.N - 1);
+        bias8[j] = p.bias ? p.bias[col] : 0.f;
+        dsc[j] = 1.f; dsh[j] = 0.f; dmean[j] = 0.f; drstd[j] = 0.f;
+        if (p.d_affine) { float2 a = p.d_affine[g * c.N + col]; dsc[j] = a.x; dsh[j] = a.y; }
+        if (p.d_meanrstd) { float2 m = p.d_meanrstd[g * c.N + col]; dmean[j] = m.x; drstd[j] = m.y; }
+    }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = row0 + wave * 32 + mt * 16 + fq * 4 + j;
-            if (r >= k.rows_per_group) continue;
-            int img = r / pix_per_img;
-            int rem = r - img * pix_per_img;
-            int oy = rem / k.OX;
-            int ox = rem - oy * k.OX;
-            const size_t opix = (size_t)((g * c.group_n + img) * c.OH + oy * c.osy + k.ooy) * c.OW + ox * c.osx + k.oox;
-            const size_t growi = (size_t)g * k.rows_per_group + r;
+    for (int ps = 0; ps < PASSES; ++ps) {
+        const int rl = ps * RPP + tid / VPR;
+        const int r = row0 + rl;
+        if (r >= k.rows_per_group || col0 >= c.N) continue;
+        const int img = r / pix_per_img;
+        const int rem = r - img * pix_per_img;
+        const int oy = rem / k.OX;
+        const int ox = rem - oy * k.OX;
+        const int nimg = g * c.group_n + img;
+        const size_t opix = (size_t)(nimg * c.OH + oy * c.osy + k.ooy) * c.OW + ox * c.osx + k.oox;
+        const size_t growi = (size_t)g * k.rows_per_group + r;
+        float v[8];
+        {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(ct + rl * LDC + cv * 8);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(ct + rl * LDC + cv * 8 + 4);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int col = n0 + nt * 16 + fr;
-                if (col >= c.N) continue;
-                float v = acc[mt][nt][j];
-                if (p.bias) v += p.bias[col];
-                if (p.d_r) {
-                    size_t rpix = opix;
-                    if (p.d_bcast_n > 0)
-                        rpix = (size_t)(((g * c.group_n + img) % p.d_bcast_n) * c.OH + oy * c.osy + k.ooy) * c.OW + ox * c.osx + k.oox;
-                    float rr = (float)p.d_r[rpix * p.d_ld + col];
-                    float b = rr;
-                    if (p.d_affine) { float2 a = p.d_affine[g * c.N + col]; b = rr * a.x + a.y; }
-                    v *= act_bwd(p.d_act, b);
-                    if (p.d_mask) v = p.d_mask[growi * c.N + col] ? v * p.d_mask_scale : 0.f;
-                    if (want_red) {
-                        float2 mr = p.d_meanrstd ? p.d_meanrstd[g * c.N + col] : make_float2(0.f, 0.f);
-                        s1[nt] += v;
-                        s2[nt] += v * (rr - mr.x) * mr.y;
-                    }
+            for (int j = 0; j < 4; ++j) { v[j] = lo[j] + bias8[j]; v[4 + j] = hi[j] + bias8[4 + j]; }
+        }
+        if (p.d_r) {
+            size_t rpix = opix;
+            if (p.d_bcast_n > 0) rpix = (size_t)((nimg % p.d_bcast_n) * c.OH + oy * c.osy + k.ooy) * c.OW + ox * c.osx + k.oox;
+            float rr[8];
+            if (vec_ok && p.d_ld % 8 == 0) {
+                const bf16x8 rv = *reinterpret_cast<const bf16x8*>(p.d_r + rpix * p.d_ld + col0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) rr[j] = (float)rv[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) rr[j] = (col0 + j < c.N) ? (float)p.d_r[rpix * p.d_ld + col0 + j] : 0.f;
+            }
+            uint64_t mb = ~0ull;
+            if (p.d_mask) {
+                if (vec_ok) mb = *reinterpret_cast<const uint64_t*>(p.d_mask + growi * c.N + col0);
+                else {
+                    mb = 0;
+                    for (int j = 0; j < 8; ++j)
+                        if (col0 + j < c.N && p.d_mask[growi * c.N + col0 + j]) mb |= 0xffull << (8 * j);
                 }
-                if (want_stats) { s1[nt] += v; s2[nt] += v * v; }
-                if (p.out_bf) p.out_bf[opix * p.ldo + col] = (bf16)v;
-                if (p.out_f) p.out_f[opix * p.ldo + col] = v;
-                if (p.out_act_bf) {
-                    float av = act_fwd(p.e_act, v);
-                    if (p.e_mask) av = p.e_mask[growi * c.N + col] ? av * p.e_mask_scale : 0.f;
-                    p.out_act_bf[opix * p.ldo + col] = (bf16)av;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float x = v[j] * act_bwd(p.d_act, rr[j] * dsc[j] + dsh[j]);
+                if (p.d_mask) x = ((mb >> (8 * j)) & 0xff) ? x * p.d_mask_scale : 0.f;
+                v[j] = x;
+                if (want_red && col0 + j < c.N) { s1[j] += x; s2[j] += x * (rr[j] - dmean[j]) * drstd[j]; }
+            }
+        }
+        if (want_stats) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (col0 + j < c.N) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
+        }
+        float av[8];
+        if (p.out_act_bf) {
+            uint64_t mb = ~0ull;
+            if (p.e_mask) {
+                if (vec_ok) mb = *reinterpret_cast<const uint64_t*>(p.e_mask + growi * c.N + col0);
+                else {
+                    mb = 0;
+                    for (int j = 0; j < 8; ++j)
+                        if (col0 + j < c.N && p.e_mask[growi * c.N + col0 + j]) mb |= 0xffull << (8 * j);
                 }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float x = act_fwd(p.e_act, v[j]);
+                if (p.e_mask) x = ((mb >> (8 * j)) & 0xff) ? x * p.e_mask_scale : 0.f;
+                av[j] = x;
+            }
+        }
+        if (vec_ok) {
+            if (p.out_bf) {
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (bf16)v[j];
+                *reinterpret_cast<bf16x8*>(p.out_bf + opix * p.ldo + col0) = o;
+            }
+            if (p.out_act_bf) {
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (bf16)av[j];
+                *reinterpret_cast<bf16x8*>(p.out_act_bf + opix * p.ldo + col0) = o;
+            }
+            if (p.out_f) {
+                *reinterpret_cast<f32x4*>(p.out_f + opix * p.ldo + col0) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(p.out_f + opix * p.ldo + col0 + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            }
+        } else {
+            for (int j = 0; j < 8; ++j) {
+                if (col0 + j >= c.N) break;
+                if (p.out_bf) p.out_bf[opix * p.ldo + col0 + j] = (bf16)v[j];
+                if (p.out_act_bf) p.out_act_bf[opix * p.ldo + col0 + j] = (bf16)av[j];
+                if (p.out_f) p.out_f[opix * p.ldo + col0 + j] = v[j];
             }
         }
     }
     if (want_stats || want_red) {
-        float2* red = reinterpret_cast<float2*>(smem);       // [4][BN], staging LDS is free after the last barrier
+        __syncthreads();                                       // everyone is done reading ct
+        float2* red = reinterpret_cast<float2*>(smem);         // [RPP][BN]
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            float a = s1[nt], b = s2[nt];
-            a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
-            a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
-            if (fq == 0) red[wave * BN + nt * 16 + fr] = make_float2(a, b);
-        }
+        for (int j = 0; j < 8; ++j) red[(tid / VPR) * BN + cv * 8 + j] = make_float2(s1[j], s2[j]);
         __syncthreads();
         if (tid < BN && n0 + tid < c.N) {
             float a = 0.f, b = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) { a += red[w * BN + tid].x; b += red[w * BN + tid].y; }
+            for (int q = 0; q < RPP; ++q) { a += red[q * BN + tid].x; b += red[q * BN + tid].y; }
             float2* dst = want_stats ? p.colstats : p.d_red;
             if (dst) {
                 atomicAdd(&dst[g * c.N + n0 + tid].x, a);
@@ -309,8 +371,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
         tx = tap - ty * k.TW;
     }
     const int pcol = n0 + kv * 8;
-    const bool has_gtf = (c.a_affine != nullptr) || (c.a_act != ACT_NONE) || (c.a_mask != nullptr);
-    const bool has_ptf = (p.p_affine != nullptr) || (p.p_act != ACT_NONE);
 
     f32x4 acc[2][2];
 #pragma unroll
@@ -320,36 +380,33 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 
     for (int rb = r_begin; rb < r_end; rb += WM) {
         bf16x8 pv[2], gv[2];
+        bool pok[2], gok[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int r = rb + (tid >> 3) + 32 * i;
-            pv[i] = zero8(); gv[i] = zero8();
-            if (r < r_end) {
-                int g = r / k.rows_per_group;
-                int rg = r - g * k.rows_per_group;
-                int img = rg / pix_per_img;
-                int rem = rg - img * pix_per_img;
-                int oy = rem / k.OX;
-                int ox = rem - oy * k.OX;
-                int n = g * c.group_n + img;
-                int an = n, ag = g;
-                if (c.a_bcast_n > 0) { an = n % c.a_bcast_n; ag = 0; }
-                if (pcol < c.N) {     // ldp >= round_up(N,8): columns >= N only feed discarded output rows
-                    const size_t ppix = (size_t)(n * c.OH + oy * c.osy + k.ooy) * c.OW + ox * c.osx + k.oox;
-                    bf16x8 v = *reinterpret_cast<const bf16x8*>(p.P + ppix * p.ldp + pcol);
-                    if (has_ptf) v = transform8(v, p.p_affine ? p.p_affine + g * c.N + pcol : nullptr, p.p_act, nullptr, 1.f);
-                    pv[i] = v;
-                }
-                int y = oy * c.sy + k.offy + ty * c.dy, x = ox * c.sx + k.offx + tx * c.dx;
-                if (kin && (unsigned)y < (unsigned)c.AH && (unsigned)x < (unsigned)c.AW) {
-                    bf16x8 v = *reinterpret_cast<const bf16x8*>(c.A + (size_t)((an * c.AH + y) * c.AW + x) * c.Ald + gc);
-                    if (has_gtf) {
-                        const uint8_t* m = c.a_mask ? c.a_mask + (size_t)r * c.C + gc : nullptr;
-                        v = transform8(v, c.a_affine ? c.a_affine + ag * c.C + gc : nullptr, c.a_act, m, c.a_mask_scale);
-                    }
-                    gv[i] = v;
-                }
-            }
+            const int rq = rb + (tid >> 3) + 32 * i;
+            const bool rin = rq < r_end;
+            const int r = rin ? rq : r_end - 1;              // clamped: loads are unconditional, results masked
+            int g = r / k.rows_per_group;
+            int rg = r - g * k.rows_per_group;
+            int img = rg / pix_per_img;
+            int rem = rg - img * pix_per_img;
+            int oy = rem / k.OX;
+            int ox = rem - oy * k.OX;
+            int n = g * c.group_n + img;
+            int an = n;
+            if (c.a_bcast_n > 0) an = n % c.a_bcast_n;
+            pok[i] = rin && pcol < c.N;       // ldp >= round_up(N,8): columns >= N only feed discarded output rows
+            const size_t ppix = (size_t)(n * c.OH + oy * c.osy + k.ooy) * c.OW + ox * c.osx + k.oox;
+            pv[i] = *reinterpret_cast<const bf16x8*>(p.P + ppix * p.ldp + (pcol < c.N ? pcol : 0));
+            int y = oy * c.sy + k.offy + ty * c.dy, x = ox * c.sx + k.offx + tx * c.dx;
+            gok[i] = rin && kin && (unsigned)y < (unsigned)c.AH && (unsigned)x < (unsigned)c.AW;
+            const int gp = gok[i] ? (an * c.AH + y) * c.AW + x : 0;
+            gv[i] = *reinterpret_cast<const bf16x8*>(c.A + (size_t)gp * c.Ald + gc);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (!pok[i]) pv[i] = zero8();
+            if (!gok[i]) gv[i] = zero8();
         }
         __syncthreads();      // previous iteration's fragment reads are done
 #pragma unroll
@@ -391,7 +448,7 @@ int launch_gemm_nt(const GemmParams& p, hipStream_t stream) {
     int max_tiles = 0;
     for (int i = 0; i < p.c.nclasses; ++i) max_tiles = max(max_tiles, ceil_div(p.cls[i].rows_per_group, BM));
     dim3 grid(max_tiles * p.c.groups, ceil_div(p.c.N, BN), p.c.nclasses);
-    size_t lds = (size_t)2 * (BM + BN) * LDA * sizeof(bf16) + (p.c.a_affine ? (size_t)p.c.C * sizeof(float2) : 0);
+    size_t lds = (size_t)2 * (BM + BN) * LDA * sizeof(bf16);
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_gather_kernel<NT>),
@@ -417,7 +474,8 @@ int launch_gemm_gather(const GemmParams& p, hipStream_t stream) {
         MMVAE_REQUIRE(k.Wp != nullptr, "gemm: class %d has no weights", i);
         MMVAE_REQUIRE((k.OY - 1) * c.osy + k.ooy < c.OH && (k.OX - 1) * c.osx + k.oox < c.OW, "gemm: class %d output grid", i);
     }
-    MMVAE_REQUIRE(c.a_mask == nullptr || (c.nclasses == 1 && p.cls[0].TH * p.cls[0].TW == 1), "gemm: mask needs a dense operand");
+    MMVAE_REQUIRE(c.a_mask == nullptr && c.a_affine == nullptr && c.a_act == ACT_NONE,
+                  "gemm: operand transforms are not supported (activations are materialised by bn_act / the epilogue)");
     if (c.N <= 16) return launch_gemm_nt<1>(p, stream);
     if (c.N <= 32) return launch_gemm_nt<2>(p, stream);
     if (c.N <= 64) return launch_gemm_nt<4>(p, stream);
@@ -430,6 +488,8 @@ int launch_wgrad(const WgradParams& p, hipStream_t stream) {
     MMVAE_REQUIRE(c.C % 8 == 0 && c.Ald % 8 == 0 && p.ldp % 8 == 0 && p.ldp >= round_up(c.N, 8),
                   "wgrad: C/Ald/ldp must be multiples of 8 and ldp >= round_up(N,8)");
     MMVAE_REQUIRE(p.rows_per_block > 0 && p.rows_per_block % WM == 0, "wgrad: rows_per_block=%d", p.rows_per_block);
+    MMVAE_REQUIRE(c.a_mask == nullptr && c.a_affine == nullptr && c.a_act == ACT_NONE && p.p_affine == nullptr && p.p_act == ACT_NONE,
+                  "wgrad: operand transforms are not supported");
     int max_rows = 0, max_kpad = 0;
     for (int i = 0; i < c.nclasses; ++i) {
         const GatherClass& k = p.cls[i];

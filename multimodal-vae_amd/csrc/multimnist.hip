@@ -41,6 +41,12 @@ struct MMPlan {
     int te_h2p, te_h2pT, g_te_h2p, td_z2h, td_z2hT, g_td_z2h, td_h2o, td_h2oT, g_td_h2o;
     MMBuffers buf;
     bool bound = false;
+    // side streams: independent branches of the step (text path, weight gradients) run beside the main chain;
+    // forks/joins are event edges, so a captured HIP graph gets parallel branches and nothing syncs the host
+    hipStream_t st_text = nullptr, st_wgrad = nullptr;
+    std::vector<hipEvent_t> events;
+    size_t next_event = 0;
+    bool wgrad_forked = false;
     // ---- workspace pointers
     struct W {
         char* zero_begin; size_t zero_bytes;
@@ -65,6 +71,15 @@ struct MMPlan {
 };
 
 namespace {
+
+int edge(MMPlan& P, hipStream_t from, hipStream_t to);
+
+// weight gradients only feed the optimizer: when the step runs multi-stream they go to the side stream
+int wgrad_async(MMPlan& P, const WgradParams& g, hipStream_t s) {
+    if (!P.wgrad_forked) return launch_wgrad(g, s);
+    MMVAE_TRY(edge(P, s, P.st_wgrad));
+    return launch_wgrad(g, P.st_wgrad);
+}
 
 void add_param(MMPlan& P, const std::string& name, std::initializer_list<int> shape) {
     ParamInfo pi{};
@@ -434,7 +449,7 @@ int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const
         GatherPlan pl = dense_plan(rows, 200, 200, D2);
         WgradParams g = wgrad_of(P, pl, &P.fc[2].gk, 1, rows);
         g.c.A = w.ay2; g.P = d_out; g.ldp = D2;
-        MMVAE_TRY(launch_wgrad(g, s));
+        MMVAE_TRY(wgrad_async(P, g, s));
         GatherPlan pd = dense_plan(rows, D2, D2, 200);
         GemmParams d = gemm_of(P, pd, &P.fc[2].pk_dgrad, 1, rows);
         d.c.A = d_out; d.out_bf = w.dy2; d.ldo = 200;
@@ -446,7 +461,7 @@ int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const
         GatherPlan pl = dense_plan(rows, 400, 400, 200);
         WgradParams g = wgrad_of(P, pl, &P.fc[1].gk, 1, rows);
         g.c.A = w.ay1; g.P = w.dy2; g.ldp = 200;
-        MMVAE_TRY(launch_wgrad(g, s));
+        MMVAE_TRY(wgrad_async(P, g, s));
         GatherPlan pd = dense_plan(rows, 200, 200, 400);
         GemmParams d = gemm_of(P, pd, &P.fc[1].pk_dgrad, 1, rows);
         d.c.A = w.dy2; d.out_bf = w.dy1; d.ldo = 400;
@@ -459,7 +474,7 @@ int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const
         WgradParams g = wgrad_of(P, pl, &P.fc[0].gk, 1, rows);
         g.c.A = w.a4; g.c.a_bcast_n = B;
         g.P = w.dy1; g.ldp = 400;
-        MMVAE_TRY(launch_wgrad(g, s));
+        MMVAE_TRY(wgrad_async(P, g, s));
         // dgrad: 4 classes = the 4 pixels of the 2x2 map, each with its own [256][400] matrix
         GatherPlan pd{};
         pd.c.AH = 1; pd.c.AW = 1; pd.c.Ald = 400; pd.c.C = 400; pd.c.sy = pd.c.sx = 1; pd.c.dy = pd.c.dx = 1;
@@ -493,7 +508,7 @@ int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const
         {   // wgrad: P = dr[l] (rows over the output grid), G = activated input gathered in forward form
             WgradParams g = wgrad_of(P, L.fwd, L.gk, 1, B);
             g.c.A = a[l - 1]; g.P = dr[l]; g.ldp = L.g.Cout;
-            MMVAE_TRY(launch_wgrad(g, s));
+            MMVAE_TRY(wgrad_async(P, g, s));
         }
         {   // dgrad (class form) with the d-activation of the producer layer fused in the epilogue
             GemmParams d = gemm_of(P, L.dgrad, L.pk_dgrad, 1, B);
@@ -507,7 +522,7 @@ int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const
         GatherPlan pl = dense_plan(B * 625, 16, 16, 32);
         WgradParams g = wgrad_of(P, pl, P.conv[0].gk, 1, B * 625);
         g.c.A = w.patches1; g.P = w.d1e; g.ldp = 32;
-        MMVAE_TRY(launch_wgrad(g, s));
+        MMVAE_TRY(wgrad_async(P, g, s));
     }
     return MMVAE_OK;
 }
@@ -559,7 +574,7 @@ int dec_bwd(MMPlan& P, const float* dlogit, int groups, float* dz, hipStream_t s
         WgradParams g = wgrad_of(P, pl, L.gk, groups, B);
         g.c.A = w.patches4; g.c.AH = 25; g.c.AW = 25; g.c.sy = g.c.sx = 1;
         g.P = w.aq3; g.ldp = 32;
-        MMVAE_TRY(launch_wgrad(g, s));
+        MMVAE_TRY(wgrad_async(P, g, s));
     }
     for (int l = 2; l >= 0; --l) {
         const ConvL& L = P.convT[l];
@@ -574,7 +589,7 @@ int dec_bwd(MMPlan& P, const float* dlogit, int groups, float* dz, hipStream_t s
         {
             WgradParams g = wgrad_of(P, L.fwd, L.gk, groups, B);
             g.c.A = aq[l]; g.P = dq[l + 1]; g.ldp = L.g.Cout;
-            MMVAE_TRY(launch_wgrad(g, s));
+            MMVAE_TRY(wgrad_async(P, g, s));
         }
         {
             GemmParams d = gemm_of(P, L.dgrad, L.pk_dgrad, groups, B);
@@ -588,7 +603,7 @@ int dec_bwd(MMPlan& P, const float* dlogit, int groups, float* dz, hipStream_t s
         GatherPlan pl = dense_plan(rows, P.ldz, P.ldz, 1024);
         WgradParams g = wgrad_of(P, pl, &P.up.gk, 1, rows);
         g.c.A = w.z_bf; g.P = w.du; g.ldp = 1024;
-        MMVAE_TRY(launch_wgrad(g, s));
+        MMVAE_TRY(wgrad_async(P, g, s));
         GatherPlan pd = dense_plan(rows, 1024, 1024, P.D);
         GemmParams d = gemm_of(P, pd, &P.up.pk_dgrad, 1, rows);
         d.c.A = w.du; d.out_f = dz; d.ldo = P.D;
@@ -717,6 +732,35 @@ __global__ void sigmoid_kernel(const float* logits, long long n, float* out) {
     if (i < n) out[i] = 1.0f / (1.0f + expf(-logits[i]));
 }
 
+hipEvent_t next_ev(MMPlan& P) {
+    if (P.next_event == P.events.size()) {
+        hipEvent_t e;
+        hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        P.events.push_back(e);
+    }
+    return P.events[P.next_event++];
+}
+// `to` waits for everything enqueued on `from` so far
+int edge(MMPlan& P, hipStream_t from, hipStream_t to) {
+    hipEvent_t e = next_ev(P);
+    if (hipEventRecord(e, from) != hipSuccess || hipStreamWaitEvent(to, e, 0) != hipSuccess) {
+        mmvae_set_error("stream fork/join failed: %s", hipGetErrorString(hipGetLastError()));
+        return MMVAE_EHIP;
+    }
+    return MMVAE_OK;
+}
+int ensure_streams(MMPlan& P) {
+    if (!P.st_text) {
+        if (hipStreamCreateWithFlags(&P.st_text, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&P.st_wgrad, hipStreamNonBlocking) != hipSuccess) {
+            mmvae_set_error("hipStreamCreate failed");
+            return MMVAE_EHIP;
+        }
+    }
+    P.next_event = 0;
+    return MMVAE_OK;
+}
+
 int check_bound(const MMPlan* P) {
     MMVAE_REQUIRE(P && P->bound, "plan has no buffers bound (mmvae_mm_bind)");
     return MMVAE_OK;
@@ -793,23 +837,24 @@ int mm_step_fwd_bwd(MMPlan* Pp, const MMStepIO& io, int training, int do_backwar
     if (training && io.enc_dropout && !m2) { MMVAE_TRY(launch_keep_mask(w.m2, (long long)2 * B * 200, DROP_P, io.seed, io.step_ctr, 3, s)); m2 = w.m2; }
     if (training && io.gru_dropout && !gk) { MMVAE_TRY(launch_keep_mask(w.gkeep, (long long)4 * B3 * 100, DROP_P, io.seed, io.step_ctr, 4, s)); gk = w.gkeep; }
     const int enc_drop = training && io.enc_dropout;
-    // ---- encoders (image features computed once for passes 1 and 2; text encoder once for passes 1 and 3)
-    MMVAE_TRY(enc_fwd(P, io.image, 2, m1, m2, enc_drop, training, 2, w.encout, s));
+    MMVAE_TRY(ensure_streams(P));
+    hipStream_t T = P.st_text;
+    // ---- encoders: image features once for passes 1 and 2 (main), text encoder once for passes 1 and 3 (side)
+    MMVAE_TRY(edge(P, s, T));
     {
         TextEncArgs a = te_args(P, io.text, w.txtout, do_backward);
-        MMVAE_TRY(launch_text_encoder_fwd(a, s));
+        MMVAE_TRY(launch_text_encoder_fwd(a, T));
     }
+    MMVAE_TRY(enc_fwd(P, io.image, 2, m1, m2, enc_drop, training, 2, w.encout, s));
+    MMVAE_TRY(edge(P, T, s));
     // ---- product of experts + reparametrisation + KL for the three passes
     Latent3Args la{};
     la.B = B; la.D = D; la.img_out = w.encout; la.txt_out = w.txtout; la.eps = eps;
     la.mu = io.mu ? io.mu : w.mu; la.logvar = io.logvar ? io.logvar : w.logvar;
     la.z_f32 = w.z_f32; la.z_bf = w.z_bf; la.ldz = P.ldz; la.kl_sum = w.sums + 8; la.training = training;
     MMVAE_TRY(launch_latent3_fwd(la, s));
-    // ---- decoders on 3B rows, BatchNorm statistics per pass
-    ConvTLastFwdArgs last{};
-    last.target = io.image; last.recon = io.recon_image; last.dlogit = do_backward ? w.dlogit : nullptr; last.loss_sum = w.sums;
-    for (int k = 0; k < 3; ++k) last.coef[k] = io.lambda_xy[k] / (float)(B * NPIX);
-    MMVAE_TRY(dec_fwd(P, 3, training, &last, s));
+    // ---- text decoder (forward, backward and its weight gradients) on the side stream, image decoder on main
+    MMVAE_TRY(edge(P, s, T));
     TextDecArgs td = td_args(P, w.z_f32, 3, do_backward);
     td.keep = (training && io.gru_dropout) ? gk : nullptr; td.keep_scale = 1.f / (1.f - DROP_P);
     td.force_tokens = io.force_tokens;
@@ -817,26 +862,46 @@ int mm_step_fwd_bwd(MMPlan* Pp, const MMStepIO& io, int training, int do_backwar
     if (io.tokens) td.tokens_out = io.tokens;
     td.target = io.text; td.nll_sum = w.sums + 4; td.dwords = do_backward ? w.dwords : nullptr;
     for (int k = 0; k < 3; ++k) td.nll_coef[k] = io.lambda_yx[k] / (float)(B * TXT_T);
-    MMVAE_TRY(launch_text_decoder_fwd(td, s));
-    if (hipMemcpyAsync(io.sums, w.sums, 16 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
-        mmvae_set_error("step: copy of the loss sums failed");
-        return MMVAE_EHIP;
+    MMVAE_TRY(launch_text_decoder_fwd(td, T));
+    if (do_backward) MMVAE_TRY(txt_dec_bwd(P, td, w.dwords, w.dz_txt, T));
+    // decoders on 3B rows, BatchNorm statistics per pass; last layer fused with sigmoid + BCE (+ gradient)
+    ConvTLastFwdArgs last{};
+    last.target = io.image; last.recon = io.recon_image; last.dlogit = do_backward ? w.dlogit : nullptr; last.loss_sum = w.sums;
+    for (int k = 0; k < 3; ++k) last.coef[k] = io.lambda_xy[k] / (float)(B * NPIX);
+    MMVAE_TRY(dec_fwd(P, 3, training, &last, s));
+    if (!do_backward) {
+        MMVAE_TRY(edge(P, T, s));
+        if (hipMemcpyAsync(io.sums, w.sums, 16 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+            mmvae_set_error("step: copy of the loss sums failed");
+            return MMVAE_EHIP;
+        }
+        return MMVAE_OK;
     }
-    if (!do_backward) return MMVAE_OK;
 
     // =============================== backward ===============================
-    MMVAE_TRY(txt_dec_bwd(P, td, w.dwords, w.dz_txt, s));
+    P.wgrad_forked = true;
     // image decoder: a pass with lambda_xy = 0 (text-only) has exactly zero gradient: only the leading groups run
     int img_groups = 3;
     while (img_groups > 0 && io.lambda_xy[img_groups - 1] == 0.f) --img_groups;
-    if (img_groups > 0) MMVAE_TRY(dec_bwd(P, w.dlogit, img_groups, w.dz_img, s));
+    int rc = MMVAE_OK;
+    if (img_groups > 0) rc = dec_bwd(P, w.dlogit, img_groups, w.dz_img, s);
+    if (rc == MMVAE_OK) rc = edge(P, T, s);          // dz of the text decoder
     Latent3BwdArgs lb{};
     lb.f = la; lb.dz_a = w.dz_img; lb.dz_b = w.dz_txt;
     for (int k = 0; k < 3; ++k) lb.kl_coef[k] = io.kl_lambda / (float)B;
     lb.d_img_out_bf = w.d_encout; lb.d_img_bias = P.buf.grads + P.fc[2].b_off; lb.d_txt_out = w.d_txtout;
-    MMVAE_TRY(launch_latent3_bwd(lb, s));
-    MMVAE_TRY(txt_enc_bwd(P, io.text, w.d_txtout, s));
-    MMVAE_TRY(enc_bwd(P, w.d_encout, 2, m1, m2, enc_drop, s));
+    if (rc == MMVAE_OK) rc = launch_latent3_bwd(lb, s);
+    if (rc == MMVAE_OK) rc = edge(P, s, T);
+    if (rc == MMVAE_OK) rc = txt_enc_bwd(P, io.text, w.d_txtout, T);
+    if (rc == MMVAE_OK) rc = enc_bwd(P, w.d_encout, 2, m1, m2, enc_drop, s);
+    P.wgrad_forked = false;
+    MMVAE_TRY(rc);
+    MMVAE_TRY(edge(P, T, s));
+    MMVAE_TRY(edge(P, P.st_wgrad, s));
+    if (hipMemcpyAsync(io.sums, w.sums, 16 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+        mmvae_set_error("step: copy of the loss sums failed");
+        return MMVAE_EHIP;
+    }
     MMVAE_TRY(mm_unpack_grads(Pp, s));
     return MMVAE_OK;
 }
