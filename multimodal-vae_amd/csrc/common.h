@@ -37,6 +37,12 @@ int mmvae_check_launch(const char* what);
 
 enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2 };
 
+// Same-address float atomics serialise at the memory side (MI355X_MICROARCH.md, Global float atomics: one row
+// shared by every workgroup is ~14x slower), so every per-channel reduction target is replicated in SLOTS copies
+// picked by the workgroup id; the (tiny) consumer sums the copies.
+#define MMVAE_STAT_SLOTS 16
+#define MMVAE_LOSS_SLOTS 32
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 __device__ __forceinline__ float act_fwd(int act, float x) {

@@ -117,7 +117,11 @@ __global__ void bn_finalize_kernel(const BnFinalizeArgs a) {
     float rm = a.running_mean ? a.running_mean[c] : 0.f;
     float rv = a.running_var ? a.running_var[c] : 0.f;
     for (int g = 0; g < a.G; ++g) {
-        float2 s = a.stats[g * a.C + c];
+        float2 s = make_float2(0.f, 0.f);
+        for (int q = 0; q < MMVAE_STAT_SLOTS; ++q) {
+            float2 t = a.stats[(g * MMVAE_STAT_SLOTS + q) * a.C + c];
+            s.x += t.x; s.y += t.y;
+        }
         float mean = s.x / a.count;
         float var = fmaxf(s.y / a.count - mean * mean, 0.f);
         float rstd = rsqrtf(var + a.eps);
@@ -138,7 +142,11 @@ __device__ __forceinline__ void bn_channel_tables(const BnFinalizeArgs& a, int g
     const float gamma = a.gamma[c], beta = a.beta[c];
     float mean, rstd;
     if (a.training) {
-        float2 s = a.stats[g * a.C + c];
+        float2 s = make_float2(0.f, 0.f);
+        for (int q = 0; q < MMVAE_STAT_SLOTS; ++q) {
+            float2 t = a.stats[(g * MMVAE_STAT_SLOTS + q) * a.C + c];
+            s.x += t.x; s.y += t.y;
+        }
         mean = s.x / a.count;
         float var = fmaxf(s.y / a.count - mean * mean, 0.f);
         rstd = rsqrtf(var + a.eps);
@@ -164,7 +172,11 @@ __global__ __launch_bounds__(TPB) void bn_act_kernel(const BnActArgs a) {
         for (int c = threadIdx.x; c < a.C; c += TPB) {
             float rm = f.running_mean[c], rv = f.running_var[c];
             for (int g = 0; g < a.G; ++g) {
-                float2 s = f.stats[g * a.C + c];
+                float2 s = make_float2(0.f, 0.f);
+                for (int q = 0; q < MMVAE_STAT_SLOTS; ++q) {
+                    float2 t = f.stats[(g * MMVAE_STAT_SLOTS + q) * a.C + c];
+                    s.x += t.x; s.y += t.y;
+                }
                 float mean = s.x / f.count;
                 float var = fmaxf(s.y / f.count - mean * mean, 0.f);
                 float unbiased = var * f.count / (f.count - 1.f);
@@ -197,9 +209,31 @@ __global__ __launch_bounds__(TPB) void bn_act_kernel(const BnActArgs a) {
 
 // ------------------------------------------------------------------ BatchNorm backward apply
 __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const BnBwdApplyArgs a) {
+    extern __shared__ float4 tab_s[];        // [G][C]: (sum db / n, sum db*xhat / n, mean, gamma*rstd)
+    const float inv_cnt = 1.f / (float)a.rows_per_group;
+    for (int i = threadIdx.x; i < a.G * a.C; i += TPB) {
+        const int g = i / a.C, c = i - g * a.C;
+        float sx = 0.f, sy = 0.f;
+        for (int q = 0; q < MMVAE_STAT_SLOTS; ++q) {
+            float2 t = a.red[(g * MMVAE_STAT_SLOTS + q) * a.C + c];
+            sx += t.x; sy += t.y;
+        }
+        const float2 mr = a.meanrstd[i];
+        tab_s[i] = make_float4(sx * inv_cnt, sy * inv_cnt, mr.x, mr.y);
+        if (blockIdx.x == 0 && g == 0) {       // parameter gradients: summed over groups by the threads of group 0
+            float tg = 0.f, tb = 0.f;
+            for (int gg = 0; gg < a.G; ++gg)
+                for (int q = 0; q < MMVAE_STAT_SLOTS; ++q) {
+                    float2 t = a.red[(gg * MMVAE_STAT_SLOTS + q) * a.C + c];
+                    tb += t.x; tg += t.y;
+                }
+            if (a.dgamma) a.dgamma[c] += tg;
+            if (a.dbeta) a.dbeta[c] += tb;
+        }
+    }
+    __syncthreads();
     const int vpr = a.C / 8;
     const long long nvec = (long long)a.rows * vpr;
-    const float inv_cnt = 1.f / (float)a.rows_per_group;
     for (long long v = (long long)blockIdx.x * TPB + threadIdx.x; v < nvec; v += (long long)gridDim.x * TPB) {
         const long long row = v / vpr;
         const int c0 = (int)(v - row * vpr) * 8;
@@ -218,21 +252,11 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const BnBwdApplyArgs 
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = c0 + j;
-            float2 red = a.red[g * a.C + c];
-            float2 mr = a.meanrstd[g * a.C + c];
-            float xh = ((float)rv[j] - mr.x) * mr.y;
-            float d = a.gamma[c] * mr.y * (dbf[j] - red.x * inv_cnt - xh * red.y * inv_cnt);
-            o[j] = (bf16)d;
+            const float4 t = tab_s[g * a.C + c];
+            const float xh = ((float)rv[j] - t.z) * t.w;
+            o[j] = (bf16)(a.gamma[c] * t.w * (dbf[j] - t.x - xh * t.y));
         }
         *reinterpret_cast<bf16x8*>(a.dr + row * a.ld + c0) = o;
-    }
-    if (blockIdx.x == 0) {
-        for (int c = threadIdx.x; c < a.C; c += TPB) {
-            float sg = 0.f, sb = 0.f;
-            for (int g = 0; g < a.G; ++g) { sg += a.red[g * a.C + c].y; sb += a.red[g * a.C + c].x; }
-            if (a.dgamma) a.dgamma[c] += sg;
-            if (a.dbeta) a.dbeta[c] += sb;
-        }
     }
 }
 
@@ -437,7 +461,7 @@ __global__ __launch_bounds__(TPB) void latent3_fwd_kernel(const Latent3Args a) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         float s = wave_sum(kl[k]);
-        if ((threadIdx.x & 63) == 0) atomicAdd(a.kl_sum + k, s);
+        if ((threadIdx.x & 63) == 0) atomicAdd(a.kl_sum + (blockIdx.x % MMVAE_LOSS_SLOTS) * 16 + k, s);
     }
 }
 
@@ -571,7 +595,8 @@ int launch_bn_act(const BnActArgs& a, hipStream_t s) {
 }
 int launch_bn_bwd_apply(const BnBwdApplyArgs& a, hipStream_t s) {
     MMVAE_REQUIRE(a.C % 8 == 0 && a.ld % 8 == 0, "bn_bwd_apply: C=%d ld=%d", a.C, a.ld);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblocks((long long)a.rows * a.C / 8)), dim3(TPB), 0, s, a);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblocks((long long)a.rows * a.C / 8, TPB, 2048)), dim3(TPB),
+                       (size_t)a.G * a.C * sizeof(float4), s, a);
     return mmvae_check_launch("bn_bwd_apply");
 }
 int launch_sigmoid_bce(const BceArgs& a, hipStream_t s) {

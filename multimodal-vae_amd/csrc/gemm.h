@@ -49,7 +49,7 @@ struct GemmParams {
     int e_act;
     const uint8_t* e_mask;  // [rows][N] keep flags or null
     float e_mask_scale;
-    float2* colstats;       // [groups][N] += (sum v, sum v^2) or null
+    float2* colstats;       // [groups][MMVAE_STAT_SLOTS][N] += (sum v, sum v^2) or null
     // d-activation epilogue: v *= act'(affine(r)) [* keep*scale], r has the output geometry (ld = d_ld)
     const bf16* d_r;
     int d_ld;
@@ -59,7 +59,7 @@ struct GemmParams {
     const uint8_t* d_mask;  // [rows][N] keep flags or null
     float d_mask_scale;
     const float2* d_meanrstd;  // [groups][N] for xhat=(r-mean)*rstd, with d_red
-    float2* d_red;             // [groups][N] += (sum v, sum v*xhat) or null
+    float2* d_red;             // [groups][MMVAE_STAT_SLOTS][N] += (sum v, sum v*xhat) or null
     float* d_colsum;           // [N] += sum v over all rows (bias gradient of the producer Linear) or null
 };
 

@@ -313,10 +313,11 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(const GemmParams p) {
         if (tid < BN && n0 + tid < c.N) {
             float a = 0.f, b = 0.f;
             for (int q = 0; q < RPP; ++q) { a += red[q * BN + tid].x; b += red[q * BN + tid].y; }
-            float2* dst = want_stats ? p.colstats : p.d_red;
+            float2* dst = want_stats ? p.colstats : p.d_red;      // [groups][SLOTS][N]
             if (dst) {
-                atomicAdd(&dst[g * c.N + n0 + tid].x, a);
-                atomicAdd(&dst[g * c.N + n0 + tid].y, b);
+                const int slot = (blockIdx.x + 5 * blockIdx.z) % MMVAE_STAT_SLOTS;
+                atomicAdd(&dst[(g * MMVAE_STAT_SLOTS + slot) * c.N + n0 + tid].x, a);
+                atomicAdd(&dst[(g * MMVAE_STAT_SLOTS + slot) * c.N + n0 + tid].y, b);
             }
             if (p.d_colsum) atomicAdd(p.d_colsum + n0 + tid, a);
         }

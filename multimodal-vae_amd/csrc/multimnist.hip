@@ -294,9 +294,10 @@ void carve(MMPlan& P, Workspace& ws) {
     const size_t B = P.B, D = P.D, B3 = 3 * B, B2 = 2 * B;
     char* z0 = ws.take<char>(0);
     const int ec[3] = {64, 128, 256}, dc[3] = {128, 64, 32};
-    for (int i = 0; i < 3; ++i) { w.st_e[i] = ws.take<float2>(ec[i]); w.red_e[i] = ws.take<float2>(ec[i]); }
-    for (int i = 0; i < 3; ++i) { w.st_d[i] = ws.take<float2>(3 * dc[i]); w.red_d[i] = ws.take<float2>(3 * dc[i]); }
-    w.sums = ws.take<float>(16);
+    const int SS = MMVAE_STAT_SLOTS;
+    for (int i = 0; i < 3; ++i) { w.st_e[i] = ws.take<float2>(SS * ec[i]); w.red_e[i] = ws.take<float2>(SS * ec[i]); }
+    for (int i = 0; i < 3; ++i) { w.st_d[i] = ws.take<float2>(3 * SS * dc[i]); w.red_d[i] = ws.take<float2>(3 * SS * dc[i]); }
+    w.sums = ws.take<float>(16 * MMVAE_LOSS_SLOTS);
     w.dz_img = ws.take<float>(B3 * D);
     w.dz_txt = ws.take<float>(B3 * D);
     char* z1 = ws.take<char>(0);
@@ -704,6 +705,14 @@ int txt_dec_bwd(MMPlan& P, const TextDecArgs& f, const float* dwords, float* dz,
     return MMVAE_OK;
 }
 
+// out[16] = sum over the MMVAE_LOSS_SLOTS replicated rows of the loss accumulators
+__global__ void sum_slots_kernel(const float* slots, float* out) {
+    const int j = threadIdx.x;
+    if (j >= 16) return;
+    float s = 0.f;
+    for (int q = 0; q < MMVAE_LOSS_SLOTS; ++q) s += slots[q * 16 + j];
+    out[j] = s;
+}
 __global__ void cast_z_kernel(const float* z, int rows, int D, bf16* out, int ldz) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * ldz) return;
@@ -871,11 +880,8 @@ int mm_step_fwd_bwd(MMPlan* Pp, const MMStepIO& io, int training, int do_backwar
     MMVAE_TRY(dec_fwd(P, 3, training, &last, s));
     if (!do_backward) {
         MMVAE_TRY(edge(P, T, s));
-        if (hipMemcpyAsync(io.sums, w.sums, 16 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
-            mmvae_set_error("step: copy of the loss sums failed");
-            return MMVAE_EHIP;
-        }
-        return MMVAE_OK;
+        hipLaunchKernelGGL(sum_slots_kernel, dim3(1), dim3(64), 0, s, w.sums, io.sums);
+        return mmvae_check_launch("sum_slots");
     }
 
     // =============================== backward ===============================
@@ -898,10 +904,8 @@ int mm_step_fwd_bwd(MMPlan* Pp, const MMStepIO& io, int training, int do_backwar
     MMVAE_TRY(rc);
     MMVAE_TRY(edge(P, T, s));
     MMVAE_TRY(edge(P, P.st_wgrad, s));
-    if (hipMemcpyAsync(io.sums, w.sums, 16 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
-        mmvae_set_error("step: copy of the loss sums failed");
-        return MMVAE_EHIP;
-    }
+    hipLaunchKernelGGL(sum_slots_kernel, dim3(1), dim3(64), 0, s, w.sums, io.sums);
+    MMVAE_TRY(mmvae_check_launch("sum_slots"));
     MMVAE_TRY(mm_unpack_grads(Pp, s));
     return MMVAE_OK;
 }

@@ -381,7 +381,7 @@ __global__ __launch_bounds__(NTHR) void text_decoder_fwd_kernel(const TextDecArg
     if (a.target && a.nll_sum && tid < TR) {
 #pragma unroll
         for (int p = 0; p < 4; ++p)
-            if (nll[p] != 0.f) atomicAdd(a.nll_sum + p, nll[p]);
+            if (nll[p] != 0.f) atomicAdd(a.nll_sum + (blockIdx.x % MMVAE_LOSS_SLOTS) * 16 + p, nll[p]);
     }
 }
 

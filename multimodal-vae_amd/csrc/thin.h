@@ -11,7 +11,7 @@ struct ConvTLastFwdArgs {
     float* recon;            // sigmoid(logits) or null
     float* dlogit;           // coef[g] * dBCE/dlogit or null
     float coef[4];
-    float* loss_sum;         // [G] += BCE sums, or null
+    float* loss_sum;         // [MMVAE_LOSS_SLOTS][16]: slot row, column g += BCE sums, or null
 };
 int launch_convt_last_fwd(const ConvTLastFwdArgs& a, hipStream_t s);
 
@@ -24,6 +24,6 @@ struct ConvTLastDgradArgs {
     const float2* meanrstd;  // [G][Cin]
     int act;
     bf16* db;                // out: grad wrt the BN output after the d-activation, same layout as r
-    float2* red;             // [G][Cin] += (sum db, sum db*xhat)
+    float2* red;             // [G][MMVAE_STAT_SLOTS][Cin] += (sum db, sum db*xhat)
 };
 int launch_convt_last_dgrad(const ConvTLastDgradArgs& a, hipStream_t s);

@@ -9,25 +9,50 @@ namespace {
 
 constexpr int TPB = 256;
 
-// forward: one thread per output pixel (all COUT channels); fused sigmoid + BCE(+gradient)
+// forward: one workgroup per (image, strip of FR input rows); the activated input strip (+1 halo row each side,
+// zero-filled outside the image) is staged once in LDS, so every input pixel is read from global memory once.
+// Each thread then produces output pixels of the strip (all COUT channels) and the fused sigmoid + BCE(+gradient).
+constexpr int FR = 5;                       // input rows per strip (25 = 5*5, 32 = 6*5+2: the tail strip is masked)
 template <int COUT>
 __global__ __launch_bounds__(TPB) void convt_last_fwd_kernel(const ConvTLastFwdArgs a) {
-    __shared__ float wl[16 * 32 * COUT];          // [kh][kw][ci][co]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* wl = reinterpret_cast<float*>(smem);                     // [kh][kw][ci][co]
+    bf16* tile = reinterpret_cast<bf16*>(wl + 16 * 32 * COUT);      // [(FR+2)][IW+2][32]
+    __shared__ float part[TPB / 64];
+    const int strips = (a.IH + FR - 1) / FR;
+    const int n_in_g = blockIdx.x / strips, strip = blockIdx.x - n_in_g * strips;
     const int g = blockIdx.y;
+    const long long n = (long long)g * a.B + n_in_g;
+    const int iy_base = strip * FR - 1;                             // first staged row (halo)
+    const int TW = a.IW + 2;
     for (int i = threadIdx.x; i < 16 * a.Cin * COUT; i += TPB) {
         int co = i % COUT, ci = (i / COUT) % a.Cin, tap = i / (COUT * a.Cin);
         wl[i] = a.w[(ci * COUT + co) * 16 + tap];                  // weight (Cin, Cout, 4, 4)
     }
+    const int nvec = (FR + 2) * TW * 4;                             // 16-byte vectors (32 channels = 4 vectors)
+    for (int v = threadIdx.x; v < nvec; v += TPB) {
+        const int q = v & 3, pixl = v >> 2;
+        const int ty = pixl / TW, tx = pixl - ty * TW;
+        const int iy = iy_base + ty, ix = tx - 1;
+        const bool ok = (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+        const long long src = ok ? ((n * a.IH + iy) * a.IW + ix) * a.Cin + q * 8 : 0;
+        bf16x8 val = *reinterpret_cast<const bf16x8*>(a.act + src);
+        if (!ok) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) val[j] = (bf16)0.f;
+        }
+        *reinterpret_cast<bf16x8*>(tile + (size_t)pixl * 32 + q * 8) = val;
+    }
     __syncthreads();
     const int OH = 2 * a.IH, OW = 2 * a.IW;
-    const long long per_group = (long long)a.B * OH * OW;
+    const int oy_lo = 2 * strip * FR;
+    const int nout = 2 * FR * OW;
     float loss = 0.f;
-    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < per_group; i += (long long)gridDim.x * TPB) {
-        const int ox = (int)(i % OW);
-        long long t1 = i / OW;
-        const int oy = (int)(t1 % OH);
-        const int nb = (int)(t1 / OH);
-        const long long n = (long long)g * a.B + nb;
+    for (int o = threadIdx.x; o < nout; o += TPB) {
+        asm volatile("" ::: "memory");        // no hoisting of the LDS weight reads out of the loop (VGPR blow-up)
+        const int oyl = o / OW, ox = o - oyl * OW;
+        const int oy = oy_lo + oyl;
+        if (oy >= OH) continue;
         const int kh0 = (oy + 1) & 1, kw0 = (ox + 1) & 1;
         const int iy0 = (oy + 1 - kh0) >> 1, ix0 = (ox + 1 - kw0) >> 1;
         float acc[COUT];
@@ -35,16 +60,14 @@ __global__ __launch_bounds__(TPB) void convt_last_fwd_kernel(const ConvTLastFwdA
         for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
 #pragma unroll
         for (int ty = 0; ty < 2; ++ty) {
-            const int iy = iy0 - ty, kh = kh0 + 2 * ty;
-            if ((unsigned)iy >= (unsigned)a.IH) continue;
 #pragma unroll
             for (int tx = 0; tx < 2; ++tx) {
-                const int ix = ix0 - tx, kw = kw0 + 2 * tx;
-                if ((unsigned)ix >= (unsigned)a.IW) continue;
-                const bf16* src = a.act + ((n * a.IH + iy) * a.IW + ix) * a.Cin;
-                const float* wp = wl + (kh * 4 + kw) * a.Cin * COUT;
-                for (int c0 = 0; c0 < a.Cin; c0 += 8) {
-                    bf16x8 v = *reinterpret_cast<const bf16x8*>(src + c0);
+                const int iy = iy0 - ty, ix = ix0 - tx;             // in [-1, IH] x [-1, IW]: inside the halo tile
+                const bf16* src = tile + ((size_t)(iy - iy_base) * TW + (ix + 1)) * 32;
+                const float* wp = wl + ((kh0 + 2 * ty) * 4 + kw0 + 2 * tx) * 32 * COUT;
+#pragma unroll
+                for (int c0 = 0; c0 < 32; c0 += 8) {
+                    const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + c0);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const float x = (float)v[j];
@@ -56,39 +79,40 @@ __global__ __launch_bounds__(TPB) void convt_last_fwd_kernel(const ConvTLastFwdA
         }
 #pragma unroll
         for (int co = 0; co < COUT; ++co) {
-            const long long o = ((n * COUT + co) * OH + oy) * OW + ox;         // NCHW
+            const long long oidx = ((n * COUT + co) * OH + oy) * OW + ox;         // NCHW
             const float l = acc[co];
             const float p = 1.0f / (1.0f + expf(-l));                           // F.sigmoid
-            if (a.logits) a.logits[o] = l;
-            if (a.recon) a.recon[o] = p;
+            if (a.logits) a.logits[oidx] = l;
+            if (a.recon) a.recon[oidx] = p;
             if (a.target) {
-                const float t = a.target[(((long long)nb * COUT + co) * OH + oy) * OW + ox];
+                const float t = a.target[(((long long)n_in_g * COUT + co) * OH + oy) * OW + ox];
                 const float lp = fmaxf(logf(p), -100.f), lq = fmaxf(logf(1.0f - p), -100.f);   // BCE log clamp
                 loss += -(t * lp + (1.0f - t) * lq);
                 if (a.dlogit) {
                     const float pq = p * (1.0f - p);
-                    a.dlogit[o] = a.coef[g] * (p - t) / fmaxf(pq, 1e-12f) * pq;
+                    a.dlogit[oidx] = a.coef[g] * (p - t) / fmaxf(pq, 1e-12f) * pq;
                 }
             }
         }
     }
     if (a.loss_sum) {
         loss = wave_sum(loss);
-        __shared__ float part[TPB / 64];
         if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = loss;
         __syncthreads();
         if (threadIdx.x == 0) {
             float s = 0.f;
             for (int w = 0; w < TPB / 64; ++w) s += part[w];
-            atomicAdd(a.loss_sum + g, s);
+            atomicAdd(a.loss_sum + (blockIdx.x % MMVAE_LOSS_SLOTS) * 16 + g, s);
         }
     }
 }
 
-// backward-data: one thread per INPUT pixel, all Cin (<= 32) channels; fused d-activation + BatchNorm-backward sums
+// backward-data: four threads per INPUT pixel (8 of the 32 channels each, one 16-byte vector); fused d-activation of
+// the producer layer + its two BatchNorm-backward sums (lanes with equal lane&3 own the same channels: xor-shuffles
+// over the other lane bits, then one LDS pass across the waves, then one atomic per channel per workgroup).
 template <int COUT>
 __global__ __launch_bounds__(TPB) void convt_last_dgrad_kernel(const ConvTLastDgradArgs a) {
-    __shared__ float wl[16 * COUT * 32];          // [kh][kw][co][ci]
+    __shared__ __attribute__((aligned(16))) float wl[16 * COUT * 32];          // [kh][kw][co][ci]
     __shared__ float2 red_s[TPB / 64][32];
     const int g = blockIdx.y;
     for (int i = threadIdx.x; i < 16 * a.Cin * COUT; i += TPB) {
@@ -98,67 +122,74 @@ __global__ __launch_bounds__(TPB) void convt_last_dgrad_kernel(const ConvTLastDg
     __syncthreads();
     const int OH = 2 * a.IH, OW = 2 * a.IW;
     const long long per_group = (long long)a.B * a.IH * a.IW;
-    float s1[32], s2[32];
+    const int cg = threadIdx.x & 3;                   // channel group: channels 8*cg .. 8*cg+7
+    float s1[8], s2[8];
 #pragma unroll
-    for (int c = 0; c < 32; ++c) { s1[c] = 0.f; s2[c] = 0.f; }
-    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < per_group; i += (long long)gridDim.x * TPB) {
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    float2 af[8], mr[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { af[j] = a.affine[g * a.Cin + cg * 8 + j]; mr[j] = a.meanrstd[g * a.Cin + cg * 8 + j]; }
+    for (long long i = (long long)blockIdx.x * (TPB / 4) + (threadIdx.x >> 2); i < per_group; i += (long long)gridDim.x * (TPB / 4)) {
+        asm volatile("" ::: "memory");        // keep the (loop-invariant) LDS weight reads inside the loop: hoisting
+                                              // all 512 of them would cost 128+ VGPRs for a loop that runs once
         const int ix = (int)(i % a.IW);
         long long t1 = i / a.IW;
         const int iy = (int)(t1 % a.IH);
         const long long n = (long long)g * a.B + t1 / a.IH;
-        float acc[32];
-#pragma unroll
-        for (int c = 0; c < 32; ++c) acc[c] = 0.f;
+        // 16*COUT upstream values: unconditional loads from clamped addresses, out-of-image taps zeroed afterwards
+        float dl[16 * COUT];
 #pragma unroll
         for (int kh = 0; kh < 4; ++kh) {
-            const int oy = 2 * iy - 1 + kh;
-            if ((unsigned)oy >= (unsigned)OH) continue;
 #pragma unroll
             for (int kw = 0; kw < 4; ++kw) {
-                const int ox = 2 * ix - 1 + kw;
-                if ((unsigned)ox >= (unsigned)OW) continue;
+                const int oy = 2 * iy - 1 + kh, ox = 2 * ix - 1 + kw;
+                const bool ok = (unsigned)oy < (unsigned)OH && (unsigned)ox < (unsigned)OW;
+                const int oyc = min(max(oy, 0), OH - 1), oxc = min(max(ox, 0), OW - 1);
 #pragma unroll
                 for (int co = 0; co < COUT; ++co) {
-                    const float d = a.dlogit[((n * COUT + co) * OH + oy) * OW + ox];
-                    const float* wp = wl + ((kh * 4 + kw) * COUT + co) * a.Cin;
-#pragma unroll
-                    for (int c = 0; c < 32; ++c) acc[c] += d * wp[c];
+                    const float d = a.dlogit[((n * COUT + co) * OH + oyc) * OW + oxc];
+                    dl[(kh * 4 + kw) * COUT + co] = ok ? d : 0.f;
                 }
             }
         }
-        // d-activation of the producer layer (BatchNorm + act) and its two backward sums
-        const long long pix = (n * a.IH + iy) * a.IW + ix;
-        const bf16* rp = a.r + pix * a.Cin;
-        bf16* op = a.db + pix * a.Cin;
+        float acc[8];
 #pragma unroll
-        for (int c0 = 0; c0 < 32; c0 += 8) {
-            bf16x8 rv = *reinterpret_cast<const bf16x8*>(rp + c0);
-            bf16x8 o;
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int c = c0 + j;
-                const float rr = (float)rv[j];
-                const float2 af = a.affine[g * a.Cin + c];
-                const float2 mr = a.meanrstd[g * a.Cin + c];
-                const float v = acc[c] * act_bwd(a.act, rr * af.x + af.y);
-                s1[c] += v;
-                s2[c] += v * (rr - mr.x) * mr.y;
-                o[j] = (bf16)v;
-            }
-            *reinterpret_cast<bf16x8*>(op + c0) = o;
+        for (int tp = 0; tp < 16 * COUT; ++tp) {
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wl + tp * 32 + cg * 8);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(wl + tp * 32 + cg * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { acc[j] += dl[tp] * w0[j]; acc[4 + j] += dl[tp] * w1[j]; }
+            if ((tp & 3) == 3) __builtin_amdgcn_sched_barrier(0);    // bound how many LDS weight reads are in flight
         }
+        const long long pix = (n * a.IH + iy) * a.IW + ix;
+        const bf16x8 rv = *reinterpret_cast<const bf16x8*>(a.r + pix * a.Cin + cg * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float rr = (float)rv[j];
+            const float v = acc[j] * act_bwd(a.act, rr * af[j].x + af[j].y);
+            s1[j] += v;
+            s2[j] += v * (rr - mr[j].x) * mr[j].y;
+            o[j] = (bf16)v;
+        }
+        *reinterpret_cast<bf16x8*>(a.db + pix * a.Cin + cg * 8) = o;
     }
 #pragma unroll
-    for (int c = 0; c < 32; ++c) {
-        float x = wave_sum(s1[c]), y = wave_sum(s2[c]);
-        if ((threadIdx.x & 63) == 0) red_s[threadIdx.x >> 6][c] = make_float2(x, y);
+    for (int j = 0; j < 8; ++j) {
+        float x = s1[j], y = s2[j];
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) { x += __shfl_xor(x, o, 64); y += __shfl_xor(y, o, 64); }
+        if ((threadIdx.x & 63) < 4) red_s[threadIdx.x >> 6][cg * 8 + j] = make_float2(x, y);
     }
     __syncthreads();
     if (threadIdx.x < 32) {
         float x = 0.f, y = 0.f;
         for (int w = 0; w < TPB / 64; ++w) { x += red_s[w][threadIdx.x].x; y += red_s[w][threadIdx.x].y; }
-        atomicAdd(&a.red[g * a.Cin + threadIdx.x].x, x);
-        atomicAdd(&a.red[g * a.Cin + threadIdx.x].y, y);
+        const int slot = blockIdx.x % MMVAE_STAT_SLOTS;
+        atomicAdd(&a.red[(g * MMVAE_STAT_SLOTS + slot) * a.Cin + threadIdx.x].x, x);
+        atomicAdd(&a.red[(g * MMVAE_STAT_SLOTS + slot) * a.Cin + threadIdx.x].y, y);
     }
 }
 
@@ -166,16 +197,17 @@ __global__ __launch_bounds__(TPB) void convt_last_dgrad_kernel(const ConvTLastDg
 
 int launch_convt_last_fwd(const ConvTLastFwdArgs& a, hipStream_t s) {
     MMVAE_REQUIRE(a.Cin == 32 && (a.Cout == 1 || a.Cout == 3) && a.G >= 1 && a.G <= 4, "convT last fwd: Cin=%d Cout=%d G=%d", a.Cin, a.Cout, a.G);
-    long long per_group = (long long)a.B * 4 * a.IH * a.IW;
-    dim3 grid((unsigned)min((per_group + TPB - 1) / TPB, (long long)4096), a.G);
-    if (a.Cout == 1) hipLaunchKernelGGL(convt_last_fwd_kernel<1>, grid, dim3(TPB), 0, s, a);
-    else hipLaunchKernelGGL(convt_last_fwd_kernel<3>, grid, dim3(TPB), 0, s, a);
+    const int strips = (a.IH + FR - 1) / FR;
+    dim3 grid(a.B * strips, a.G);
+    size_t lds = (size_t)16 * 32 * a.Cout * sizeof(float) + (size_t)(FR + 2) * (a.IW + 2) * 32 * sizeof(bf16);
+    if (a.Cout == 1) hipLaunchKernelGGL(convt_last_fwd_kernel<1>, grid, dim3(TPB), lds, s, a);
+    else hipLaunchKernelGGL(convt_last_fwd_kernel<3>, grid, dim3(TPB), lds, s, a);
     return mmvae_check_launch("convt_last_fwd");
 }
 int launch_convt_last_dgrad(const ConvTLastDgradArgs& a, hipStream_t s) {
     MMVAE_REQUIRE(a.Cin == 32 && (a.Cout == 1 || a.Cout == 3) && a.G >= 1 && a.G <= 4, "convT last dgrad: Cin=%d Cout=%d", a.Cin, a.Cout);
     long long per_group = (long long)a.B * a.IH * a.IW;
-    dim3 grid((unsigned)min((per_group + TPB - 1) / TPB, (long long)4096), a.G);
+    dim3 grid((unsigned)min((per_group * 4 + TPB - 1) / TPB, (long long)8192), a.G);
     if (a.Cout == 1) hipLaunchKernelGGL(convt_last_dgrad_kernel<1>, grid, dim3(TPB), 0, s, a);
     else hipLaunchKernelGGL(convt_last_dgrad_kernel<3>, grid, dim3(TPB), 0, s, a);
     return mmvae_check_launch("convt_last_dgrad");
