@@ -41,6 +41,12 @@ struct GatherCommon {
 struct GemmParams {
     GatherCommon c;
     GatherClass cls[MMVAE_MAX_CLASSES];
+    // split-K for small row counts (few workgroups, long K): `ksplit` workgroups share one output tile; partial
+    // tiles are added into zeroed fp32 scratch with float atomics, an arrival ticket elects the last workgroup,
+    // which runs the epilogue and leaves scratch + ticket zeroed again.  sk_buf: tiles*128*BN floats.
+    int ksplit;
+    float* sk_buf;
+    unsigned* sk_cnt;
     const float* bias;      // [N] or null
     bf16* out_bf;           // [Nimg][OH][OW][ldo] or null
     float* out_f;           // same geometry, fp32, or null

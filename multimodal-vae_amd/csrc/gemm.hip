@@ -61,9 +61,13 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(const GemmParams p) {
     if ((int)blockIdx.x >= tiles_per_group * c.groups) return;
     const int g = blockIdx.x / tiles_per_group;
     const int row0 = (blockIdx.x - g * tiles_per_group) * BM;
-    const int n0 = blockIdx.y * BN;
+    const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
+    const int nblk = blockIdx.y / ksplit, ksi = blockIdx.y - nblk * ksplit;
+    const int n0 = nblk * BN;
     const int K = k.K;
-    const int nk = (K + BK - 1) / BK;
+    const int nk_all = (K + BK - 1) / BK;
+    const int kt0 = (int)((long long)nk_all * ksi / ksplit), kt1 = (int)((long long)nk_all * (ksi + 1) / ksplit);
+    const int nk = kt1 - kt0;
     const int pix_per_img = k.OY * k.OX;
 
     // ---- per-thread staging coordinates: 4 A rows, vector column kv ----
@@ -143,14 +147,14 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(const GemmParams p) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    load_tile(0);
+    load_tile(kt0);
     store_tile(0);
     __syncthreads();
 
     const int fr = lane & 15, fq = lane >> 4;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
+        if (kt + 1 < nk) load_tile(kt0 + kt + 1);
         const bf16* a_src = As + buf * BM * LDA + (wave * 32 + fr) * LDA + fq * 8;
         const bf16* b_src = Bs + buf * BN * LDA + fr * LDA + fq * 8;
         bf16x8 af[2][2], bfr[2][NT];
@@ -181,13 +185,38 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(const GemmParams p) {
     constexpr int RPP = 256 / VPR;           // tile rows per pass
     constexpr int PASSES = BM / RPP;
     float* ct = reinterpret_cast<float*>(smem);
+    if (ksplit > 1) {
+        const int tile_id = ((int)blockIdx.z * gridDim.x + blockIdx.x) * (gridDim.y / ksplit) + nblk;
+        float* sk = p.sk_buf + (size_t)tile_id * BM * BN;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                ct[(wave * 32 + mt * 16 + fq * 4 + j) * LDC + nt * 16 + fr] = acc[mt][nt][j];
+                for (int j = 0; j < 4; ++j)
+                    atomicAdd(sk + (wave * 32 + mt * 16 + fq * 4 + j) * BN + nt * 16 + fr, acc[mt][nt][j]);
+        __threadfence();                        // release: this workgroup's adds are performed before its ticket
+        __syncthreads();
+        __shared__ unsigned ticket_s;
+        if (tid == 0) ticket_s = atomicAdd(p.sk_cnt + tile_id, 1u);
+        __syncthreads();
+        if (ticket_s != (unsigned)(ksplit - 1)) return;
+        __threadfence();                        // acquire side of the ticket
+        for (int e = tid; e < BM * BN; e += 256) {
+            const int r = e / BN, cidx = e - r * BN;
+            ct[r * LDC + cidx] = __hip_atomic_load(sk + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sk[e] = 0.f;                        // leave the scratch tile clean for the next user
+        }
+        if (tid == 0) p.sk_cnt[tile_id] = 0u;
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    ct[(wave * 32 + mt * 16 + fq * 4 + j) * LDC + nt * 16 + fr] = acc[mt][nt][j];
+    }
     __syncthreads();
 
     const bool want_stats = p.colstats != nullptr;
@@ -448,7 +477,8 @@ int launch_gemm_nt(const GemmParams& p, hipStream_t stream) {
     constexpr int BN = NT * 16;
     int max_tiles = 0;
     for (int i = 0; i < p.c.nclasses; ++i) max_tiles = max(max_tiles, ceil_div(p.cls[i].rows_per_group, BM));
-    dim3 grid(max_tiles * p.c.groups, ceil_div(p.c.N, BN), p.c.nclasses);
+    const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
+    dim3 grid(max_tiles * p.c.groups, ceil_div(p.c.N, BN) * ksplit, p.c.nclasses);
     size_t lds = (size_t)2 * (BM + BN) * LDA * sizeof(bf16);
     static bool attr_set = false;
     if (!attr_set) {
@@ -477,6 +507,7 @@ int launch_gemm_gather(const GemmParams& p, hipStream_t stream) {
     }
     MMVAE_REQUIRE(c.a_mask == nullptr && c.a_affine == nullptr && c.a_act == ACT_NONE,
                   "gemm: operand transforms are not supported (activations are materialised by bn_act / the epilogue)");
+    MMVAE_REQUIRE(p.ksplit <= 1 || (p.sk_buf != nullptr && p.sk_cnt != nullptr), "gemm: split-K needs scratch");
     if (c.N <= 16) return launch_gemm_nt<1>(p, stream);
     if (c.N <= 32) return launch_gemm_nt<2>(p, stream);
     if (c.N <= 64) return launch_gemm_nt<4>(p, stream);

@@ -52,6 +52,7 @@ struct MMPlan {
         char* zero_begin; size_t zero_bytes;
         float2 *st_e[3], *red_e[3], *st_d[3], *red_d[3];
         float* sums; float* dz_img; float* dz_txt;
+        float* sk_buf; unsigned* sk_cnt; size_t sk_floats;
         float2 *aff_e[3], *mr_e[3], *aff_d[3], *mr_d[3];
         bf16 *patches1, *r1, *r2, *r3, *r4, *y1, *y2;
         bf16 *a1, *a2, *a3, *a4, *ay1, *ay2, *au, *aq1, *aq2, *aq3;
@@ -298,6 +299,8 @@ void carve(MMPlan& P, Workspace& ws) {
     for (int i = 0; i < 3; ++i) { w.st_e[i] = ws.take<float2>(SS * ec[i]); w.red_e[i] = ws.take<float2>(SS * ec[i]); }
     for (int i = 0; i < 3; ++i) { w.st_d[i] = ws.take<float2>(3 * SS * dc[i]); w.red_d[i] = ws.take<float2>(3 * SS * dc[i]); }
     w.sums = ws.take<float>(16 * MMVAE_LOSS_SLOTS);
+    w.sk_floats = (size_t)64 * 128 * 128;                  // split-K scratch: up to 64 output tiles of 128x128 fp32
+    w.sk_buf = ws.take<float>(w.sk_floats); w.sk_cnt = ws.take<unsigned>(1024);
     w.dz_img = ws.take<float>(B3 * D);
     w.dz_txt = ws.take<float>(B3 * D);
     char* z1 = ws.take<char>(0);
@@ -346,10 +349,23 @@ void carve(MMPlan& P, Workspace& ws) {
 GemmParams gemm_of(const MMPlan& P, const GatherPlan& pl, const int* pk, int groups, int group_n) {
     GemmParams g{};
     g.c = pl.c; g.c.groups = groups; g.c.group_n = group_n;
+    int max_tiles = 0, min_nk = 1 << 30;
     for (int i = 0; i < pl.c.nclasses; ++i) {
         g.cls[i] = pl.cls[i];
         g.cls[i].rows_per_group = group_n * pl.cls[i].OY * pl.cls[i].OX;
         g.cls[i].Wp = P.buf.packed + P.pk.d[pk[i]].dst_off;
+        max_tiles = max(max_tiles, ceil_div(g.cls[i].rows_per_group, 128));
+        min_nk = min(min_nk, ceil_div(g.cls[i].K, 64));
+    }
+    // few workgroups and a long K loop: split K so the chip is not idle behind a serial chain of tile latencies
+    const int bn = pl.c.N <= 16 ? 16 : pl.c.N <= 32 ? 32 : pl.c.N <= 64 ? 64 : 128;
+    const int tiles = max_tiles * groups * pl.c.nclasses * ceil_div(pl.c.N, bn);
+    g.ksplit = 1;
+    // (measured: the float-atomic partial-tile adds cost more than the latency chain they remove -> disabled;
+    //  kept for shapes where K is much longer.  See DESIGN.md, 'what did not pay'.)
+    if (false && tiles <= 64 && min_nk >= 4) {
+        int ks = min(min(8, min_nk / 2), max(1, 192 / tiles));
+        if (ks > 1 && (size_t)tiles * 128 * bn <= P.w.sk_floats) { g.ksplit = ks; g.sk_buf = P.w.sk_buf; g.sk_cnt = P.w.sk_cnt; }
     }
     return g;
 }

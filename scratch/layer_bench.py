@@ -1,0 +1,23 @@
+import os, sys, ctypes, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import multimodal_vae_amd
+from multimodal_vae_amd.core import MultimnistState, FusedELBOStep
+from multimodal_vae_amd.init import default_init_
+from multimodal_vae_amd._lib import call
+sys.path.insert(0, '.')
+from bench import synthetic_batch
+dev = torch.device('cuda:0'); B = 256
+st = MultimnistState(100, dev); default_init_(st, 1234)
+img, txt = synthetic_batch(B, 1234)
+eng = FusedELBOStep(st, B)
+eng(img.to(dev), txt.to(dev)); torch.cuda.synchronize()
+layers = sys.argv[1:] or ['enc_conv2', 'enc_conv3', 'enc_conv4', 'dec_convT1', 'dec_convT2', 'dec_convT3', 'dec_convT1_dgrad', 'dec_convT2_dgrad', 'dec_convT3_dgrad']
+s = torch.cuda.current_stream(); sp = ctypes.c_void_p(s.cuda_stream)
+for L in layers:
+    fl = call("mmvae_mm_layer_flops", eng.h, L.encode())
+    call("mmvae_mm_bench_layer", eng.h, eng.ws.data_ptr(), eng.ws.numel(), L.encode(), 3, sp)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(s); call("mmvae_mm_bench_layer", eng.h, eng.ws.data_ptr(), eng.ws.numel(), L.encode(), 20, sp); e1.record(s)
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / 20
+    print(f"{L:20s} {us:8.1f} us  {fl/1e9:7.2f} GFLOP  {fl/us/1e6:7.1f} TFLOP/s")
