@@ -88,6 +88,9 @@ def load():
     """dlopen the library and declare every prototype (works without a GPU)."""
     global _lib
     if _lib is None:
+        # PyTorch ships its own libamdhip64: it must be mapped first so that this library's NEEDED entry binds to the
+        # same HIP runtime (two runtimes in one process see no devices)
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise MMVAEError("%s not found: run `python multimodal-vae_amd/build.py` (hipcc, gfx950). "
                              "There is no CPU fallback." % LIB_PATH)

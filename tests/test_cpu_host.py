@@ -1,0 +1,100 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol of include/mmvae_hip.h, the host-side plan
+(parameter table, pack tables, workspace) agrees with the oracle's table, the Python face has the reference's
+state_dict surface, and the product path refuses to run without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mmvae_ref as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import multimodal_vae_amd  # noqa: F401
+    from multimodal_vae_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        from multimodal_vae_amd import build  # type: ignore  # noqa: F401
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("mmvae_build", os.path.join(ROOT, "multimodal-vae_amd", "build.py"))
+        mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod); mod.build()
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "mmvae_hip.h")).read()
+    names = set(re.findall(r"\b(mmvae_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 40
+    for n in sorted(names):
+        assert hasattr(lib, n), "library does not export %s" % n
+    from multimodal_vae_amd import _lib
+    assert set(_lib.SIGNATURES) <= names | {"mmvae_last_error", "mmvae_version"}
+
+
+@pytest.mark.parametrize("D", [20, 100])
+def test_param_table_matches_reference_state_dict_order(lib, D):
+    from multimodal_vae_amd._lib import call
+    h = call("mmvae_mm_create", D, 8)
+    assert h
+    table = R.param_table("multimnist", D)
+    assert call("mmvae_mm_num_params", h) == len(table) == 52
+    name = C.create_string_buffer(128); nd = C.c_int(); off = C.c_longlong(); shape = (C.c_int * 4)()
+    expect_off = 0
+    for i, (n, s) in enumerate(table):
+        call("mmvae_mm_param_info", h, i, name, C.byref(nd), shape, C.byref(off))
+        assert name.value.decode() == n and tuple(shape[k] for k in range(nd.value)) == tuple(s) and off.value == expect_off
+        expect_off += int(np.prod(s))
+    assert call("mmvae_mm_param_count", h) == expect_off
+    assert call("mmvae_mm_workspace_bytes", h) > 0
+    assert call("mmvae_mm_packed_elems", h) > expect_off           # forward + backward packings
+    assert call("mmvae_mm_num_bn", h) == 6 and call("mmvae_mm_bn_floats", h) == 2 * (64 + 128 + 256 + 128 + 64 + 32)
+    call("mmvae_mm_destroy", h)
+
+
+def test_error_reporting_without_exceptions(lib):
+    from multimodal_vae_amd._lib import call, MMVAEError
+    assert call("mmvae_mm_create", 0, 8) is None                   # invalid n_latents -> NULL + message
+    assert b"n_latents" in lib.mmvae_last_error()
+    h = call("mmvae_mm_create", 100, 4)
+    with pytest.raises(MMVAEError):                                # unbound plan
+        call("mmvae_mm_pack_weights", h, None)
+    call("mmvae_mm_destroy", h)
+
+
+def test_python_face_has_the_reference_state_dict():
+    from multimodal_vae_amd import multimnist as M
+    vae = M.MultimodalVAE(100)
+    sd = vae.state_dict()
+    P = R.formula_params("multimnist", 100)
+    assert list(sd.keys()) == list(P.keys()) or set(sd.keys()) == set(P.keys())
+    for k, v in P.items():
+        assert tuple(sd[k].shape) == tuple(v.shape), k
+    assert [n for n, _ in vae.named_parameters()] == [n for n, _ in R.param_table("multimnist", 100)]
+    assert M.elbo_loss is M.loss_function
+    assert (M.max_length, M.n_characters, M.SOS, M.FILL) == (4, 12, 10, 11)      # multimnist/utils.py:14-19
+    enc = M.ImageEncoder(100)                                                     # standalone modules keep local names
+    assert "features.0.weight" in enc.state_dict() and "classifier.6.bias" in enc.state_dict()
+
+
+def test_product_path_refuses_cpu():
+    from multimodal_vae_amd import multimnist as M, MMVAEError
+    vae = M.MultimodalVAE(100)
+    with pytest.raises(MMVAEError):
+        vae(image=torch.zeros(2, 1, 50, 50))
+    with pytest.raises(MMVAEError):
+        M.ProductOfExperts()(torch.zeros(2, 3, 4), torch.zeros(2, 3, 4))
+    with pytest.raises(AssertionError):
+        vae()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "multimodal-vae_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src.replace("no oracle", ""), fn
