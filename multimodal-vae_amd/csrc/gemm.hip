@@ -354,10 +354,9 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(const GemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-constexpr int WT = 64;          // wgrad tile (N and K)
 constexpr int WM = 64;          // rows per iteration
-constexpr int LDW = 80;         // bf16 elements per LDS row (160 B): conflict-free ds_read_b64_tr_b16
 
+template <int LDW>
 __device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int mb, int c0, int lane) {
     // MFMA operand fragment whose k index runs over LDS rows (pixel rows), element i over columns.
     const int g4 = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
@@ -371,105 +370,154 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int mb, int c0, int 
     return u.v;
 }
 
+// Block tile TN x TK = (16*NWT*WN) x (16*KWT*WK), 4 waves as WN x WK, 64 pixel rows per iteration.
+// Thread t stages row (t>>2) of the iteration: TN/32 vectors of the plain operand and TK/32 vectors of the gathered
+// operand (vector index (t&3) + 4*i), so one row decomposition serves all of a thread's loads; the (tap, channel)
+// of each gathered vector is fixed for the whole kernel.  Loads of iteration i+1 are issued before the MFMAs of
+// iteration i (register prefetch), LDS is single-buffered.
+template <int NWT, int KWT, int WN, int WK>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
-    __shared__ __attribute__((aligned(16))) bf16 Ps[WM * LDW];
-    __shared__ __attribute__((aligned(16))) bf16 Gs[WM * LDW];
+    constexpr int TN = 16 * NWT * WN, TK = 16 * KWT * WK;
+    constexpr int LDP = TN + 16, LDG = TK + 16;          // +16 elements: conflict-free 8-row transposed reads
+    constexpr int NPV = TN / 32, NGV = TK / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* Ps = reinterpret_cast<bf16*>(smem);            // [64][LDP]
+    bf16* Gs = Ps + WM * LDP;                            // [64][LDG]
     const GatherCommon& c = p.c;
     const int ncls = c.nclasses;
     const int cls_i = blockIdx.z % ncls;
     const int chunk = blockIdx.z / ncls;
     const GatherClass& k = p.cls[cls_i];
-    const int n0 = blockIdx.x * WT, k0 = blockIdx.y * WT;
-    if (k0 >= k.Kpad) return;
+    const int n0 = blockIdx.x * TN, k0 = blockIdx.y * TK;
+    if (k0 >= k.K) return;
     const int rows_total = c.groups * k.rows_per_group;
     const int r_begin = chunk * p.rows_per_block;
     if (r_begin >= rows_total) return;
     const int r_end = min(rows_total, r_begin + p.rows_per_block);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave >> 1, wk = wave & 1;
+    const int wn = wave / WK, wk = wave % WK;
     const int pix_per_img = k.OY * k.OX;
+    const int row_l = tid >> 2, sub = tid & 3;
 
-    // fixed (tap, channel) of this thread's gathered vector
-    const int kv = tid & 7;
-    const int kk = k0 + kv * 8;
-    const bool kin = kk < k.K;
-    int ty = 0, tx = 0, gc = 0;
-    if (kin) {
-        int tap = kk / c.C;
-        gc = kk - tap * c.C;
-        ty = tap / k.TW;
-        tx = tap - ty * k.TW;
+    int g_dy[NGV], g_dx[NGV], g_c[NGV];
+    unsigned g_kin = 0;
+#pragma unroll
+    for (int i = 0; i < NGV; ++i) {
+        const int kk = k0 + (sub + 4 * i) * 8;
+        g_dy[i] = 0; g_dx[i] = 0; g_c[i] = 0;
+        if (kk < k.K) {
+            int tap = kk / c.C;
+            g_c[i] = kk - tap * c.C;
+            int ty = tap / k.TW;
+            g_dy[i] = ty * c.dy; g_dx[i] = (tap - ty * k.TW) * c.dx;
+            g_kin |= 1u << i;
+        }
     }
-    const int pcol = n0 + kv * 8;
 
-    f32x4 acc[2][2];
+    f32x4 acc[NWT][KWT];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NWT; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < KWT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int rb = r_begin; rb < r_end; rb += WM) {
-        bf16x8 pv[2], gv[2];
-        bool pok[2], gok[2];
+    bf16x8 pv[NPV], gv[NGV];
+    unsigned pok = 0, gok = 0;
+    auto load_rows = [&](int rb) {
+        const int rq = rb + row_l;
+        const bool rin = rq < r_end;
+        const int r = rin ? rq : r_end - 1;                  // clamped: loads are unconditional, results masked
+        const int g = r / k.rows_per_group;
+        const int rg = r - g * k.rows_per_group;
+        const int img = rg / pix_per_img;
+        const int rem = rg - img * pix_per_img;
+        const int oy = rem / k.OX;
+        const int ox = rem - oy * k.OX;
+        const int n = g * c.group_n + img;
+        const int an = c.a_bcast_n > 0 ? n % c.a_bcast_n : n;
+        const size_t ppix = (size_t)(n * c.OH + oy * c.osy + k.ooy) * c.OW + ox * c.osx + k.oox;
+        pok = 0; gok = 0;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int rq = rb + (tid >> 3) + 32 * i;
-            const bool rin = rq < r_end;
-            const int r = rin ? rq : r_end - 1;              // clamped: loads are unconditional, results masked
-            int g = r / k.rows_per_group;
-            int rg = r - g * k.rows_per_group;
-            int img = rg / pix_per_img;
-            int rem = rg - img * pix_per_img;
-            int oy = rem / k.OX;
-            int ox = rem - oy * k.OX;
-            int n = g * c.group_n + img;
-            int an = n;
-            if (c.a_bcast_n > 0) an = n % c.a_bcast_n;
-            pok[i] = rin && pcol < c.N;       // ldp >= round_up(N,8): columns >= N only feed discarded output rows
-            const size_t ppix = (size_t)(n * c.OH + oy * c.osy + k.ooy) * c.OW + ox * c.osx + k.oox;
+        for (int i = 0; i < NPV; ++i) {
+            const int pcol = n0 + (sub + 4 * i) * 8;
+            const bool ok = rin && pcol < c.N;               // ldp >= round_up(N,8)
             pv[i] = *reinterpret_cast<const bf16x8*>(p.P + ppix * p.ldp + (pcol < c.N ? pcol : 0));
-            int y = oy * c.sy + k.offy + ty * c.dy, x = ox * c.sx + k.offx + tx * c.dx;
-            gok[i] = rin && kin && (unsigned)y < (unsigned)c.AH && (unsigned)x < (unsigned)c.AW;
-            const int gp = gok[i] ? (an * c.AH + y) * c.AW + x : 0;
-            gv[i] = *reinterpret_cast<const bf16x8*>(c.A + (size_t)gp * c.Ald + gc);
+            pok |= (ok ? 1u : 0u) << i;
         }
+        const int y0 = oy * c.sy + k.offy, x0 = ox * c.sx + k.offx;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (!pok[i]) pv[i] = zero8();
-            if (!gok[i]) gv[i] = zero8();
+        for (int i = 0; i < NGV; ++i) {
+            const int y = y0 + g_dy[i], x = x0 + g_dx[i];
+            const bool ok = rin && ((g_kin >> i) & 1) && (unsigned)y < (unsigned)c.AH && (unsigned)x < (unsigned)c.AW;
+            const int gp = ok ? (an * c.AH + y) * c.AW + x : 0;
+            gv[i] = *reinterpret_cast<const bf16x8*>(c.A + (size_t)gp * c.Ald + g_c[i]);
+            gok |= (ok ? 1u : 0u) << i;
         }
-        __syncthreads();      // previous iteration's fragment reads are done
+    };
+    auto store_rows = [&]() {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<bf16x8*>(Ps + ((tid >> 3) + 32 * i) * LDW + kv * 8) = pv[i];
-            *reinterpret_cast<bf16x8*>(Gs + ((tid >> 3) + 32 * i) * LDW + kv * 8) = gv[i];
-        }
+        for (int i = 0; i < NPV; ++i)
+            *reinterpret_cast<bf16x8*>(Ps + row_l * LDP + (sub + 4 * i) * 8) = ((pok >> i) & 1) ? pv[i] : zero8();
+#pragma unroll
+        for (int i = 0; i < NGV; ++i)
+            *reinterpret_cast<bf16x8*>(Gs + row_l * LDG + (sub + 4 * i) * 8) = ((gok >> i) & 1) ? gv[i] : zero8();
+    };
+
+    load_rows(r_begin);
+    for (int rb = r_begin; rb < r_end; rb += WM) {
+        __syncthreads();                                  // previous iteration's fragment reads are done
+        store_rows();
         __syncthreads();
+        if (rb + WM < r_end) load_rows(rb + WM);          // prefetch the next 64 rows while the MFMAs run
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[2], bfr[2];
+            bf16x8 af[NWT], bfr[KWT];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) af[a] = tr_frag(Ps, ks * 32, wn * 32 + a * 16, lane);
+            for (int a = 0; a < NWT; ++a) af[a] = tr_frag<LDP>(Ps, ks * 32, (wn * NWT + a) * 16, lane);
 #pragma unroll
-            for (int b = 0; b < 2; ++b) bfr[b] = tr_frag(Gs, ks * 32, wk * 32 + b * 16, lane);
+            for (int b = 0; b < KWT; ++b) bfr[b] = tr_frag<LDG>(Gs, ks * 32, (wk * KWT + b) * 16, lane);
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < NWT; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
+                for (int b = 0; b < KWT; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
         }
     }
     const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NWT; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < KWT; ++b)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                int n = n0 + wn * 32 + a * 16 + fq * 4 + j;
-                int kc = k0 + wk * 32 + b * 16 + fr;
+                const int n = n0 + (wn * NWT + a) * 16 + fq * 4 + j;
+                const int kc = k0 + (wk * KWT + b) * 16 + fr;
                 if (n < c.N && kc < k.K) atomicAdd(k.dWp + (size_t)n * k.Kpad + kc, acc[a][b][j]);
             }
+}
+
+template <int NWT, int KWT, int WN, int WK>
+int launch_wgrad_v(WgradParams p, hipStream_t stream) {
+    constexpr int TN = 16 * NWT * WN, TK = 16 * KWT * WK;
+    const GatherCommon& c = p.c;
+    int max_rows = 0, max_k = 0;
+    for (int i = 0; i < c.nclasses; ++i) {
+        max_rows = max(max_rows, c.groups * p.cls[i].rows_per_group);
+        max_k = max(max_k, p.cls[i].K);
+    }
+    const int tiles = ceil_div(c.N, TN) * ceil_div(max_k, TK) * c.nclasses;
+    // enough row chunks for ~3 workgroups per CU, each at least 4 iterations long
+    int chunks = max(1, min(ceil_div(max_rows, 4 * WM), ceil_div(768, tiles)));
+    p.rows_per_block = round_up(ceil_div(max_rows, chunks), WM);
+    dim3 grid(ceil_div(c.N, TN), ceil_div(max_k, TK), ceil_div(max_rows, p.rows_per_block) * c.nclasses);
+    const size_t lds = (size_t)WM * (TN + 16 + TK + 16) * sizeof(bf16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<NWT, KWT, WN, WK>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wgrad_kernel<NWT, KWT, WN, WK>), grid, dim3(256), lds, stream, p);
+    return mmvae_check_launch("wgrad");
 }
 
 template <int NT>
@@ -519,18 +567,18 @@ int launch_wgrad(const WgradParams& p, hipStream_t stream) {
     MMVAE_REQUIRE(c.nclasses >= 1 && c.nclasses <= MMVAE_MAX_CLASSES, "wgrad: bad class count %d", c.nclasses);
     MMVAE_REQUIRE(c.C % 8 == 0 && c.Ald % 8 == 0 && p.ldp % 8 == 0 && p.ldp >= round_up(c.N, 8),
                   "wgrad: C/Ald/ldp must be multiples of 8 and ldp >= round_up(N,8)");
-    MMVAE_REQUIRE(p.rows_per_block > 0 && p.rows_per_block % WM == 0, "wgrad: rows_per_block=%d", p.rows_per_block);
     MMVAE_REQUIRE(c.a_mask == nullptr && c.a_affine == nullptr && c.a_act == ACT_NONE && p.p_affine == nullptr && p.p_act == ACT_NONE,
                   "wgrad: operand transforms are not supported");
-    int max_rows = 0, max_kpad = 0;
+    int max_k = 0;
     for (int i = 0; i < c.nclasses; ++i) {
         const GatherClass& k = p.cls[i];
-        MMVAE_REQUIRE(k.Kpad % WT == 0 && k.Kpad >= k.K && k.K == k.TH * k.TW * c.C, "wgrad: class %d K=%d Kpad=%d", i, k.K, k.Kpad);
+        MMVAE_REQUIRE(k.Kpad >= k.K && k.K == k.TH * k.TW * c.C, "wgrad: class %d K=%d Kpad=%d", i, k.K, k.Kpad);
         MMVAE_REQUIRE(k.rows_per_group == c.group_n * k.OY * k.OX && k.dWp != nullptr, "wgrad: class %d", i);
-        max_rows = max(max_rows, c.groups * k.rows_per_group);
-        max_kpad = max(max_kpad, k.Kpad);
+        max_k = max(max_k, k.K);
     }
-    dim3 grid(ceil_div(c.N, WT), max_kpad / WT, ceil_div(max_rows, p.rows_per_block) * c.nclasses);
-    hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), 0, stream, p);
-    return mmvae_check_launch("wgrad");
+    // tile shape by problem shape: thin outputs get a wide K tile so each staged pixel row feeds more MFMAs
+    if (max_k <= 64) return launch_wgrad_v<2, 1, 1, 4>(p, stream);          //  32 x  64
+    if (c.N <= 32) return launch_wgrad_v<2, 4, 1, 4>(p, stream);            //  32 x 256
+    if (c.N <= 64) return launch_wgrad_v<4, 4, 1, 4>(p, stream);            //  64 x 256
+    return launch_wgrad_v<4, 4, 2, 2>(p, stream);                           // 128 x 128
 }
