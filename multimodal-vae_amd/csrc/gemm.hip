@@ -47,178 +47,17 @@ __device__ __forceinline__ bf16x8 transform8(bf16x8 v, const float2* aff, int ac
     return o;
 }
 
-template <int NT>
-__global__ __launch_bounds__(256) void gemm_gather_kernel(const GemmParams p) {
+// Shared epilogue: consumes the fp32 tile `ct` ([BM][BN+4] in LDS) of output rows row0.. / columns n0..
+template <int NT, int ROWS>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const GatherClass& k, int g, int row0, int n0,
+                                              float* ct, char* smem, int tid) {
     constexpr int BN = NT * 16;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16* As = reinterpret_cast<bf16*>(smem);                 // [2][BM][LDA]
-    bf16* Bs = As + 2 * BM * LDA;                             // [2][BN][LDA]
-
-    const GatherCommon& c = p.c;
-    const GatherClass& k = p.cls[blockIdx.z];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles_per_group = (k.rows_per_group + BM - 1) / BM;
-    if ((int)blockIdx.x >= tiles_per_group * c.groups) return;
-    const int g = blockIdx.x / tiles_per_group;
-    const int row0 = (blockIdx.x - g * tiles_per_group) * BM;
-    const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
-    const int nblk = blockIdx.y / ksplit, ksi = blockIdx.y - nblk * ksplit;
-    const int n0 = nblk * BN;
-    const int K = k.K;
-    const int nk_all = (K + BK - 1) / BK;
-    const int kt0 = (int)((long long)nk_all * ksi / ksplit), kt1 = (int)((long long)nk_all * (ksi + 1) / ksplit);
-    const int nk = kt1 - kt0;
-    const int pix_per_img = k.OY * k.OX;
-
-    // ---- per-thread staging coordinates: 4 A rows, vector column kv ----
-    const int kv = tid & 7;
-    RowCoord rc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int r = row0 + (tid >> 3) + 32 * i;
-        if (r < k.rows_per_group) {
-            int img = r / pix_per_img;
-            int rem = r - img * pix_per_img;
-            int oy = rem / k.OX;
-            int ox = rem - oy * k.OX;
-            int aimg = g * c.group_n + img;
-            if (c.a_bcast_n > 0) aimg %= c.a_bcast_n;
-            rc[i].pix = aimg * c.AH * c.AW;
-            rc[i].y = oy * c.sy + k.offy;
-            rc[i].x = ox * c.sx + k.offx;
-        } else {
-            rc[i].pix = -1; rc[i].y = 0; rc[i].x = 0;
-        }
-    }
-
-    bf16x8 areg[4];
-    unsigned avalid = 0;
-    int a_c = 0;
-    constexpr int NB = (BN * 8 + 255) / 256;       // B vectors per thread
-    bf16x8 breg[NB];
-
-    auto load_tile = [&](int kt) {
-        const int kk = kt * BK + kv * 8;
-        avalid = 0;
-        int ty = 0, tx = 0;
-        a_c = 0;
-        const bool kin = kk < K;
-        if (kin) {
-            int tap = kk / c.C;
-            a_c = kk - tap * c.C;
-            ty = tap / k.TW;
-            tx = tap - ty * k.TW;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int y = rc[i].y + ty * c.dy, x = rc[i].x + tx * c.dx;
-            const bool ok = kin && rc[i].pix >= 0 && (unsigned)y < (unsigned)c.AH && (unsigned)x < (unsigned)c.AW;
-            // unconditional load from a clamped in-bounds address (no branch around the load: the loads of a tile
-            // issue back to back and are waited for once); invalid vectors are zeroed when they are stored to LDS
-            const int pix = ok ? rc[i].pix + y * c.AW + x : 0;
-            areg[i] = *reinterpret_cast<const bf16x8*>(c.A + (size_t)pix * c.Ald + a_c);
-            avalid |= (ok ? 1u : 0u) << i;
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            int v = (tid + 256 * i) % (BN * 8);
-            const bf16* src = k.Wp + (size_t)(n0 + (v >> 3)) * k.Kpad + kt * BK + (v & 7) * 8;
-            breg[i] = *reinterpret_cast<const bf16x8*>(src);
-        }
-    };
-    auto store_tile = [&](int buf) {
-        bf16* a_dst = As + buf * BM * LDA;
-        bf16* b_dst = Bs + buf * BN * LDA;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            bf16x8 v = ((avalid >> i) & 1) ? areg[i] : zero8();
-            *reinterpret_cast<bf16x8*>(a_dst + ((tid >> 3) + 32 * i) * LDA + kv * 8) = v;
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            int v = tid + 256 * i;
-            if (v < BN * 8) *reinterpret_cast<bf16x8*>(b_dst + (v >> 3) * LDA + (v & 7) * 8) = breg[i];
-        }
-    };
-
-    f32x4 acc[2][NT];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    load_tile(kt0);
-    store_tile(0);
-    __syncthreads();
-
-    const int fr = lane & 15, fq = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kt0 + kt + 1);
-        const bf16* a_src = As + buf * BM * LDA + (wave * 32 + fr) * LDA + fq * 8;
-        const bf16* b_src = Bs + buf * BN * LDA + fr * LDA + fq * 8;
-        bf16x8 af[2][2], bfr[2][NT];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            af[ks][0] = *reinterpret_cast<const bf16x8*>(a_src + ks * 32);
-            af[ks][1] = *reinterpret_cast<const bf16x8*>(a_src + 16 * LDA + ks * 32);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bfr[ks][nt] = *reinterpret_cast<const bf16x8*>(b_src + nt * 16 * LDA + ks * 32);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][0], bfr[ks][nt], acc[0][nt], 0, 0, 0);
-                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][1], bfr[ks][nt], acc[1][nt], 0, 0, 0);
-            }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
-        __syncthreads();
-    }
-
-    // ---------------- epilogue ----------------
-    // The accumulator tile goes through LDS (fp32 [BM][BN+4]; the staging buffers are free after the last barrier)
-    // so that every global access below is a 16-byte vector of 8 consecutive columns of one row: coalesced stores,
-    // one row decomposition per vector, and loads that do not depend on each other across passes.
     constexpr int LDC = BN + 4;
     constexpr int VPR = BN / 8;              // vectors per tile row
     constexpr int RPP = 256 / VPR;           // tile rows per pass
-    constexpr int PASSES = BM / RPP;
-    float* ct = reinterpret_cast<float*>(smem);
-    if (ksplit > 1) {
-        const int tile_id = ((int)blockIdx.z * gridDim.x + blockIdx.x) * (gridDim.y / ksplit) + nblk;
-        float* sk = p.sk_buf + (size_t)tile_id * BM * BN;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    atomicAdd(sk + (wave * 32 + mt * 16 + fq * 4 + j) * BN + nt * 16 + fr, acc[mt][nt][j]);
-        __threadfence();                        // release: this workgroup's adds are performed before its ticket
-        __syncthreads();
-        __shared__ unsigned ticket_s;
-        if (tid == 0) ticket_s = atomicAdd(p.sk_cnt + tile_id, 1u);
-        __syncthreads();
-        if (ticket_s != (unsigned)(ksplit - 1)) return;
-        __threadfence();                        // acquire side of the ticket
-        for (int e = tid; e < BM * BN; e += 256) {
-            const int r = e / BN, cidx = e - r * BN;
-            ct[r * LDC + cidx] = __hip_atomic_load(sk + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sk[e] = 0.f;                        // leave the scratch tile clean for the next user
-        }
-        if (tid == 0) p.sk_cnt[tile_id] = 0u;
-    } else {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    ct[(wave * 32 + mt * 16 + fq * 4 + j) * LDC + nt * 16 + fr] = acc[mt][nt][j];
-    }
-    __syncthreads();
-
+    constexpr int PASSES = ROWS / RPP;
+    const GatherCommon& c = p.c;
+    const int pix_per_img = k.OY * k.OX;
     const bool want_stats = p.colstats != nullptr;
     const bool want_red = p.d_red != nullptr || p.d_colsum != nullptr;
     const int cv = tid % VPR;
@@ -351,6 +190,200 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(const GemmParams p) {
             if (p.d_colsum) atomicAdd(p.d_colsum + n0 + tid, a);
         }
     }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void gemm_gather_kernel(const GemmParams p) {
+    constexpr int BN = NT * 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* As = reinterpret_cast<bf16*>(smem);                 // [2][BM][LDA]
+    bf16* Bs = As + 2 * BM * LDA;                             // [2][BN][LDA]
+
+    const GatherCommon& c = p.c;
+    const GatherClass& k = p.cls[blockIdx.z];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_per_group = (k.rows_per_group + BM - 1) / BM;
+    if ((int)blockIdx.x >= tiles_per_group * c.groups) return;
+    const int g = blockIdx.x / tiles_per_group;
+    const int row0 = (blockIdx.x - g * tiles_per_group) * BM;
+    const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
+    const int nblk = blockIdx.y / ksplit, ksi = blockIdx.y - nblk * ksplit;
+    const int n0 = nblk * BN;
+    const int K = k.K;
+    const int nk_all = (K + BK - 1) / BK;
+    const int kt0 = (int)((long long)nk_all * ksi / ksplit), kt1 = (int)((long long)nk_all * (ksi + 1) / ksplit);
+    const int nk = kt1 - kt0;
+    const int pix_per_img = k.OY * k.OX;
+
+    // ---- per-thread staging coordinates: 4 A rows, vector column kv ----
+    const int kv = tid & 7;
+    RowCoord rc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int r = row0 + (tid >> 3) + 32 * i;
+        if (r < k.rows_per_group) {
+            int img = r / pix_per_img;
+            int rem = r - img * pix_per_img;
+            int oy = rem / k.OX;
+            int ox = rem - oy * k.OX;
+            int aimg = g * c.group_n + img;
+            if (c.a_bcast_n > 0) aimg %= c.a_bcast_n;
+            rc[i].pix = aimg * c.AH * c.AW;
+            rc[i].y = oy * c.sy + k.offy;
+            rc[i].x = ox * c.sx + k.offx;
+        } else {
+            rc[i].pix = -1; rc[i].y = 0; rc[i].x = 0;
+        }
+    }
+
+    bf16x8 areg[4];
+    unsigned avalid = 0;
+    int a_c = 0;
+    constexpr int NB = (BN * 8 + 255) / 256;       // B vectors per thread
+    bf16x8 breg[NB];
+
+    auto load_tile = [&](int kt) {
+        const int kk = kt * BK + kv * 8;
+        avalid = 0;
+        int ty = 0, tx = 0;
+        a_c = 0;
+        const bool kin = kk < K;
+        if (kin) {
+            int tap = kk / c.C;
+            a_c = kk - tap * c.C;
+            ty = tap / k.TW;
+            tx = tap - ty * k.TW;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int y = rc[i].y + ty * c.dy, x = rc[i].x + tx * c.dx;
+            const bool ok = kin && rc[i].pix >= 0 && (unsigned)y < (unsigned)c.AH && (unsigned)x < (unsigned)c.AW;
+            // unconditional load from a clamped in-bounds address (no branch around the load: the loads of a tile
+            // issue back to back and are waited for once); invalid vectors are zeroed when they are stored to LDS
+            const int pix = ok ? rc[i].pix + y * c.AW + x : 0;
+            areg[i] = *reinterpret_cast<const bf16x8*>(c.A + (size_t)pix * c.Ald + a_c);
+            avalid |= (ok ? 1u : 0u) << i;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            int v = (tid + 256 * i) % (BN * 8);
+            const bf16* src = k.Wp + (size_t)(n0 + (v >> 3)) * k.Kpad + kt * BK + (v & 7) * 8;
+            breg[i] = *reinterpret_cast<const bf16x8*>(src);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        bf16* a_dst = As + buf * BM * LDA;
+        bf16* b_dst = Bs + buf * BN * LDA;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bf16x8 v = ((avalid >> i) & 1) ? areg[i] : zero8();
+            *reinterpret_cast<bf16x8*>(a_dst + ((tid >> 3) + 32 * i) * LDA + kv * 8) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            int v = tid + 256 * i;
+            if (v < BN * 8) *reinterpret_cast<bf16x8*>(b_dst + (v >> 3) * LDA + (v & 7) * 8) = breg[i];
+        }
+    };
+
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    load_tile(kt0);
+    store_tile(0);
+    __syncthreads();
+
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile(kt0 + kt + 1);
+        const bf16* a_src = As + buf * BM * LDA + (wave * 32 + fr) * LDA + fq * 8;
+        const bf16* b_src = Bs + buf * BN * LDA + fr * LDA + fq * 8;
+        bf16x8 af[2][2], bfr[2][NT];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            af[ks][0] = *reinterpret_cast<const bf16x8*>(a_src + ks * 32);
+            af[ks][1] = *reinterpret_cast<const bf16x8*>(a_src + 16 * LDA + ks * 32);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bfr[ks][nt] = *reinterpret_cast<const bf16x8*>(b_src + nt * 16 * LDA + ks * 32);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][0], bfr[ks][nt], acc[0][nt], 0, 0, 0);
+                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][1], bfr[ks][nt], acc[1][nt], 0, 0, 0);
+            }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---------------- epilogue ----------------
+    // The accumulator tile goes through LDS (fp32 [BM][BN+4]; the staging buffers are free after the last barrier)
+    // so that every global access is a 16-byte vector of 8 consecutive columns of one row.
+    constexpr int LDC = BN + 4;
+    float* ct = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                ct[(wave * 32 + mt * 16 + fq * 4 + j) * LDC + nt * 16 + fr] = acc[mt][nt][j];
+    __syncthreads();
+    if (ksplit > 1) {
+        // split-K: this workgroup only publishes its partial tile (plain 16-byte stores into its own slab);
+        // splitk_finish_kernel sums the slabs and runs the epilogue after the kernel boundary
+        const int tile_id = ((int)blockIdx.z * gridDim.x + blockIdx.x) * (gridDim.y / ksplit) + nblk;
+        float* slab = p.sk_buf + ((size_t)tile_id * ksplit + ksi) * BM * BN;
+        for (int e = tid; e < BM * BN / 4; e += 256) {
+            const int r = e / (BN / 4), q = e - r * (BN / 4);
+            *reinterpret_cast<f32x4*>(slab + r * BN + q * 4) = *reinterpret_cast<const f32x4*>(ct + r * LDC + q * 4);
+        }
+        return;
+    }
+    gemm_epilogue<NT, BM>(p, k, g, row0, n0, ct, smem, tid);
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const GemmParams p) {
+    // one workgroup per (tile, slice of RS rows): every thread sums ONE 8-column vector over the ksplit slabs
+    // (2*ksplit independent 16-byte loads in flight), then the common epilogue runs on the slice
+    constexpr int BN = NT * 16;
+    constexpr int LDC = BN + 4;
+    constexpr int VPR = BN / 8;
+    constexpr int RS = 256 / VPR;
+    constexpr int SLICES = BM / RS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ct = reinterpret_cast<float*>(smem);
+    const GatherCommon& c = p.c;
+    const GatherClass& k = p.cls[blockIdx.z];
+    const int tid = threadIdx.x;
+    const int tiles_per_group = (k.rows_per_group + BM - 1) / BM;
+    const int tile_x = blockIdx.x / SLICES, slice = blockIdx.x - tile_x * SLICES;
+    if (tile_x >= tiles_per_group * c.groups) return;
+    const int g = tile_x / tiles_per_group;
+    const int row0 = (tile_x - g * tiles_per_group) * BM + slice * RS;
+    if (row0 >= k.rows_per_group) return;
+    const int nblk = blockIdx.y, n0 = nblk * BN;
+    const int tile_id = ((int)blockIdx.z * (gridDim.x / SLICES) + tile_x) * gridDim.y + nblk;
+    const float* slab = p.sk_buf + (size_t)tile_id * p.ksplit * BM * BN + (size_t)slice * RS * BN;
+    const int rl = tid / VPR, cv = tid - rl * VPR;
+    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < p.ksplit; ++q) {
+        const float* s = slab + (size_t)q * BM * BN + rl * BN + cv * 8;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(s);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(s + 4);
+        lo[0] += a[0]; lo[1] += a[1]; lo[2] += a[2]; lo[3] += a[3];
+        hi[0] += b[0]; hi[1] += b[1]; hi[2] += b[2]; hi[3] += b[3];
+    }
+    *reinterpret_cast<f32x4*>(ct + rl * LDC + cv * 8) = lo;
+    *reinterpret_cast<f32x4*>(ct + rl * LDC + cv * 8 + 4) = hi;
+    __syncthreads();
+    gemm_epilogue<NT, RS>(p, k, g, row0, n0, ct, smem, tid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -520,6 +553,234 @@ int launch_wgrad_v(WgradParams p, hipStream_t stream) {
     return mmvae_check_launch("wgrad");
 }
 
+// ------------------------------------------------------------------------------------------------
+// gemm_rowtile_kernel: the small-M regime (a few hundred..thousand pixel rows, long K: classifier / upsample
+// Linears, the 2x2 bottleneck convs and their data gradients).  A 128-row tile would leave most CUs idle behind a
+// serial chain of K-tile latencies; here one workgroup owns 16 rows and ALL output columns: the gathered 16 x K
+// operand sits in LDS, every wave streams its share of the packed weight rows straight from L2 into MFMA B
+// fragments (independent 16-byte loads, deep in flight), so the chip runs rows/16 workgroups with no inter-tile
+// dependency.  Same GemmParams / epilogue semantics as gemm_gather_kernel.
+constexpr int RT_R = 16;
+constexpr int RT_KC = 2048;            // K chunk staged in LDS
+
+template <int NTW>                      // N tiles (of 16 columns) per wave, 4 waves: N <= 64*NTW
+__global__ __launch_bounds__(256) void gemm_rowtile_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    struct RowInfo { int apix, y, x, ok; long long opix, rpix, grow; };
+    __shared__ RowInfo rinfo[RT_R];
+    const GatherCommon& c = p.c;
+    const GatherClass& k = p.cls[blockIdx.z];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int tiles_per_group = (k.rows_per_group + RT_R - 1) / RT_R;
+    if ((int)blockIdx.x >= tiles_per_group * c.groups) return;
+    const int g = blockIdx.x / tiles_per_group;
+    const int row0 = (blockIdx.x - g * tiles_per_group) * RT_R;
+    const int K = k.K, N = c.N;
+    const int kc_max = min(round_up(K, 32), RT_KC);
+    const int LDK = kc_max + 8;
+    bf16* As = reinterpret_cast<bf16*>(smem);                          // [16][LDK]
+    const int LDC = round_up(N, 16) + 4;
+    float* ct = reinterpret_cast<float*>(As + RT_R * LDK);            // [16][LDC]
+    float2* cstat = reinterpret_cast<float2*>(ct + RT_R * LDC);       // [round_up(N,16)] column sums
+    const int pix_per_img = k.OY * k.OX;
+    if (tid < RT_R) {
+        RowInfo ri{};
+        const int r = row0 + tid;
+        ri.ok = r < k.rows_per_group;
+        if (ri.ok) {
+            const int img = r / pix_per_img, rem = r - img * pix_per_img;
+            const int oy = rem / k.OX, ox = rem - oy * k.OX;
+            const int nimg = g * c.group_n + img;
+            const int aimg = c.a_bcast_n > 0 ? nimg % c.a_bcast_n : nimg;
+            ri.apix = aimg * c.AH * c.AW; ri.y = oy * c.sy + k.offy; ri.x = ox * c.sx + k.offx;
+            ri.opix = (long long)(nimg * c.OH + oy * c.osy + k.ooy) * c.OW + ox * c.osx + k.oox;
+            const int rimg = p.d_bcast_n > 0 ? nimg % p.d_bcast_n : nimg;
+            ri.rpix = (long long)(rimg * c.OH + oy * c.osy + k.ooy) * c.OW + ox * c.osx + k.oox;
+            ri.grow = (long long)g * k.rows_per_group + r;
+        }
+        rinfo[tid] = ri;
+    }
+    for (int i = tid; i < round_up(N, 16); i += 256) cstat[i] = make_float2(0.f, 0.f);
+    const int ntiles = (N + 15) / 16;
+
+    f32x4 acc[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kc0 = 0; kc0 < K; kc0 += RT_KC) {
+        const int kc_len = min(round_up(K - kc0, 32), RT_KC);
+        __syncthreads();                                               // rinfo ready / previous chunk consumed
+        // ---- stage the gathered 16 x kc_len operand chunk (unconditional clamped loads, zero-fill)
+        const int vpr = kc_len / 8;
+        for (int v = tid; v < RT_R * vpr; v += 256) {
+            const int row = v / vpr, kk = kc0 + (v - row * vpr) * 8;
+            const RowInfo ri = rinfo[row];
+            bool ok = ri.ok && kk < K;
+            int tap = 0, ch = 0, ty = 0, tx = 0;
+            if (kk < K) { tap = kk / c.C; ch = kk - tap * c.C; ty = tap / k.TW; tx = tap - ty * k.TW; }
+            const int y = ri.y + ty * c.dy, x = ri.x + tx * c.dx;
+            ok = ok && (unsigned)y < (unsigned)c.AH && (unsigned)x < (unsigned)c.AW;
+            const int pix = ok ? ri.apix + y * c.AW + x : 0;
+            bf16x8 val = *reinterpret_cast<const bf16x8*>(c.A + (size_t)pix * c.Ald + ch);
+            if (!ok) val = zero8();
+            *reinterpret_cast<bf16x8*>(As + row * LDK + (kk - kc0)) = val;
+        }
+        __syncthreads();
+        // ---- MFMA: this wave's column tiles over the whole chunk; B fragments come straight from L2.
+        // All loads of a k-group (KG k-steps x NTW tiles) are issued unconditionally (clamped) before its MFMAs,
+        // so each wave keeps NTW*KG independent 16-byte loads in flight instead of one dependent chain per tile.
+        constexpr int KG = NTW <= 4 ? 4 : (NTW <= 8 ? 2 : 1);
+        const int ksteps = kc_len / 32;
+        const bf16* a_src = As + fr * LDK + fq * 8;
+        const bf16* wrow[NTW];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+            const int nt = min(t * 4 + wave, ntiles - 1);
+            wrow[t] = k.Wp + (size_t)(nt * 16 + fr) * k.Kpad + kc0 + fq * 8;
+        }
+        for (int ks0 = 0; ks0 < ksteps; ks0 += KG) {
+            bf16x8 bq[NTW][KG], aq[KG];
+#pragma unroll
+            for (int j = 0; j < KG; ++j) {
+                const int ks = min(ks0 + j, ksteps - 1);
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) bq[t][j] = *reinterpret_cast<const bf16x8*>(wrow[t] + ks * 32);
+                aq[j] = *reinterpret_cast<const bf16x8*>(a_src + ks * 32);
+            }
+#pragma unroll
+            for (int j = 0; j < KG; ++j) {
+                if (ks0 + j < ksteps) {
+#pragma unroll
+                    for (int t = 0; t < NTW; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[j], bq[t][j], acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- accumulators -> LDS tile
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int nt = t * 4 + wave;
+        if (nt >= ntiles) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ct[(fq * 4 + j) * LDC + nt * 16 + fr] = acc[t][j];
+    }
+    __syncthreads();
+    // ---- epilogue: 16-byte vectors of 8 columns (same semantics as gemm_gather_kernel's)
+    const bool want_stats = p.colstats != nullptr;
+    const bool want_red = p.d_red != nullptr || p.d_colsum != nullptr;
+    const int nvec = (N + 7) / 8;
+    const bool ld_ok = (p.ldo % 8 == 0);
+    for (int v = tid; v < RT_R * nvec; v += 256) {
+        const int row = v / nvec, col0 = (v - row * nvec) * 8;
+        const RowInfo ri = rinfo[row];
+        if (!ri.ok) continue;
+        const bool vec_ok = ld_ok && col0 + 8 <= N;
+        float val[8], rr[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int col = min(col0 + j, N - 1);
+            val[j] = ct[row * LDC + col0 + j] + (p.bias ? p.bias[col] : 0.f);
+        }
+        if (p.d_r) {
+            if (vec_ok && p.d_ld % 8 == 0) {
+                const bf16x8 rv = *reinterpret_cast<const bf16x8*>(p.d_r + ri.rpix * p.d_ld + col0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) rr[j] = (float)rv[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) rr[j] = (col0 + j < N) ? (float)p.d_r[ri.rpix * p.d_ld + col0 + j] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int col = min(col0 + j, N - 1);
+                float sc = 1.f, sh = 0.f;
+                if (p.d_affine) { const float2 a = p.d_affine[g * N + col]; sc = a.x; sh = a.y; }
+                float x = val[j] * act_bwd(p.d_act, rr[j] * sc + sh);
+                if (p.d_mask) x = (col0 + j < N && p.d_mask[ri.grow * N + col0 + j]) ? x * p.d_mask_scale : 0.f;
+                val[j] = x;
+                if (want_red && col0 + j < N) {
+                    float2 mr = p.d_meanrstd ? p.d_meanrstd[g * N + col] : make_float2(0.f, 0.f);
+                    atomicAdd(&cstat[col0 + j].x, x);
+                    atomicAdd(&cstat[col0 + j].y, x * (rr[j] - mr.x) * mr.y);
+                }
+            }
+        }
+        if (want_stats) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (col0 + j < N) { atomicAdd(&cstat[col0 + j].x, val[j]); atomicAdd(&cstat[col0 + j].y, val[j] * val[j]); }
+        }
+        float av[8];
+        if (p.out_act_bf) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float x = act_fwd(p.e_act, val[j]);
+                if (p.e_mask) x = (col0 + j < N && p.e_mask[ri.grow * N + col0 + j]) ? x * p.e_mask_scale : 0.f;
+                av[j] = x;
+            }
+        }
+        if (vec_ok) {
+            if (p.out_bf) {
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (bf16)val[j];
+                *reinterpret_cast<bf16x8*>(p.out_bf + ri.opix * p.ldo + col0) = o;
+            }
+            if (p.out_act_bf) {
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (bf16)av[j];
+                *reinterpret_cast<bf16x8*>(p.out_act_bf + ri.opix * p.ldo + col0) = o;
+            }
+            if (p.out_f) {
+                *reinterpret_cast<f32x4*>(p.out_f + ri.opix * p.ldo + col0) = f32x4{val[0], val[1], val[2], val[3]};
+                *reinterpret_cast<f32x4*>(p.out_f + ri.opix * p.ldo + col0 + 4) = f32x4{val[4], val[5], val[6], val[7]};
+            }
+        } else {
+            for (int j = 0; j < 8 && col0 + j < N; ++j) {
+                if (p.out_bf) p.out_bf[ri.opix * p.ldo + col0 + j] = (bf16)val[j];
+                if (p.out_act_bf) p.out_act_bf[ri.opix * p.ldo + col0 + j] = (bf16)av[j];
+                if (p.out_f) p.out_f[ri.opix * p.ldo + col0 + j] = val[j];
+            }
+        }
+    }
+    if (want_stats || want_red) {
+        __syncthreads();
+        float2* dst = want_stats ? p.colstats : p.d_red;
+        const int slot = (blockIdx.x + 5 * blockIdx.z) % MMVAE_STAT_SLOTS;
+        for (int col = tid; col < N; col += 256) {
+            const float2 s = cstat[col];
+            if (dst) {
+                atomicAdd(&dst[(g * MMVAE_STAT_SLOTS + slot) * N + col].x, s.x);
+                atomicAdd(&dst[(g * MMVAE_STAT_SLOTS + slot) * N + col].y, s.y);
+            }
+            if (p.d_colsum) atomicAdd(p.d_colsum + col, s.x);
+        }
+    }
+}
+
+template <int NTW>
+int launch_rowtile(const GemmParams& p, hipStream_t stream) {
+    int max_tiles = 0, max_k = 0;
+    for (int i = 0; i < p.c.nclasses; ++i) {
+        max_tiles = max(max_tiles, ceil_div(p.cls[i].rows_per_group, RT_R));
+        max_k = max(max_k, p.cls[i].K);
+    }
+    const int kc = min(round_up(max_k, 32), RT_KC);
+    const size_t lds = (size_t)RT_R * (kc + 8) * sizeof(bf16) + (size_t)RT_R * (round_up(p.c.N, 16) + 4) * sizeof(float) +
+                       (size_t)round_up(p.c.N, 16) * sizeof(float2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rowtile_kernel<NTW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        attr_set = true;
+    }
+    dim3 grid(max_tiles * p.c.groups, 1, p.c.nclasses);
+    hipLaunchKernelGGL(gemm_rowtile_kernel<NTW>, grid, dim3(256), lds, stream, p);
+    return mmvae_check_launch("gemm_rowtile");
+}
+
 template <int NT>
 int launch_gemm_nt(const GemmParams& p, hipStream_t stream) {
     constexpr int BN = NT * 16;
@@ -532,10 +793,19 @@ int launch_gemm_nt(const GemmParams& p, hipStream_t stream) {
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_gather_kernel<NT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&splitk_finish_kernel<NT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr_set = true;
     }
     hipLaunchKernelGGL(gemm_gather_kernel<NT>, grid, dim3(256), lds, stream, p);
-    return mmvae_check_launch("gemm_gather");
+    MMVAE_TRY(mmvae_check_launch("gemm_gather"));
+    if (ksplit > 1) {
+        constexpr int SLICES = BM / (256 / (BN / 8));
+        dim3 fgrid(max_tiles * p.c.groups * SLICES, ceil_div(p.c.N, BN), p.c.nclasses);
+        hipLaunchKernelGGL(splitk_finish_kernel<NT>, fgrid, dim3(256), (size_t)32 * 1024, stream, p);
+        return mmvae_check_launch("splitk_finish");
+    }
+    return MMVAE_OK;
 }
 
 }  // namespace
@@ -555,7 +825,24 @@ int launch_gemm_gather(const GemmParams& p, hipStream_t stream) {
     }
     MMVAE_REQUIRE(c.a_mask == nullptr && c.a_affine == nullptr && c.a_act == ACT_NONE,
                   "gemm: operand transforms are not supported (activations are materialised by bn_act / the epilogue)");
-    MMVAE_REQUIRE(p.ksplit <= 1 || (p.sk_buf != nullptr && p.sk_cnt != nullptr), "gemm: split-K needs scratch");
+    MMVAE_REQUIRE(p.ksplit <= 1 || p.sk_buf != nullptr, "gemm: split-K needs scratch");
+    {
+        // few 128-row tiles and a long K loop: use the 16-row weight-streaming kernel (rows/16 workgroups)
+        int max_tiles = 0, min_k = 1 << 30, max_k = 0;
+        for (int i = 0; i < c.nclasses; ++i) {
+            max_tiles = max(max_tiles, ceil_div(p.cls[i].rows_per_group, BM));
+            min_k = min(min_k, p.cls[i].K);
+            max_k = max(max_k, p.cls[i].K);
+        }
+        const int tiles128 = max_tiles * c.groups * c.nclasses * ceil_div(c.N, 128);
+        // (long K chains are better served by split-K on the 128-row kernel: each 16-row workgroup would have to
+        //  stream the whole weight matrix through one CU)
+        if (p.ksplit <= 1 && tiles128 <= 96 && c.N <= 1024 && min_k >= 96 && max_k <= 384) {
+            if (c.N <= 256) return launch_rowtile<4>(p, stream);
+            if (c.N <= 512) return launch_rowtile<8>(p, stream);
+            return launch_rowtile<16>(p, stream);
+        }
+    }
     if (c.N <= 16) return launch_gemm_nt<1>(p, stream);
     if (c.N <= 32) return launch_gemm_nt<2>(p, stream);
     if (c.N <= 64) return launch_gemm_nt<4>(p, stream);

@@ -5,6 +5,7 @@
 #include "thin.h"
 #include <map>
 #include <cstring>
+#include <cstdlib>
 
 namespace {
 constexpr int IMG = 50, NPIX = 2500;
@@ -77,7 +78,8 @@ int edge(MMPlan& P, hipStream_t from, hipStream_t to);
 
 // weight gradients only feed the optimizer: when the step runs multi-stream they go to the side stream
 int wgrad_async(MMPlan& P, const WgradParams& g, hipStream_t s) {
-    if (!P.wgrad_forked) return launch_wgrad(g, s);
+    static const bool serial = getenv("MMVAE_SERIAL") != nullptr;
+    if (!P.wgrad_forked || serial) return launch_wgrad(g, s);
     MMVAE_TRY(edge(P, s, P.st_wgrad));
     return launch_wgrad(g, P.st_wgrad);
 }
@@ -299,8 +301,7 @@ void carve(MMPlan& P, Workspace& ws) {
     for (int i = 0; i < 3; ++i) { w.st_e[i] = ws.take<float2>(SS * ec[i]); w.red_e[i] = ws.take<float2>(SS * ec[i]); }
     for (int i = 0; i < 3; ++i) { w.st_d[i] = ws.take<float2>(3 * SS * dc[i]); w.red_d[i] = ws.take<float2>(3 * SS * dc[i]); }
     w.sums = ws.take<float>(16 * MMVAE_LOSS_SLOTS);
-    w.sk_floats = (size_t)64 * 128 * 128;                  // split-K scratch: up to 64 output tiles of 128x128 fp32
-    w.sk_buf = ws.take<float>(w.sk_floats); w.sk_cnt = ws.take<unsigned>(1024);
+    w.sk_cnt = ws.take<unsigned>(1024);
     w.dz_img = ws.take<float>(B3 * D);
     w.dz_txt = ws.take<float>(B3 * D);
     char* z1 = ws.take<char>(0);
@@ -343,6 +344,8 @@ void carve(MMPlan& P, Workspace& ws) {
     w.db4 = ws.take<bf16>(B2 * 1024); w.dr4 = ws.take<bf16>(B * 1024);
     w.d3e = ws.take<bf16>(B * 36 * 128); w.d2e = ws.take<bf16>(B * 144 * 64); w.d1e = ws.take<bf16>(B * 625 * 32);
     w.tmp_f32 = ws.take<float>(B3 * NPIX);
+    w.sk_floats = (size_t)256 * 128 * 128;                 // split-K partial slabs (fully overwritten, never zeroed)
+    w.sk_buf = ws.take<float>(w.sk_floats);
 }
 
 // ------------------------------------------------------------------ launch helpers
@@ -361,10 +364,10 @@ GemmParams gemm_of(const MMPlan& P, const GatherPlan& pl, const int* pk, int gro
     const int bn = pl.c.N <= 16 ? 16 : pl.c.N <= 32 ? 32 : pl.c.N <= 64 ? 64 : 128;
     const int tiles = max_tiles * groups * pl.c.nclasses * ceil_div(pl.c.N, bn);
     g.ksplit = 1;
-    // (measured: the float-atomic partial-tile adds cost more than the latency chain they remove -> disabled;
-    //  kept for shapes where K is much longer.  See DESIGN.md, 'what did not pay'.)
-    if (false && tiles <= 64 && min_nk >= 4) {
-        int ks = min(min(8, min_nk / 2), max(1, 192 / tiles));
+    // (partial tiles go to per-split slabs with plain stores; a finish kernel sums them and runs the epilogue --
+    //  float-atomic accumulation of the partial tiles measured slower than the latency chain it removed)
+    if (tiles <= 128 && min_nk >= 6) {
+        int ks = min(min(8, min_nk / 3), max(1, 256 / tiles));
         if (ks > 1 && (size_t)tiles * 128 * bn <= P.w.sk_floats) { g.ksplit = ks; g.sk_buf = P.w.sk_buf; g.sk_cnt = P.w.sk_cnt; }
     }
     return g;
@@ -863,7 +866,8 @@ int mm_step_fwd_bwd(MMPlan* Pp, const MMStepIO& io, int training, int do_backwar
     if (training && io.gru_dropout && !gk) { MMVAE_TRY(launch_keep_mask(w.gkeep, (long long)4 * B3 * 100, DROP_P, io.seed, io.step_ctr, 4, s)); gk = w.gkeep; }
     const int enc_drop = training && io.enc_dropout;
     MMVAE_TRY(ensure_streams(P));
-    hipStream_t T = P.st_text;
+    static const bool serial = getenv("MMVAE_SERIAL") != nullptr;      // profiling aid: one stream, no overlap
+    hipStream_t T = serial ? s : P.st_text;
     // ---- encoders: image features once for passes 1 and 2 (main), text encoder once for passes 1 and 3 (side)
     MMVAE_TRY(edge(P, s, T));
     {
@@ -1070,7 +1074,7 @@ long long mm_debug_offset(MMPlan* P, const char* name) {
         {"dz_img", w.dz_img}, {"dz_txt", w.dz_txt}, {"d_encout", w.d_encout}, {"d_txtout", w.d_txtout}, {"dy2", w.dy2},
         {"dy1", w.dy1}, {"db4", w.db4}, {"dr4", w.dr4}, {"d3e", w.d3e}, {"d2e", w.d2e}, {"d1e", w.d1e},
         {"aff_d0", w.aff_d[0]}, {"aff_d1", w.aff_d[1]}, {"aff_d2", w.aff_d[2]}, {"st_d0", w.st_d[0]}, {"patches4", w.patches4},
-        {"aff_e0", w.aff_e[0]}, {"aff_e1", w.aff_e[1]}, {"aff_e2", w.aff_e[2]},
+        {"tmp_f32", w.tmp_f32}, {"aff_e0", w.aff_e[0]}, {"aff_e1", w.aff_e[1]}, {"aff_e2", w.aff_e[2]},
     };
     auto it = m.find(name);
     if (it == m.end()) return -1;

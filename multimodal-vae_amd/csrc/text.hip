@@ -9,33 +9,45 @@
 namespace {
 
 constexpr int TR = 16;       // rows per workgroup
-constexpr int NW = 4;        // waves per workgroup
+constexpr int NW = 8;        // waves per workgroup (2 per SIMD: one streams weights while the other does gate math)
 constexpr int NTHR = NW * 64;
 constexpr int H = TXT_H;
 constexpr int HP = TXT_HP;
 constexpr int GL = TXT_G3P;  // fp32 gate buffer row stride (304)
 constexpr int GK = TXT_G3K;  // 320
-constexpr int MAXKS = 10;
 
-__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float sigm(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
 // out[16][ldo] = A[16][32*ksteps] * Wp[16*ntiles][kpad]^T
+// Each wave owns the column tiles wave, wave+NW, ... (at most MAXT).  ALL of its weight fragments (MAXT x ksteps
+// independent 16-byte loads, clamped so that no branch surrounds a load) are issued before the first MFMA: one L2
+// round trip per GEMM instead of one per tile -- the recurrence is a latency chain, not a bandwidth problem.
+// KS = compile-time bound on the k-steps, MAXT = tiles per wave (ceil(ntiles / NW)).
+template <int KS, int MAXT>
 __device__ __forceinline__ void rowtile_gemm(const bf16* A, int lda, int ksteps, const bf16* __restrict__ Wp, int kpad, int ntiles,
                                              float* out, int ldo, int wave, int lane) {
+    constexpr int MAXKS = KS;
     const int fr = lane & 15, fq = lane >> 4;
-    bf16x8 af[MAXKS];
+    bf16x8 bw[MAXT][MAXKS];
 #pragma unroll
-    for (int ks = 0; ks < MAXKS; ++ks)
-        if (ks < ksteps) af[ks] = *reinterpret_cast<const bf16x8*>(A + fr * lda + ks * 32 + fq * 8);
-    for (int nt = wave; nt < ntiles; nt += NW) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < MAXT; ++t) {
+        const int nt = min(wave + t * NW, ntiles - 1);
         const bf16* w = Wp + (size_t)(nt * 16 + fr) * kpad + fq * 8;
 #pragma unroll
+        for (int ks = 0; ks < MAXKS; ++ks) bw[t][ks] = *reinterpret_cast<const bf16x8*>(w + min(ks, ksteps - 1) * 32);
+    }
+    bf16x8 af[MAXKS];
+#pragma unroll
+    for (int ks = 0; ks < MAXKS; ++ks) af[ks] = *reinterpret_cast<const bf16x8*>(A + fr * lda + min(ks, ksteps - 1) * 32 + fq * 8);
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        const int nt = wave + t * NW;
+        if (nt >= ntiles) break;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
         for (int ks = 0; ks < MAXKS; ++ks)
-            if (ks < ksteps) {
-                bf16x8 b = *reinterpret_cast<const bf16x8*>(w + ks * 32);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], b, acc, 0, 0, 0);
-            }
+            if (ks < ksteps) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], bw[t][ks], acc, 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) out[(fq * 4 + j) * ldo + nt * 16 + fr] = acc[j];
     }
@@ -43,8 +55,8 @@ __device__ __forceinline__ void rowtile_gemm(const bf16* A, int lda, int ksteps,
 
 // GRU gate math for 16 rows (PyTorch gate order r,z,n). hf: fp32 state in/out, hb: bf16 copy for the next MFMA.
 // save: [5][R][100] (r, z, n, W_hn h + b_hn, h_prev) or null.
-__device__ __forceinline__ void gru_gates(const float* gi, const float* gh, const float* __restrict__ bih,
-                                          const float* __restrict__ bhh, float* hf, bf16* hb, int ldh, int r0, int R,
+__device__ __forceinline__ void gru_gates(const float* gi, const float* gh, const float* bih,
+                                          const float* bhh, float* hf, bf16* hb, int ldh, int r0, int R,
                                           float* save, int tid) {
     for (int idx = tid; idx < TR * H; idx += NTHR) {
         const int row = idx / H, j = idx - row * H;
@@ -53,7 +65,7 @@ __device__ __forceinline__ void gru_gates(const float* gi, const float* gh, cons
         float r = sigm(a[j] + bih[j] + b[j] + bhh[j]);
         float z = sigm(a[H + j] + bih[H + j] + b[H + j] + bhh[H + j]);
         float ghn = b[2 * H + j] + bhh[2 * H + j];
-        float n = tanhf(a[2 * H + j] + bih[2 * H + j] + r * ghn);
+        float n = tanh_fast(a[2 * H + j] + bih[2 * H + j] + r * ghn);
         float hp = hf[row * H + j];
         float hn = (1.0f - z) * n + z * hp;
         hf[row * H + j] = hn;
@@ -126,32 +138,38 @@ __global__ __launch_bounds__(NTHR) void text_encoder_fwd_kernel(const TextEncArg
     bf16* xb = reinterpret_cast<bf16*>(hr + TR * H);         // [16][136]
     bf16* hb = xb + TR * LH;                                 // [16][136]
     bf16* hrb = hb + TR * LH;                                // [16][136]
+    float* cst = reinterpret_cast<float*>(hrb + TR * LH);   // embed[1200] | bih_f bhh_f bih_r bhh_r [1200]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = blockIdx.x * TR, R = a.B;
     zero_bf(xb, 3 * TR * LH, tid);
     zero_f(hf, 2 * TR * H, tid);
+    float* c_emb = cst; float* c_b = cst + 1200;
+    for (int i = tid; i < 1200; i += NTHR) c_emb[i] = a.embed[i];
+    for (int i = tid; i < 300; i += NTHR) {
+        c_b[i] = a.fwd.bih[i]; c_b[300 + i] = a.fwd.bhh[i]; c_b[600 + i] = a.rev.bih[i]; c_b[900 + i] = a.rev.bhh[i];
+    }
     __syncthreads();
     const size_t plane = (size_t)R * HP;
     for (int t = 0; t < TXT_T; ++t) {
         for (int idx = tid; idx < TR * H; idx += NTHR) {
             int row = idx / H, j = idx - row * H;
             int tok = (r0 + row < R) ? (int)a.tokens[(size_t)(r0 + row) * TXT_T + t] : 0;
-            xb[row * LH + j] = (bf16)a.embed[tok * H + j];
+            xb[row * LH + j] = (bf16)c_emb[tok * H + j];
         }
         __syncthreads();
         save_tile(xb, LH, HP, a.x_bf ? a.x_bf + t * plane : nullptr, HP, r0, R, tid);
         save_tile(hb, LH, HP, a.hprev_bf ? a.hprev_bf + t * plane : nullptr, HP, r0, R, tid);
-        rowtile_gemm(xb, LH, HP / 32, a.fwd.wih, a.fwd.kih, GL / 16, gi, GL, wave, lane);
-        rowtile_gemm(hb, LH, HP / 32, a.fwd.whh, HP, GL / 16, gh, GL, wave, lane);
+        rowtile_gemm<4, 3>(xb, LH, HP / 32, a.fwd.wih, a.fwd.kih, GL / 16, gi, GL, wave, lane);
+        rowtile_gemm<4, 3>(hb, LH, HP / 32, a.fwd.whh, HP, GL / 16, gh, GL, wave, lane);
         __syncthreads();
-        gru_gates(gi, gh, a.fwd.bih, a.fwd.bhh, hf, hb, LH, r0, R, a.gates_f ? a.gates_f + (size_t)t * 5 * R * H : nullptr, tid);
+        gru_gates(gi, gh, c_b, c_b + 300, hf, hb, LH, r0, R, a.gates_f ? a.gates_f + (size_t)t * 5 * R * H : nullptr, tid);
         __syncthreads();
     }
     // reverse direction at the last time step: one step from h = 0 on token T-1 (xb still holds it)
-    rowtile_gemm(xb, LH, HP / 32, a.rev.wih, a.rev.kih, GL / 16, gi, GL, wave, lane);
+    rowtile_gemm<4, 3>(xb, LH, HP / 32, a.rev.wih, a.rev.kih, GL / 16, gi, GL, wave, lane);
     zero_f(gh, TR * GL, tid);       // W_hh * 0
     __syncthreads();
-    gru_gates(gi, gh, a.rev.bih, a.rev.bhh, hr, hrb, LH, r0, R, a.gates_r, tid);
+    gru_gates(gi, gh, c_b + 600, c_b + 900, hr, hrb, LH, r0, R, a.gates_r, tid);
     __syncthreads();
     for (int idx = tid; idx < TR * H; idx += NTHR) {
         int row = idx / H, j = idx - row * H;
@@ -160,7 +178,7 @@ __global__ __launch_bounds__(NTHR) void text_encoder_fwd_kernel(const TextEncArg
     __syncthreads();
     save_tile(xb, LH, HP, a.hsum_bf, HP, r0, R, tid);
     const int D2 = 2 * a.D;
-    rowtile_gemm(xb, LH, HP / 32, a.h2p, HP, a.nh2p / 16, gi, GL, wave, lane);
+    rowtile_gemm<4, 2>(xb, LH, HP / 32, a.h2p, HP, a.nh2p / 16, gi, GL, wave, lane);
     __syncthreads();
     for (int idx = tid; idx < TR * D2; idx += NTHR) {
         int row = idx / D2, j = idx - row * D2;
@@ -199,7 +217,7 @@ __global__ __launch_bounds__(NTHR) void text_encoder_bwd_kernel(const TextEncBwd
         atomicAdd(a.g_h2p_bias + tid, bsum);
     }
     // d(hf + hr) = d_out * W_h2p
-    rowtile_gemm(dob, LD2, K2 / 32, f.h2pT, K2, 7, o1, HP, wave, lane);
+    rowtile_gemm<8, 1>(dob, LD2, K2 / 32, f.h2pT, K2, 7, o1, HP, wave, lane);
     __syncthreads();
     for (int idx = tid; idx < TR * H; idx += NTHR) dh[idx] = o1[(idx / H) * HP + idx % H];
     __syncthreads();
@@ -210,7 +228,7 @@ __global__ __launch_bounds__(NTHR) void text_encoder_bwd_kernel(const TextEncBwd
 #pragma unroll
     for (int q = 0; q < 2; ++q)
         if (tid + q * NTHR < TXT_G3) { gb[2][q] += colsum16(dgi, LG, tid + q * NTHR); gb[3][q] += colsum16(dgh, LG, tid + q * NTHR); }
-    rowtile_gemm(dgi, LG, GK / 32, f.rev.wihT, GK, 7, o1, HP, wave, lane);
+    rowtile_gemm<10, 1>(dgi, LG, GK / 32, f.rev.wihT, GK, 7, o1, HP, wave, lane);
     __syncthreads();
     for (int idx = tid; idx < TR * H; idx += NTHR) {
         int row = idx / H, j = idx - row * H;
@@ -225,14 +243,14 @@ __global__ __launch_bounds__(NTHR) void text_encoder_bwd_kernel(const TextEncBwd
 #pragma unroll
         for (int q = 0; q < 2; ++q)
             if (tid + q * NTHR < TXT_G3) { gb[0][q] += colsum16(dgi, LG, tid + q * NTHR); gb[1][q] += colsum16(dgh, LG, tid + q * NTHR); }
-        rowtile_gemm(dgi, LG, GK / 32, f.fwd.wihT, GK, 7, o1, HP, wave, lane);
+        rowtile_gemm<10, 1>(dgi, LG, GK / 32, f.fwd.wihT, GK, 7, o1, HP, wave, lane);
         __syncthreads();
         for (int idx = tid; idx < TR * H; idx += NTHR) {
             int row = idx / H, j = idx - row * H;
             if (r0 + row < R) atomicAdd(demb + (int)f.tokens[(size_t)(r0 + row) * TXT_T + t] * H + j, o1[row * HP + j]);
         }
         __syncthreads();
-        rowtile_gemm(dgh, LG, GK / 32, f.fwd.whhT, GK, 7, o1, HP, wave, lane);
+        rowtile_gemm<10, 1>(dgh, LG, GK / 32, f.fwd.whhT, GK, 7, o1, HP, wave, lane);
         __syncthreads();
         for (int idx = tid; idx < TR * H; idx += NTHR) dh[idx] = dhd[idx] + o1[(idx / H) * HP + idx % H];
         __syncthreads();
@@ -250,7 +268,7 @@ __global__ __launch_bounds__(NTHR) void text_encoder_bwd_kernel(const TextEncBwd
 
 // ============================================================== text decoder forward
 struct DecLds {
-    float *gi, *gh, *h0f, *h1f, *zf, *lg;
+    float *gi, *gh, *h0f, *h1f, *zf, *lg, *cst;     // cst: embed[12*100] | bih0 bhh0 bih1 bhh1 [4*300] | h2o_bias[16] | z2h_bias[100]
     bf16 *x0b, *zb, *h0b, *midb, *h1b, *hzb;
     int LX, LZ;
 };
@@ -263,7 +281,8 @@ __device__ __forceinline__ DecLds dec_lds(char* smem, int kx, int kz) {
     L.h1f = L.h0f + TR * H;
     L.zf = L.h1f + TR * H;               // [16][128]
     L.lg = L.zf + TR * 128;              // [16][16]
-    L.x0b = reinterpret_cast<bf16*>(L.lg + TR * 16);
+    L.cst = L.lg + TR * 16;              // [2528]
+    L.x0b = reinterpret_cast<bf16*>(L.cst + 2528);
     L.hzb = L.x0b + TR * L.LX;
     L.zb = L.hzb + TR * L.LX;
     L.h0b = L.zb + TR * L.LZ;
@@ -272,7 +291,7 @@ __device__ __forceinline__ DecLds dec_lds(char* smem, int kx, int kz) {
     return L;
 }
 inline size_t dec_lds_bytes(int kx, int kz) {
-    return (size_t)(2 * TR * GL + 2 * TR * H + TR * 128 + TR * 16) * 4 +
+    return (size_t)(2 * TR * GL + 2 * TR * H + TR * 128 + TR * 16 + 2528) * 4 +
            (size_t)(2 * TR * (kx + 8) + TR * (kz + 8) + 3 * TR * (HP + 8)) * 2;
 }
 
@@ -285,6 +304,14 @@ __global__ __launch_bounds__(NTHR) void text_decoder_fwd_kernel(const TextDecArg
     const int r0 = blockIdx.x * TR, R = a.R, D = a.D;
     zero_bf(L.x0b, 2 * TR * L.LX + TR * L.LZ + 3 * TR * LH, tid);
     if (tid < TR) ctok[tid] = 10;     // SOS (multimnist/utils.py:17)
+    // small read-only vectors live in LDS for the whole recurrence (no global round trip inside a step)
+    float* c_emb = L.cst; float* c_b = L.cst + 1200; float* c_h2o = L.cst + 2400; float* c_z2h = L.cst + 2416;
+    for (int i = tid; i < 1200; i += NTHR) c_emb[i] = a.embed[i];
+    for (int i = tid; i < 300; i += NTHR) {
+        c_b[i] = a.l0.bih[i]; c_b[300 + i] = a.l0.bhh[i]; c_b[600 + i] = a.l1.bih[i]; c_b[900 + i] = a.l1.bhh[i];
+    }
+    if (tid < TXT_V) c_h2o[tid] = a.h2o_bias[tid];
+    if (tid < H) c_z2h[tid] = a.z2h_bias[tid];
     __syncthreads();
     for (int idx = tid; idx < TR * D; idx += NTHR) {
         int row = idx / D, j = idx - row * D;
@@ -298,11 +325,11 @@ __global__ __launch_bounds__(NTHR) void text_decoder_fwd_kernel(const TextDecArg
     __syncthreads();
     save_tile(L.zb, L.LZ, a.kz, a.z_bf, a.kz, r0, R, tid);
     // h = z2h(z) replicated into both layers (model.py:280)
-    rowtile_gemm(L.zb, L.LZ, a.kz / 32, a.z2h, a.kz, 7, L.gi, GL, wave, lane);
+    rowtile_gemm<4, 1>(L.zb, L.LZ, a.kz / 32, a.z2h, a.kz, 7, L.gi, GL, wave, lane);
     __syncthreads();
     for (int idx = tid; idx < TR * H; idx += NTHR) {
         int row = idx / H, j = idx - row * H;
-        float h = L.gi[row * GL + j] + a.z2h_bias[j];
+        float h = L.gi[row * GL + j] + c_z2h[j];
         L.h0f[idx] = h; L.h1f[idx] = h;
         L.h0b[row * LH + j] = (bf16)h; L.h1b[row * LH + j] = (bf16)h;
     }
@@ -313,17 +340,17 @@ __global__ __launch_bounds__(NTHR) void text_decoder_fwd_kernel(const TextDecArg
         // c_in = swish(embed(c_in)) ; x0 = [c_in | z]   (model.py:299-300)
         for (int idx = tid; idx < TR * H; idx += NTHR) {
             int row = idx / H, j = idx - row * H;
-            float e = a.embed[ctok[row] * H + j];
+            float e = c_emb[ctok[row] * H + j];
             L.x0b[row * L.LX + j] = (bf16)(e / (1.0f + expf(-e)));
         }
         __syncthreads();
         save_tile(L.x0b, L.LX, a.kx, a.x0_bf ? a.x0_bf + i * plx : nullptr, a.kx, r0, R, tid);
         save_tile(L.h0b, LH, HP, a.h0p_bf ? a.h0p_bf + i * pl128 : nullptr, HP, r0, R, tid);
         save_tile(L.h1b, LH, HP, a.h1p_bf ? a.h1p_bf + i * pl128 : nullptr, HP, r0, R, tid);
-        rowtile_gemm(L.x0b, L.LX, a.kx / 32, a.l0.wih, a.l0.kih, GL / 16, L.gi, GL, wave, lane);
-        rowtile_gemm(L.h0b, LH, HP / 32, a.l0.whh, HP, GL / 16, L.gh, GL, wave, lane);
+        rowtile_gemm<8, 3>(L.x0b, L.LX, a.kx / 32, a.l0.wih, a.l0.kih, GL / 16, L.gi, GL, wave, lane);
+        rowtile_gemm<4, 3>(L.h0b, LH, HP / 32, a.l0.whh, HP, GL / 16, L.gh, GL, wave, lane);
         __syncthreads();
-        gru_gates(L.gi, L.gh, a.l0.bih, a.l0.bhh, L.h0f, L.h0b, LH, r0, R,
+        gru_gates(L.gi, L.gh, c_b, c_b + 300, L.h0f, L.h0b, LH, r0, R,
                   a.gates ? a.gates + (size_t)(i * 2 + 0) * 5 * R * H : nullptr, tid);
         __syncthreads();
         // inter-layer dropout (nn.GRU dropout=0.1, train only)
@@ -335,10 +362,10 @@ __global__ __launch_bounds__(NTHR) void text_decoder_fwd_kernel(const TextDecArg
         }
         __syncthreads();
         save_tile(L.midb, LH, HP, a.mid_bf ? a.mid_bf + i * pl128 : nullptr, HP, r0, R, tid);
-        rowtile_gemm(L.midb, LH, HP / 32, a.l1.wih, a.l1.kih, GL / 16, L.gi, GL, wave, lane);
-        rowtile_gemm(L.h1b, LH, HP / 32, a.l1.whh, HP, GL / 16, L.gh, GL, wave, lane);
+        rowtile_gemm<4, 3>(L.midb, LH, HP / 32, a.l1.wih, a.l1.kih, GL / 16, L.gi, GL, wave, lane);
+        rowtile_gemm<4, 3>(L.h1b, LH, HP / 32, a.l1.whh, HP, GL / 16, L.gh, GL, wave, lane);
         __syncthreads();
-        gru_gates(L.gi, L.gh, a.l1.bih, a.l1.bhh, L.h1f, L.h1b, LH, r0, R,
+        gru_gates(L.gi, L.gh, c_b + 600, c_b + 900, L.h1f, L.h1b, LH, r0, R,
                   a.gates ? a.gates + (size_t)(i * 2 + 1) * 5 * R * H : nullptr, tid);
         __syncthreads();
         for (int idx = tid; idx < TR * H; idx += NTHR) {
@@ -347,12 +374,12 @@ __global__ __launch_bounds__(NTHR) void text_decoder_fwd_kernel(const TextDecArg
         }
         __syncthreads();
         save_tile(L.hzb, L.LX, a.kx, a.hz_bf ? a.hz_bf + i * plx : nullptr, a.kx, r0, R, tid);
-        rowtile_gemm(L.hzb, L.LX, a.kx / 32, a.h2o, a.kx, 1, L.lg, 16, wave, lane);
+        rowtile_gemm<8, 1>(L.hzb, L.LX, a.kx / 32, a.h2o, a.kx, 1, L.lg, 16, wave, lane);
         __syncthreads();
         if (tid < TR) {
             const int row = tid;
             float v[TXT_V], mx = -INFINITY;
-            for (int c = 0; c < TXT_V; ++c) { v[c] = L.lg[row * 16 + c] + a.h2o_bias[c]; mx = fmaxf(mx, v[c]); }
+            for (int c = 0; c < TXT_V; ++c) { v[c] = L.lg[row * 16 + c] + c_h2o[c]; mx = fmaxf(mx, v[c]); }
             float se = 0.f;
             for (int c = 0; c < TXT_V; ++c) se += expf(v[c] - mx);
             const float lse = mx + logf(se);
@@ -427,7 +454,7 @@ __global__ __launch_bounds__(NTHR) void text_decoder_bwd_kernel(const TextDecBwd
         __syncthreads();
         if (tid < TXT_V) gho += colsum16(dlg, 40, tid);
         // d[h1 | z] = dlogit * W_h2o
-        rowtile_gemm(dlg, 40, 1, f.h2oT, 32, nxt, o1, LO, wave, lane);
+        rowtile_gemm<1, 2>(dlg, 40, 1, f.h2oT, 32, nxt, o1, LO, wave, lane);
         __syncthreads();
         for (int idx = tid; idx < TR * XI; idx += NTHR) {
             int row = idx / XI, j = idx - row * XI;
@@ -442,11 +469,11 @@ __global__ __launch_bounds__(NTHR) void text_decoder_bwd_kernel(const TextDecBwd
 #pragma unroll
         for (int q = 0; q < 2; ++q)
             if (tid + q * NTHR < TXT_G3) { gb[2][q] += colsum16(dgi, LG, tid + q * NTHR); gb[3][q] += colsum16(dgh, LG, tid + q * NTHR); }
-        rowtile_gemm(dgh, LG, GK / 32, f.l1.whhT, GK, 7, o1, LO, wave, lane);
+        rowtile_gemm<10, 1>(dgh, LG, GK / 32, f.l1.whhT, GK, 7, o1, LO, wave, lane);
         __syncthreads();
         for (int idx = tid; idx < TR * H; idx += NTHR) dh1[idx] = dhd[idx] + o1[(idx / H) * LO + idx % H];
         __syncthreads();
-        rowtile_gemm(dgi, LG, GK / 32, f.l1.wihT, GK, 7, o1, LO, wave, lane);     // d mid
+        rowtile_gemm<10, 1>(dgi, LG, GK / 32, f.l1.wihT, GK, 7, o1, LO, wave, lane);     // d mid
         __syncthreads();
         for (int idx = tid; idx < TR * H; idx += NTHR) {
             int row = idx / H, j = idx - row * H;
@@ -462,11 +489,11 @@ __global__ __launch_bounds__(NTHR) void text_decoder_bwd_kernel(const TextDecBwd
 #pragma unroll
         for (int q = 0; q < 2; ++q)
             if (tid + q * NTHR < TXT_G3) { gb[0][q] += colsum16(dgi, LG, tid + q * NTHR); gb[1][q] += colsum16(dgh, LG, tid + q * NTHR); }
-        rowtile_gemm(dgh, LG, GK / 32, f.l0.whhT, GK, 7, o1, LO, wave, lane);
+        rowtile_gemm<10, 1>(dgh, LG, GK / 32, f.l0.whhT, GK, 7, o1, LO, wave, lane);
         __syncthreads();
         for (int idx = tid; idx < TR * H; idx += NTHR) dh0[idx] = dhd[idx] + o1[(idx / H) * LO + idx % H];
         __syncthreads();
-        rowtile_gemm(dgi, LG, GK / 32, f.l0.wihT, GK, nxt, o1, LO, wave, lane);   // d[x_embed | z]
+        rowtile_gemm<10, 2>(dgi, LG, GK / 32, f.l0.wihT, GK, nxt, o1, LO, wave, lane);   // d[x_embed | z]
         __syncthreads();
         for (int idx = tid; idx < TR * XI; idx += NTHR) {
             int row = idx / XI, j = idx - row * XI;
@@ -494,7 +521,7 @@ __global__ __launch_bounds__(NTHR) void text_decoder_bwd_kernel(const TextDecBwd
     }
     __syncthreads();
     if (tid < H) atomicAdd(a.g_z2h_bias + tid, colsum16(dhb, 136, tid));
-    rowtile_gemm(dhb, 136, HP / 32, f.z2hT, HP, ndt, o1, LO, wave, lane);
+    rowtile_gemm<4, 1>(dhb, 136, HP / 32, f.z2hT, HP, ndt, o1, LO, wave, lane);
     __syncthreads();
     for (int idx = tid; idx < TR * D; idx += NTHR) {
         int row = idx / D, j = idx - row * D;
@@ -520,7 +547,7 @@ void set_lds_attr(K kernel) {
 
 int launch_text_encoder_fwd(const TextEncArgs& a, hipStream_t s) {
     MMVAE_REQUIRE(a.B >= 1 && 2 * a.D <= 256 && a.nh2p % 16 == 0, "text encoder: B=%d D=%d", a.B, a.D);
-    size_t lds = (size_t)(2 * TR * GL + 2 * TR * H) * 4 + (size_t)3 * TR * (HP + 8) * 2;
+    size_t lds = (size_t)(2 * TR * GL + 2 * TR * H + 2400) * 4 + (size_t)3 * TR * (HP + 8) * 2;
     static bool once = false;
     if (!once) { set_lds_attr(text_encoder_fwd_kernel); once = true; }
     hipLaunchKernelGGL(text_encoder_fwd_kernel, dim3(ceil_div(a.B, TR)), dim3(NTHR), lds, s, a);
