@@ -51,8 +51,8 @@ int mmvae_mm_bind(mmvae_mm_t*, float* params, float* grads, float* bn_stats, lon
 int mmvae_mm_pack_weights(mmvae_mm_t*, void* stream);       /* refresh bf16 GEMM-layout copies after params change */
 
 /* One 3-pass ELBO step (multimnist/train.py:150-168): forward of (image,text), (image), (text), the three
- * loss_function sums and -- if do_backward -- the gradient of loss_1+loss_2+loss_3 accumulated into `grads`
- * (the caller zeroes `grads`, like optimizer.zero_grad()). */
+ * loss_function sums and -- if do_backward -- the gradient of loss_1+loss_2+loss_3 written to `grads`
+ * (the step zeroes `grads` first, i.e. it includes optimizer.zero_grad()). */
 typedef struct {
     void* ws; size_t ws_bytes;
     const long long* step_counter;          /* device int64 keying the RNG streams, may be NULL */

@@ -173,8 +173,7 @@ class FusedELBOStep:
         io.lambda_yx = (C.c_float * 3)(*self.LAMBDA_YX)
         io.seed = self.seed
         io.sums = self.sums.data_ptr()
-        if backward:
-            self.state.grads.zero_()                                   # optimizer.zero_grad()  (train.py:150)
+        # optimizer.zero_grad() (train.py:150) happens inside the step's prologue kernel when backward is requested
         call("mmvae_mm_step", self.h, C.byref(io), int(training), int(backward), _stream())
         return StepOutputs(self.sums, self.B, self.kl_lambda, self.LAMBDA_XY, self.LAMBDA_YX)
 

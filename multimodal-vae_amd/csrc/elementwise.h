@@ -130,3 +130,14 @@ int launch_bce_fwd(const float* p, const float* t, long long n, float* out, hipS
 int launch_bce_bwd(const float* p, const float* t, long long n, float coef, float* dp, hipStream_t s);
 int launch_nll_fwd(const float* lp, const long long* tg, int rows, int classes, float* out, hipStream_t s);
 int launch_nll_bwd(const long long* tg, int rows, int classes, float coef, float* dlp, hipStream_t s);
+
+// One launch at the top of the fused step: zero the accumulation buffers (16-byte stores) and draw the step's
+// stochastic inputs (eps ~ N(0,1), dropout keep flags) from Philox streams keyed by (seed, step counter).
+struct StepBeginArgs {
+    void* zero_ptr[4]; size_t zero_bytes[4];      // multiples of 16 bytes, 16-byte aligned (unused: null/0)
+    float* eps; long long n_eps;                  // null -> not drawn
+    uint8_t* mask[3]; long long n_mask[3];        // null -> not drawn
+    float p;
+    unsigned long long seed; const long long* step;
+};
+int launch_step_begin(const StepBeginArgs& a, hipStream_t s);

@@ -29,44 +29,81 @@ __device__ __forceinline__ long long pack_src(const PackDesc& d, int n, int k) {
            (long long)(d.o_ty + ty * d.step_t) * d.s_ty + (long long)(d.o_tx + tx * d.step_t) * d.s_tx + (long long)c * d.s_c;
 }
 
+// one thread = 8 consecutive columns of one packed row (16-byte bf16 store); Kpad is a multiple of 8
 __global__ __launch_bounds__(TPB) void pack_kernel(const PackDesc* __restrict__ table, int nd, const float* __restrict__ params,
                                                    bf16* __restrict__ packed_bf, float* __restrict__ packed_f32) {
     const int di = find_desc(table, nd, blockIdx.x);
     const PackDesc d = table[di];
-    const long long e = (long long)(blockIdx.x - d.first_block) * TPB + threadIdx.x;
-    const long long total = (long long)d.Npad * d.Kpad;
-    if (e >= total) return;
-    const int n = (int)(e / d.Kpad), k = (int)(e - (long long)n * d.Kpad);
-    float v = 0.f;
-    if (n < d.N && k < d.K) v = params[pack_src(d, n, k)];
-    else if (n < d.N && k == d.K && d.bias_off >= 0) {
-        int nhi = n / d.NL, nlo = n - nhi * d.NL;
-        v = params[d.bias_off + (long long)nhi * d.b_nhi + (long long)nlo * d.b_nlo];
+    const long long v = (long long)(blockIdx.x - d.first_block) * TPB + threadIdx.x;
+    const int vpr = d.Kpad / 8;
+    if (v >= (long long)d.Npad * vpr) return;
+    const int n = (int)(v / vpr), k0 = (int)(v - (long long)n * vpr) * 8;
+    float val[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) val[j] = 0.f;
+    if (n < d.N) {
+        const int nhi = n / d.NL, nlo = n - nhi * d.NL;
+        const long long rowbase = d.src_off + (long long)nhi * d.s_nhi + (long long)nlo * d.s_nlo;
+        if (d.C % 8 == 0 && k0 + 8 <= d.K) {              // the 8 columns share one tap
+            const int tap = k0 / d.C, c = k0 - tap * d.C;
+            const int ty = tap / d.TW, tx = tap - ty * d.TW;
+            const long long b = rowbase + (long long)(d.o_ty + ty * d.step_t) * d.s_ty + (long long)(d.o_tx + tx * d.step_t) * d.s_tx + (long long)c * d.s_c;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) val[j] = params[b + (long long)j * d.s_c];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + j;
+                if (k < d.K) val[j] = params[pack_src(d, n, k)];
+                else if (k == d.K && d.bias_off >= 0) val[j] = params[d.bias_off + (long long)nhi * d.b_nhi + (long long)nlo * d.b_nlo];
+            }
+        }
     }
-    if (d.is_f32) packed_f32[d.dst_off + e] = v;
-    else packed_bf[d.dst_off + e] = (bf16)v;
+    const long long e = (long long)n * d.Kpad + k0;
+    if (d.is_f32) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) packed_f32[d.dst_off + e + j] = val[j];
+    } else {
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)val[j];
+        *reinterpret_cast<bf16x8*>(packed_bf + d.dst_off + e) = o;
+    }
 }
 
 __global__ __launch_bounds__(TPB) void unpack_kernel(const PackDesc* __restrict__ table, int nd, const float* __restrict__ gmat,
                                                      const float* __restrict__ gvec, float* __restrict__ grads) {
     const int di = find_desc(table, nd, blockIdx.x);
     const PackDesc d = table[di];
-    const long long e = (long long)(blockIdx.x - d.first_block) * TPB + threadIdx.x;
-    const long long total = (long long)d.Npad * d.Kpad;
-    if (e >= total) return;
-    const int n = (int)(e / d.Kpad), k = (int)(e - (long long)n * d.Kpad);
-    if (n < d.N && k < d.K) {
-        float v = d.is_f32 ? gvec[d.dst_off + e] : gmat[d.dst_off + e];
-        grads[pack_src(d, n, k)] += v;
-    } else if (n < d.N && k == d.K && d.bias_off >= 0) {
-        int nhi = n / d.NL, nlo = n - nhi * d.NL;
-        grads[d.bias_off + (long long)nhi * d.b_nhi + (long long)nlo * d.b_nlo] += gmat[d.dst_off + e];
+    const long long v = (long long)(blockIdx.x - d.first_block) * TPB + threadIdx.x;
+    const int vpr = d.Kpad / 8;
+    if (v >= (long long)d.N * vpr) return;
+    const int n = (int)(v / vpr), k0 = (int)(v - (long long)n * vpr) * 8;
+    if (k0 > d.K) return;
+    const int nhi = n / d.NL, nlo = n - nhi * d.NL;
+    const float* src = (d.is_f32 ? gvec : gmat) + d.dst_off + (long long)n * d.Kpad + k0;
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
+    const float val[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    if (d.C % 8 == 0 && k0 + 8 <= d.K) {
+        const long long rowbase = d.src_off + (long long)nhi * d.s_nhi + (long long)nlo * d.s_nlo;
+        const int tap = k0 / d.C, c = k0 - tap * d.C;
+        const int ty = tap / d.TW, tx = tap - ty * d.TW;
+        const long long b = rowbase + (long long)(d.o_ty + ty * d.step_t) * d.s_ty + (long long)(d.o_tx + tx * d.step_t) * d.s_tx + (long long)c * d.s_c;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) grads[b + (long long)j * d.s_c] += val[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + j;
+            if (k < d.K) grads[pack_src(d, n, k)] += val[j];
+            else if (k == d.K && d.bias_off >= 0) grads[d.bias_off + (long long)nhi * d.b_nhi + (long long)nlo * d.b_nlo] += val[j];
+        }
     }
 }
 
 int table_blocks(const PackDesc* host, int nd) {
     const PackDesc& l = host[nd - 1];
-    return l.first_block + (int)(((long long)l.Npad * l.Kpad + TPB - 1) / TPB);
+    return l.first_block + (int)(((long long)l.Npad * (l.Kpad / 8) + TPB - 1) / TPB);
 }
 
 // ------------------------------------------------------------------ im2col for thin (1/3-channel) inputs
@@ -404,6 +441,42 @@ __global__ __launch_bounds__(TPB) void keep_mask_kernel(uint8_t* out, long long 
     }
 }
 
+// ------------------------------------------------------------------ step prologue: zeroing + RNG in one launch
+__global__ __launch_bounds__(TPB) void step_begin_kernel(const StepBeginArgs a) {
+    const long long gtid = (long long)blockIdx.x * TPB + threadIdx.x, gstride = (long long)gridDim.x * TPB;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (!a.zero_ptr[r]) continue;
+        u32x4* p = reinterpret_cast<u32x4*>(a.zero_ptr[r]);
+        const long long n16 = (long long)(a.zero_bytes[r] / 16);
+        for (long long i = gtid; i < n16; i += gstride) p[i] = u32x4{0u, 0u, 0u, 0u};
+    }
+    const unsigned long long st = a.step ? (unsigned long long)*a.step : 0ull;
+    const unsigned long long key = a.seed ^ (st * 0x9E3779B97F4A7C15ull);
+    if (a.eps) {
+        for (long long q = gtid; q * 4 < a.n_eps; q += gstride) {
+            uint32_t r[4];
+            Philox::gen(key, (uint64_t)q, 1, r);
+            float u0 = u01(r[0]), u1 = u01(r[1]), u2 = u01(r[2]), u3 = u01(r[3]);
+            float m0 = sqrtf(-2.0f * logf(u0)), m1 = sqrtf(-2.0f * logf(u2));
+            float v[4] = {m0 * cosf(6.28318530718f * u1), m0 * sinf(6.28318530718f * u1),
+                          m1 * cosf(6.28318530718f * u3), m1 * sinf(6.28318530718f * u3)};
+            for (int j = 0; j < 4; ++j)
+                if (q * 4 + j < a.n_eps) a.eps[q * 4 + j] = v[j];
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        if (!a.mask[m]) continue;
+        for (long long q = gtid; q * 4 < a.n_mask[m]; q += gstride) {
+            uint32_t r[4];
+            Philox::gen(key, (uint64_t)q, 2 + m, r);
+            for (int j = 0; j < 4; ++j)
+                if (q * 4 + j < a.n_mask[m]) a.mask[m][q * 4 + j] = u01(r[j]) >= a.p ? 1 : 0;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ standalone loss pieces (drop-in loss_function)
 __global__ __launch_bounds__(TPB) void bce_fwd_kernel(const float* p, const float* t, long long n, float* out) {
     float acc = 0.f;
@@ -650,7 +723,7 @@ int launch_adam(const AdamArgs& a, hipStream_t s) {
     MMVAE_REQUIRE(a.step != nullptr, "adam: step counter is null");
     // the word after the step counter is the block ticket (both live in the caller's 16-byte state block)
     unsigned* done = reinterpret_cast<unsigned*>(a.step + 1);
-    hipLaunchKernelGGL(adam_kernel, dim3(nblocks((a.n + 3) / 4, TPB, 2048)), dim3(TPB), 0, s, a, done);
+    hipLaunchKernelGGL(adam_kernel, dim3(nblocks((a.n + 3) / 4, TPB, 512)), dim3(TPB), 0, s, a, done);   // few blocks: one ticket atomic each
     return mmvae_check_launch("adam");
 }
 int launch_fill_zero(void* p, size_t bytes, hipStream_t s) {
@@ -676,4 +749,11 @@ int launch_nll_fwd(const float* lp, const long long* tg, int rows, int classes, 
 int launch_nll_bwd(const long long* tg, int rows, int classes, float coef, float* dlp, hipStream_t s) {
     hipLaunchKernelGGL(nll_bwd_kernel, dim3(ceil_div(rows * classes, TPB)), dim3(TPB), 0, s, tg, rows, classes, coef, dlp);
     return mmvae_check_launch("nll_bwd");
+}
+
+int launch_step_begin(const StepBeginArgs& a, hipStream_t s) {
+    for (int r = 0; r < 4; ++r)
+        MMVAE_REQUIRE(a.zero_ptr[r] == nullptr || (a.zero_bytes[r] % 16 == 0 && ((uintptr_t)a.zero_ptr[r] & 15) == 0), "step_begin: zero range %d is not 16-byte aligned", r);
+    hipLaunchKernelGGL(step_begin_kernel, dim3(2048), dim3(TPB), 0, s, a);
+    return mmvae_check_launch("step_begin");
 }

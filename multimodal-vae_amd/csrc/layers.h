@@ -77,7 +77,8 @@ struct PackList {
     long long mat_elems = 0, vec_elems = 0;
     // returns index; the packed matrix is [Npad][Kpad] at element offset d[i].dst_off
     int add(PackDesc x) {
-        x.first_block = d.empty() ? 0 : d.back().first_block + (int)(((long long)d.back().Npad * d.back().Kpad + 255) / 256);
+        // one 256-thread block packs 256 vectors of 8 columns (elementwise.hip pack_kernel)
+        x.first_block = d.empty() ? 0 : d.back().first_block + (int)(((long long)d.back().Npad * (d.back().Kpad / 8) + 255) / 256);
         if (x.is_f32) { x.dst_off = vec_elems; vec_elems += round_up(x.Npad * x.Kpad, 64); }
         else { x.dst_off = mat_elems; mat_elems += (long long)x.Npad * x.Kpad; }
         d.push_back(x);

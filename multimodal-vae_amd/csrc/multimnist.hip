@@ -855,15 +855,24 @@ int mm_step_fwd_bwd(MMPlan* Pp, const MMStepIO& io, int training, int do_backwar
     MMPlan::W& w = P.w;
     const int B = P.B, D = P.D, B3 = 3 * B;
     MMVAE_REQUIRE(io.image && io.text && io.sums, "step: image/text/sums must be given");
-    MMVAE_TRY(launch_fill_zero(w.zero_begin, w.zero_bytes, s));
-    if (do_backward) MMVAE_TRY(zero_gpk(Pp, s));
-    // ---- stochastic inputs (injected, or Philox keyed by the device step counter)
+    // ---- one prologue launch: zero every accumulation buffer, draw eps / dropout keep flags (Philox keyed by the
+    //      device step counter) unless the caller injected them
     const float* eps = io.eps;
-    if (training && !eps) { MMVAE_TRY(launch_normal(w.eps, (long long)B3 * D, io.seed, io.step_ctr, 1, s)); eps = w.eps; }
     const uint8_t *m1 = io.enc_mask1, *m2 = io.enc_mask2, *gk = io.gru_keep;
-    if (training && io.enc_dropout && !m1) { MMVAE_TRY(launch_keep_mask(w.m1, (long long)2 * B * 400, DROP_P, io.seed, io.step_ctr, 2, s)); m1 = w.m1; }
-    if (training && io.enc_dropout && !m2) { MMVAE_TRY(launch_keep_mask(w.m2, (long long)2 * B * 200, DROP_P, io.seed, io.step_ctr, 3, s)); m2 = w.m2; }
-    if (training && io.gru_dropout && !gk) { MMVAE_TRY(launch_keep_mask(w.gkeep, (long long)4 * B3 * 100, DROP_P, io.seed, io.step_ctr, 4, s)); gk = w.gkeep; }
+    StepBeginArgs sb{};
+    sb.zero_ptr[0] = w.zero_begin; sb.zero_bytes[0] = w.zero_bytes;
+    if (do_backward) {
+        sb.zero_ptr[1] = P.buf.gpk; sb.zero_bytes[1] = (size_t)P.gk.mat_elems * sizeof(float);
+        sb.zero_ptr[2] = P.buf.grads; sb.zero_bytes[2] = (size_t)(P.nparams / 4) * 16;     // tail (< 4 floats) below
+    }
+    sb.p = DROP_P; sb.seed = io.seed; sb.step = io.step_ctr;
+    if (training && !eps) { sb.eps = w.eps; sb.n_eps = (long long)B3 * D; eps = w.eps; }
+    if (training && io.enc_dropout && !m1) { sb.mask[0] = w.m1; sb.n_mask[0] = (long long)2 * B * 400; m1 = w.m1; }
+    if (training && io.enc_dropout && !m2) { sb.mask[1] = w.m2; sb.n_mask[1] = (long long)2 * B * 200; m2 = w.m2; }
+    if (training && io.gru_dropout && !gk) { sb.mask[2] = w.gkeep; sb.n_mask[2] = (long long)4 * B3 * 100; gk = w.gkeep; }
+    MMVAE_TRY(launch_step_begin(sb, s));
+    if (do_backward && P.nparams % 4 != 0)
+        MMVAE_TRY(launch_fill_zero(P.buf.grads + (P.nparams / 4) * 4, (size_t)(P.nparams % 4) * sizeof(float), s));
     const int enc_drop = training && io.enc_dropout;
     MMVAE_TRY(ensure_streams(P));
     static const bool serial = getenv("MMVAE_SERIAL") != nullptr;      // profiling aid: one stream, no overlap
