@@ -785,6 +785,8 @@ int ensure_streams(MMPlan& P) {
             return MMVAE_EHIP;
         }
     }
+    static const bool one_side = getenv("MMVAE_ONE_SIDE") != nullptr;   // experiment: text path and wgrads share a stream
+    if (one_side) P.st_wgrad = P.st_text;
     P.next_event = 0;
     return MMVAE_OK;
 }

@@ -9,15 +9,27 @@ namespace {
 
 constexpr int TPB = 256;
 
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+
+__device__ __forceinline__ float dot8(bf16x8 a, bf16x8 b, float acc) {
+    // 8 bf16 MACs as 4 packed v_dot2c_f32_bf16 (fp32 accumulate)
+    union { bf16x8 v; bf16x2 p[4]; } ua, ub;
+    ua.v = a; ub.v = b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_fdot2_f32_bf16(ua.p[i], ub.p[i], acc, false);
+    return acc;
+}
+
 // forward: one workgroup per (image, strip of FR input rows); the activated input strip (+1 halo row each side,
 // zero-filled outside the image) is staged once in LDS, so every input pixel is read from global memory once.
-// Each thread then produces output pixels of the strip (all COUT channels) and the fused sigmoid + BCE(+gradient).
+// Weights sit in LDS as bf16 [kh][kw][co][32 ci]; each output pixel is 4 taps x 32 channels = 16 dot2 x 4 per
+// output channel.  Fused sigmoid + BCE (+ gradient).
 constexpr int FR = 5;                       // input rows per strip (25 = 5*5, 32 = 6*5+2: the tail strip is masked)
 template <int COUT>
 __global__ __launch_bounds__(TPB) void convt_last_fwd_kernel(const ConvTLastFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* wl = reinterpret_cast<float*>(smem);                     // [kh][kw][ci][co]
-    bf16* tile = reinterpret_cast<bf16*>(wl + 16 * 32 * COUT);      // [(FR+2)][IW+2][32]
+    bf16* wl = reinterpret_cast<bf16*>(smem);                       // [16 taps][COUT][32]
+    bf16* tile = wl + 16 * COUT * 32;                               // [(FR+2)][IW+2][32]
     __shared__ float part[TPB / 64];
     const int strips = (a.IH + FR - 1) / FR;
     const int n_in_g = blockIdx.x / strips, strip = blockIdx.x - n_in_g * strips;
@@ -25,9 +37,9 @@ __global__ __launch_bounds__(TPB) void convt_last_fwd_kernel(const ConvTLastFwdA
     const long long n = (long long)g * a.B + n_in_g;
     const int iy_base = strip * FR - 1;                             // first staged row (halo)
     const int TW = a.IW + 2;
-    for (int i = threadIdx.x; i < 16 * a.Cin * COUT; i += TPB) {
-        int co = i % COUT, ci = (i / COUT) % a.Cin, tap = i / (COUT * a.Cin);
-        wl[i] = a.w[(ci * COUT + co) * 16 + tap];                  // weight (Cin, Cout, 4, 4)
+    for (int i = threadIdx.x; i < 16 * COUT * 32; i += TPB) {
+        const int ci = i & 31, co = (i >> 5) % COUT, tap = i / (32 * COUT);
+        wl[i] = (bf16)a.w[(ci * COUT + co) * 16 + tap];            // weight (Cin, Cout, 4, 4)
     }
     const int nvec = (FR + 2) * TW * 4;                             // 16-byte vectors (32 channels = 4 vectors)
     for (int v = threadIdx.x; v < nvec; v += TPB) {
@@ -49,7 +61,6 @@ __global__ __launch_bounds__(TPB) void convt_last_fwd_kernel(const ConvTLastFwdA
     const int nout = 2 * FR * OW;
     float loss = 0.f;
     for (int o = threadIdx.x; o < nout; o += TPB) {
-        asm volatile("" ::: "memory");        // no hoisting of the LDS weight reads out of the loop (VGPR blow-up)
         const int oyl = o / OW, ox = o - oyl * OW;
         const int oy = oy_lo + oyl;
         if (oy >= OH) continue;
@@ -64,16 +75,13 @@ __global__ __launch_bounds__(TPB) void convt_last_fwd_kernel(const ConvTLastFwdA
             for (int tx = 0; tx < 2; ++tx) {
                 const int iy = iy0 - ty, ix = ix0 - tx;             // in [-1, IH] x [-1, IW]: inside the halo tile
                 const bf16* src = tile + ((size_t)(iy - iy_base) * TW + (ix + 1)) * 32;
-                const float* wp = wl + ((kh0 + 2 * ty) * 4 + kw0 + 2 * tx) * 32 * COUT;
+                const bf16* wp = wl + ((kh0 + 2 * ty) * 4 + kw0 + 2 * tx) * COUT * 32;
 #pragma unroll
                 for (int c0 = 0; c0 < 32; c0 += 8) {
                     const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + c0);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float x = (float)v[j];
-#pragma unroll
-                        for (int co = 0; co < COUT; ++co) acc[co] += x * wp[(c0 + j) * COUT + co];
-                    }
+                    for (int co = 0; co < COUT; ++co)
+                        acc[co] = dot8(v, *reinterpret_cast<const bf16x8*>(wp + co * 32 + c0), acc[co]);
                 }
             }
         }
@@ -107,17 +115,19 @@ __global__ __launch_bounds__(TPB) void convt_last_fwd_kernel(const ConvTLastFwdA
     }
 }
 
-// backward-data: four threads per INPUT pixel (8 of the 32 channels each, one 16-byte vector); fused d-activation of
-// the producer layer + its two BatchNorm-backward sums (lanes with equal lane&3 own the same channels: xor-shuffles
-// over the other lane bits, then one LDS pass across the waves, then one atomic per channel per workgroup).
+// backward-data: four threads per INPUT pixel (8 of the 32 channels each, one 16-byte vector).  The 16*COUT upstream
+// values of the pixel are packed to bf16 pairs once; per channel the reduction over (co, tap) is 8*COUT dot2 against
+// bf16 weights [ci][co][16 taps] read from LDS as 16-byte vectors.  Fused d-activation of the producer layer + its two
+// BatchNorm-backward sums (lanes with equal lane&3 own the same channels: xor-shuffles over the other lane bits,
+// one LDS pass across the waves, one atomic per channel per workgroup into a slot).
 template <int COUT>
 __global__ __launch_bounds__(TPB) void convt_last_dgrad_kernel(const ConvTLastDgradArgs a) {
-    __shared__ __attribute__((aligned(16))) float wl[16 * COUT * 32];          // [kh][kw][co][ci]
+    __shared__ __attribute__((aligned(16))) bf16 wl[32 * COUT * 16];          // [ci][co][tap]
     __shared__ float2 red_s[TPB / 64][32];
     const int g = blockIdx.y;
-    for (int i = threadIdx.x; i < 16 * a.Cin * COUT; i += TPB) {
-        int ci = i % a.Cin, co = (i / a.Cin) % COUT, tap = i / (COUT * a.Cin);
-        wl[i] = a.w[(ci * COUT + co) * 16 + tap];
+    for (int i = threadIdx.x; i < 32 * COUT * 16; i += TPB) {
+        const int tap = i & 15, co = (i >> 4) % COUT, ci = i / (16 * COUT);
+        wl[i] = (bf16)a.w[(ci * COUT + co) * 16 + tap];
     }
     __syncthreads();
     const int OH = 2 * a.IH, OW = 2 * a.IW;
@@ -126,52 +136,44 @@ __global__ __launch_bounds__(TPB) void convt_last_dgrad_kernel(const ConvTLastDg
     float s1[8], s2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-    float2 af[8], mr[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { af[j] = a.affine[g * a.Cin + cg * 8 + j]; mr[j] = a.meanrstd[g * a.Cin + cg * 8 + j]; }
     for (long long i = (long long)blockIdx.x * (TPB / 4) + (threadIdx.x >> 2); i < per_group; i += (long long)gridDim.x * (TPB / 4)) {
-        asm volatile("" ::: "memory");        // keep the (loop-invariant) LDS weight reads inside the loop: hoisting
-                                              // all 512 of them would cost 128+ VGPRs for a loop that runs once
         const int ix = (int)(i % a.IW);
         long long t1 = i / a.IW;
         const int iy = (int)(t1 % a.IH);
         const long long n = (long long)g * a.B + t1 / a.IH;
-        // 16*COUT upstream values: unconditional loads from clamped addresses, out-of-image taps zeroed afterwards
-        float dl[16 * COUT];
+        // upstream values: unconditional loads from clamped addresses, out-of-image taps zeroed, packed to bf16 pairs
+        bf16x8 dlp[2 * COUT];
 #pragma unroll
-        for (int kh = 0; kh < 4; ++kh) {
+        for (int co = 0; co < COUT; ++co)
 #pragma unroll
-            for (int kw = 0; kw < 4; ++kw) {
-                const int oy = 2 * iy - 1 + kh, ox = 2 * ix - 1 + kw;
-                const bool ok = (unsigned)oy < (unsigned)OH && (unsigned)ox < (unsigned)OW;
-                const int oyc = min(max(oy, 0), OH - 1), oxc = min(max(ox, 0), OW - 1);
+            for (int kh = 0; kh < 4; ++kh) {
+                const int oy = 2 * iy - 1 + kh;
+                const int oyc = min(max(oy, 0), OH - 1);
+                const float* row = a.dlogit + ((n * COUT + co) * OH + oyc) * OW;
 #pragma unroll
-                for (int co = 0; co < COUT; ++co) {
-                    const float d = a.dlogit[((n * COUT + co) * OH + oyc) * OW + oxc];
-                    dl[(kh * 4 + kw) * COUT + co] = ok ? d : 0.f;
+                for (int kw = 0; kw < 4; ++kw) {
+                    const int ox = 2 * ix - 1 + kw;
+                    const bool ok = (unsigned)oy < (unsigned)OH && (unsigned)ox < (unsigned)OW;
+                    const float d = row[min(max(ox, 0), OW - 1)];
+                    dlp[co * 2 + (kh >> 1)][(kh & 1) * 4 + kw] = (bf16)(ok ? d : 0.f);
                 }
             }
-        }
-        float acc[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-#pragma unroll
-        for (int tp = 0; tp < 16 * COUT; ++tp) {
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wl + tp * 32 + cg * 8);
-            const f32x4 w1 = *reinterpret_cast<const f32x4*>(wl + tp * 32 + cg * 8 + 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { acc[j] += dl[tp] * w0[j]; acc[4 + j] += dl[tp] * w1[j]; }
-            if ((tp & 3) == 3) __builtin_amdgcn_sched_barrier(0);    // bound how many LDS weight reads are in flight
-        }
         const long long pix = (n * a.IH + iy) * a.IW + ix;
         const bf16x8 rv = *reinterpret_cast<const bf16x8*>(a.r + pix * a.Cin + cg * 8);
         bf16x8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
+            const int c = cg * 8 + j;
+            float acc = 0.f;
+            const bf16* wp = wl + c * COUT * 16;
+#pragma unroll
+            for (int q = 0; q < 2 * COUT; ++q) acc = dot8(dlp[q], *reinterpret_cast<const bf16x8*>(wp + q * 8), acc);
             const float rr = (float)rv[j];
-            const float v = acc[j] * act_bwd(a.act, rr * af[j].x + af[j].y);
+            const float2 af = a.affine[g * a.Cin + c];
+            const float2 mr = a.meanrstd[g * a.Cin + c];
+            const float v = acc * act_bwd(a.act, rr * af.x + af.y);
             s1[j] += v;
-            s2[j] += v * (rr - mr[j].x) * mr[j].y;
+            s2[j] += v * (rr - mr.x) * mr.y;
             o[j] = (bf16)v;
         }
         *reinterpret_cast<bf16x8*>(a.db + pix * a.Cin + cg * 8) = o;
@@ -199,7 +201,7 @@ int launch_convt_last_fwd(const ConvTLastFwdArgs& a, hipStream_t s) {
     MMVAE_REQUIRE(a.Cin == 32 && (a.Cout == 1 || a.Cout == 3) && a.G >= 1 && a.G <= 4, "convT last fwd: Cin=%d Cout=%d G=%d", a.Cin, a.Cout, a.G);
     const int strips = (a.IH + FR - 1) / FR;
     dim3 grid(a.B * strips, a.G);
-    size_t lds = (size_t)16 * 32 * a.Cout * sizeof(float) + (size_t)(FR + 2) * (a.IW + 2) * 32 * sizeof(bf16);
+    size_t lds = (size_t)16 * 32 * a.Cout * sizeof(bf16) + (size_t)(FR + 2) * (a.IW + 2) * 32 * sizeof(bf16);
     if (a.Cout == 1) hipLaunchKernelGGL(convt_last_fwd_kernel<1>, grid, dim3(TPB), lds, s, a);
     else hipLaunchKernelGGL(convt_last_fwd_kernel<3>, grid, dim3(TPB), lds, s, a);
     return mmvae_check_launch("convt_last_fwd");
