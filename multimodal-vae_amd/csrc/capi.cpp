@@ -1,6 +1,7 @@
 // extern "C" boundary of libmmvae_hip.so (see include/mmvae_hip.h).
 #include "../../include/mmvae_hip.h"
 #include "multimnist.h"
+#include "plan_base.h"
 #include <cstring>
 #include <exception>
 

@@ -3,18 +3,8 @@
 #include "layers.h"
 #include "text.h"
 
-struct MMBuffers {          // caller-owned device memory bound to a plan
-    float* params = nullptr;        // flat fp32 parameters, state_dict order
-    float* grads = nullptr;         // flat fp32 gradients (accumulated)
-    float* bn_stats = nullptr;      // running_mean | running_var of the 6 BatchNorms, state_dict order
-    long long* bn_nbt = nullptr;    // num_batches_tracked [6]
-    bf16* packed = nullptr;         // bf16 GEMM-layout weights
-    float* packed_vec = nullptr;    // fp32 packed vectors (permuted biases)
-    float* gpk = nullptr;           // fp32 packed weight gradients
-    float* gpk_vec = nullptr;
-    PackDesc* desc_dev = nullptr;   // device copies of the descriptor tables
-    PackDesc* gdesc_dev = nullptr;
-};
+struct ModelBuffers;
+typedef ModelBuffers MMBuffers;
 
 struct MMStepIO {
     void* ws = nullptr; size_t ws_bytes = 0;   // caller-owned scratch (mm_workspace_bytes)

@@ -2,58 +2,27 @@
 // Reference: multimnist/model.py:21-93 (MultimodalVAE), :150-216 (image enc/dec), :219-307 (text enc/dec),
 //            multimnist/train.py:69-87 (loss_function), :146-173 (3-pass step).
 #include "multimnist.h"
+#include "plan_base.h"
 #include "thin.h"
-#include <map>
 #include <cstring>
-#include <cstdlib>
 
 namespace {
 constexpr int IMG = 50, NPIX = 2500;
-constexpr float BN_EPS = 1e-5f, BN_MOM = 0.1f, DROP_P = 0.1f;
 }
 
-struct ConvL {
-    ConvGeom g;
-    long long w_off;
-    int bn;                       // index into bn tables or -1
-    GatherPlan fwd, dgrad;        // geometry templates (groups/pointers filled per call)
-    int pk_fwd[4], pk_dgrad[4], gk[4];
-};
-struct LinL {
-    long long w_off, b_off;
-    int N, K;
-    int pk_fwd, pk_dgrad, gk;
-    int pk_dgrad4[4];             // classifier.0 only: one dgrad matrix per pixel of the 2x2 feature map
-};
-struct BnL { long long w_off, b_off; int C; long long stat_off; int idx; };
-
-struct MMPlan {
-    int D, B;
+struct MMPlan : PlanBase {
     int ldz, kx, kz;
-    std::vector<ParamInfo> params;
-    std::map<std::string, int> pidx;
-    long long nparams = 0;
-    PackList pk, gk;
     ConvL conv[4], convT[4];
     LinL fc[3], up;
     BnL bn[6];
     // text packs
     struct GruIdx { int wih, whh, wihT, whhT, g_wih, g_whh; long long bih, bhh; } te_f, te_r, td0, td1;
     int te_h2p, te_h2pT, g_te_h2p, td_z2h, td_z2hT, g_td_z2h, td_h2o, td_h2oT, g_td_h2o;
-    MMBuffers buf;
-    bool bound = false;
-    // side streams: independent branches of the step (text path, weight gradients) run beside the main chain;
-    // forks/joins are event edges, so a captured HIP graph gets parallel branches and nothing syncs the host
-    hipStream_t st_text = nullptr, st_wgrad = nullptr;
-    std::vector<hipEvent_t> events;
-    size_t next_event = 0;
-    bool wgrad_forked = false;
     // ---- workspace pointers
     struct W {
         char* zero_begin; size_t zero_bytes;
         float2 *st_e[3], *red_e[3], *st_d[3], *red_d[3];
         float* sums; float* dz_img; float* dz_txt;
-        float* sk_buf; unsigned* sk_cnt; size_t sk_floats;
         float2 *aff_e[3], *mr_e[3], *aff_d[3], *mr_d[3];
         bf16 *patches1, *r1, *r2, *r3, *r4, *y1, *y2;
         bf16 *a1, *a2, *a3, *a4, *ay1, *ay2, *au, *aq1, *aq2, *aq3;
@@ -73,28 +42,6 @@ struct MMPlan {
 };
 
 namespace {
-
-int edge(MMPlan& P, hipStream_t from, hipStream_t to);
-
-// weight gradients only feed the optimizer: when the step runs multi-stream they go to the side stream
-int wgrad_async(MMPlan& P, const WgradParams& g, hipStream_t s) {
-    static const bool serial = getenv("MMVAE_SERIAL") != nullptr;
-    if (!P.wgrad_forked || serial) return launch_wgrad(g, s);
-    MMVAE_TRY(edge(P, s, P.st_wgrad));
-    return launch_wgrad(g, P.st_wgrad);
-}
-
-void add_param(MMPlan& P, const std::string& name, std::initializer_list<int> shape) {
-    ParamInfo pi{};
-    pi.name = name; pi.ndim = (int)shape.size(); pi.numel = 1;
-    int i = 0;
-    for (int s : shape) { pi.shape[i++] = s; pi.numel *= s; }
-    pi.offset = P.nparams;
-    P.nparams += pi.numel;
-    P.pidx[name] = (int)P.params.size();
-    P.params.push_back(pi);
-}
-long long off(const MMPlan& P, const std::string& n) { return P.params[P.pidx.at(n)].offset; }
 
 void build_params(MMPlan& P) {
     const int D = P.D;
@@ -122,76 +69,6 @@ void build_params(MMPlan& P) {
     add_param(P, "text_decoder.z2h.weight", {100, D}); add_param(P, "text_decoder.z2h.bias", {100});
     gru("text_decoder.gru", 100 + D, "l0"); gru("text_decoder.gru", 100, "l1");
     add_param(P, "text_decoder.h2o.weight", {12, 100 + D}); add_param(P, "text_decoder.h2o.bias", {12});
-}
-
-// ---- conv-like layer: builds both gather plans and the pack descriptors
-void build_conv(MMPlan& P, ConvL& L, const std::string& wname, ConvGeom g, int bn_idx, bool need_dgrad, bool thin_in, bool thin_out) {
-    L.g = g; L.w_off = off(P, wname); L.bn = bn_idx;
-    const int kk = g.KH * g.KW;
-    for (int i = 0; i < 4; ++i) { L.pk_fwd[i] = L.pk_dgrad[i] = L.gk[i] = -1; }
-    if (!g.transposed) {
-        // Conv2d weight (Cout, Cin, KH, KW)
-        if (thin_in) {      // dense over im2col patches: K = kk*Cin
-            const int K = kk * g.Cin, ld = round_up(K, 8);
-            L.fwd = plan_dense(1, ld, ld, g.Cout);
-            PackDesc d = pack_dense(L.w_off, g.Cout, K, npad_for(g.Cout), L.fwd.cls[0].Kpad, g.Cin * kk, 1);
-            // patches order k = (kh*KW+kw)*Cin + ci ; weight order ci*kk + kh*KW + kw
-            d.TW = g.KW; d.C = g.Cin; d.s_ty = g.KW; d.s_tx = 1; d.s_c = kk;
-            L.pk_fwd[0] = P.pk.add(d);
-            PackDesc gd = d; gd.Npad = round_up(g.Cout, 64);
-            L.gk[0] = P.gk.add(gd);
-        } else {
-            L.fwd = plan_fwdform(g.IH, g.IW, g.OH, g.OW, g.Cin, g.KH, g.KW, g.stride, g.pad, g.Cout, 1, 1);
-            PackDesc d = pack_conv(L.w_off, L.fwd.c, L.fwd.cls[0], npad_for(g.Cout), g.Cin * kk, kk, g.KW, 0, 0, 1);
-            L.pk_fwd[0] = P.pk.add(d);
-            PackDesc gd = d; gd.Npad = round_up(g.Cout, 64);
-            L.gk[0] = P.gk.add(gd);
-        }
-        if (need_dgrad) {   // rows over the input (big) side, gathers dr (small side, Cout channels)
-            L.dgrad = plan_classform(g.IH, g.IW, g.OH, g.OW, g.Cout, g.KH, g.KW, g.stride, g.pad, g.Cin, 1, 1);
-            for (int ci = 0; ci < L.dgrad.c.nclasses; ++ci) {
-                const int ph = ci / g.stride, pw = ci % g.stride;
-                PackDesc d = pack_conv(L.w_off, L.dgrad.c, L.dgrad.cls[ci], npad_for(g.Cin), kk, g.Cin * kk, g.KW,
-                                       (ph + g.pad) % g.stride, (pw + g.pad) % g.stride, g.stride);
-                L.pk_dgrad[ci] = P.pk.add(d);
-            }
-        }
-    } else {
-        // ConvTranspose2d weight (Cin, Cout, KH, KW); forward rows over the output (big) side
-        if (!thin_out) {
-            L.fwd = plan_classform(g.OH, g.OW, g.IH, g.IW, g.Cin, g.KH, g.KW, g.stride, g.pad, g.Cout, 1, 1);
-            for (int ci = 0; ci < L.fwd.c.nclasses; ++ci) {
-                const int ph = ci / g.stride, pw = ci % g.stride;
-                PackDesc d = pack_conv(L.w_off, L.fwd.c, L.fwd.cls[ci], npad_for(g.Cout), kk, g.Cout * kk, g.KW,
-                                       (ph + g.pad) % g.stride, (pw + g.pad) % g.stride, g.stride);
-                L.pk_fwd[ci] = P.pk.add(d);
-                PackDesc gd = d; gd.Npad = round_up(g.Cout, 64);
-                L.gk[ci] = P.gk.add(gd);
-            }
-            if (need_dgrad) {
-                L.dgrad = plan_fwdform(g.OH, g.OW, g.IH, g.IW, g.Cout, g.KH, g.KW, g.stride, g.pad, g.Cin, 1, 1);
-                PackDesc d = pack_conv(L.w_off, L.dgrad.c, L.dgrad.cls[0], npad_for(g.Cin), g.Cout * kk, kk, g.KW, 0, 0, 1);
-                L.pk_dgrad[0] = P.pk.add(d);
-            }
-        } else {
-            // thin output (Cout small): forward still class-form (N = Cout padded to 16); backward goes through
-            // im2col patches of dlogit: dgrad = dense [rows][kk*Cout] x W_D[Cin][kk*Cout], wgrad in the same layout
-            L.fwd = plan_classform(g.OH, g.OW, g.IH, g.IW, g.Cin, g.KH, g.KW, g.stride, g.pad, g.Cout, 1, 1);
-            for (int ci = 0; ci < L.fwd.c.nclasses; ++ci) {
-                const int ph = ci / g.stride, pw = ci % g.stride;
-                PackDesc d = pack_conv(L.w_off, L.fwd.c, L.fwd.cls[ci], npad_for(g.Cout), kk, g.Cout * kk, g.KW,
-                                       (ph + g.pad) % g.stride, (pw + g.pad) % g.stride, g.stride);
-                L.pk_fwd[ci] = P.pk.add(d);
-            }
-            const int K = kk * g.Cout, ld = round_up(K, 8);
-            L.dgrad = plan_dense(1, ld, ld, g.Cin);
-            PackDesc d = pack_dense(L.w_off, g.Cin, K, npad_for(g.Cin), L.dgrad.cls[0].Kpad, g.Cout * kk, 1);
-            d.TW = g.KW; d.C = g.Cout; d.s_ty = g.KW; d.s_tx = 1; d.s_c = kk;   // k = (kh*KW+kw)*Cout + co
-            L.pk_dgrad[0] = P.pk.add(d);
-            PackDesc gd = d; gd.Npad = round_up(g.Cin, 64);
-            L.gk[0] = P.gk.add(gd);
-        }
-    }
 }
 
 void build_plan(MMPlan& P) {
@@ -301,7 +178,7 @@ void carve(MMPlan& P, Workspace& ws) {
     for (int i = 0; i < 3; ++i) { w.st_e[i] = ws.take<float2>(SS * ec[i]); w.red_e[i] = ws.take<float2>(SS * ec[i]); }
     for (int i = 0; i < 3; ++i) { w.st_d[i] = ws.take<float2>(3 * SS * dc[i]); w.red_d[i] = ws.take<float2>(3 * SS * dc[i]); }
     w.sums = ws.take<float>(16 * MMVAE_LOSS_SLOTS);
-    w.sk_cnt = ws.take<unsigned>(1024);
+    P.sk_cnt = ws.take<unsigned>(1024);
     w.dz_img = ws.take<float>(B3 * D);
     w.dz_txt = ws.take<float>(B3 * D);
     char* z1 = ws.take<char>(0);
@@ -344,64 +221,8 @@ void carve(MMPlan& P, Workspace& ws) {
     w.db4 = ws.take<bf16>(B2 * 1024); w.dr4 = ws.take<bf16>(B * 1024);
     w.d3e = ws.take<bf16>(B * 36 * 128); w.d2e = ws.take<bf16>(B * 144 * 64); w.d1e = ws.take<bf16>(B * 625 * 32);
     w.tmp_f32 = ws.take<float>(B3 * NPIX);
-    w.sk_floats = (size_t)256 * 128 * 128;                 // split-K partial slabs (fully overwritten, never zeroed)
-    w.sk_buf = ws.take<float>(w.sk_floats);
-}
-
-// ------------------------------------------------------------------ launch helpers
-GemmParams gemm_of(const MMPlan& P, const GatherPlan& pl, const int* pk, int groups, int group_n) {
-    GemmParams g{};
-    g.c = pl.c; g.c.groups = groups; g.c.group_n = group_n;
-    int max_tiles = 0, min_nk = 1 << 30;
-    for (int i = 0; i < pl.c.nclasses; ++i) {
-        g.cls[i] = pl.cls[i];
-        g.cls[i].rows_per_group = group_n * pl.cls[i].OY * pl.cls[i].OX;
-        g.cls[i].Wp = P.buf.packed + P.pk.d[pk[i]].dst_off;
-        max_tiles = max(max_tiles, ceil_div(g.cls[i].rows_per_group, 128));
-        min_nk = min(min_nk, ceil_div(g.cls[i].K, 64));
-    }
-    // few workgroups and a long K loop: split K so the chip is not idle behind a serial chain of tile latencies
-    const int bn = pl.c.N <= 16 ? 16 : pl.c.N <= 32 ? 32 : pl.c.N <= 64 ? 64 : 128;
-    const int tiles = max_tiles * groups * pl.c.nclasses * ceil_div(pl.c.N, bn);
-    g.ksplit = 1;
-    // (partial tiles go to per-split slabs with plain stores; a finish kernel sums them and runs the epilogue --
-    //  float-atomic accumulation of the partial tiles measured slower than the latency chain it removed)
-    if (tiles <= 128 && min_nk >= 6) {
-        int ks = min(min(8, min_nk / 3), max(1, 256 / tiles));
-        if (ks > 1 && (size_t)tiles * 128 * bn <= P.w.sk_floats) { g.ksplit = ks; g.sk_buf = P.w.sk_buf; g.sk_cnt = P.w.sk_cnt; }
-    }
-    return g;
-}
-WgradParams wgrad_of(const MMPlan& P, const GatherPlan& pl, const int* gk, int groups, int group_n) {
-    WgradParams g{};
-    g.c = pl.c; g.c.groups = groups; g.c.group_n = group_n;
-    int max_rows = 0, max_kpad = 0;
-    for (int i = 0; i < pl.c.nclasses; ++i) {
-        g.cls[i] = pl.cls[i];
-        g.cls[i].rows_per_group = group_n * pl.cls[i].OY * pl.cls[i].OX;
-        g.cls[i].dWp = P.buf.gpk + P.gk.d[gk[i]].dst_off;
-        g.cls[i].Kpad = P.gk.d[gk[i]].Kpad;
-        max_rows = max(max_rows, groups * g.cls[i].rows_per_group);
-        max_kpad = max(max_kpad, g.cls[i].Kpad);
-    }
-    const int tiles = ceil_div(pl.c.N, 64) * (max_kpad / 64) * pl.c.nclasses;
-    int chunks = max(1, min(ceil_div(max_rows, 64), 768 / max(tiles, 1)));
-    g.rows_per_block = round_up(ceil_div(max_rows, chunks), 64);
-    return g;
-}
-GatherPlan dense_plan(int rows, int C, int ld, int N) { return plan_dense(rows, C, ld, N); }
-
-int bn_act(MMPlan& P, const BnL& b, const bf16* r, bf16* a, int rows, int rows_per_group, int G, const float2* stats,
-           int updates, float2* aff, float2* mr, int training, hipStream_t s) {
-    BnActArgs x{};
-    x.r = r; x.a = a; x.rows = rows; x.C = b.C; x.ld = b.C; x.rows_per_group = rows_per_group; x.G = G; x.act = ACT_SWISH;
-    BnFinalizeArgs& f = x.fin;
-    f.stats = stats; f.G = G; f.C = b.C; f.count = (float)rows_per_group;
-    f.gamma = P.buf.params + b.w_off; f.beta = P.buf.params + b.b_off;
-    f.running_mean = P.buf.bn_stats + b.stat_off; f.running_var = P.buf.bn_stats + b.stat_off + b.C;
-    f.num_batches_tracked = P.buf.bn_nbt + b.idx;
-    f.updates_per_group = updates; f.affine = aff; f.meanrstd = mr; f.eps = BN_EPS; f.momentum = BN_MOM; f.training = training;
-    return launch_bn_act(x, s);
+    P.sk_floats = (size_t)256 * 128 * 128;                 // split-K partial slabs (fully overwritten, never zeroed)
+    P.sk_buf = ws.take<float>(P.sk_floats);
 }
 
 // ================================================================== image encoder
@@ -721,78 +542,6 @@ int txt_dec_bwd(MMPlan& P, const TextDecArgs& f, const float* dwords, float* dz,
     MMVAE_TRY(wg(P.td1.g_whh, w.dgh1, 300, 304, w.td_h1p, TXT_HP, 4 * R));
     MMVAE_TRY(wg(P.g_td_h2o, w.dlogit_bf, 12, 16, w.td_hz, P.kx, 4 * R));
     MMVAE_TRY(wg(P.g_td_z2h, w.dhinit, 100, 112, w.td_zbf, P.kz, R));
-    return MMVAE_OK;
-}
-
-// out[16] = sum over the MMVAE_LOSS_SLOTS replicated rows of the loss accumulators
-__global__ void sum_slots_kernel(const float* slots, float* out) {
-    const int j = threadIdx.x;
-    if (j >= 16) return;
-    float s = 0.f;
-    for (int q = 0; q < MMVAE_LOSS_SLOTS; ++q) s += slots[q * 16 + j];
-    out[j] = s;
-}
-__global__ void cast_z_kernel(const float* z, int rows, int D, bf16* out, int ldz) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * ldz) return;
-    int r = i / ldz, d = i - r * ldz;
-    float v = d < D ? z[(size_t)r * D + d] : (d == D ? 1.0f : 0.0f);
-    out[i] = (bf16)v;
-}
-__global__ void cast_bf_kernel(const float* x, long long n, bf16* out) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (bf16)x[i];
-}
-__global__ void colsum_kernel(const float* x, int rows, int cols, float* out) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
-    float s = 0.f;
-    for (int r = 0; r < rows; ++r) s += x[(size_t)r * cols + c];
-    out[c] += s;
-}
-// dlogit = d_recon * p * (1 - p)   (sigmoid backward for the drop-in decoder module)
-__global__ void sigmoid_bwd_kernel(const float* d_recon, const float* recon, long long n, float* dlogit) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { float p = recon[i]; dlogit[i] = d_recon[i] * p * (1.0f - p); }
-}
-__global__ void sigmoid_kernel(const float* logits, long long n, float* out) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = 1.0f / (1.0f + expf(-logits[i]));
-}
-
-hipEvent_t next_ev(MMPlan& P) {
-    if (P.next_event == P.events.size()) {
-        hipEvent_t e;
-        hipEventCreateWithFlags(&e, hipEventDisableTiming);
-        P.events.push_back(e);
-    }
-    return P.events[P.next_event++];
-}
-// `to` waits for everything enqueued on `from` so far
-int edge(MMPlan& P, hipStream_t from, hipStream_t to) {
-    hipEvent_t e = next_ev(P);
-    if (hipEventRecord(e, from) != hipSuccess || hipStreamWaitEvent(to, e, 0) != hipSuccess) {
-        mmvae_set_error("stream fork/join failed: %s", hipGetErrorString(hipGetLastError()));
-        return MMVAE_EHIP;
-    }
-    return MMVAE_OK;
-}
-int ensure_streams(MMPlan& P) {
-    if (!P.st_text) {
-        if (hipStreamCreateWithFlags(&P.st_text, hipStreamNonBlocking) != hipSuccess ||
-            hipStreamCreateWithFlags(&P.st_wgrad, hipStreamNonBlocking) != hipSuccess) {
-            mmvae_set_error("hipStreamCreate failed");
-            return MMVAE_EHIP;
-        }
-    }
-    static const bool one_side = getenv("MMVAE_ONE_SIDE") != nullptr;   // experiment: text path and wgrads share a stream
-    if (one_side) P.st_wgrad = P.st_text;
-    P.next_event = 0;
-    return MMVAE_OK;
-}
-
-int check_bound(const MMPlan* P) {
-    MMVAE_REQUIRE(P && P->bound, "plan has no buffers bound (mmvae_mm_bind)");
     return MMVAE_OK;
 }
 
