@@ -100,6 +100,63 @@ double mmvae_mm_layer_flops(const mmvae_mm_t*, const char* layer);
 /* test aid: byte offset of a named intermediate inside the workspace (-1 if unknown) */
 long long mmvae_mm_debug_offset(mmvae_mm_t*, const char* name);
 
+/* ---------------------------------------------------------------- MNIST (mnist/model.py, mnist/train.py)
+ * MultimodalVAE of mnist/model.py:14-50: Linear -> BatchNorm1d -> ReLU stacks (ImageEncoder :99-118, ImageDecoder
+ * :121-133, TextEncoder :136-153, TextDecoder :156-170), ProductOfExperts :173-185, loss_function mnist/train.py:64-81.
+ * The plan/query/bind/pack functions have the same meaning as their mmvae_mm_* counterparts above. */
+typedef struct MnistPlan mmvae_mnist_t;
+mmvae_mnist_t* mmvae_mnist_create(int n_latents, int batch);      /* MultimodalVAE(n_latents) mnist/model.py:14-20 */
+void mmvae_mnist_destroy(mmvae_mnist_t*);
+long long mmvae_mnist_param_count(const mmvae_mnist_t*);
+int mmvae_mnist_num_params(const mmvae_mnist_t*);
+int mmvae_mnist_param_info(const mmvae_mnist_t*, int i, char* name128, int* ndim, int* shape4, long long* offset);
+long long mmvae_mnist_bn_floats(const mmvae_mnist_t*);
+int mmvae_mnist_num_bn(const mmvae_mnist_t*);
+int mmvae_mnist_bn_info(const mmvae_mnist_t*, int i, char* prefix128, int* channels, long long* offset);
+long long mmvae_mnist_packed_elems(const mmvae_mnist_t*);
+long long mmvae_mnist_packed_vec_elems(const mmvae_mnist_t*);
+long long mmvae_mnist_gpk_elems(const mmvae_mnist_t*);
+long long mmvae_mnist_gpk_vec_elems(const mmvae_mnist_t*);
+size_t mmvae_mnist_desc_bytes(const mmvae_mnist_t*, int which);
+int mmvae_mnist_desc_copy(const mmvae_mnist_t*, int which, void* host_out);
+size_t mmvae_mnist_workspace_bytes(const mmvae_mnist_t*);
+int mmvae_mnist_bind(mmvae_mnist_t*, float* params, float* grads, float* bn_stats, long long* num_batches_tracked,
+                     void* packed_bf16, float* packed_vec, float* gpk, float* gpk_vec, void* desc_dev, void* gdesc_dev);
+int mmvae_mnist_pack_weights(mmvae_mnist_t*, void* stream);
+/* The train() closure body of mnist/train.py:131-147 (3 passes, 3 losses, backward): same contract as mmvae_mm_step */
+typedef struct {
+    void* ws; size_t ws_bytes;
+    const long long* step_counter;          /* device int64 keying the Philox eps stream, or NULL */
+    const float* image;                     /* [B][1][28][28] fp32 */
+    const long long* label;                 /* [B] int64 */
+    const float* eps;                       /* [3][B][D] or NULL (drawn on device) */
+    float lambda_xy[3]; float lambda_yx[3]; /* mnist/train.py:137-146: all 1 */
+    float kl_coef;                          /* 1 / (B * 784/3)  (mnist/train.py:78-79) */
+    unsigned long long seed;
+    float* sums;                            /* out [16]: bce_sum[0..2], nll_sum[4..6], kl_sum[8..10] */
+    float* recon_image;                     /* out [3][B][784] or NULL */
+    float* recon_text;                      /* out [3][B][10] log-probs or NULL */
+    float* mu; float* logvar;               /* out [3][B][D] or NULL */
+} mmvae_mnist_step_io;
+int mmvae_mnist_step(mmvae_mnist_t*, const mmvae_mnist_step_io*, int training, int do_backward, void* stream);
+/* Granular modules of mnist/model.py (forward + autograd backward); workspace rules as for mmvae_mm_*_fwd/bwd.
+ * Parameter gradients accumulate into the bound `grads`. */
+int mmvae_mnist_image_encoder_fwd(mmvae_mnist_t*, void* ws, size_t ws_bytes, const float* image, int training,
+                                  float* out_mu_logvar, void* stream);                          /* mnist/model.py:114-118 */
+int mmvae_mnist_image_encoder_bwd(mmvae_mnist_t*, void* ws, size_t ws_bytes, const float* d_out, void* stream);
+int mmvae_mnist_image_decoder_fwd(mmvae_mnist_t*, void* ws, size_t ws_bytes, const float* z, int training, float* recon,
+                                  void* stream);                                                /* mnist/model.py:131-133 */
+int mmvae_mnist_image_decoder_bwd(mmvae_mnist_t*, void* ws, size_t ws_bytes, const float* d_recon, const float* recon,
+                                  float* dz, void* stream);
+int mmvae_mnist_text_encoder_fwd(mmvae_mnist_t*, void* ws, size_t ws_bytes, const long long* label, int training,
+                                 float* out_mu_logvar, void* stream);                           /* mnist/model.py:149-153 */
+int mmvae_mnist_text_encoder_bwd(mmvae_mnist_t*, void* ws, size_t ws_bytes, const long long* label, const float* d_out,
+                                 void* stream);
+int mmvae_mnist_text_decoder_fwd(mmvae_mnist_t*, void* ws, size_t ws_bytes, const float* z, int training, float* log_probs,
+                                 void* stream);                                                 /* mnist/model.py:168-170 */
+int mmvae_mnist_text_decoder_bwd(mmvae_mnist_t*, void* ws, size_t ws_bytes, const float* d_log_probs, const float* log_probs,
+                                 float* dz, void* stream);
+
 /* ---------------------------------------------------------------- dataset-independent ops */
 /* ProductOfExperts.forward (multimnist/model.py:355-360) over M stacked experts of n scalars each */
 int mmvae_poe_fwd(const float* mu, const float* logvar, int M, int n, float* out_mu, float* out_logvar, void* stream);

@@ -28,6 +28,20 @@ class StepIO(C.Structure):
     ]
 
 
+class MnistStepIO(C.Structure):
+    """mmvae_mnist_step_io"""
+    _fields_ = [
+        ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
+        ("step_counter", C.c_void_p),
+        ("image", C.c_void_p), ("label", C.c_void_p), ("eps", C.c_void_p),
+        ("lambda_xy", C.c_float * 3), ("lambda_yx", C.c_float * 3),
+        ("kl_coef", C.c_float),
+        ("seed", C.c_ulonglong),
+        ("sums", C.c_void_p), ("recon_image", C.c_void_p), ("recon_text", C.c_void_p),
+        ("mu", C.c_void_p), ("logvar", C.c_void_p),
+    ]
+
+
 _P, _I, _F, _LL, _SZ, _ULL, _U = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_size_t, C.c_ulonglong, C.c_uint
 
 # name -> (restype, argtypes); restype int means "status code, raise on != 0"
@@ -78,7 +92,40 @@ SIGNATURES = {
     "mmvae_keep_mask": (_I, [_P, _LL, _F, _ULL, _P, _U, _P]),
     "mmvae_adam_step": (_I, [_P, _P, _P, _P, _LL, _P, _F, _F, _F, _F, _F, _P]),
 }
-_STATUS = {n for n, (r, _) in SIGNATURES.items() if r is _I and n not in ("mmvae_mm_num_params", "mmvae_mm_num_bn")}
+
+
+def _plan_api(pfx):
+    """The plan/query/bind/pack entry points every model family exports under its own prefix."""
+    return {
+        "mmvae_%s_create" % pfx: (_P, [_I, _I]),
+        "mmvae_%s_destroy" % pfx: (None, [_P]),
+        "mmvae_%s_param_count" % pfx: (_LL, [_P]),
+        "mmvae_%s_num_params" % pfx: (_I, [_P]),
+        "mmvae_%s_param_info" % pfx: (_I, [_P, _I, C.c_char_p, C.POINTER(_I), C.POINTER(_I), C.POINTER(_LL)]),
+        "mmvae_%s_bn_floats" % pfx: (_LL, [_P]),
+        "mmvae_%s_num_bn" % pfx: (_I, [_P]),
+        "mmvae_%s_bn_info" % pfx: (_I, [_P, _I, C.c_char_p, C.POINTER(_I), C.POINTER(_LL)]),
+        "mmvae_%s_packed_elems" % pfx: (_LL, [_P]),
+        "mmvae_%s_packed_vec_elems" % pfx: (_LL, [_P]),
+        "mmvae_%s_gpk_elems" % pfx: (_LL, [_P]),
+        "mmvae_%s_gpk_vec_elems" % pfx: (_LL, [_P]),
+        "mmvae_%s_desc_bytes" % pfx: (_SZ, [_P, _I]),
+        "mmvae_%s_desc_copy" % pfx: (_I, [_P, _I, _P]),
+        "mmvae_%s_workspace_bytes" % pfx: (_SZ, [_P]),
+        "mmvae_%s_bind" % pfx: (_I, [_P] * 11),
+        "mmvae_%s_pack_weights" % pfx: (_I, [_P, _P]),
+    }
+
+
+SIGNATURES.update(_plan_api("mnist"))
+SIGNATURES["mmvae_mnist_step"] = (_I, [_P, C.POINTER(MnistStepIO), _I, _I, _P])
+for _m in ("image_encoder", "image_decoder", "text_encoder", "text_decoder"):
+    SIGNATURES["mmvae_mnist_%s_fwd" % _m] = (_I, [_P, _P, _SZ, _P, _I, _P, _P])
+SIGNATURES["mmvae_mnist_image_encoder_bwd"] = (_I, [_P, _P, _SZ, _P, _P])
+SIGNATURES["mmvae_mnist_image_decoder_bwd"] = (_I, [_P, _P, _SZ, _P, _P, _P, _P])
+SIGNATURES["mmvae_mnist_text_encoder_bwd"] = (_I, [_P, _P, _SZ, _P, _P, _P])
+SIGNATURES["mmvae_mnist_text_decoder_bwd"] = (_I, [_P, _P, _SZ, _P, _P, _P, _P])
+_STATUS = {n for n, (r, _) in SIGNATURES.items() if r is _I and not n.endswith(("_num_params", "_num_bn"))}
 
 _lib = None
 _inited = set()

@@ -18,11 +18,17 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-class MultimnistState:
+class PlanState:
     """Flat parameter / gradient / BatchNorm-buffer storage plus the packed bf16 GEMM copies of the weights.
 
-    The nn.Module face (``multimnist.MultimodalVAE``) exposes views of ``params`` as its nn.Parameters, so
-    ``optim.Adam(vae.parameters())``, ``state_dict()`` and the fused engine all see the same memory."""
+    The nn.Module face (``multimnist.MultimodalVAE`` ...) exposes views of ``params`` as its nn.Parameters, so
+    ``optim.Adam(vae.parameters())``, ``state_dict()`` and the fused engine all see the same memory.
+    ``API`` is the C-ABI prefix of the model family (mmvae_<API>_create ...)."""
+
+    API = "mm"
+
+    def _c(self, fn, *args):
+        return call("mmvae_%s_%s" % (self.API, fn), *args)
 
     def __init__(self, n_latents: int, device: torch.device):
         if device.type != "cuda":
@@ -32,35 +38,35 @@ class MultimnistState:
         self.n_latents = int(n_latents)
         self._plans: Dict[int, int] = {}
         h = self._handle(1, bind=False)
-        self.nparams = call("mmvae_mm_param_count", h)
+        self.nparams = self._c("param_count", h)
         self.table: List[Tuple[str, Tuple[int, ...], int]] = []
         name = C.create_string_buffer(128)
         nd, off = C.c_int(), C.c_longlong()
         shape = (C.c_int * 4)()
-        for i in range(call("mmvae_mm_num_params", h)):
-            call("mmvae_mm_param_info", h, i, name, C.byref(nd), shape, C.byref(off))
+        for i in range(self._c("num_params", h)):
+            self._c("param_info", h, i, name, C.byref(nd), shape, C.byref(off))
             self.table.append((name.value.decode(), tuple(shape[k] for k in range(nd.value)), off.value))
         self.bn_table: List[Tuple[str, int, int]] = []
         ch = C.c_int()
-        for i in range(call("mmvae_mm_num_bn", h)):
-            call("mmvae_mm_bn_info", h, i, name, C.byref(ch), C.byref(off))
+        for i in range(self._c("num_bn", h)):
+            self._c("bn_info", h, i, name, C.byref(ch), C.byref(off))
             self.bn_table.append((name.value.decode(), ch.value, off.value))
         f32 = dict(dtype=torch.float32, device=device)
         self.params = torch.zeros(self.nparams, **f32)
         self.grads = torch.zeros(self.nparams, **f32)
-        self.bn_stats = torch.zeros(call("mmvae_mm_bn_floats", h), **f32)
+        self.bn_stats = torch.zeros(self._c("bn_floats", h), **f32)
         for _, c, o in self.bn_table:
             self.bn_stats[o + c:o + 2 * c] = 1.0                       # running_var = 1
         self.bn_nbt = torch.zeros(len(self.bn_table), dtype=torch.int64, device=device)
-        self.packed = torch.zeros(call("mmvae_mm_packed_elems", h), dtype=torch.bfloat16, device=device)
-        self.packed_vec = torch.zeros(call("mmvae_mm_packed_vec_elems", h), **f32)
-        self.gpk = torch.zeros(call("mmvae_mm_gpk_elems", h), **f32)
-        self.gpk_vec = torch.zeros(call("mmvae_mm_gpk_vec_elems", h), **f32)
+        self.packed = torch.zeros(self._c("packed_elems", h), dtype=torch.bfloat16, device=device)
+        self.packed_vec = torch.zeros(self._c("packed_vec_elems", h), **f32)
+        self.gpk = torch.zeros(self._c("gpk_elems", h), **f32)
+        self.gpk_vec = torch.zeros(self._c("gpk_vec_elems", h), **f32)
         self._desc = []
         for which in (0, 1):
-            nbytes = call("mmvae_mm_desc_bytes", h, which)
+            nbytes = self._c("desc_bytes", h, which)
             host = torch.empty(nbytes, dtype=torch.uint8)
-            call("mmvae_mm_desc_copy", h, which, C.c_void_p(host.data_ptr()))
+            self._c("desc_copy", h, which, C.c_void_p(host.data_ptr()))
             self._desc.append(host.to(device))
         self._bind(h)
         self.packed_version = -1          # bumped by whoever changes params
@@ -69,16 +75,16 @@ class MultimnistState:
     def _handle(self, batch: int, bind: bool = True) -> int:
         h = self._plans.get(batch)
         if h is None:
-            h = call("mmvae_mm_create", self.n_latents, int(batch))
+            h = self._c("create", self.n_latents, int(batch))
             if not h:
-                raise MMVAEError("mmvae_mm_create failed: %s" % _lib.load().mmvae_last_error().decode())
+                raise MMVAEError("mmvae_%s_create failed: %s" % (self.API, _lib.load().mmvae_last_error().decode()))
             self._plans[batch] = h
             if bind:
                 self._bind(h)
         return h
 
     def _bind(self, h: int) -> None:
-        call("mmvae_mm_bind", h, ptr(self.params), ptr(self.grads), ptr(self.bn_stats), ptr(self.bn_nbt),
+        self._c("bind", h, ptr(self.params), ptr(self.grads), ptr(self.bn_stats), ptr(self.bn_nbt),
              ptr(self.packed), ptr(self.packed_vec), ptr(self.gpk), ptr(self.gpk_vec), ptr(self._desc[0]), ptr(self._desc[1]))
 
     def rebind(self) -> None:
@@ -90,10 +96,10 @@ class MultimnistState:
         return self._handle(int(batch))
 
     def workspace_bytes(self, batch: int) -> int:
-        return call("mmvae_mm_workspace_bytes", self.plan(batch))
+        return self._c("workspace_bytes", self.plan(batch))
 
     def pack_weights(self) -> None:
-        call("mmvae_mm_pack_weights", self.plan(1), _stream())
+        self._c("pack_weights", self.plan(1), _stream())
 
     def view(self, name: str) -> torch.Tensor:
         for n, shape, off in self.table:
@@ -107,40 +113,48 @@ class MultimnistState:
     def __del__(self):
         try:
             for h in self._plans.values():
-                call("mmvae_mm_destroy", h)
+                self._c("destroy", h)
         except Exception:
             pass
+
+
+class MultimnistState(PlanState):
+    """multimnist/model.py MultimodalVAE"""
+    API = "mm"
+
+
+class MnistState(PlanState):
+    """mnist/model.py MultimodalVAE"""
+    API = "mnist"
 
 
 class StepOutputs:
     """Lazy view of the loss sums of one fused step (no host sync until a value is read)."""
 
-    def __init__(self, sums: torch.Tensor, batch: int, kl_lambda: float, lambda_xy, lambda_yx):
-        self.sums, self.B, self.kl_lambda, self.lxy, self.lyx = sums, batch, kl_lambda, lambda_xy, lambda_yx
+    def __init__(self, sums: torch.Tensor, bce_div: float, nll_div: float, kl_scale: float, lambda_xy, lambda_yx):
+        self.sums, self.bce_div, self.nll_div, self.kl_scale = sums, bce_div, nll_div, kl_scale
+        self.lxy, self.lyx = lambda_xy, lambda_yx
 
     def losses(self) -> torch.Tensor:
-        """loss_1, loss_2, loss_3 of multimnist/train.py:158-166 as a device tensor [3]."""
+        """loss_1, loss_2, loss_3 of the reference's train() closure as a device tensor [3]."""
         s = self.sums
         lxy = torch.tensor(self.lxy, device=s.device)
         lyx = torch.tensor(self.lyx, device=s.device)
-        return lxy * s[0:3] / (self.B * 2500) + lyx * s[4:7] / (self.B * 4) + s[8:11] / self.B * self.kl_lambda
+        return lxy * s[0:3] / self.bce_div + lyx * s[4:7] / self.nll_div + s[8:11] * self.kl_scale
 
     def parts(self):
+        """(mean BCE, mean NLL, KL sum) per pass"""
         s = self.sums
-        return s[0:3] / (self.B * 2500), s[4:7] / (self.B * 4), s[8:11]
+        return s[0:3] / self.bce_div, s[4:7] / self.nll_div, s[8:11]
 
 
-class FusedELBOStep:
-    """The 3-pass ELBO step of multimnist/train.py:146-173 as ONE enqueue of HIP kernels:
-    zero_grad -> (image,text) / (image) / (text) forward -> 3 losses -> backward -> [grad all-reduce] -> Adam."""
+class _FusedStepBase:
+    """zero_grad -> 3-pass forward -> 3 losses -> backward -> [grad all-reduce] -> Adam, as ONE enqueue of HIP kernels."""
 
-    LAMBDA_XY = (1.0, 1.0, 0.0)
-    LAMBDA_YX = (1.0, 0.5, 1.0)
-
-    def __init__(self, state: MultimnistState, batch: int, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 kl_lambda: float = 1e-3, seed: int = 1234, world_size: int = 1, all_reduce=None):
+    def __init__(self, state: PlanState, batch: int, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 seed: int = 1234, world_size: int = 1, all_reduce=None):
         self.state, self.B, self.D = state, int(batch), state.n_latents
-        self.lr, self.betas, self.eps, self.kl_lambda, self.seed = lr, betas, eps, kl_lambda, seed
+        self.lr, self.betas, self.eps, self.seed = lr, betas, eps, seed
         self.world_size, self.all_reduce = world_size, all_reduce
         dev = state.device
         self.h = state.plan(batch)
@@ -149,11 +163,62 @@ class FusedELBOStep:
         self.exp_avg_sq = torch.zeros_like(state.params)
         self.adam_state = torch.zeros(2, dtype=torch.int64, device=dev)      # {step, ticket}
         self.sums = torch.zeros(16, dtype=torch.float32, device=dev)
-        self.enc_dropout = self.gru_dropout = True
         self._graph = None
         state.pack_weights()
 
-    # -- pieces ---------------------------------------------------------------------------------------
+    def _outputs(self) -> StepOutputs:
+        raise NotImplementedError
+
+    def optimizer_step(self) -> None:
+        """torch.optim.Adam(lr) semantics on the flat buffers, then refresh the packed bf16 weights."""
+        st = self.state
+        if self.all_reduce is not None and self.world_size > 1:
+            self.all_reduce(st.grads)                                  # sum over ranks (RCCL), scaled inside Adam
+        call("mmvae_adam_step", ptr(st.params), ptr(st.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq), st.nparams,
+             ptr(self.adam_state), self.lr, self.betas[0], self.betas[1], self.eps, 1.0 / self.world_size, _stream())
+        st.pack_weights()
+
+    def __call__(self, a, b, **kw) -> StepOutputs:
+        out = self.forward_backward(a, b, True, True, **kw)
+        self.optimizer_step()
+        return out
+
+    # -- HIP graph ------------------------------------------------------------------------------------
+    def capture(self, a: torch.Tensor, b: torch.Tensor) -> None:
+        """Capture the whole step (static input buffers) into a HIP graph; ``replay()`` launches it."""
+        self._static = (a, b)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):          # warm-up: sets kernel attributes, primes the allocator
+                self(a, b)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self(a, b)
+        self._graph = g
+
+    def replay(self) -> StepOutputs:
+        self._graph.replay()
+        return self._outputs()
+
+
+class FusedELBOStep(_FusedStepBase):
+    """The 3-pass ELBO step of multimnist/train.py:146-173."""
+
+    LAMBDA_XY = (1.0, 1.0, 0.0)
+    LAMBDA_YX = (1.0, 0.5, 1.0)
+
+    def __init__(self, state: PlanState, batch: int, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 kl_lambda: float = 1e-3, seed: int = 1234, world_size: int = 1, all_reduce=None):
+        super().__init__(state, batch, lr, betas, eps, seed, world_size, all_reduce)
+        self.kl_lambda = kl_lambda
+        self.enc_dropout = self.gru_dropout = True
+
+    def _outputs(self) -> StepOutputs:
+        return StepOutputs(self.sums, self.B * 2500, self.B * 4, self.kl_lambda / self.B, self.LAMBDA_XY, self.LAMBDA_YX)
+
     def forward_backward(self, image, text, training=True, backward=True, eps=None, enc_mask1=None, enc_mask2=None,
                          gru_keep=None, force_tokens=None, recon_image=None, recon_text=None, mu=None, logvar=None,
                          tokens=None) -> StepOutputs:
@@ -175,38 +240,32 @@ class FusedELBOStep:
         io.sums = self.sums.data_ptr()
         # optimizer.zero_grad() (train.py:150) happens inside the step's prologue kernel when backward is requested
         call("mmvae_mm_step", self.h, C.byref(io), int(training), int(backward), _stream())
-        return StepOutputs(self.sums, self.B, self.kl_lambda, self.LAMBDA_XY, self.LAMBDA_YX)
+        return self._outputs()
 
-    def optimizer_step(self) -> None:
-        """torch.optim.Adam(lr) semantics on the flat buffers, then refresh the packed bf16 weights."""
-        st = self.state
-        if self.all_reduce is not None and self.world_size > 1:
-            self.all_reduce(st.grads)                                  # sum over ranks (RCCL), scaled inside Adam
-        call("mmvae_adam_step", ptr(st.params), ptr(st.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq), st.nparams,
-             ptr(self.adam_state), self.lr, self.betas[0], self.betas[1], self.eps, 1.0 / self.world_size, _stream())
-        st.pack_weights()
 
-    def __call__(self, image, text, **kw) -> StepOutputs:
-        out = self.forward_backward(image, text, True, True, **kw)
-        self.optimizer_step()
-        return out
+class FusedMnistStep(_FusedStepBase):
+    """The 3-pass step of mnist/train.py:131-147 (all lambdas 1, KL divided by B*784/3, no annealing)."""
 
-    # -- HIP graph ------------------------------------------------------------------------------------
-    def capture(self, image: torch.Tensor, text: torch.Tensor) -> None:
-        """Capture the whole step (static input buffers) into a HIP graph; ``replay()`` launches it."""
-        self._static_image, self._static_text = image, text
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for _ in range(2):          # warm-up: sets kernel attributes, primes the allocator
-                self(image, text)
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self(image, text)
-        self._graph = g
+    LAMBDA_XY = (1.0, 1.0, 1.0)
+    LAMBDA_YX = (1.0, 1.0, 1.0)
 
-    def replay(self) -> StepOutputs:
-        self._graph.replay()
-        return StepOutputs(self.sums, self.B, self.kl_lambda, self.LAMBDA_XY, self.LAMBDA_YX)
+    def _outputs(self) -> StepOutputs:
+        return StepOutputs(self.sums, self.B * 784, self.B, 1.0 / (self.B * (784 / 3)), self.LAMBDA_XY, self.LAMBDA_YX)
+
+    def forward_backward(self, image, label, training=True, backward=True, eps=None, recon_image=None, recon_text=None,
+                         mu=None, logvar=None) -> StepOutputs:
+        assert image.is_contiguous() and label.is_contiguous() and image.dtype == torch.float32 and label.dtype == torch.int64
+        assert image.numel() == self.B * 784 and label.shape == (self.B,)
+        io = _lib.MnistStepIO()
+        io.ws, io.ws_bytes = self.ws.data_ptr(), self.ws.numel()
+        io.step_counter = self.adam_state.data_ptr()
+        io.image, io.label = image.data_ptr(), label.data_ptr()
+        for k, t in (("eps", eps), ("recon_image", recon_image), ("recon_text", recon_text), ("mu", mu), ("logvar", logvar)):
+            setattr(io, k, None if t is None else t.data_ptr())
+        io.lambda_xy = (C.c_float * 3)(*self.LAMBDA_XY)
+        io.lambda_yx = (C.c_float * 3)(*self.LAMBDA_YX)
+        io.kl_coef = 1.0 / (self.B * (784 / 3))
+        io.seed = self.seed
+        io.sums = self.sums.data_ptr()
+        call("mmvae_mnist_step", self.h, C.byref(io), int(training), int(backward), _stream())
+        return self._outputs()

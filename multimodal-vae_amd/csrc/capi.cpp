@@ -1,6 +1,7 @@
 // extern "C" boundary of libmmvae_hip.so (see include/mmvae_hip.h).
 #include "../../include/mmvae_hip.h"
 #include "multimnist.h"
+#include "mnist.h"
 #include "plan_base.h"
 #include <cstring>
 #include <exception>
@@ -18,6 +19,74 @@ const char* mmvae_error_string();
     }
 
 static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+
+// ---- generic plan queries / bind / pack for the models built on PlanBase alone (mnist, celeba)
+static long long pb_bn_floats(const PlanBase* b) { return b->bn_list.empty() ? 0 : b->bn_list.back().stat_off + 2 * b->bn_list.back().C; }
+static int pb_param_info(const PlanBase* b, int i, char* name, int* ndim, int* shape, long long* offset) {
+    const auto& v = b->params;
+    MMVAE_REQUIRE(i >= 0 && i < (int)v.size(), "param index %d out of range", i);
+    strncpy(name, v[i].name.c_str(), 127); name[127] = 0;
+    *ndim = v[i].ndim;
+    for (int k = 0; k < 4; ++k) shape[k] = k < v[i].ndim ? v[i].shape[k] : 1;
+    *offset = v[i].offset;
+    return MMVAE_OK;
+}
+static int pb_bn_info(const PlanBase* b, int i, char* prefix, int* channels, long long* offset) {
+    MMVAE_REQUIRE(i >= 0 && i < (int)b->bn_list.size(), "bn index %d out of range", i);
+    strncpy(prefix, b->bn_names[i].c_str(), 127); prefix[127] = 0;
+    *channels = b->bn_list[i].C; *offset = b->bn_list[i].stat_off;
+    return MMVAE_OK;
+}
+static int pb_bind(PlanBase* P, float* params, float* grads, float* bn_stats, long long* nbt, void* packed, float* packed_vec,
+                   float* gpk, float* gpk_vec, void* desc_dev, void* gdesc_dev) {
+    MMVAE_REQUIRE(P && params && grads && bn_stats && nbt && packed && packed_vec && gpk && gpk_vec && desc_dev && gdesc_dev,
+                  "bind: null buffer");
+    ModelBuffers& b = P->buf;
+    b.params = params; b.grads = grads; b.bn_stats = bn_stats; b.bn_nbt = nbt; b.packed = (bf16*)packed; b.packed_vec = packed_vec;
+    b.gpk = gpk; b.gpk_vec = gpk_vec; b.desc_dev = (PackDesc*)desc_dev; b.gdesc_dev = (PackDesc*)gdesc_dev;
+    P->bound = true;
+    return MMVAE_OK;
+}
+static int pb_pack(PlanBase* P, hipStream_t s) {
+    MMVAE_TRY(check_bound(P));
+    return launch_pack(P->buf.desc_dev, P->pk.d.data(), (int)P->pk.d.size(), P->buf.params, P->buf.packed, P->buf.packed_vec, s);
+}
+#define MMVAE_PLAN_API(pfx, T, BASE)                                                                                      \
+    long long mmvae_##pfx##_param_count(const T* p) { return BASE(p)->nparams; }                                          \
+    int mmvae_##pfx##_num_params(const T* p) { return (int)BASE(p)->params.size(); }                                      \
+    int mmvae_##pfx##_param_info(const T* p, int i, char* name, int* ndim, int* shape, long long* offset) {               \
+        return pb_param_info(BASE(p), i, name, ndim, shape, offset);                                                      \
+    }                                                                                                                     \
+    long long mmvae_##pfx##_bn_floats(const T* p) { return pb_bn_floats(BASE(p)); }                                       \
+    int mmvae_##pfx##_num_bn(const T* p) { return (int)BASE(p)->bn_list.size(); }                                         \
+    int mmvae_##pfx##_bn_info(const T* p, int i, char* prefix, int* channels, long long* offset) {                        \
+        return pb_bn_info(BASE(p), i, prefix, channels, offset);                                                          \
+    }                                                                                                                     \
+    long long mmvae_##pfx##_packed_elems(const T* p) { return BASE(p)->pk.mat_elems; }                                    \
+    long long mmvae_##pfx##_packed_vec_elems(const T* p) { return BASE(p)->pk.vec_elems > 0 ? BASE(p)->pk.vec_elems : 64; } \
+    long long mmvae_##pfx##_gpk_elems(const T* p) { return BASE(p)->gk.mat_elems; }                                       \
+    long long mmvae_##pfx##_gpk_vec_elems(const T* p) { return BASE(p)->gk.vec_elems > 0 ? BASE(p)->gk.vec_elems : 64; }  \
+    size_t mmvae_##pfx##_desc_bytes(const T* p, int which) {                                                              \
+        return sizeof(PackDesc) * (which == 0 ? BASE(p)->pk.d.size() : BASE(p)->gk.d.size());                             \
+    }                                                                                                                     \
+    int mmvae_##pfx##_desc_copy(const T* p, int which, void* host_out) {                                                  \
+        memcpy(host_out, which == 0 ? BASE(p)->pk.d.data() : BASE(p)->gk.d.data(), mmvae_##pfx##_desc_bytes(p, which));   \
+        return MMVAE_OK;                                                                                                  \
+    }                                                                                                                     \
+    size_t mmvae_##pfx##_workspace_bytes(const T* p) { return BASE(p)->ws_bytes; }                                        \
+    int mmvae_##pfx##_bind(T* p, float* params, float* grads, float* bn_stats, long long* nbt, void* packed,              \
+                           float* packed_vec, float* gpk, float* gpk_vec, void* desc_dev, void* gdesc_dev) {              \
+        API_GUARD_BEGIN                                                                                                   \
+        return pb_bind(BASE(p), params, grads, bn_stats, nbt, packed, packed_vec, gpk, gpk_vec, desc_dev, gdesc_dev);     \
+        API_GUARD_END                                                                                                     \
+    }                                                                                                                     \
+    int mmvae_##pfx##_pack_weights(T* p, void* stream) {                                                                  \
+        API_GUARD_BEGIN                                                                                                   \
+        return pb_pack(BASE(p), S(stream));                                                                               \
+        API_GUARD_END                                                                                                     \
+    }
+static inline PlanBase* mnist_b(const mmvae_mnist_t* p) { return mnist_base(const_cast<mmvae_mnist_t*>(p)); }
 
 extern "C" {
 
@@ -150,6 +219,55 @@ int mmvae_mm_bench_layer(mmvae_mm_t* p, void* ws, size_t wsb, const char* layer,
 }
 double mmvae_mm_layer_flops(const mmvae_mm_t* p, const char* layer) { return mm_layer_flops(p, layer); }
 long long mmvae_mm_debug_offset(mmvae_mm_t* p, const char* name) { return mm_debug_offset(p, name); }
+
+// ---- MNIST (mnist/model.py, mnist/train.py)
+mmvae_mnist_t* mmvae_mnist_create(int n_latents, int batch) {
+    try { return mnist_create(n_latents, batch); } catch (...) { mmvae_set_error("mnist_create failed"); return nullptr; }
+}
+void mmvae_mnist_destroy(mmvae_mnist_t* p) { mnist_destroy(p); }
+MMVAE_PLAN_API(mnist, mmvae_mnist_t, mnist_b)
+int mmvae_mnist_step(mmvae_mnist_t* p, const mmvae_mnist_step_io* io, int training, int do_backward, void* stream) {
+    API_GUARD_BEGIN
+    MMVAE_REQUIRE(p && io, "mmvae_mnist_step: null argument");
+    MnistStepIO s;
+    s.ws = io->ws; s.ws_bytes = io->ws_bytes; s.step_ctr = io->step_counter; s.image = io->image; s.label = io->label; s.eps = io->eps;
+    for (int k = 0; k < 3; ++k) { s.lambda_xy[k] = io->lambda_xy[k]; s.lambda_yx[k] = io->lambda_yx[k]; }
+    s.kl_coef = io->kl_coef; s.seed = io->seed; s.sums = io->sums; s.recon_image = io->recon_image; s.recon_text = io->recon_text;
+    s.mu = io->mu; s.logvar = io->logvar;
+    return mnist_step(p, s, training, do_backward, S(stream));
+    API_GUARD_END
+}
+
+#define MNIST_FWD(name, in_t)                                                                                             \
+    int mmvae_mnist_##name##_fwd(mmvae_mnist_t* p, void* ws, size_t wsb, const in_t* in, int training, float* out, void* st) { \
+        API_GUARD_BEGIN                                                                                                   \
+        return mnist_##name##_fwd(p, ws, wsb, in, training, out, S(st));                                                  \
+        API_GUARD_END                                                                                                     \
+    }
+MNIST_FWD(image_encoder, float)
+MNIST_FWD(image_decoder, float)
+MNIST_FWD(text_encoder, long long)
+MNIST_FWD(text_decoder, float)
+int mmvae_mnist_image_encoder_bwd(mmvae_mnist_t* p, void* ws, size_t wsb, const float* d_out, void* st) {
+    API_GUARD_BEGIN
+    return mnist_image_encoder_bwd(p, ws, wsb, d_out, S(st));
+    API_GUARD_END
+}
+int mmvae_mnist_image_decoder_bwd(mmvae_mnist_t* p, void* ws, size_t wsb, const float* d_recon, const float* recon, float* dz, void* st) {
+    API_GUARD_BEGIN
+    return mnist_image_decoder_bwd(p, ws, wsb, d_recon, recon, dz, S(st));
+    API_GUARD_END
+}
+int mmvae_mnist_text_encoder_bwd(mmvae_mnist_t* p, void* ws, size_t wsb, const long long* label, const float* d_out, void* st) {
+    API_GUARD_BEGIN
+    return mnist_text_encoder_bwd(p, ws, wsb, label, d_out, S(st));
+    API_GUARD_END
+}
+int mmvae_mnist_text_decoder_bwd(mmvae_mnist_t* p, void* ws, size_t wsb, const float* d_logp, const float* logp, float* dz, void* st) {
+    API_GUARD_BEGIN
+    return mnist_text_decoder_bwd(p, ws, wsb, d_logp, logp, dz, S(st));
+    API_GUARD_END
+}
 
 int mmvae_poe_fwd(const float* mu, const float* lv, int M, int n, float* omu, float* olv, void* s) { return launch_poe_fwd(mu, lv, M, n, omu, olv, S(s)); }
 int mmvae_poe_bwd(const float* mu, const float* lv, int M, int n, const float* gmu, const float* glv, float* dmu, float* dlv, void* s) {

@@ -96,6 +96,7 @@ int launch_keep_mask(uint8_t* out, long long n, float p, unsigned long long seed
 struct Latent3Args {
     int B, D;
     const float* img_out;    // [2][B][2D]  image encoder (mu|logvar) of pass 1 and pass 2
+    const float* img_out_b;  // optional: pass-2 encoder output elsewhere (null -> img_out + B*2D)
     const float* txt_out;    // [B][2D]
     const float* eps;        // [3][B][D]
     float* mu; float* logvar;   // [3][B][D]
@@ -113,7 +114,10 @@ struct Latent3BwdArgs {
     float kl_coef[3];        // kl_lambda / B (or the MNIST divisor) per pass
     bf16* d_img_out_bf;      // [2][B][2D]
     float* d_img_bias;       // [2D] += column sums over both passes (classifier last bias), may be null
-    float* d_txt_out;        // [B][2D]
+    float* d_txt_out;        // [B][2D] or null
+    int sum_img_variants;    // 1: d_img_out_bf is [B][2D] = pass-1 + pass-2 gradient
+    bf16* d_txt_out_bf;      // optional bf16 copy [B][2D]
+    float* d_txt_bias;       // optional [2D] += column sums of the text-encoder output gradient
 };
 int launch_latent3_bwd(const Latent3BwdArgs& a, hipStream_t s);
 
@@ -141,3 +145,25 @@ struct StepBeginArgs {
     unsigned long long seed; const long long* step;
 };
 int launch_step_begin(const StepBeginArgs& a, hipStream_t s);
+
+// ---- small ops of the MLP models (mnist/model.py:136-170) ----
+// x[r][:] = table[idx[r % idx_rows]][:] as bf16 rows of stride ld (pad columns zero) + BatchNorm column statistics
+int launch_embed_gather_stats(const float* table, int C, const long long* idx, int rows, int idx_rows, int rows_per_group,
+                              bf16* x, int ld, float2* colstats, hipStream_t s);
+// g_table[idx[r]][c] += d[r][c]
+int launch_embed_scatter_add(const bf16* d, int ld, int C, const long long* idx, int rows, float* g_table, hipStream_t s);
+// log_softmax over `classes` columns of logits [rows][classes] (+ NLL against target[r % target_rows]):
+// words = log-probs, nll_sum[g] += sum(-logp[target]) per group, dlogits (bf16 [rows][ld_d], pads zero) = coef[g]*(softmax - onehot)
+struct LogSoftmaxNllArgs {
+    const float* logits; int rows, classes;
+    float* words;                      // [rows][classes]
+    const long long* target; int target_rows; int rows_per_group;
+    float* nll_sum;                    // [MMVAE_LOSS_SLOTS][16] column g, or null
+    bf16* dlogits; int ld_d;           // or null
+    float coef[4];
+};
+int launch_logsoftmax_nll(const LogSoftmaxNllArgs& a, hipStream_t s);
+int launch_cast_bf16(const float* x, long long n, bf16* out, hipStream_t s);
+// out[c] += sum_r x[r][c]   (x: fp32 [rows][cols]) -- bias gradients of the last Linear of a stack
+int launch_colsum_f32(const float* x, int rows, int cols, float* out, hipStream_t s);
+int launch_colsum_bf16(const bf16* x, int ld, int rows, int cols, float* out, hipStream_t s);

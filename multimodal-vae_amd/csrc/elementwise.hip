@@ -227,7 +227,7 @@ __global__ __launch_bounds__(TPB) void bn_act_kernel(const BnActArgs a) {
         if (threadIdx.x == 0 && f.num_batches_tracked) *f.num_batches_tracked += (long long)a.G * f.updates_per_group;
     }
     __syncthreads();
-    const int vpr = a.C / 8;
+    const int vpr = (a.C + 7) / 8;           // C need not be a multiple of 8: pad columns (< ld) are written as zero
     const long long nvec = (long long)a.rows * vpr;
     for (long long v = (long long)blockIdx.x * TPB + threadIdx.x; v < nvec; v += (long long)gridDim.x * TPB) {
         const long long row = v / vpr;
@@ -237,8 +237,12 @@ __global__ __launch_bounds__(TPB) void bn_act_kernel(const BnActArgs a) {
         bf16x8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float2 af = aff_s[g * a.C + c0 + j];
-            o[j] = (bf16)act_fwd(a.act, (float)rv[j] * af.x + af.y);
+            float val = 0.f;
+            if (c0 + j < a.C) {
+                float2 af = aff_s[g * a.C + c0 + j];
+                val = act_fwd(a.act, (float)rv[j] * af.x + af.y);
+            }
+            o[j] = (bf16)val;
         }
         *reinterpret_cast<bf16x8*>(a.a + row * a.ld + c0) = o;
     }
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const BnBwdApplyArgs 
         }
     }
     __syncthreads();
-    const int vpr = a.C / 8;
+    const int vpr = (a.C + 7) / 8;
     const long long nvec = (long long)a.rows * vpr;
     for (long long v = (long long)blockIdx.x * TPB + threadIdx.x; v < nvec; v += (long long)gridDim.x * TPB) {
         const long long row = v / vpr;
@@ -289,9 +293,13 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const BnBwdApplyArgs 
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = c0 + j;
-            const float4 t = tab_s[g * a.C + c];
-            const float xh = ((float)rv[j] - t.z) * t.w;
-            o[j] = (bf16)(a.gamma[c] * t.w * (dbf[j] - t.x - xh * t.y));
+            float val = 0.f;
+            if (c < a.C) {
+                const float4 t = tab_s[g * a.C + c];
+                const float xh = ((float)rv[j] - t.z) * t.w;
+                val = a.gamma[c] * t.w * (dbf[j] - t.x - xh * t.y);
+            }
+            o[j] = (bf16)val;
         }
         *reinterpret_cast<bf16x8*>(a.dr + row * a.ld + c0) = o;
     }
@@ -515,7 +523,8 @@ __global__ __launch_bounds__(TPB) void latent3_fwd_kernel(const Latent3Args a) {
         }
         const int D2 = 2 * a.D;
         const float im0 = a.img_out[(size_t)b * D2 + d], il0 = a.img_out[(size_t)b * D2 + a.D + d];
-        const float im1 = a.img_out[(size_t)(a.B + b) * D2 + d], il1 = a.img_out[(size_t)(a.B + b) * D2 + a.D + d];
+        const float* img_b = a.img_out_b ? a.img_out_b : a.img_out + (size_t)a.B * D2;
+        const float im1 = img_b[(size_t)b * D2 + d], il1 = img_b[(size_t)b * D2 + a.D + d];
         const float tm = a.txt_out[(size_t)b * D2 + d], tl = a.txt_out[(size_t)b * D2 + a.D + d];
         Poe2 o[3];
         { float m[2] = {im0, tm}, l[2] = {il0, tl}; o[0] = poe_fwd_m<2>(m, l); }
@@ -545,7 +554,8 @@ __global__ __launch_bounds__(TPB) void latent3_bwd_kernel(const Latent3BwdArgs a
     if (i >= n) return;
     const int b = i / f.D, d = i - b * f.D;
     const float im0 = f.img_out[(size_t)b * D2 + d], il0 = f.img_out[(size_t)b * D2 + f.D + d];
-    const float im1 = f.img_out[(size_t)(f.B + b) * D2 + d], il1 = f.img_out[(size_t)(f.B + b) * D2 + f.D + d];
+    const float* img_b = f.img_out_b ? f.img_out_b : f.img_out + (size_t)f.B * D2;
+    const float im1 = img_b[(size_t)b * D2 + d], il1 = img_b[(size_t)b * D2 + f.D + d];
     const float tm = f.txt_out[(size_t)b * D2 + d], tl = f.txt_out[(size_t)b * D2 + f.D + d];
     float gmu[3], glv[3];
 #pragma unroll
@@ -575,12 +585,27 @@ __global__ __launch_bounds__(TPB) void latent3_bwd_kernel(const Latent3BwdArgs a
         poe_bwd_m<1>(m, l, gmu[2], glv[2], dm, dl);
         d_tm += dm[0]; d_tl += dl[0];
     }
-    a.d_img_out_bf[(size_t)b * D2 + d] = (bf16)d_im0;
-    a.d_img_out_bf[(size_t)b * D2 + f.D + d] = (bf16)d_il0;
-    a.d_img_out_bf[(size_t)(f.B + b) * D2 + d] = (bf16)d_im1;
-    a.d_img_out_bf[(size_t)(f.B + b) * D2 + f.D + d] = (bf16)d_il1;
-    a.d_txt_out[(size_t)b * D2 + d] = d_tm;
-    a.d_txt_out[(size_t)b * D2 + f.D + d] = d_tl;
+    if (a.sum_img_variants) {       // the two variants share one encoder forward: its backward needs the summed gradient
+        a.d_img_out_bf[(size_t)b * D2 + d] = (bf16)(d_im0 + d_im1);
+        a.d_img_out_bf[(size_t)b * D2 + f.D + d] = (bf16)(d_il0 + d_il1);
+    } else {
+        a.d_img_out_bf[(size_t)b * D2 + d] = (bf16)d_im0;
+        a.d_img_out_bf[(size_t)b * D2 + f.D + d] = (bf16)d_il0;
+        a.d_img_out_bf[(size_t)(f.B + b) * D2 + d] = (bf16)d_im1;
+        a.d_img_out_bf[(size_t)(f.B + b) * D2 + f.D + d] = (bf16)d_il1;
+    }
+    if (a.d_txt_out) {
+        a.d_txt_out[(size_t)b * D2 + d] = d_tm;
+        a.d_txt_out[(size_t)b * D2 + f.D + d] = d_tl;
+    }
+    if (a.d_txt_out_bf) {
+        a.d_txt_out_bf[(size_t)b * D2 + d] = (bf16)d_tm;
+        a.d_txt_out_bf[(size_t)b * D2 + f.D + d] = (bf16)d_tl;
+    }
+    if (a.d_txt_bias) {
+        atomicAdd(a.d_txt_bias + d, d_tm);
+        atomicAdd(a.d_txt_bias + f.D + d, d_tl);
+    }
     if (a.d_img_bias) {
         atomicAdd(a.d_img_bias + d, d_im0 + d_im1);
         atomicAdd(a.d_img_bias + f.D + d, d_il0 + d_il1);
@@ -633,6 +658,102 @@ __global__ __launch_bounds__(TPB) void adam_kernel(const AdamArgs a, unsigned* d
     }
 }
 
+__global__ __launch_bounds__(TPB) void embed_gather_stats_kernel(const float* table, int C, const long long* idx, int rows, int idx_rows,
+                                                                 int rows_per_group, bf16* x, int ld, float2* colstats) {
+    // block = 64 rows x all channels (thread t: channel t % 64 .., rows strided)
+    const int r0 = blockIdx.x * 64;
+    for (int c = threadIdx.x & 63; c < ld; c += 64) {
+        float s1 = 0.f, s2 = 0.f;
+        int g_cur = -1;
+        for (int rr = threadIdx.x >> 6; rr < 64; rr += TPB / 64) {
+            const int r = r0 + rr;
+            if (r >= rows) break;
+            const int g = r / rows_per_group;
+            if (g != g_cur && g_cur >= 0 && c < C && colstats) {
+                atomicAdd(&colstats[(g_cur * MMVAE_STAT_SLOTS + blockIdx.x % MMVAE_STAT_SLOTS) * C + c].x, s1);
+                atomicAdd(&colstats[(g_cur * MMVAE_STAT_SLOTS + blockIdx.x % MMVAE_STAT_SLOTS) * C + c].y, s2);
+                s1 = s2 = 0.f;
+            }
+            g_cur = g;
+            float v = 0.f;
+            if (c < C) v = table[idx[r % idx_rows] * C + c];
+            const bf16 b = (bf16)v;
+            x[(size_t)r * ld + c] = b;
+            const float vb = (float)b;
+            s1 += vb; s2 += vb * vb;
+        }
+        if (g_cur >= 0 && c < C && colstats) {
+            atomicAdd(&colstats[(g_cur * MMVAE_STAT_SLOTS + blockIdx.x % MMVAE_STAT_SLOTS) * C + c].x, s1);
+            atomicAdd(&colstats[(g_cur * MMVAE_STAT_SLOTS + blockIdx.x % MMVAE_STAT_SLOTS) * C + c].y, s2);
+        }
+    }
+}
+__global__ __launch_bounds__(TPB) void embed_scatter_add_kernel(const bf16* d, int ld, int C, const long long* idx, int rows, float* g_table) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= rows * C) return;
+    const int r = i / C, c = i - r * C;
+    atomicAdd(g_table + idx[r] * C + c, (float)d[(size_t)r * ld + c]);
+}
+__global__ __launch_bounds__(TPB) void logsoftmax_nll_kernel(const LogSoftmaxNllArgs a) {
+    const int r = blockIdx.x * TPB + threadIdx.x;
+    float nll = 0.f;
+    int g = 0;
+    if (r < a.rows) {
+        g = r / a.rows_per_group;
+        const float* l = a.logits + (size_t)r * a.classes;
+        float mx = -INFINITY;
+        for (int c = 0; c < a.classes; ++c) mx = fmaxf(mx, l[c]);
+        float se = 0.f;
+        for (int c = 0; c < a.classes; ++c) se += expf(l[c] - mx);
+        const float lse = mx + logf(se);
+        const int tg = a.target ? (int)a.target[r % a.target_rows] : -1;
+        for (int c = 0; c < a.classes; ++c) {
+            const float lp = l[c] - lse;
+            a.words[(size_t)r * a.classes + c] = lp;
+            if (c == tg) nll = -lp;
+            if (a.dlogits) a.dlogits[(size_t)r * a.ld_d + c] = (bf16)(a.coef[g & 3] * (expf(lp) - (c == tg ? 1.f : 0.f)));
+        }
+        if (a.dlogits)
+            for (int c = a.classes; c < a.ld_d; ++c) a.dlogits[(size_t)r * a.ld_d + c] = (bf16)0.f;
+    }
+    if (a.nll_sum && a.target) {
+        // rows of one wave may straddle a group boundary only when rows_per_group % 64 != 0: add per lane then
+        if (a.rows_per_group % 64 == 0) {
+            float s = wave_sum(nll);
+            if ((threadIdx.x & 63) == 0 && r < a.rows) atomicAdd(a.nll_sum + (blockIdx.x % MMVAE_LOSS_SLOTS) * 16 + g, s);
+        } else if (r < a.rows) {
+            atomicAdd(a.nll_sum + (r % MMVAE_LOSS_SLOTS) * 16 + g, nll);
+        }
+    }
+}
+__global__ __launch_bounds__(TPB) void cast_bf16_kernel(const float* x, long long n, bf16* out) {
+    const long long i = ((long long)blockIdx.x * TPB + threadIdx.x) * 4;
+    if (i + 4 <= n) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
+        bf16x4 o;
+        for (int j = 0; j < 4; ++j) o[j] = (bf16)v[j];
+        *reinterpret_cast<bf16x4*>(out + i) = o;
+    } else {
+        for (long long q = i; q < n; ++q) out[q] = (bf16)x[q];
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(TPB) void colsum_kernel_t(const T* x, int ld, int rows, int cols, float* out) {
+    // block = 64 columns x (TPB/64) row lanes; partial sums through LDS
+    __shared__ float part[TPB / 64][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    float s = 0.f;
+    if (c < cols)
+        for (int r = blockIdx.y * (TPB / 64) + (threadIdx.x >> 6); r < rows; r += gridDim.y * (TPB / 64)) s += (float)x[(size_t)r * ld + c];
+    part[threadIdx.x >> 6][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (threadIdx.x < 64 && c < cols) {
+        float t = 0.f;
+        for (int w = 0; w < TPB / 64; ++w) t += part[w][threadIdx.x];
+        atomicAdd(out + c, t);
+    }
+}
+
 }  // namespace
 
 int launch_pack(const PackDesc* table_dev, const PackDesc* table_host, int nd, const float* params, bf16* packed_bf,
@@ -660,15 +781,15 @@ int launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s) {
     return mmvae_check_launch("bn_finalize");
 }
 int launch_bn_act(const BnActArgs& a, hipStream_t s) {
-    MMVAE_REQUIRE(a.C % 8 == 0 && a.ld % 8 == 0 && a.G * a.C <= 4096, "bn_act: C=%d ld=%d G=%d", a.C, a.ld, a.G);
+    MMVAE_REQUIRE(a.ld % 8 == 0 && a.ld >= round_up(a.C, 8) && a.G * a.C <= 4096, "bn_act: C=%d ld=%d G=%d", a.C, a.ld, a.G);
     MMVAE_REQUIRE(!a.fin.training || a.fin.count > 1.f, "Expected more than 1 value per channel when training");
-    hipLaunchKernelGGL(bn_act_kernel, dim3(nblocks((long long)a.rows * a.C / 8, TPB, 2048)), dim3(TPB),
+    hipLaunchKernelGGL(bn_act_kernel, dim3(nblocks((long long)a.rows * ((a.C + 7) / 8), TPB, 2048)), dim3(TPB),
                        (size_t)a.G * a.C * sizeof(float2), s, a);
     return mmvae_check_launch("bn_act");
 }
 int launch_bn_bwd_apply(const BnBwdApplyArgs& a, hipStream_t s) {
-    MMVAE_REQUIRE(a.C % 8 == 0 && a.ld % 8 == 0, "bn_bwd_apply: C=%d ld=%d", a.C, a.ld);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblocks((long long)a.rows * a.C / 8, TPB, 2048)), dim3(TPB),
+    MMVAE_REQUIRE(a.ld % 8 == 0 && a.ld >= round_up(a.C, 8), "bn_bwd_apply: C=%d ld=%d", a.C, a.ld);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblocks((long long)a.rows * ((a.C + 7) / 8), TPB, 2048)), dim3(TPB),
                        (size_t)a.G * a.C * sizeof(float4), s, a);
     return mmvae_check_launch("bn_bwd_apply");
 }
@@ -756,4 +877,31 @@ int launch_step_begin(const StepBeginArgs& a, hipStream_t s) {
         MMVAE_REQUIRE(a.zero_ptr[r] == nullptr || (a.zero_bytes[r] % 16 == 0 && ((uintptr_t)a.zero_ptr[r] & 15) == 0), "step_begin: zero range %d is not 16-byte aligned", r);
     hipLaunchKernelGGL(step_begin_kernel, dim3(2048), dim3(TPB), 0, s, a);
     return mmvae_check_launch("step_begin");
+}
+
+int launch_embed_gather_stats(const float* table, int C, const long long* idx, int rows, int idx_rows, int rows_per_group,
+                              bf16* x, int ld, float2* colstats, hipStream_t s) {
+    MMVAE_REQUIRE(ld >= C && ld % 8 == 0, "embed_gather: C=%d ld=%d", C, ld);
+    hipLaunchKernelGGL(embed_gather_stats_kernel, dim3(ceil_div(rows, 64)), dim3(TPB), 0, s, table, C, idx, rows, idx_rows, rows_per_group, x, ld, colstats);
+    return mmvae_check_launch("embed_gather_stats");
+}
+int launch_embed_scatter_add(const bf16* d, int ld, int C, const long long* idx, int rows, float* g_table, hipStream_t s) {
+    hipLaunchKernelGGL(embed_scatter_add_kernel, dim3(ceil_div(rows * C, TPB)), dim3(TPB), 0, s, d, ld, C, idx, rows, g_table);
+    return mmvae_check_launch("embed_scatter_add");
+}
+int launch_logsoftmax_nll(const LogSoftmaxNllArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(logsoftmax_nll_kernel, dim3(ceil_div(a.rows, TPB)), dim3(TPB), 0, s, a);
+    return mmvae_check_launch("logsoftmax_nll");
+}
+int launch_cast_bf16(const float* x, long long n, bf16* out, hipStream_t s) {
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)((n + 4 * TPB - 1) / (4 * TPB))), dim3(TPB), 0, s, x, n, out);
+    return mmvae_check_launch("cast_bf16");
+}
+int launch_colsum_f32(const float* x, int rows, int cols, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(colsum_kernel_t<float>, dim3(ceil_div(cols, 64), min(64, ceil_div(rows, 16))), dim3(TPB), 0, s, x, cols, rows, cols, out);
+    return mmvae_check_launch("colsum_f32");
+}
+int launch_colsum_bf16(const bf16* x, int ld, int rows, int cols, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(colsum_kernel_t<bf16>, dim3(ceil_div(cols, 64), min(64, ceil_div(rows, 16))), dim3(TPB), 0, s, x, ld, rows, cols, out);
+    return mmvae_check_launch("colsum_bf16");
 }

@@ -38,7 +38,6 @@ struct MMPlan : PlanBase {
         bf16 *dy2, *dy1, *db4, *dr4, *d3e, *d2e, *d1e;
         float* tmp_f32;
     } w;
-    size_t ws_bytes = 0;
 };
 
 namespace {

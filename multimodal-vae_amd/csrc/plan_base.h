@@ -54,6 +54,11 @@ struct PlanBase {
     bool wgrad_forked = false;
     // split-K partial slabs (carved from the caller's workspace)
     float* sk_buf = nullptr; size_t sk_floats = 0; unsigned* sk_cnt = nullptr;
+    // generic queries (capi.cpp): BatchNorm layers in state_dict order and the workspace size
+    std::vector<std::string> bn_names;
+    std::vector<BnL> bn_list;
+    size_t ws_bytes = 0;
+    virtual ~PlanBase() {}
 };
 
 

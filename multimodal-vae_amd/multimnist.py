@@ -54,7 +54,8 @@ def _seed_from_torch() -> int:
 class _Core:
     """Binds the nn.Parameters / BatchNorm buffers of a module tree to one flat ``MultimnistState``."""
 
-    def __init__(self, owner: nn.Module, prefix: str, n_latents: int):
+    def __init__(self, owner: nn.Module, prefix: str, n_latents: int, state_cls=MultimnistState):
+        self.state_cls = state_cls
         self.owner = weakref.ref(owner)
         self.prefix = prefix            # "" for MultimodalVAE, "image_encoder." for a standalone ImageEncoder, ...
         self.n_latents = n_latents
@@ -73,7 +74,7 @@ class _Core:
             raise MMVAEError("MMVAE HIP modules need CUDA/HIP tensors (got %s); move the module and its inputs to the GPU. "
                              "There is no CPU fallback." % device)
         if self.state is None or self.state.device != device:
-            self.state = MultimnistState(self.n_latents, device)
+            self.state = self.state_cls(self.n_latents, device)
             self._sig = None
         st = self.state
         owner, params, bufs = self._named()
@@ -135,13 +136,13 @@ def _set_buffer(root: nn.Module, dotted: str, value: torch.Tensor) -> None:
     mod._buffers[parts[-1]] = value
 
 
-def _core_of(module: nn.Module, prefix: str) -> _Core:
+def _core_of(module: nn.Module, prefix: str, state_cls=MultimnistState) -> _Core:
     root = getattr(module, "_mmvae_root", None)
     root = root() if root is not None else None
     if root is not None:
         return root._core
     if getattr(module, "_core", None) is None:
-        module._core = _Core(module, prefix, module.n_latents)
+        module._core = _Core(module, prefix, module.n_latents, state_cls)
     return module._core
 
 

@@ -40,6 +40,65 @@ DROP_P = 0.1         # multimnist/model.py:175,178,230,262 ; celeba/model.py:116
 
 
 # ----------------------------------------------------------------------------
+# bf16 storage-contract emulation (test instrument, OFF by default = the reference's fp32 arithmetic)
+# ----------------------------------------------------------------------------
+# The HIP engine feeds its MFMA GEMMs bf16 operands (fp32 accumulate) and keeps layer activations / activation
+# gradients in bf16.  With ``bf16_contract(True)`` the MLP models below apply the same roundings at the same places
+# (GEMM operands, stored pre-BatchNorm tensors, stored activation gradients), everything else staying fp32, so a
+# test can separate "rounding the engine is designed to do" from an implementation error.  ReLU makes the MNIST
+# gradients discontinuous in those roundings, which is why this instrument exists.
+_BF16_CONTRACT = False
+
+
+class bf16_contract:
+    def __init__(self, on: bool = True):
+        self.on = on
+
+    def __enter__(self):
+        global _BF16_CONTRACT
+        self.prev, _BF16_CONTRACT = _BF16_CONTRACT, self.on
+
+    def __exit__(self, *a):
+        global _BF16_CONTRACT
+        _BF16_CONTRACT = self.prev
+
+
+class _RoundFwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundBwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32)
+
+
+def _q(x: Tensor) -> Tensor:
+    """value stored / fed to a GEMM as bf16"""
+    return _RoundFwd.apply(x) if _BF16_CONTRACT else x
+
+
+def _qg(x: Tensor) -> Tensor:
+    """gradient w.r.t. x stored as bf16"""
+    return _RoundBwd.apply(x) if _BF16_CONTRACT else x
+
+
+def linear(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
+    """F.linear; under the bf16 contract both GEMM operands are rounded, the accumulation and bias stay fp32."""
+    return F.linear(_q(x), _q(w), b)
+
+
+# ----------------------------------------------------------------------------
 # primitives
 # ----------------------------------------------------------------------------
 def swish(x: Tensor) -> Tensor:
@@ -70,7 +129,7 @@ def batch_norm(x: Tensor, p: Params, prefix: str, training: bool) -> Tensor:
                 p[prefix + ".num_batches_tracked"] += 1
     else:
         mean, var = rm, rv
-    xh = (x - mean.view(shape)) * torch.rsqrt(var.view(shape) + BN_EPS)
+    xh = (_q(x) - mean.view(shape)) * torch.rsqrt(var.view(shape) + BN_EPS)   # _q: identity unless bf16_contract
     return xh * w.view(shape) + b.view(shape)
 
 
@@ -275,10 +334,10 @@ def multimnist_step_losses(p: Params, image: Tensor, text: Tensor, training: boo
 def _mlp_bn_relu(p: Params, x: Tensor, pre: str, idx: Sequence[int], training: bool) -> Tensor:
     """Linear -> BatchNorm1d -> ReLU stacks of mnist/model.py:103-111,123-131."""
     for i in idx[:-1]:
-        x = F.linear(x, p[f"{pre}net.{i}.weight"], p[f"{pre}net.{i}.bias"])
-        x = torch.relu(batch_norm(x, p, f"{pre}net.{i + 1}", training))
+        x = _qg(linear(x, p[f"{pre}net.{i}.weight"], p[f"{pre}net.{i}.bias"]))
+        x = torch.relu(_qg(batch_norm(x, p, f"{pre}net.{i + 1}", training)))
     i = idx[-1]
-    return F.linear(x, p[f"{pre}net.{i}.weight"], p[f"{pre}net.{i}.bias"])
+    return _qg(linear(x, p[f"{pre}net.{i}.weight"], p[f"{pre}net.{i}.bias"]))
 
 
 def mnist_forward(p: Params, image: Optional[Tensor], text: Optional[Tensor], training: bool,
@@ -291,9 +350,9 @@ def mnist_forward(p: Params, image: Optional[Tensor], text: Optional[Tensor], tr
         o = _mlp_bn_relu(p, image, "image_encoder.", (0, 3, 6), training)          # :99-118
         mus.append(o[:, :D]); lvs.append(o[:, D:])
     if text is not None:
-        x = p["text_encoder.net.0.weight"][text]                                    # :136-153
-        x = torch.relu(batch_norm(x, p, "text_encoder.net.1", training))
-        o = F.linear(x, p["text_encoder.net.3.weight"], p["text_encoder.net.3.bias"])
+        x = _qg(_q(p["text_encoder.net.0.weight"][text]))                           # :136-153
+        x = torch.relu(_qg(batch_norm(x, p, "text_encoder.net.1", training)))
+        o = _qg(linear(x, p["text_encoder.net.3.weight"], p["text_encoder.net.3.bias"]))
         mus.append(o[:, :D]); lvs.append(o[:, D:])
     mu, logvar = product_of_experts(torch.stack(mus, 0), torch.stack(lvs, 0))
     z = reparametrize(mu, logvar, training, eps)
