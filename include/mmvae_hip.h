@@ -157,6 +157,64 @@ int mmvae_mnist_text_decoder_fwd(mmvae_mnist_t*, void* ws, size_t ws_bytes, cons
 int mmvae_mnist_text_decoder_bwd(mmvae_mnist_t*, void* ws, size_t ws_bytes, const float* d_log_probs, const float* log_probs,
                                  float* dz, void* stream);
 
+/* ---------------------------------------------------------------- CelebA (celeba/model.py, celeba/train.py)
+ * MultimodalVAE of celeba/model.py:14-57: conv ImageEncoder :91-128 / ImageDecoder :131-161 on 3x64x64 images,
+ * AttributeEncoder :164-178 / AttributeDecoder :181-196 on 18 binary attributes (celeba/datasets.py:26-28),
+ * loss_function celeba/train.py:60-81.  Plan/query/bind/pack functions as for mmvae_mm_*. */
+typedef struct CelebaPlan mmvae_celeba_t;
+mmvae_celeba_t* mmvae_celeba_create(int n_latents, int batch);    /* MultimodalVAE(n_latents) celeba/model.py:15-22 */
+void mmvae_celeba_destroy(mmvae_celeba_t*);
+long long mmvae_celeba_param_count(const mmvae_celeba_t*);
+int mmvae_celeba_num_params(const mmvae_celeba_t*);
+int mmvae_celeba_param_info(const mmvae_celeba_t*, int i, char* name128, int* ndim, int* shape4, long long* offset);
+long long mmvae_celeba_bn_floats(const mmvae_celeba_t*);
+int mmvae_celeba_num_bn(const mmvae_celeba_t*);
+int mmvae_celeba_bn_info(const mmvae_celeba_t*, int i, char* prefix128, int* channels, long long* offset);
+long long mmvae_celeba_packed_elems(const mmvae_celeba_t*);
+long long mmvae_celeba_packed_vec_elems(const mmvae_celeba_t*);
+long long mmvae_celeba_gpk_elems(const mmvae_celeba_t*);
+long long mmvae_celeba_gpk_vec_elems(const mmvae_celeba_t*);
+size_t mmvae_celeba_desc_bytes(const mmvae_celeba_t*, int which);
+int mmvae_celeba_desc_copy(const mmvae_celeba_t*, int which, void* host_out);
+size_t mmvae_celeba_workspace_bytes(const mmvae_celeba_t*);
+int mmvae_celeba_bind(mmvae_celeba_t*, float* params, float* grads, float* bn_stats, long long* num_batches_tracked,
+                      void* packed_bf16, float* packed_vec, float* gpk, float* gpk_vec, void* desc_dev, void* gdesc_dev);
+int mmvae_celeba_pack_weights(mmvae_celeba_t*, void* stream);
+/* The train() closure body of celeba/train.py:131-147 (3 passes, 3 losses, backward) */
+typedef struct {
+    void* ws; size_t ws_bytes;
+    const long long* step_counter;          /* device int64 keying the Philox streams, or NULL */
+    const float* image;                     /* [B][3][64][64] fp32 */
+    const float* attrs;                     /* [B][18] fp32 */
+    const float* eps;                       /* [3][B][D] or NULL (drawn on device) */
+    const uint8_t* enc_mask;                /* [2][B][1024] keep flags of classifier Dropout(0.1) or NULL (drawn) */
+    int enc_dropout;                        /* 0: no dropout */
+    float kl_lambda;                        /* celeba/train.py:61 (1e-3) */
+    float lambda_x[3]; float lambda_y[3];   /* celeba/train.py:138-147: all 1 */
+    unsigned long long seed;
+    float* sums;                            /* out [16]: image bce_sum[0..2], attrs bce_sum[4..6], kl_sum[8..10] */
+    float* recon_image;                     /* out [3][B][3][64][64] or NULL */
+    float* recon_attrs;                     /* out [3][B][18] or NULL */
+    float* mu; float* logvar;               /* out [3][B][D] or NULL */
+} mmvae_celeba_step_io;
+int mmvae_celeba_step(mmvae_celeba_t*, const mmvae_celeba_step_io*, int training, int do_backward, void* stream);
+/* Granular modules (forward + autograd backward), workspace rules as for mmvae_mm_*_fwd/bwd */
+int mmvae_celeba_image_encoder_fwd(mmvae_celeba_t*, void* ws, size_t ws_bytes, const float* image, const uint8_t* mask,
+                                   int training, float* out_mu_logvar, void* stream);            /* celeba/model.py:124-128 */
+int mmvae_celeba_image_encoder_bwd(mmvae_celeba_t*, void* ws, size_t ws_bytes, const float* d_out, const uint8_t* mask,
+                                   void* stream);
+int mmvae_celeba_image_decoder_fwd(mmvae_celeba_t*, void* ws, size_t ws_bytes, const float* z, int training, float* recon,
+                                   void* stream);                                                /* celeba/model.py:157-161 */
+int mmvae_celeba_image_decoder_bwd(mmvae_celeba_t*, void* ws, size_t ws_bytes, const float* d_recon, const float* recon,
+                                   float* dz, void* stream);
+int mmvae_celeba_attrs_encoder_fwd(mmvae_celeba_t*, void* ws, size_t ws_bytes, const float* attrs, int training,
+                                   float* out_mu_logvar, void* stream);                          /* celeba/model.py:175-178 */
+int mmvae_celeba_attrs_encoder_bwd(mmvae_celeba_t*, void* ws, size_t ws_bytes, const float* d_out, void* stream);
+int mmvae_celeba_attrs_decoder_fwd(mmvae_celeba_t*, void* ws, size_t ws_bytes, const float* z, int training, float* recon,
+                                   void* stream);                                                /* celeba/model.py:191-196 */
+int mmvae_celeba_attrs_decoder_bwd(mmvae_celeba_t*, void* ws, size_t ws_bytes, const float* d_recon, const float* recon,
+                                   float* dz, void* stream);
+
 /* ---------------------------------------------------------------- dataset-independent ops */
 /* ProductOfExperts.forward (multimnist/model.py:355-360) over M stacked experts of n scalars each */
 int mmvae_poe_fwd(const float* mu, const float* logvar, int M, int n, float* out_mu, float* out_logvar, void* stream);

@@ -42,6 +42,21 @@ class MnistStepIO(C.Structure):
     ]
 
 
+class CelebaStepIO(C.Structure):
+    """mmvae_celeba_step_io"""
+    _fields_ = [
+        ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
+        ("step_counter", C.c_void_p),
+        ("image", C.c_void_p), ("attrs", C.c_void_p), ("eps", C.c_void_p),
+        ("enc_mask", C.c_void_p), ("enc_dropout", C.c_int),
+        ("kl_lambda", C.c_float),
+        ("lambda_x", C.c_float * 3), ("lambda_y", C.c_float * 3),
+        ("seed", C.c_ulonglong),
+        ("sums", C.c_void_p), ("recon_image", C.c_void_p), ("recon_attrs", C.c_void_p),
+        ("mu", C.c_void_p), ("logvar", C.c_void_p),
+    ]
+
+
 _P, _I, _F, _LL, _SZ, _ULL, _U = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_size_t, C.c_ulonglong, C.c_uint
 
 # name -> (restype, argtypes); restype int means "status code, raise on != 0"
@@ -125,6 +140,16 @@ SIGNATURES["mmvae_mnist_image_encoder_bwd"] = (_I, [_P, _P, _SZ, _P, _P])
 SIGNATURES["mmvae_mnist_image_decoder_bwd"] = (_I, [_P, _P, _SZ, _P, _P, _P, _P])
 SIGNATURES["mmvae_mnist_text_encoder_bwd"] = (_I, [_P, _P, _SZ, _P, _P, _P])
 SIGNATURES["mmvae_mnist_text_decoder_bwd"] = (_I, [_P, _P, _SZ, _P, _P, _P, _P])
+SIGNATURES.update(_plan_api("celeba"))
+SIGNATURES["mmvae_celeba_step"] = (_I, [_P, C.POINTER(CelebaStepIO), _I, _I, _P])
+SIGNATURES["mmvae_celeba_image_encoder_fwd"] = (_I, [_P, _P, _SZ, _P, _P, _I, _P, _P])
+SIGNATURES["mmvae_celeba_image_encoder_bwd"] = (_I, [_P, _P, _SZ, _P, _P, _P])
+SIGNATURES["mmvae_celeba_image_decoder_fwd"] = (_I, [_P, _P, _SZ, _P, _I, _P, _P])
+SIGNATURES["mmvae_celeba_image_decoder_bwd"] = (_I, [_P, _P, _SZ, _P, _P, _P, _P])
+SIGNATURES["mmvae_celeba_attrs_encoder_fwd"] = (_I, [_P, _P, _SZ, _P, _I, _P, _P])
+SIGNATURES["mmvae_celeba_attrs_encoder_bwd"] = (_I, [_P, _P, _SZ, _P, _P])
+SIGNATURES["mmvae_celeba_attrs_decoder_fwd"] = (_I, [_P, _P, _SZ, _P, _I, _P, _P])
+SIGNATURES["mmvae_celeba_attrs_decoder_bwd"] = (_I, [_P, _P, _SZ, _P, _P, _P, _P])
 _STATUS = {n for n, (r, _) in SIGNATURES.items() if r is _I and not n.endswith(("_num_params", "_num_bn"))}
 
 _lib = None

@@ -128,6 +128,11 @@ class MnistState(PlanState):
     API = "mnist"
 
 
+class CelebaState(PlanState):
+    """celeba/model.py MultimodalVAE"""
+    API = "celeba"
+
+
 class StepOutputs:
     """Lazy view of the loss sums of one fused step (no host sync until a value is read)."""
 
@@ -268,4 +273,41 @@ class FusedMnistStep(_FusedStepBase):
         io.seed = self.seed
         io.sums = self.sums.data_ptr()
         call("mmvae_mnist_step", self.h, C.byref(io), int(training), int(backward), _stream())
+        return self._outputs()
+
+
+class FusedCelebaStep(_FusedStepBase):
+    """The 3-pass step of celeba/train.py:131-147 (loss_function defaults: lambdas 1, kl_lambda 1e-3)."""
+
+    LAMBDA_X = (1.0, 1.0, 1.0)
+    LAMBDA_Y = (1.0, 1.0, 1.0)
+    N_ATTRS = 18
+
+    def __init__(self, state: PlanState, batch: int, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 kl_lambda: float = 1e-3, seed: int = 1234, world_size: int = 1, all_reduce=None):
+        super().__init__(state, batch, lr, betas, eps, seed, world_size, all_reduce)
+        self.kl_lambda = kl_lambda
+        self.enc_dropout = True
+
+    def _outputs(self) -> StepOutputs:
+        return StepOutputs(self.sums, self.B * 3 * 64 * 64, self.B * self.N_ATTRS, self.kl_lambda / self.B, self.LAMBDA_X, self.LAMBDA_Y)
+
+    def forward_backward(self, image, attrs, training=True, backward=True, eps=None, enc_mask=None, recon_image=None,
+                         recon_attrs=None, mu=None, logvar=None) -> StepOutputs:
+        assert image.is_contiguous() and attrs.is_contiguous() and image.dtype == torch.float32 and attrs.dtype == torch.float32
+        assert image.shape == (self.B, 3, 64, 64) and attrs.shape == (self.B, self.N_ATTRS)
+        io = _lib.CelebaStepIO()
+        io.ws, io.ws_bytes = self.ws.data_ptr(), self.ws.numel()
+        io.step_counter = self.adam_state.data_ptr()
+        io.image, io.attrs = image.data_ptr(), attrs.data_ptr()
+        for k, t in (("eps", eps), ("enc_mask", enc_mask), ("recon_image", recon_image), ("recon_attrs", recon_attrs),
+                     ("mu", mu), ("logvar", logvar)):
+            setattr(io, k, None if t is None else t.data_ptr())
+        io.enc_dropout = int(self.enc_dropout)
+        io.kl_lambda = self.kl_lambda
+        io.lambda_x = (C.c_float * 3)(*self.LAMBDA_X)
+        io.lambda_y = (C.c_float * 3)(*self.LAMBDA_Y)
+        io.seed = self.seed
+        io.sums = self.sums.data_ptr()
+        call("mmvae_celeba_step", self.h, C.byref(io), int(training), int(backward), _stream())
         return self._outputs()

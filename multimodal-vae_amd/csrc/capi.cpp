@@ -2,6 +2,7 @@
 #include "../../include/mmvae_hip.h"
 #include "multimnist.h"
 #include "mnist.h"
+#include "celeba.h"
 #include "plan_base.h"
 #include <cstring>
 #include <exception>
@@ -87,6 +88,7 @@ static int pb_pack(PlanBase* P, hipStream_t s) {
         API_GUARD_END                                                                                                     \
     }
 static inline PlanBase* mnist_b(const mmvae_mnist_t* p) { return mnist_base(const_cast<mmvae_mnist_t*>(p)); }
+static inline PlanBase* celeba_b(const mmvae_celeba_t* p) { return celeba_base(const_cast<mmvae_celeba_t*>(p)); }
 
 extern "C" {
 
@@ -266,6 +268,65 @@ int mmvae_mnist_text_encoder_bwd(mmvae_mnist_t* p, void* ws, size_t wsb, const l
 int mmvae_mnist_text_decoder_bwd(mmvae_mnist_t* p, void* ws, size_t wsb, const float* d_logp, const float* logp, float* dz, void* st) {
     API_GUARD_BEGIN
     return mnist_text_decoder_bwd(p, ws, wsb, d_logp, logp, dz, S(st));
+    API_GUARD_END
+}
+
+// ---- CelebA (celeba/model.py, celeba/train.py)
+mmvae_celeba_t* mmvae_celeba_create(int n_latents, int batch) {
+    try { return celeba_create(n_latents, batch); } catch (...) { mmvae_set_error("celeba_create failed"); return nullptr; }
+}
+void mmvae_celeba_destroy(mmvae_celeba_t* p) { celeba_destroy(p); }
+MMVAE_PLAN_API(celeba, mmvae_celeba_t, celeba_b)
+int mmvae_celeba_step(mmvae_celeba_t* p, const mmvae_celeba_step_io* io, int training, int do_backward, void* stream) {
+    API_GUARD_BEGIN
+    MMVAE_REQUIRE(p && io, "mmvae_celeba_step: null argument");
+    CelebaStepIO s;
+    s.ws = io->ws; s.ws_bytes = io->ws_bytes; s.step_ctr = io->step_counter; s.image = io->image; s.attrs = io->attrs; s.eps = io->eps;
+    s.enc_mask = io->enc_mask; s.enc_dropout = io->enc_dropout; s.kl_lambda = io->kl_lambda;
+    for (int k = 0; k < 3; ++k) { s.lambda_x[k] = io->lambda_x[k]; s.lambda_y[k] = io->lambda_y[k]; }
+    s.seed = io->seed; s.sums = io->sums; s.recon_image = io->recon_image; s.recon_attrs = io->recon_attrs;
+    s.mu = io->mu; s.logvar = io->logvar;
+    return celeba_step(p, s, training, do_backward, S(stream));
+    API_GUARD_END
+}
+int mmvae_celeba_image_encoder_fwd(mmvae_celeba_t* p, void* ws, size_t wsb, const float* image, const uint8_t* mask, int training, float* out, void* st) {
+    API_GUARD_BEGIN
+    return celeba_image_encoder_fwd(p, ws, wsb, image, mask, training, out, S(st));
+    API_GUARD_END
+}
+int mmvae_celeba_image_encoder_bwd(mmvae_celeba_t* p, void* ws, size_t wsb, const float* d_out, const uint8_t* mask, void* st) {
+    API_GUARD_BEGIN
+    return celeba_image_encoder_bwd(p, ws, wsb, d_out, mask, S(st));
+    API_GUARD_END
+}
+int mmvae_celeba_image_decoder_fwd(mmvae_celeba_t* p, void* ws, size_t wsb, const float* z, int training, float* recon, void* st) {
+    API_GUARD_BEGIN
+    return celeba_image_decoder_fwd(p, ws, wsb, z, training, recon, S(st));
+    API_GUARD_END
+}
+int mmvae_celeba_image_decoder_bwd(mmvae_celeba_t* p, void* ws, size_t wsb, const float* d_recon, const float* recon, float* dz, void* st) {
+    API_GUARD_BEGIN
+    return celeba_image_decoder_bwd(p, ws, wsb, d_recon, recon, dz, S(st));
+    API_GUARD_END
+}
+int mmvae_celeba_attrs_encoder_fwd(mmvae_celeba_t* p, void* ws, size_t wsb, const float* attrs, int training, float* out, void* st) {
+    API_GUARD_BEGIN
+    return celeba_attrs_encoder_fwd(p, ws, wsb, attrs, training, out, S(st));
+    API_GUARD_END
+}
+int mmvae_celeba_attrs_encoder_bwd(mmvae_celeba_t* p, void* ws, size_t wsb, const float* d_out, void* st) {
+    API_GUARD_BEGIN
+    return celeba_attrs_encoder_bwd(p, ws, wsb, d_out, S(st));
+    API_GUARD_END
+}
+int mmvae_celeba_attrs_decoder_fwd(mmvae_celeba_t* p, void* ws, size_t wsb, const float* z, int training, float* recon, void* st) {
+    API_GUARD_BEGIN
+    return celeba_attrs_decoder_fwd(p, ws, wsb, z, training, recon, S(st));
+    API_GUARD_END
+}
+int mmvae_celeba_attrs_decoder_bwd(mmvae_celeba_t* p, void* ws, size_t wsb, const float* d_recon, const float* recon, float* dz, void* st) {
+    API_GUARD_BEGIN
+    return celeba_attrs_decoder_bwd(p, ws, wsb, d_recon, recon, dz, S(st));
     API_GUARD_END
 }
 

@@ -67,6 +67,8 @@ struct GemmParams {
     const float2* d_meanrstd;  // [groups][N] for xhat=(r-mean)*rstd, with d_red
     float2* d_red;             // [groups][MMVAE_STAT_SLOTS][N] += (sum v, sum v*xhat) or null
     float* d_colsum;           // [N] += sum v over all rows (bias gradient of the producer Linear) or null
+    int d_cmod;                // >0: the BatchNorm tables (d_affine/d_meanrstd/d_red) have d_cmod channels and output
+                               // column n belongs to channel n % d_cmod (Linear over a flattened NHWC feature map)
 };
 
 struct WgradParams {

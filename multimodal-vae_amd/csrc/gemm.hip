@@ -72,8 +72,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const GatherC
         const int col = min(col0 + j, c.N - 1);
         bias8[j] = p.bias ? p.bias[col] : 0.f;
         dsc[j] = 1.f; dsh[j] = 0.f; dmean[j] = 0.f; drstd[j] = 0.f;
-        if (p.d_affine) { float2 a = p.d_affine[g * c.N + col]; dsc[j] = a.x; dsh[j] = a.y; }
-        if (p.d_meanrstd) { float2 m = p.d_meanrstd[g * c.N + col]; dmean[j] = m.x; drstd[j] = m.y; }
+        const int tn = p.d_cmod > 0 ? p.d_cmod : c.N, tcol = p.d_cmod > 0 ? col % p.d_cmod : col;
+        if (p.d_affine) { float2 a = p.d_affine[g * tn + tcol]; dsc[j] = a.x; dsh[j] = a.y; }
+        if (p.d_meanrstd) { float2 m = p.d_meanrstd[g * tn + tcol]; dmean[j] = m.x; drstd[j] = m.y; }
     }
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
@@ -183,9 +184,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const GatherC
             for (int q = 0; q < RPP; ++q) { a += red[q * BN + tid].x; b += red[q * BN + tid].y; }
             float2* dst = want_stats ? p.colstats : p.d_red;      // [groups][SLOTS][N]
             if (dst) {
-                const int slot = (blockIdx.x + 5 * blockIdx.z) % MMVAE_STAT_SLOTS;
-                atomicAdd(&dst[(g * MMVAE_STAT_SLOTS + slot) * c.N + n0 + tid].x, a);
-                atomicAdd(&dst[(g * MMVAE_STAT_SLOTS + slot) * c.N + n0 + tid].y, b);
+                const bool cm = !want_stats && p.d_cmod > 0;
+                const int tn = cm ? p.d_cmod : c.N, tcol = cm ? (n0 + tid) % p.d_cmod : n0 + tid;
+                const int slot = (blockIdx.x + 5 * blockIdx.z + (cm ? (n0 + tid) / p.d_cmod : 0)) % MMVAE_STAT_SLOTS;
+                atomicAdd(&dst[(g * MMVAE_STAT_SLOTS + slot) * tn + tcol].x, a);
+                atomicAdd(&dst[(g * MMVAE_STAT_SLOTS + slot) * tn + tcol].y, b);
             }
             if (p.d_colsum) atomicAdd(p.d_colsum + n0 + tid, a);
         }
@@ -815,7 +818,6 @@ int launch_gemm_gather(const GemmParams& p, hipStream_t stream) {
     MMVAE_REQUIRE(c.nclasses >= 1 && c.nclasses <= MMVAE_MAX_CLASSES, "gemm: bad class count %d", c.nclasses);
     MMVAE_REQUIRE(c.C % 8 == 0 && c.Ald % 8 == 0, "gemm: C=%d / Ald=%d must be multiples of 8", c.C, c.Ald);
     MMVAE_REQUIRE(c.groups >= 1 && c.group_n >= 1 && c.N >= 1, "gemm: empty problem");
-    MMVAE_REQUIRE(c.C <= 1024, "gemm: C=%d too large for the LDS affine table", c.C);
     for (int i = 0; i < c.nclasses; ++i) {
         const GatherClass& k = p.cls[i];
         MMVAE_REQUIRE(k.Kpad % BK == 0 && k.Kpad >= k.K && k.K == k.TH * k.TW * c.C, "gemm: class %d K=%d Kpad=%d", i, k.K, k.Kpad);

@@ -10,18 +10,9 @@
 #include "plan_base.h"
 #include <cstring>
 
-struct MnLin {                  // one Linear (+ optional BatchNorm1d + ReLU)
-    long long w_off, b_off;
-    int N, K;                   // out / in features
-    int Kc;                     // operand row width (K padded to 8)
-    int ldo;                    // output row stride (N padded to 8)
-    int bn;                     // BN index or -1
-    int pk_fwd, pk_dgrad, gk;
-};
-
 struct MnistPlan : PlanBase {
     int ldz;
-    MnLin ie[3], id[3], te_lin, td[2];
+    MlpLin ie[3], id[3], te_lin, td[2];
     BnL bn[6];
     long long emb_off;
     struct W {
@@ -40,14 +31,6 @@ struct MnistPlan : PlanBase {
 };
 
 namespace {
-
-void mn_lin(MnistPlan& P, MnLin& L, const std::string& name, int N, int K, int bn, bool need_dgrad) {
-    L.w_off = off(P, name + ".weight"); L.b_off = off(P, name + ".bias");
-    L.N = N; L.K = K; L.Kc = round_up(K, 8); L.ldo = round_up(N, 8); L.bn = bn;
-    L.pk_fwd = P.pk.add(pack_dense(L.w_off, N, K, npad_for(N), round_up(L.Kc, 64), K, 1));
-    L.gk = P.gk.add(pack_dense(L.w_off, N, K, round_up(N, 64), round_up(L.Kc, 64), K, 1));
-    L.pk_dgrad = need_dgrad ? P.pk.add(pack_dense(L.w_off, K, N, npad_for(K), round_up(L.ldo, 64), 1, K)) : -1;
-}
 
 void build(MnistPlan& P) {
     const int D = P.D;
@@ -74,19 +57,15 @@ void build(MnistPlan& P) {
         so += 2 * bnc[i];
     }
     P.emb_off = off(P, "text_encoder.net.0.weight");
-    mn_lin(P, P.ie[0], "image_encoder.net.0", 400, 784, 0, false);
-    mn_lin(P, P.ie[1], "image_encoder.net.3", 200, 400, 1, true);
-    mn_lin(P, P.ie[2], "image_encoder.net.6", 2 * D, 200, -1, true);
-    mn_lin(P, P.id[0], "image_decoder.net.0", 200, D, 2, true);
-    P.id[0].Kc = P.ldz;     // operand is z_bf (column D carries a 1.0 that multiplies a zero weight column)
-    P.pk.d[P.id[0].pk_fwd].Kpad = P.gk.d[P.id[0].gk].Kpad = round_up(P.ldz, 64);
-    mn_lin(P, P.id[1], "image_decoder.net.3", 400, 200, 3, true);
-    mn_lin(P, P.id[2], "image_decoder.net.6", 784, 400, -1, true);
-    mn_lin(P, P.te_lin, "text_encoder.net.3", 2 * D, 50, -1, true);
-    mn_lin(P, P.td[0], "text_decoder.net.0", 10, D, 5, true);
-    P.td[0].Kc = P.ldz;
-    P.pk.d[P.td[0].pk_fwd].Kpad = P.gk.d[P.td[0].gk].Kpad = round_up(P.ldz, 64);
-    mn_lin(P, P.td[1], "text_decoder.net.3", 10, 10, -1, true);
+    mlp_lin_init(P, P.ie[0], "image_encoder.net.0", 400, 784, 0, false);
+    mlp_lin_init(P, P.ie[1], "image_encoder.net.3", 200, 400, 1, true);
+    mlp_lin_init(P, P.ie[2], "image_encoder.net.6", 2 * D, 200, -1, true);
+    mlp_lin_init(P, P.id[0], "image_decoder.net.0", 200, D, 2, true, P.ldz);    // operand is z_bf
+    mlp_lin_init(P, P.id[1], "image_decoder.net.3", 400, 200, 3, true);
+    mlp_lin_init(P, P.id[2], "image_decoder.net.6", 784, 400, -1, true);
+    mlp_lin_init(P, P.te_lin, "text_encoder.net.3", 2 * D, 50, -1, true);
+    mlp_lin_init(P, P.td[0], "text_decoder.net.0", 10, D, 5, true, P.ldz);
+    mlp_lin_init(P, P.td[1], "text_decoder.net.3", 10, 10, -1, true);
 }
 
 void carve(MnistPlan& P, Workspace& ws) {
@@ -118,65 +97,32 @@ void carve(MnistPlan& P, Workspace& ws) {
     w.d_encout = ws.take<bf16>(B * 2 * D); w.d_txtout_bf = ws.take<bf16>(B * 2 * D);
     w.d_ie[0] = ws.take<bf16>(B * 400); w.d_ie[1] = ws.take<bf16>(B * 200); w.d_te = ws.take<bf16>(B * 56);
     P.sk_cnt = ws.take<unsigned>(1024);
-    P.sk_floats = (size_t)128 * 128 * 128;
+    P.sk_floats = (size_t)256 * 128 * 128;
     P.sk_buf = ws.take<float>(P.sk_floats);
 }
 
-// y = A W^T + b  (A: [rows][L.Kc] bf16 activated operand).  groups > 1: BatchNorm groups of rows/groups rows.
-int lin_fwd(MnistPlan& P, const MnLin& L, const bf16* A, int rows, int groups, bf16* out_bf, float* out_f, float2* stats,
-            hipStream_t s) {
-    GatherPlan pl = dense_plan(rows / groups, L.Kc, L.Kc, L.N);
-    GemmParams g = gemm_of(P, pl, &L.pk_fwd, groups, rows / groups);
-    g.c.A = A; g.bias = P.buf.params + L.b_off;
-    g.out_bf = out_bf; g.out_f = out_f; g.ldo = out_f ? L.N : L.ldo; g.colstats = stats;
-    return launch_gemm_gather(g, s);
+BnTabs tabs(MnistPlan& P, int bi) { MnistPlan::W& w = P.w; return BnTabs{w.st[bi], w.red[bi], w.aff[bi], w.mr[bi]}; }
+int lin_fwd(MnistPlan& P, const MlpLin& L, const bf16* A, int rows, int groups, bf16* out_bf, float* out_f, float2* stats, hipStream_t s) {
+    return mlp_fwd(P, L, A, rows, groups, out_bf, out_f, stats, s);
 }
-// dA = dY W with the d-activation of the producer (ReLU after BatchNorm `pbn`) fused; dY: [rows][L.ldo] bf16
-int lin_dgrad(MnistPlan& P, const MnLin& L, const bf16* dY, int rows, int groups, bf16* out_bf, float* out_f, int out_ld,
+int lin_dgrad(MnistPlan& P, const MlpLin& L, const bf16* dY, int rows, int groups, bf16* out_bf, float* out_f, int out_ld,
               const bf16* r_prev, int pbn, hipStream_t s) {
-    MnistPlan::W& w = P.w;
-    GatherPlan pl = dense_plan(rows / groups, L.ldo, L.ldo, L.K);
-    GemmParams g = gemm_of(P, pl, &L.pk_dgrad, groups, rows / groups);
-    g.c.A = dY; g.out_bf = out_bf; g.out_f = out_f; g.ldo = out_ld;
-    if (r_prev) {
-        g.d_r = r_prev; g.d_ld = out_ld; g.d_act = ACT_RELU;
-        g.d_affine = w.aff[pbn]; g.d_meanrstd = w.mr[pbn]; g.d_red = w.red[pbn];
-    }
-    return launch_gemm_gather(g, s);
+    BnTabs t{};
+    if (r_prev) t = tabs(P, pbn);
+    return mlp_dgrad(P, L, dY, rows, groups, out_bf, out_f, out_ld, r_prev, r_prev ? &t : nullptr, ACT_RELU, s);
 }
-int lin_wgrad(MnistPlan& P, const MnLin& L, const bf16* dY, const bf16* A, int rows, hipStream_t s) {
-    GatherPlan pl = dense_plan(rows, L.Kc, L.Kc, L.N);
-    WgradParams g = wgrad_of(P, pl, &L.gk, 1, rows);
-    g.c.A = A; g.P = dY; g.ldp = L.ldo;
-    return wgrad_async(P, g, s);
-}
+int lin_wgrad(MnistPlan& P, const MlpLin& L, const bf16* dY, const bf16* A, int rows, hipStream_t s) { return mlp_wgrad(P, L, dY, A, rows, s); }
 int mn_bn_act(MnistPlan& P, int bi, const bf16* r, bf16* a, int rows, int groups, int ld, int updates, int training, hipStream_t s) {
-    MnistPlan::W& w = P.w;
-    BnActArgs x{};
-    const BnL& b = P.bn[bi];
-    x.r = r; x.a = a; x.rows = rows; x.C = b.C; x.ld = ld; x.rows_per_group = rows / groups; x.G = groups; x.act = ACT_RELU;
-    BnFinalizeArgs& f = x.fin;
-    f.stats = w.st[bi]; f.G = groups; f.C = b.C; f.count = (float)(rows / groups);
-    f.gamma = P.buf.params + b.w_off; f.beta = P.buf.params + b.b_off;
-    f.running_mean = P.buf.bn_stats + b.stat_off; f.running_var = P.buf.bn_stats + b.stat_off + b.C;
-    f.num_batches_tracked = P.buf.bn_nbt + b.idx;
-    f.updates_per_group = updates; f.affine = w.aff[bi]; f.meanrstd = w.mr[bi]; f.eps = BN_EPS; f.momentum = BN_MOM; f.training = training;
-    return launch_bn_act(x, s);
+    return bn1d_act(P, P.bn[bi], tabs(P, bi), r, a, rows, groups, ld, updates, training, ACT_RELU, s);
 }
 int mn_bn_bwd(MnistPlan& P, int bi, bf16* d, const bf16* r, int rows, int groups, int ld, hipStream_t s) {
-    MnistPlan::W& w = P.w;
-    const BnL& b = P.bn[bi];
-    BnBwdApplyArgs x{};
-    x.db = d; x.r = r; x.dr = d; x.rows = rows; x.C = b.C; x.ld = ld; x.rows_per_group = rows / groups; x.G = groups;
-    x.red = w.red[bi]; x.meanrstd = w.mr[bi]; x.gamma = P.buf.params + b.w_off;
-    x.dgamma = P.buf.grads + b.w_off; x.dbeta = P.buf.grads + b.b_off;
-    return launch_bn_bwd_apply(x, s);
+    return bn1d_bwd(P, P.bn[bi], tabs(P, bi), d, r, rows, groups, ld, s);
 }
 
 }  // namespace
 
 MnistPlan* mnist_create(int D, int B) {
-    if (D < 1 || D > 127 || B < 1) { mmvae_set_error("mnist_create: need 1 <= n_latents <= 127 and batch >= 1"); return nullptr; }
+    if (D < 4 || D > 124 || D % 4 != 0 || B < 1) { mmvae_set_error("mnist_create: need n_latents in 4..124, a multiple of 4, and batch >= 1"); return nullptr; }
     MnistPlan* P = new MnistPlan();
     P->D = D; P->B = B;
     build(*P);

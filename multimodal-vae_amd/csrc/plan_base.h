@@ -52,6 +52,7 @@ struct PlanBase {
     std::vector<hipEvent_t> events;
     size_t next_event = 0;
     bool wgrad_forked = false;
+    bool no_splitk = false;         // set while enqueueing on a side stream: the split-K slabs belong to the main chain
     // split-K partial slabs (carved from the caller's workspace)
     float* sk_buf = nullptr; size_t sk_floats = 0; unsigned* sk_cnt = nullptr;
     // generic queries (capi.cpp): BatchNorm layers in state_dict order and the workspace size
@@ -172,9 +173,9 @@ inline GemmParams gemm_of(const PlanBase& P, const GatherPlan& pl, const int* pk
     g.ksplit = 1;
     // (partial tiles go to per-split slabs with plain stores; a finish kernel sums them and runs the epilogue --
     //  float-atomic accumulation of the partial tiles measured slower than the latency chain it removed)
-    if (tiles <= 128 && min_nk >= 6) {
+    if (!P.no_splitk && tiles <= 128 && min_nk >= 6) {
         int ks = min(min(8, min_nk / 3), max(1, 256 / tiles));
-        if (ks > 1 && (size_t)tiles * 128 * bn <= P.sk_floats) { g.ksplit = ks; g.sk_buf = P.sk_buf; g.sk_cnt = P.sk_cnt; }
+        if (ks > 1 && (size_t)tiles * ks * 128 * bn <= P.sk_floats) { g.ksplit = ks; g.sk_buf = P.sk_buf; g.sk_cnt = P.sk_cnt; }
     }
     return g;
 }
@@ -208,6 +209,74 @@ inline int bn_act(PlanBase& P, const BnL& b, const bf16* r, bf16* a, int rows, i
     f.num_batches_tracked = P.buf.bn_nbt + b.idx;
     f.updates_per_group = updates; f.affine = aff; f.meanrstd = mr; f.eps = BN_EPS; f.momentum = BN_MOM; f.training = training;
     return launch_bn_act(x, s);
+}
+
+
+// ------------------------------------------------------------------ MLP layers (Linear [+ BatchNorm1d + activation])
+struct MlpLin {
+    long long w_off, b_off;
+    int N, K;                   // out / in features
+    int Kc;                     // operand row width (K padded to 8)
+    int ldo;                    // output row stride (N padded to 8)
+    int bn;                     // BN index or -1
+    int pk_fwd, pk_dgrad, gk;
+};
+struct BnTabs { float2 *st, *red, *aff, *mr; };   // per-BatchNorm workspace tables: [G][SLOTS][C] x2, [G][C] x2
+
+// Kc > 0 overrides the operand row width (e.g. the z operand [rows][ldz] whose column D holds a 1.0: it meets a
+// zero weight column here)
+inline void mlp_lin_init(PlanBase& P, MlpLin& L, const std::string& name, int N, int K, int bn, bool need_dgrad, int Kc = 0) {
+    L.w_off = off(P, name + ".weight"); L.b_off = off(P, name + ".bias");
+    L.N = N; L.K = K; L.Kc = Kc > 0 ? Kc : round_up(K, 8); L.ldo = round_up(N, 8); L.bn = bn;
+    L.pk_fwd = P.pk.add(pack_dense(L.w_off, N, K, npad_for(N), round_up(L.Kc, 64), K, 1));
+    L.gk = P.gk.add(pack_dense(L.w_off, N, K, round_up(N, 64), round_up(L.Kc, 64), K, 1));
+    L.pk_dgrad = need_dgrad ? P.pk.add(pack_dense(L.w_off, K, N, npad_for(K), round_up(L.ldo, 64), 1, K)) : -1;
+}
+// y = A W^T + b  (A: [rows][L.Kc] bf16 activated operand).  groups > 1: BatchNorm groups of rows/groups rows.
+inline int mlp_fwd(PlanBase& P, const MlpLin& L, const bf16* A, int rows, int groups, bf16* out_bf, float* out_f, float2* stats,
+                   hipStream_t s) {
+    GatherPlan pl = dense_plan(rows / groups, L.Kc, L.Kc, L.N);
+    GemmParams g = gemm_of(P, pl, &L.pk_fwd, groups, rows / groups);
+    g.c.A = A; g.bias = P.buf.params + L.b_off;
+    g.out_bf = out_bf; g.out_f = out_f; g.ldo = out_f ? L.N : L.ldo; g.colstats = stats;
+    return launch_gemm_gather(g, s);
+}
+// dA = dY W with the d-activation of the producer (`act` after the BatchNorm whose tables are `pbn`) fused; dY: [rows][L.ldo]
+inline int mlp_dgrad(PlanBase& P, const MlpLin& L, const bf16* dY, int rows, int groups, bf16* out_bf, float* out_f, int out_ld,
+                     const bf16* r_prev, const BnTabs* pbn, int act, hipStream_t s) {
+    GatherPlan pl = dense_plan(rows / groups, L.ldo, L.ldo, L.K);
+    GemmParams g = gemm_of(P, pl, &L.pk_dgrad, groups, rows / groups);
+    g.c.A = dY; g.out_bf = out_bf; g.out_f = out_f; g.ldo = out_ld;
+    if (r_prev) {
+        g.d_r = r_prev; g.d_ld = out_ld; g.d_act = act;
+        if (pbn) { g.d_affine = pbn->aff; g.d_meanrstd = pbn->mr; g.d_red = pbn->red; }
+    }
+    return launch_gemm_gather(g, s);
+}
+inline int mlp_wgrad(PlanBase& P, const MlpLin& L, const bf16* dY, const bf16* A, int rows, hipStream_t s) {
+    GatherPlan pl = dense_plan(rows, L.Kc, L.Kc, L.N);
+    WgradParams g = wgrad_of(P, pl, &L.gk, 1, rows);
+    g.c.A = A; g.P = dY; g.ldp = L.ldo;
+    return wgrad_async(P, g, s);
+}
+inline int bn1d_act(PlanBase& P, const BnL& b, const BnTabs& t, const bf16* r, bf16* a, int rows, int groups, int ld, int updates,
+                    int training, int act, hipStream_t s) {
+    BnActArgs x{};
+    x.r = r; x.a = a; x.rows = rows; x.C = b.C; x.ld = ld; x.rows_per_group = rows / groups; x.G = groups; x.act = act;
+    BnFinalizeArgs& f = x.fin;
+    f.stats = t.st; f.G = groups; f.C = b.C; f.count = (float)(rows / groups);
+    f.gamma = P.buf.params + b.w_off; f.beta = P.buf.params + b.b_off;
+    f.running_mean = P.buf.bn_stats + b.stat_off; f.running_var = P.buf.bn_stats + b.stat_off + b.C;
+    f.num_batches_tracked = P.buf.bn_nbt + b.idx;
+    f.updates_per_group = updates; f.affine = t.aff; f.meanrstd = t.mr; f.eps = BN_EPS; f.momentum = BN_MOM; f.training = training;
+    return launch_bn_act(x, s);
+}
+inline int bn1d_bwd(PlanBase& P, const BnL& b, const BnTabs& t, bf16* d, const bf16* r, int rows, int groups, int ld, hipStream_t s) {
+    BnBwdApplyArgs x{};
+    x.db = d; x.r = r; x.dr = d; x.rows = rows; x.C = b.C; x.ld = ld; x.rows_per_group = rows / groups; x.G = groups;
+    x.red = t.red; x.meanrstd = t.mr; x.gamma = P.buf.params + b.w_off;
+    x.dgamma = P.buf.grads + b.w_off; x.dbeta = P.buf.grads + b.b_off;
+    return launch_bn_bwd_apply(x, s);
 }
 
 inline hipEvent_t next_ev(PlanBase& P) {

