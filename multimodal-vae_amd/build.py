@@ -7,8 +7,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmmvae_hip.so")
-SOURCES = ["gemm.hip", "elementwise.hip", "text.hip", "thin.hip", "multimnist.hip", "mnist.hip", "celeba.hip", "capi.cpp", "util.cpp"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result", "-ffp-contract=fast"]
+SOURCES = ["gemm.hip", "gemm_direct.hip", "elementwise.hip", "text.hip", "thin.hip", "multimnist.hip", "mnist.hip", "celeba.hip", "capi.cpp", "util.cpp"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result", "-Wno-unused-value", "-ffp-contract=fast"]
 
 
 def _stale(out, deps):
@@ -36,7 +36,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     def run(cmd):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
-            raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), r.stderr[-4000:]))
+            errs = [l for l in r.stderr.splitlines() if "error" in l]
+            raise RuntimeError("hipcc failed: %s\n%s\n%s" % (" ".join(cmd), "\n".join(errs[:20]), r.stderr[-2000:]))
         if verbose and r.stderr:
             sys.stderr.write(r.stderr)
 

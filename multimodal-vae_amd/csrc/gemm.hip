@@ -12,6 +12,7 @@
 //   ds_read_b64_tr_b16 (LDS row stride 160 B makes the 8-row transposed reads conflict-free),
 //   split over row chunks with fp32 atomics into a packed gradient matrix.
 #include "gemm.h"
+#include <cstdlib>
 
 namespace {
 
@@ -828,6 +829,13 @@ int launch_gemm_gather(const GemmParams& p, hipStream_t stream) {
     MMVAE_REQUIRE(c.a_mask == nullptr && c.a_affine == nullptr && c.a_act == ACT_NONE,
                   "gemm: operand transforms are not supported (activations are materialised by bn_act / the epilogue)");
     MMVAE_REQUIRE(p.ksplit <= 1 || p.sk_buf != nullptr, "gemm: split-K needs scratch");
+    {
+        static const bool no_direct = getenv("MMVAE_NO_DIRECT") != nullptr;      // A/B aid
+        if (!no_direct) {
+            const int rc = try_launch_gemm_direct(p, stream);
+            if (rc != 0) return rc < 0 ? rc : MMVAE_OK;
+        }
+    }
     {
         // few 128-row tiles and a long K loop: use the 16-row weight-streaming kernel (rows/16 workgroups)
         int max_tiles = 0, min_k = 1 << 30, max_k = 0;

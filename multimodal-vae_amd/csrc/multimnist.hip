@@ -762,32 +762,51 @@ int mm_text_decoder_bwd(MMPlan* P, void* ws, size_t wsb, const float* z, const u
 
 // ---------------------------------------------------------------- profiling aid: replay one GEMM of the step
 static bool layer_gemm(MMPlan& P, const std::string& name, GemmParams& g) {
+    // the GEMMs exactly as the step launches them (epilogue options included); statistics land in the (dead)
+    // accumulation buffers of the last step
     MMPlan::W& w = P.w;
     const int B = P.B;
     bf16* r[4] = {w.r1, w.r2, w.r3, w.r4};
+    bf16* a[4] = {w.a1, w.a2, w.a3, w.a4};
+    bf16* dre[4] = {w.d1e, w.d2e, w.d3e, w.dr4};
     bf16* q[4] = {w.u, w.q1, w.q2, w.q3};
+    bf16* aq[4] = {w.au, w.aq1, w.aq2, w.aq3};
     bf16* dq[4] = {w.du, w.d1, w.d2, w.d3};
-    for (int l = 1; l < 4; ++l)
+    if (name == "enc_conv1") {
+        GatherPlan pl = dense_plan(B * 625, 16, 16, 32);
+        g = gemm_of(P, pl, P.conv[0].pk_fwd, 1, B * 625);
+        g.c.A = w.patches1; g.out_bf = w.r1; g.ldo = 32; g.out_act_bf = w.a1; g.e_act = ACT_SWISH;
+        return true;
+    }
+    for (int l = 1; l < 4; ++l) {
+        const ConvL& L = P.conv[l];
         if (name == "enc_conv" + std::to_string(l + 1)) {
-            const ConvL& L = P.conv[l];
             g = gemm_of(P, L.fwd, L.pk_fwd, 1, B);
-            bf16* a[4] = {w.a1, w.a2, w.a3, w.a4};
             g.c.A = a[l - 1];
-            g.out_bf = r[l]; g.ldo = L.g.Cout;
+            g.out_bf = r[l]; g.ldo = L.g.Cout; g.colstats = w.st_e[l - 1];
             return true;
         }
+        if (name == "enc_conv" + std::to_string(l + 1) + "_dgrad") {
+            g = gemm_of(P, L.dgrad, L.pk_dgrad, 1, B);
+            g.c.A = dre[l]; g.out_bf = dre[l - 1]; g.ldo = L.g.Cin;
+            g.d_r = r[l - 1]; g.d_ld = L.g.Cin; g.d_act = ACT_SWISH;
+            if (l > 1) { g.d_affine = w.aff_e[l - 2]; g.d_meanrstd = w.mr_e[l - 2]; g.d_red = w.red_e[l - 2]; }
+            return true;
+        }
+    }
     for (int l = 0; l < 3; ++l) {
         const ConvL& L = P.convT[l];
         if (name == "dec_convT" + std::to_string(l + 1)) {
             g = gemm_of(P, L.fwd, L.pk_fwd, 3, B);
-            bf16* aq[4] = {w.au, w.aq1, w.aq2, w.aq3};
             g.c.A = aq[l];
-            g.out_bf = q[l + 1]; g.ldo = L.g.Cout;
+            g.out_bf = q[l + 1]; g.ldo = L.g.Cout; g.colstats = w.st_d[l];
             return true;
         }
         if (name == "dec_convT" + std::to_string(l + 1) + "_dgrad") {
             g = gemm_of(P, L.dgrad, L.pk_dgrad, 2, B);
             g.c.A = dq[l + 1]; g.out_bf = dq[l]; g.ldo = L.g.Cin;
+            g.d_r = q[l]; g.d_ld = L.g.Cin; g.d_act = ACT_SWISH;
+            if (l > 0) { g.d_affine = w.aff_d[l - 1]; g.d_meanrstd = w.mr_d[l - 1]; g.d_red = w.red_d[l - 1]; }
             return true;
         }
     }

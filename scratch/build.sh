@@ -1,3 +1,8 @@
 #!/bin/bash
-cd /root/repo && python multimodal-vae_amd/build.py 2>&1 | grep -E "error|Error" | head -20
-ls -la --time-style=full-iso multimodal-vae_amd/libmmvae_hip.so | awk '{print $6, $7}'
+cd /root/repo
+python multimodal-vae_amd/build.py > /tmp/mmvae_build.log 2>&1
+rc=$?
+grep -E "error|Error" /tmp/mmvae_build.log | head -20
+echo "build rc=$rc"
+ls -la --time-style=full-iso multimodal-vae_amd/libmmvae_hip.so | awk '{print $5, $6, $7}'
+date
