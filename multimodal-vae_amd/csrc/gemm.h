@@ -67,6 +67,7 @@ struct GemmParams {
     const float2* d_meanrstd;  // [groups][N] for xhat=(r-mean)*rstd, with d_red
     float2* d_red;             // [groups][MMVAE_STAT_SLOTS][N] += (sum v, sum v*xhat) or null
     float* d_colsum;           // [N] += sum v over all rows (bias gradient of the producer Linear) or null
+    int npad;                  // rows of the packed weight matrices (gemm_small range-checks weight rows against it)
     int dblk[MMVAE_MAX_CLASSES + 1];   // gemm_direct: prefix sums of workgroups per class (filled by its launcher)
     int d_cmod;                // >0: the BatchNorm tables (d_affine/d_meanrstd/d_red) have d_cmod channels and output
                                // column n belongs to channel n % d_cmod (Linear over a flattened NHWC feature map)
@@ -85,4 +86,7 @@ struct WgradParams {
 int launch_gemm_gather(const GemmParams& p, hipStream_t stream);
 // gemm_direct.hip: narrow-output problems (N <= 64, large pixel grids); 1 = launched, 0 = not applicable, < 0 = error
 int try_launch_gemm_direct(const GemmParams& p, hipStream_t stream);
+// gemm_direct.hip: problems too small to fill the chip with 128-row tiles (classifier / bottleneck layers): one output
+// tile per wave, both operands loaded straight into MFMA fragments, K optionally split over the waves of a workgroup
+int try_launch_gemm_small(const GemmParams& p, hipStream_t stream);
 int launch_wgrad(const WgradParams& p, hipStream_t stream);

@@ -830,8 +830,13 @@ int launch_gemm_gather(const GemmParams& p, hipStream_t stream) {
                   "gemm: operand transforms are not supported (activations are materialised by bn_act / the epilogue)");
     MMVAE_REQUIRE(p.ksplit <= 1 || p.sk_buf != nullptr, "gemm: split-K needs scratch");
     {
-        static const bool no_direct = getenv("MMVAE_NO_DIRECT") != nullptr;      // A/B aid
-        if (!no_direct) {
+        static const bool no_small = getenv("MMVAE_NO_SMALL") != nullptr;        // A/B aids
+        static const bool direct = getenv("MMVAE_DIRECT") != nullptr;
+        if (!no_small) {
+            const int rc = try_launch_gemm_small(p, stream);
+            if (rc != 0) return rc < 0 ? rc : MMVAE_OK;
+        }
+        if (direct) {
             const int rc = try_launch_gemm_direct(p, stream);
             if (rc != 0) return rc < 0 ? rc : MMVAE_OK;
         }

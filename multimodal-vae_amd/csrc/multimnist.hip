@@ -794,6 +794,58 @@ static bool layer_gemm(MMPlan& P, const std::string& name, GemmParams& g) {
             return true;
         }
     }
+    {   // classifier / upsample Linears (2 dropout variants, masks as drawn by the last step)
+        const int rows = 2 * B;
+        const float ms = 1.f / (1.f - DROP_P);
+        if (name == "enc_fc1") {
+            GatherPlan pl = plan_fwdform(2, 2, 1, 1, 256, 2, 2, 1, 0, 400, 1, rows);
+            g = gemm_of(P, pl, &P.fc[0].pk_fwd, 1, rows);
+            g.c.A = w.a4; g.c.a_bcast_n = B; g.bias = P.buf.params + P.fc[0].b_off; g.out_bf = w.y1; g.ldo = 400;
+            g.out_act_bf = w.ay1; g.e_act = ACT_SWISH; g.e_mask = w.m1; g.e_mask_scale = ms;
+            return true;
+        }
+        if (name == "enc_fc2") {
+            GatherPlan pl = dense_plan(rows, 400, 400, 200);
+            g = gemm_of(P, pl, &P.fc[1].pk_fwd, 1, rows);
+            g.c.A = w.ay1; g.bias = P.buf.params + P.fc[1].b_off; g.out_bf = w.y2; g.ldo = 200;
+            g.out_act_bf = w.ay2; g.e_act = ACT_SWISH; g.e_mask = w.m2; g.e_mask_scale = ms;
+            return true;
+        }
+        if (name == "enc_fc3") {
+            GatherPlan pl = dense_plan(rows, 200, 200, 2 * P.D);
+            g = gemm_of(P, pl, &P.fc[2].pk_fwd, 1, rows);
+            g.c.A = w.ay2; g.bias = P.buf.params + P.fc[2].b_off; g.out_f = w.tmp_f32; g.ldo = 2 * P.D;
+            return true;
+        }
+        if (name == "enc_fc3_dgrad") {
+            GatherPlan pd = dense_plan(rows, 2 * P.D, 2 * P.D, 200);
+            g = gemm_of(P, pd, &P.fc[2].pk_dgrad, 1, rows);
+            g.c.A = w.d_encout; g.out_bf = w.dy2; g.ldo = 200;
+            g.d_r = w.y2; g.d_ld = 200; g.d_act = ACT_SWISH; g.d_mask = w.m2; g.d_mask_scale = ms;
+            g.d_colsum = w.tmp_f32;
+            return true;
+        }
+        if (name == "enc_fc2_dgrad") {
+            GatherPlan pd = dense_plan(rows, 200, 200, 400);
+            g = gemm_of(P, pd, &P.fc[1].pk_dgrad, 1, rows);
+            g.c.A = w.dy2; g.out_bf = w.dy1; g.ldo = 400;
+            g.d_r = w.y1; g.d_ld = 400; g.d_act = ACT_SWISH; g.d_mask = w.m1; g.d_mask_scale = ms;
+            g.d_colsum = w.tmp_f32;
+            return true;
+        }
+        if (name == "dec_up") {
+            GatherPlan pl = dense_plan(3 * B, P.ldz, P.ldz, 1024);
+            g = gemm_of(P, pl, &P.up.pk_fwd, 1, 3 * B);
+            g.c.A = w.z_bf; g.out_bf = w.u; g.ldo = 1024; g.out_act_bf = w.au; g.e_act = ACT_SWISH;
+            return true;
+        }
+        if (name == "dec_up_dgrad") {
+            GatherPlan pd = dense_plan(rows, 1024, 1024, P.D);
+            g = gemm_of(P, pd, &P.up.pk_dgrad, 1, rows);
+            g.c.A = w.du; g.out_f = w.tmp_f32; g.ldo = P.D;
+            return true;
+        }
+    }
     for (int l = 0; l < 3; ++l) {
         const ConvL& L = P.convT[l];
         if (name == "dec_convT" + std::to_string(l + 1)) {

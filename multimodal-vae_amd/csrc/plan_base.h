@@ -159,6 +159,7 @@ inline void build_conv(PlanBase& P, ConvL& L, const std::string& wname, ConvGeom
 inline GemmParams gemm_of(const PlanBase& P, const GatherPlan& pl, const int* pk, int groups, int group_n) {
     GemmParams g{};
     g.c = pl.c; g.c.groups = groups; g.c.group_n = group_n;
+    g.npad = P.pk.d[pk[0]].Npad;
     int max_tiles = 0, min_nk = 1 << 30;
     for (int i = 0; i < pl.c.nclasses; ++i) {
         g.cls[i] = pl.cls[i];
