@@ -20,6 +20,8 @@ constexpr int BM = 128;
 constexpr int BK = 64;
 constexpr int LDA = BK + 8;    // bf16 elements per LDS row (144 B)
 
+typedef __attribute__((ext_vector_type(4))) int i32x4g;
+
 struct RowCoord {
     int pix;    // n*AH*AW (gather base) -- or -1 when the row is out of range
     int y, x;   // oy*sy+offy, ox*sx+offx
@@ -240,49 +242,62 @@ __global__ __launch_bounds__(256) void gemm_gather_kernel(const GemmParams p) {
         }
     }
 
+    // Operand A goes through a buffer descriptor: 32-bit byte offsets, and an invalid vector (padding tap, row past
+    // the end, k past K) is an offset of 0xFFFFFFFF that the hardware range check turns into zeros -- no clamped
+    // address, no select, no validity state.  The tap walk of this thread's k-vector is kept incrementally (the two
+    // integer divisions per k-tile of the first version cost more VALU time than the tile's MFMAs for NT <= 4).
+    const int nimg_a = c.a_bcast_n > 0 ? c.a_bcast_n : c.groups * c.group_n;
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16*>(c.A), 0, (int)((size_t)nimg_a * c.AH * c.AW * c.Ald * sizeof(bf16)), 0x00020000);
+    int rbase[4];                                  // byte offset of (tap 0, channel 0) of this thread's rows
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rbase[i] = ((rc[i].pix + rc[i].y * c.AW + rc[i].x) * c.Ald) * (int)sizeof(bf16);
+    int t_ty, t_tx, t_ac;
+    {
+        const int kk = kt0 * BK + kv * 8;
+        const int tap = kk / c.C;
+        t_ac = kk - tap * c.C;
+        t_ty = tap / k.TW;
+        t_tx = tap - t_ty * k.TW;
+    }
     bf16x8 areg[4];
-    unsigned avalid = 0;
-    int a_c = 0;
     constexpr int NB = (BN * 8 + 255) / 256;       // B vectors per thread
     bf16x8 breg[NB];
+    const bf16* bsrc[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int v = (tid + 256 * i) % (BN * 8);
+        bsrc[i] = k.Wp + (size_t)(n0 + (v >> 3)) * k.Kpad + (size_t)kt0 * BK + (v & 7) * 8;
+    }
 
+    // loads tile kt (tiles are visited in order: the tap walk advances by one k-tile per call)
     auto load_tile = [&](int kt) {
-        const int kk = kt * BK + kv * 8;
-        avalid = 0;
-        int ty = 0, tx = 0;
-        a_c = 0;
-        const bool kin = kk < K;
-        if (kin) {
-            int tap = kk / c.C;
-            a_c = kk - tap * c.C;
-            ty = tap / k.TW;
-            tx = tap - ty * k.TW;
-        }
+        const bool kin = kt * BK + kv * 8 < K;
+        const int toff = (((t_ty * c.dy) * c.AW + t_tx * c.dx) * c.Ald + t_ac) * (int)sizeof(bf16);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int y = rc[i].y + ty * c.dy, x = rc[i].x + tx * c.dx;
+            const int y = rc[i].y + t_ty * c.dy, x = rc[i].x + t_tx * c.dx;
             const bool ok = kin && rc[i].pix >= 0 && (unsigned)y < (unsigned)c.AH && (unsigned)x < (unsigned)c.AW;
-            // unconditional load from a clamped in-bounds address (no branch around the load: the loads of a tile
-            // issue back to back and are waited for once); invalid vectors are zeroed when they are stored to LDS
-            const int pix = ok ? rc[i].pix + y * c.AW + x : 0;
-            areg[i] = *reinterpret_cast<const bf16x8*>(c.A + (size_t)pix * c.Ald + a_c);
-            avalid |= (ok ? 1u : 0u) << i;
+            const i32x4g v = __builtin_bit_cast(i32x4g, __builtin_amdgcn_raw_buffer_load_b128(arsrc, ok ? rbase[i] + toff : -1, 0, 0));
+            areg[i] = __builtin_bit_cast(bf16x8, v);
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            int v = (tid + 256 * i) % (BN * 8);
-            const bf16* src = k.Wp + (size_t)(n0 + (v >> 3)) * k.Kpad + kt * BK + (v & 7) * 8;
-            breg[i] = *reinterpret_cast<const bf16x8*>(src);
+            breg[i] = *reinterpret_cast<const bf16x8*>(bsrc[i]);
+            bsrc[i] += BK;
+        }
+        t_ac += BK;
+        while (t_ac >= c.C) {
+            t_ac -= c.C;
+            if (++t_tx == k.TW) { t_tx = 0; ++t_ty; }
         }
     };
     auto store_tile = [&](int buf) {
         bf16* a_dst = As + buf * BM * LDA;
         bf16* b_dst = Bs + buf * BN * LDA;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            bf16x8 v = ((avalid >> i) & 1) ? areg[i] : zero8();
-            *reinterpret_cast<bf16x8*>(a_dst + ((tid >> 3) + 32 * i) * LDA + kv * 8) = v;
-        }
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<bf16x8*>(a_dst + ((tid >> 3) + 32 * i) * LDA + kv * 8) = areg[i];
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             int v = tid + 256 * i;
@@ -829,6 +844,10 @@ int launch_gemm_gather(const GemmParams& p, hipStream_t stream) {
     MMVAE_REQUIRE(c.a_mask == nullptr && c.a_affine == nullptr && c.a_act == ACT_NONE,
                   "gemm: operand transforms are not supported (activations are materialised by bn_act / the epilogue)");
     MMVAE_REQUIRE(p.ksplit <= 1 || p.sk_buf != nullptr, "gemm: split-K needs scratch");
+    {
+        const long long nimg_a = c.a_bcast_n > 0 ? c.a_bcast_n : (long long)c.groups * c.group_n;
+        MMVAE_REQUIRE(nimg_a * c.AH * c.AW * c.Ald * 2 < (1ll << 31), "gemm: gathered operand exceeds 2 GiB (32-bit buffer offsets)");
+    }
     {
         static const bool no_small = getenv("MMVAE_NO_SMALL") != nullptr;        // A/B aids
         static const bool direct = getenv("MMVAE_DIRECT") != nullptr;

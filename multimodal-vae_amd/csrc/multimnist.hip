@@ -846,6 +846,14 @@ static bool layer_gemm(MMPlan& P, const std::string& name, GemmParams& g) {
             return true;
         }
     }
+    if (name == "dec_last_dgrad_gemm") {       // thin last layer's input gradient as a dense GEMM over im2col(dlogit)
+        const ConvL& L = P.convT[3];
+        GatherPlan pl = dense_plan(B * 625, 16, 16, 32);
+        g = gemm_of(P, pl, L.pk_dgrad, 2, B * 625);
+        g.c.A = w.patches4; g.out_bf = w.d3; g.ldo = 32;
+        g.d_r = w.q3; g.d_ld = 32; g.d_act = ACT_SWISH; g.d_affine = w.aff_d[2]; g.d_meanrstd = w.mr_d[2]; g.d_red = w.red_d[2];
+        return true;
+    }
     for (int l = 0; l < 3; ++l) {
         const ConvL& L = P.convT[l];
         if (name == "dec_convT" + std::to_string(l + 1)) {
