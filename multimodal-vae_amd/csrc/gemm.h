@@ -67,6 +67,7 @@ struct GemmParams {
     const float2* d_meanrstd;  // [groups][N] for xhat=(r-mean)*rstd, with d_red
     float2* d_red;             // [groups][MMVAE_STAT_SLOTS][N] += (sum v, sum v*xhat) or null
     float* d_colsum;           // [N] += sum v over all rows (bias gradient of the producer Linear) or null
+    int dbg;                   // experiments (gemm_direct): 1 no A loads, 2 no MFMA, 4 no epilogue
     int npad;                  // rows of the packed weight matrices (gemm_small range-checks weight rows against it)
     int dblk[MMVAE_MAX_CLASSES + 1];   // gemm_direct: prefix sums of workgroups per class (filled by its launcher)
     int d_cmod;                // >0: the BatchNorm tables (d_affine/d_meanrstd/d_red) have d_cmod channels and output

@@ -19,10 +19,18 @@
 //   * workgroups are persistent over row tiles of their class (weights stay resident) and classes get workgroups in
 //     proportion to their work.
 #include "gemm.h"
+#include <cstdlib>
 
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+__device__ __forceinline__ bf16x8 zero8() {
+    bf16x8 z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = (bf16)0.0f;
+    return z;
+}
 
 __device__ __forceinline__ bf16x8 buf_load16(__amdgpu_buffer_rsrc_t rsrc, unsigned off) {
     const i32x4 v = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 0));
@@ -52,6 +60,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_direct_kernel(const GemmParams p
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const GatherCommon& c = p.c;
+    if (p.dbg & 16) return;
     // class of this workgroup (p.dblk = prefix sums of workgroups per class)
     int ci = 0;
 #pragma unroll
@@ -91,6 +100,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_direct_kernel(const GemmParams p
         }
     }
     __syncthreads();
+    if (p.dbg & 8) return;
 
     const int nimg_a = c.a_bcast_n > 0 ? c.a_bcast_n : c.groups * c.group_n;
     const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -173,7 +183,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_direct_kernel(const GemmParams p
             for (int mt = 0; mt < MT; ++mt) {
                 const unsigned bit = kin ? (rs[mt].mtap >> tap) & 1u : 0u;
                 const unsigned off = (unsigned)(rs[mt].a_off + toff) | (bit - 1u);   // invalid -> 0xFFFFFFFF -> zeros
-                a[ks][mt] = buf_load16(arsrc, off);
+                if (p.dbg & 1) { a[ks][mt] = zero8(); a[ks][mt][0] = (bf16)(float)off; }
+                else a[ks][mt] = buf_load16(arsrc, off);
             }
         }
     };
@@ -198,6 +209,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_direct_kernel(const GemmParams p
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 if (ch * 64 + ks * 32 >= K) continue;
+                if (p.dbg & 2) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[mt][0][0] += (float)a[ks][mt][0];
+                    continue;
+                }
                 bf16x8 bfr[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
@@ -227,7 +243,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_direct_kernel(const GemmParams p
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int opix = cur[mt].opix;
-            if (opix < 0) continue;
+            if (opix < 0 || ((p.dbg & 4) && acc[mt][0][0] != 12345.f)) continue;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int n0 = nt * 16 + fq * 4;
@@ -276,12 +292,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_direct_kernel(const GemmParams p
 
 template <int NT, int MT, int NW, bool DGRAD>
 int launch_direct(GemmParams p, const double* work, hipStream_t stream) {
+    static const int dbg = getenv("MMVAE_DIRECT_DBG") ? atoi(getenv("MMVAE_DIRECT_DBG")) : 0;
+    p.dbg = dbg;
     constexpr int BN = NT * 16, BMD = NW * MT * 16;
     const GatherCommon& c = p.c;
     int max_kpad = 0;
     for (int i = 0; i < c.nclasses; ++i) max_kpad = max(max_kpad, p.cls[i].Kpad);
     const size_t lds = (size_t)BN * (max_kpad + 8) * sizeof(bf16) + 32 * sizeof(int) + (DGRAD ? (size_t)c.groups * BN * sizeof(float4) : 0);
-    const int per_cu = (int)max((size_t)1, min((size_t)(MT >= 4 ? 2 : 3), (size_t)(160 * 1024) / (lds + 512)));
+    static const int cap = getenv("MMVAE_DIRECT_WGS") ? atoi(getenv("MMVAE_DIRECT_WGS")) : 4;
+    const int per_cu = (int)max((size_t)1, min((size_t)cap, (size_t)(160 * 1024) / (lds + 512)));
     const int budget = 256 * per_cu;         // resident workgroups of the whole chip
     double total = 0;
     for (int i = 0; i < c.nclasses; ++i) total += work[i];
