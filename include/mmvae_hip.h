@@ -236,6 +236,9 @@ int mmvae_nll_bwd(const long long* target, int rows, int classes, float coef, fl
 int mmvae_normal(float* out, long long n, unsigned long long seed, const long long* step_counter, unsigned stream_id, void* stream);
 int mmvae_keep_mask(uint8_t* out, long long n, float p, unsigned long long seed, const long long* step_counter,
                     unsigned stream_id, void* stream);
+/* Input pipeline: the ToTensor() transform of the reference's loaders (multimnist/train.py:113-121; dataset tensors are
+ * uint8 (N,50,50), multimnist/datasets.py:180-181) done on the device: dst[i] = src[i] / denom (denom = 255, IEEE division: bit-equal to ToTensor) */
+int mmvae_u8_to_f32(const uint8_t* src, long long n, float denom, float* dst, void* stream);
 /* torch.optim.Adam defaults (multimnist/train.py:129,173) on flat buffers; state = device int64[2] {step, ticket},
  * zero-initialised by the caller; grad_scale multiplies g first (1/world_size after a sum all-reduce). */
 int mmvae_adam_step(float* p, const float* g, float* m, float* v, long long n, long long* state, float lr, float beta1,

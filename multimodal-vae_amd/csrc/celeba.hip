@@ -506,6 +506,7 @@ int celeba_step(CelebaPlan* Pp, const CelebaStepIO& io, int training, int do_bac
     MMVAE_TRY(rc);
     MMVAE_TRY(edge(P, T, s));
     MMVAE_TRY(edge(P, P.st_wgrad, s));
+    if (P.st_wgrad2 != P.st_wgrad) MMVAE_TRY(edge(P, P.st_wgrad2, s));
     hipLaunchKernelGGL(sum_slots_kernel, dim3(1), dim3(64), 0, s, w.sums, io.sums);
     MMVAE_TRY(mmvae_check_launch("sum_slots"));
     return unpack(P, s);

@@ -167,3 +167,5 @@ int launch_cast_bf16(const float* x, long long n, bf16* out, hipStream_t s);
 // out[c] += sum_r x[r][c]   (x: fp32 [rows][cols]) -- bias gradients of the last Linear of a stack
 int launch_colsum_f32(const float* x, int rows, int cols, float* out, hipStream_t s);
 int launch_colsum_bf16(const bf16* x, int ld, int rows, int cols, float* out, hipStream_t s);
+// input pipeline (multimnist/datasets.py:45-74 + torchvision ToTensor): uint8 pixels -> fp32 / denom
+int launch_u8_to_f32(const uint8_t* src, long long n, float denom, float* dst, hipStream_t s);

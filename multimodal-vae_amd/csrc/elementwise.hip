@@ -737,6 +737,22 @@ __global__ __launch_bounds__(TPB) void cast_bf16_kernel(const float* x, long lon
         for (long long q = i; q < n; ++q) out[q] = (bf16)x[q];
     }
 }
+// torchvision ToTensor on the device: uint8 pixels -> fp32 / denom (255; a true division, bit-equal to .div(255)), 16 pixels per thread
+__global__ __launch_bounds__(TPB) void u8_to_f32_kernel(const uint8_t* __restrict__ src, long long n, float denom, float* __restrict__ dst) {
+    const long long i = ((long long)blockIdx.x * TPB + threadIdx.x) * 16;
+    if (i + 16 <= n && (reinterpret_cast<uintptr_t>(src + i) & 15) == 0) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(src + i);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = __fdiv_rn((float)((v[q] >> (8 * j)) & 0xffu), denom);
+            *reinterpret_cast<f32x4*>(dst + i + 4 * q) = o;
+        }
+    } else {
+        for (long long q = i; q < n && q < i + 16; ++q) dst[q] = __fdiv_rn((float)src[q], denom);
+    }
+}
 template <typename T>
 __global__ __launch_bounds__(TPB) void colsum_kernel_t(const T* x, int ld, int rows, int cols, float* out) {
     // block = 64 columns x (TPB/64) row lanes; partial sums through LDS
@@ -756,6 +772,12 @@ __global__ __launch_bounds__(TPB) void colsum_kernel_t(const T* x, int ld, int r
 
 }  // namespace
 
+int launch_u8_to_f32(const uint8_t* src, long long n, float denom, float* dst, hipStream_t s) {
+    MMVAE_REQUIRE(src && dst && n >= 0, "u8_to_f32: null argument");
+    if (n == 0) return MMVAE_OK;
+    hipLaunchKernelGGL(u8_to_f32_kernel, dim3((unsigned)((n + 16 * TPB - 1) / (16 * TPB))), dim3(TPB), 0, s, src, n, denom, dst);
+    return mmvae_check_launch("u8_to_f32");
+}
 int launch_pack(const PackDesc* table_dev, const PackDesc* table_host, int nd, const float* params, bf16* packed_bf,
                 float* packed_f32, hipStream_t s) {
     MMVAE_REQUIRE(nd > 0, "pack: empty table");

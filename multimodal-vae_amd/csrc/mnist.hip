@@ -245,6 +245,7 @@ int mnist_step(MnistPlan* Pp, const MnistStepIO& io, int training, int do_backwa
     P.wgrad_forked = false;
     MMVAE_TRY(rc);
     MMVAE_TRY(edge(P, P.st_wgrad, s));
+    if (P.st_wgrad2 != P.st_wgrad) MMVAE_TRY(edge(P, P.st_wgrad2, s));
     return launch_unpack_grads(P.buf.gdesc_dev, P.gk.d.data(), (int)P.gk.d.size(), P.buf.gpk, P.buf.gpk_vec, P.buf.grads, s);
 }
 

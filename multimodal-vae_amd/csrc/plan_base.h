@@ -48,7 +48,8 @@ struct PlanBase {
     bool bound = false;
     // side streams: independent branches of the step (second-modality path, weight gradients) run beside the main
     // chain; forks/joins are event edges, so nothing syncs the host (and a captured HIP graph gets parallel branches)
-    hipStream_t st_text = nullptr, st_wgrad = nullptr;
+    hipStream_t st_text = nullptr, st_wgrad = nullptr, st_wgrad2 = nullptr;
+    int wgrad_rr = 0;               // weight gradients alternate between the two side streams
     std::vector<hipEvent_t> events;
     size_t next_event = 0;
     bool wgrad_forked = false;
@@ -69,8 +70,9 @@ inline int edge(PlanBase& P, hipStream_t from, hipStream_t to);
 inline int wgrad_async(PlanBase& P, const WgradParams& g, hipStream_t s) {
     static const bool serial = getenv("MMVAE_SERIAL") != nullptr;
     if (!P.wgrad_forked || serial) return launch_wgrad(g, s);
-    MMVAE_TRY(edge(P, s, P.st_wgrad));
-    return launch_wgrad(g, P.st_wgrad);
+    hipStream_t w = (P.wgrad_rr++ & 1) ? P.st_wgrad2 : P.st_wgrad;
+    MMVAE_TRY(edge(P, s, w));
+    return launch_wgrad(g, w);
 }
 
 inline void add_param(PlanBase& P, const std::string& name, std::initializer_list<int> shape) {
@@ -299,15 +301,24 @@ inline int edge(PlanBase& P, hipStream_t from, hipStream_t to) {
 }
 inline int ensure_streams(PlanBase& P) {
     if (!P.st_text) {
-        if (hipStreamCreateWithFlags(&P.st_text, hipStreamNonBlocking) != hipSuccess ||
-            hipStreamCreateWithFlags(&P.st_wgrad, hipStreamNonBlocking) != hipSuccess) {
+        // side work (second-modality path, weight gradients) only feeds the optimizer at the end of the step: it runs at
+        // the LOWEST stream priority so that its workgroups fill CUs the main chain leaves idle instead of sharing them
+        int least = 0, greatest = 0;
+        hipDeviceGetStreamPriorityRange(&least, &greatest);
+        static const bool flat = getenv("MMVAE_FLAT_PRIORITY") != nullptr;     // A/B aid
+        const int prio = flat ? 0 : least;
+        if (hipStreamCreateWithPriority(&P.st_text, hipStreamNonBlocking, prio) != hipSuccess ||
+            hipStreamCreateWithPriority(&P.st_wgrad, hipStreamNonBlocking, prio) != hipSuccess ||
+            hipStreamCreateWithPriority(&P.st_wgrad2, hipStreamNonBlocking, prio) != hipSuccess) {
             mmvae_set_error("hipStreamCreate failed");
             return MMVAE_EHIP;
         }
     }
     static const bool one_side = getenv("MMVAE_ONE_SIDE") != nullptr;   // experiment: text path and wgrads share a stream
-    if (one_side) P.st_wgrad = P.st_text;
-    P.next_event = 0;
+    static const bool one_wgrad = getenv("MMVAE_ONE_WGRAD") != nullptr; // experiment: a single weight-gradient stream
+    if (one_side) P.st_wgrad = P.st_wgrad2 = P.st_text;
+    if (one_wgrad) P.st_wgrad2 = P.st_wgrad;
+    P.next_event = 0; P.wgrad_rr = 0;
     return MMVAE_OK;
 }
 

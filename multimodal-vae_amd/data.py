@@ -1,0 +1,122 @@
+"""Input side of the hot path: the reference's on-disk MultiMNIST format and a device-resident batcher.
+
+The reference stores ``(uint8 tensor (N,50,50), list of digit lists)`` in ``<root>/processed/{training,test}.pt``
+(multimnist/datasets.py:180-190) and turns one sample at a time into fp32 with PIL + ``ToTensor`` on the host
+(``:57-71``), the labels with ``charlist_tensor`` (multimnist/utils.py:34-37).  Here the uint8 pixels go to the GPU as
+they are (4x fewer H2D bytes, from pinned memory, on a copy stream, double-buffered) and ``ToTensor`` is the device
+kernel ``mmvae_u8_to_f32``; labels are padded once up front.
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterator, List, Sequence, Tuple
+
+import torch
+
+from ._lib import call, ptr
+from .utils import FILL, charlist_tensor, max_length
+
+PROCESSED = "processed"
+TRAIN_FILE, TEST_FILE = "training.pt", "test.pt"      # multimnist/datasets.py:28-30
+
+
+def save_multimnist(root: str, train: bool, images_u8: torch.Tensor, labels: Sequence[Sequence[int]]) -> str:
+    """Write a split in the reference's format (used by tests and by the synthetic generator)."""
+    assert images_u8.dtype == torch.uint8 and images_u8.dim() == 3
+    d = os.path.join(os.path.expanduser(root), PROCESSED)
+    os.makedirs(d, exist_ok=True)
+    path = os.path.join(d, TRAIN_FILE if train else TEST_FILE)
+    torch.save((images_u8, [list(map(int, l)) for l in labels]), path)
+    return path
+
+
+def load_multimnist(root: str, train: bool) -> Tuple[torch.Tensor, torch.Tensor]:
+    """-> (uint8 (N,H,W), int64 (N,4) FILL-padded) from the reference's file."""
+    path = os.path.join(os.path.expanduser(root), PROCESSED, TRAIN_FILE if train else TEST_FILE)
+    if not os.path.exists(path):
+        raise RuntimeError("Dataset not found at %s (the reference builds it from MNIST: multimnist/datasets.py:163-190)" % path)
+    images, labels = torch.load(path, weights_only=False)
+    text = torch.stack([charlist_tensor(l) for l in labels]) if len(labels) else torch.zeros(0, max_length, dtype=torch.long)
+    return images.contiguous(), text
+
+
+def synthetic_multimnist(n: int, seed: int = 0, size: int = 50) -> Tuple[torch.Tensor, List[List[int]]]:
+    """MultiMNIST-shaped stand-in (no MNIST files in this environment): 0..4 blobs per canvas, one label digit each."""
+    g = torch.Generator().manual_seed(seed)
+    images = torch.zeros(n, size, size, dtype=torch.uint8)
+    labels: List[List[int]] = []
+    for i in range(n):
+        k = int(torch.randint(0, max_length + 1, (1,), generator=g))
+        digs = []
+        for _ in range(k):
+            d = int(torch.randint(0, 10, (1,), generator=g))
+            y, x = (int(v) for v in torch.randint(0, size - 14, (2,), generator=g))
+            w = 6 + d                                   # blob extent encodes the digit
+            patch = (torch.rand(w, w, generator=g) * 255).to(torch.uint8)
+            images[i, y:y + w, x:x + w] = torch.maximum(images[i, y:y + w, x:x + w], patch)
+            digs.append(d)
+        labels.append(digs)
+    return images, labels
+
+
+class DeviceBatcher:
+    """Iterates ``(image fp32 (B,1,H,W), text int64 (B,4))`` device batches over a uint8 dataset.
+
+    Host: one index gather per batch into a pinned uint8 staging buffer (two of them, alternating).  Copy stream: async
+    H2D of B*H*W bytes + B*4 labels.  Compute stream: waits for the copy event, then the u8->f32 kernel.  Batch i+1 is
+    copied while batch i trains.  ``drop_last`` because the fused plans are built for a fixed batch size."""
+
+    def __init__(self, images_u8: torch.Tensor, text: torch.Tensor, batch_size: int, device: torch.device, shuffle: bool = True,
+                 seed: int = 0):
+        assert images_u8.dtype == torch.uint8 and text.dtype == torch.int64 and len(images_u8) == len(text)
+        self.images, self.text, self.B, self.device = images_u8, text, int(batch_size), device
+        self.shuffle, self.seed, self.epoch = shuffle, seed, 0
+        n, h, w = images_u8.shape
+        self.hw = (h, w)
+        self.stage_u8 = [torch.empty(self.B, h, w, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self.stage_tx = [torch.empty(self.B, text.shape[1], dtype=torch.int64).pin_memory() for _ in range(2)]
+        self.dev_u8 = [torch.empty(self.B, h, w, dtype=torch.uint8, device=device) for _ in range(2)]
+        self.dev_tx = [torch.empty(self.B, text.shape[1], dtype=torch.int64, device=device) for _ in range(2)]
+        self.dev_f32 = [torch.empty(self.B, 1, h, w, dtype=torch.float32, device=device) for _ in range(2)]
+        self.copy_stream = torch.cuda.Stream(device=device)
+        self.ready = [torch.cuda.Event() for _ in range(2)]
+        self.consumed = [torch.cuda.Event() for _ in range(2)]
+
+    def __len__(self) -> int:
+        return len(self.images) // self.B
+
+    def _stage(self, slot: int, idx: torch.Tensor) -> None:
+        self.consumed[slot].synchronize()                   # the previous user of this slot finished with the buffers
+        torch.index_select(self.images, 0, idx, out=self.stage_u8[slot])
+        torch.index_select(self.text, 0, idx, out=self.stage_tx[slot])
+        with torch.cuda.stream(self.copy_stream):
+            self.dev_u8[slot].copy_(self.stage_u8[slot], non_blocking=True)
+            self.dev_tx[slot].copy_(self.stage_tx[slot], non_blocking=True)
+            self.ready[slot].record(self.copy_stream)
+
+    def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
+        n = len(self.images)
+        if self.shuffle:
+            g = torch.Generator().manual_seed(self.seed + self.epoch)
+            order = torch.randperm(n, generator=g)
+        else:
+            order = torch.arange(n)
+        self.epoch += 1
+        nb = len(self)
+        if nb == 0:
+            return
+        self._stage(0, order[0:self.B])
+        for b in range(nb):
+            slot = b & 1
+            if b + 1 < nb:
+                self._stage(slot ^ 1, order[(b + 1) * self.B:(b + 2) * self.B])
+            cur = torch.cuda.current_stream(self.device)
+            cur.wait_event(self.ready[slot])
+            import ctypes as C
+            call("mmvae_u8_to_f32", ptr(self.dev_u8[slot]), self.dev_u8[slot].numel(), 255.0, ptr(self.dev_f32[slot]),
+                 C.c_void_p(cur.cuda_stream))
+            yield self.dev_f32[slot], self.dev_tx[slot]
+            self.consumed[slot].record(cur)
+
+
+__all__ = ["save_multimnist", "load_multimnist", "synthetic_multimnist", "DeviceBatcher", "FILL"]
