@@ -72,6 +72,8 @@ typedef struct {
     float* recon_text;                      /* out [3][B][4][12] or NULL */
     float* mu; float* logvar;               /* out [3][B][D] or NULL */
     long long* tokens;                      /* out [3][B][4] or NULL */
+    int pass_skip[3];                       /* 1: pass k absent from this step (multimnist/paired_weak.py:84-117,
+                                             * modal_weak.py:87-117): no loss, no gradient, no BatchNorm running update */
 } mmvae_mm_step_io;
 int mmvae_mm_step(mmvae_mm_t*, const mmvae_mm_step_io*, int training, int do_backward, void* stream);
 
@@ -137,6 +139,7 @@ typedef struct {
     float* recon_image;                     /* out [3][B][784] or NULL */
     float* recon_text;                      /* out [3][B][10] log-probs or NULL */
     float* mu; float* logvar;               /* out [3][B][D] or NULL */
+    int pass_skip[3];                       /* 1: pass k absent from this step (mnist/paired_weak.py, mnist/modal_weak.py) */
 } mmvae_mnist_step_io;
 int mmvae_mnist_step(mmvae_mnist_t*, const mmvae_mnist_step_io*, int training, int do_backward, void* stream);
 /* Granular modules of mnist/model.py (forward + autograd backward); workspace rules as for mmvae_mm_*_fwd/bwd.
@@ -196,6 +199,7 @@ typedef struct {
     float* recon_image;                     /* out [3][B][3][64][64] or NULL */
     float* recon_attrs;                     /* out [3][B][18] or NULL */
     float* mu; float* logvar;               /* out [3][B][D] or NULL */
+    int pass_skip[3];                       /* 1: pass k absent from this step */
 } mmvae_celeba_step_io;
 int mmvae_celeba_step(mmvae_celeba_t*, const mmvae_celeba_step_io*, int training, int do_backward, void* stream);
 /* Granular modules (forward + autograd backward), workspace rules as for mmvae_mm_*_fwd/bwd */

@@ -25,6 +25,7 @@ class StepIO(C.Structure):
         ("seed", C.c_ulonglong),
         ("sums", C.c_void_p), ("recon_image", C.c_void_p), ("recon_text", C.c_void_p),
         ("mu", C.c_void_p), ("logvar", C.c_void_p), ("tokens", C.c_void_p),
+        ("pass_skip", C.c_int * 3),
     ]
 
 
@@ -39,6 +40,7 @@ class MnistStepIO(C.Structure):
         ("seed", C.c_ulonglong),
         ("sums", C.c_void_p), ("recon_image", C.c_void_p), ("recon_text", C.c_void_p),
         ("mu", C.c_void_p), ("logvar", C.c_void_p),
+        ("pass_skip", C.c_int * 3),
     ]
 
 
@@ -54,6 +56,7 @@ class CelebaStepIO(C.Structure):
         ("seed", C.c_ulonglong),
         ("sums", C.c_void_p), ("recon_image", C.c_void_p), ("recon_attrs", C.c_void_p),
         ("mu", C.c_void_p), ("logvar", C.c_void_p),
+        ("pass_skip", C.c_int * 3),
     ]
 
 

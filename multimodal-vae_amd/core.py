@@ -136,16 +136,21 @@ class CelebaState(PlanState):
 class StepOutputs:
     """Lazy view of the loss sums of one fused step (no host sync until a value is read)."""
 
-    def __init__(self, sums: torch.Tensor, bce_div: float, nll_div: float, kl_scale: float, lambda_xy, lambda_yx):
+    def __init__(self, sums: torch.Tensor, bce_div: float, nll_div: float, kl_scale: float, lambda_xy, lambda_yx,
+                 passes=(True, True, True)):
         self.sums, self.bce_div, self.nll_div, self.kl_scale = sums, bce_div, nll_div, kl_scale
         self.lxy, self.lyx = lambda_xy, lambda_yx
+        self.passes = tuple(bool(x) for x in passes)
 
     def losses(self) -> torch.Tensor:
         """loss_1, loss_2, loss_3 of the reference's train() closure as a device tensor [3]."""
         s = self.sums
         lxy = torch.tensor(self.lxy, device=s.device)
         lyx = torch.tensor(self.lyx, device=s.device)
-        return lxy * s[0:3] / self.bce_div + lyx * s[4:7] / self.nll_div + s[8:11] * self.kl_scale
+        out = lxy * s[0:3] / self.bce_div + lyx * s[4:7] / self.nll_div + s[8:11] * self.kl_scale
+        if not all(self.passes):                                   # absent passes (weak supervision) report 0
+            out = out * torch.tensor([float(x) for x in self.passes], device=s.device)
+        return out
 
     def parts(self):
         """(mean BCE, mean NLL, KL sum) per pass"""
@@ -173,6 +178,18 @@ class _FusedStepBase:
 
     def _outputs(self) -> StepOutputs:
         raise NotImplementedError
+
+    def _pass_config(self, io, passes, la, lb, name_a, name_b):
+        """Fills the lambda arrays and pass_skip flags of a step-io struct; returns (passes, lambda_a, lambda_b)."""
+        passes = (True, True, True) if passes is None else tuple(bool(x) for x in passes)
+        assert len(passes) == 3 and any(passes), "at least one of the three passes must be present"
+        la = tuple(float(x) for x in (self._LA if la is None else la))
+        lb = tuple(float(x) for x in (self._LB if lb is None else lb))
+        setattr(io, name_a, (C.c_float * 3)(*la))
+        setattr(io, name_b, (C.c_float * 3)(*lb))
+        io.pass_skip = (C.c_int * 3)(*[0 if x else 1 for x in passes])
+        self._last = (passes, la, lb)
+        return passes, la, lb
 
     def optimizer_step(self) -> None:
         """torch.optim.Adam(lr) semantics on the flat buffers, then refresh the packed bf16 weights."""
@@ -220,13 +237,18 @@ class FusedELBOStep(_FusedStepBase):
         super().__init__(state, batch, lr, betas, eps, seed, world_size, all_reduce)
         self.kl_lambda = kl_lambda
         self.enc_dropout = self.gru_dropout = True
+        self._LA, self._LB = self.LAMBDA_XY, self.LAMBDA_YX
+        self._last = ((True, True, True), self.LAMBDA_XY, self.LAMBDA_YX)
 
     def _outputs(self) -> StepOutputs:
-        return StepOutputs(self.sums, self.B * 2500, self.B * 4, self.kl_lambda / self.B, self.LAMBDA_XY, self.LAMBDA_YX)
+        passes, lxy, lyx = self._last
+        return StepOutputs(self.sums, self.B * 2500, self.B * 4, self.kl_lambda / self.B, lxy, lyx, passes)
 
     def forward_backward(self, image, text, training=True, backward=True, eps=None, enc_mask1=None, enc_mask2=None,
                          gru_keep=None, force_tokens=None, recon_image=None, recon_text=None, mu=None, logvar=None,
-                         tokens=None) -> StepOutputs:
+                         tokens=None, passes=None, lambda_xy=None, lambda_yx=None) -> StepOutputs:
+        """``passes`` = which of (joint, image-only, text-only) exist in this step and ``lambda_xy/lambda_yx`` = their loss
+        weights: the weak-supervision steps of multimnist/paired_weak.py:84-117 and modal_weak.py:87-117."""
         assert image.is_contiguous() and text.is_contiguous() and image.dtype == torch.float32 and text.dtype == torch.int64
         assert image.shape[0] == self.B and text.shape == (self.B, 4)
         io = StepIO()
@@ -239,8 +261,7 @@ class FusedELBOStep(_FusedStepBase):
             setattr(io, k, None if t is None else t.data_ptr())
         io.enc_dropout, io.gru_dropout = int(self.enc_dropout), int(self.gru_dropout)
         io.kl_lambda = self.kl_lambda
-        io.lambda_xy = (C.c_float * 3)(*self.LAMBDA_XY)
-        io.lambda_yx = (C.c_float * 3)(*self.LAMBDA_YX)
+        self._pass_config(io, passes, lambda_xy, lambda_yx, "lambda_xy", "lambda_yx")
         io.seed = self.seed
         io.sums = self.sums.data_ptr()
         # optimizer.zero_grad() (train.py:150) happens inside the step's prologue kernel when backward is requested
@@ -254,11 +275,17 @@ class FusedMnistStep(_FusedStepBase):
     LAMBDA_XY = (1.0, 1.0, 1.0)
     LAMBDA_YX = (1.0, 1.0, 1.0)
 
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self._LA, self._LB = self.LAMBDA_XY, self.LAMBDA_YX
+        self._last = ((True, True, True), self.LAMBDA_XY, self.LAMBDA_YX)
+
     def _outputs(self) -> StepOutputs:
-        return StepOutputs(self.sums, self.B * 784, self.B, 1.0 / (self.B * (784 / 3)), self.LAMBDA_XY, self.LAMBDA_YX)
+        passes, lxy, lyx = self._last
+        return StepOutputs(self.sums, self.B * 784, self.B, 1.0 / (self.B * (784 / 3)), lxy, lyx, passes)
 
     def forward_backward(self, image, label, training=True, backward=True, eps=None, recon_image=None, recon_text=None,
-                         mu=None, logvar=None) -> StepOutputs:
+                         mu=None, logvar=None, passes=None, lambda_xy=None, lambda_yx=None) -> StepOutputs:
         assert image.is_contiguous() and label.is_contiguous() and image.dtype == torch.float32 and label.dtype == torch.int64
         assert image.numel() == self.B * 784 and label.shape == (self.B,)
         io = _lib.MnistStepIO()
@@ -267,8 +294,7 @@ class FusedMnistStep(_FusedStepBase):
         io.image, io.label = image.data_ptr(), label.data_ptr()
         for k, t in (("eps", eps), ("recon_image", recon_image), ("recon_text", recon_text), ("mu", mu), ("logvar", logvar)):
             setattr(io, k, None if t is None else t.data_ptr())
-        io.lambda_xy = (C.c_float * 3)(*self.LAMBDA_XY)
-        io.lambda_yx = (C.c_float * 3)(*self.LAMBDA_YX)
+        self._pass_config(io, passes, lambda_xy, lambda_yx, "lambda_xy", "lambda_yx")
         io.kl_coef = 1.0 / (self.B * (784 / 3))
         io.seed = self.seed
         io.sums = self.sums.data_ptr()
@@ -288,12 +314,15 @@ class FusedCelebaStep(_FusedStepBase):
         super().__init__(state, batch, lr, betas, eps, seed, world_size, all_reduce)
         self.kl_lambda = kl_lambda
         self.enc_dropout = True
+        self._LA, self._LB = self.LAMBDA_X, self.LAMBDA_Y
+        self._last = ((True, True, True), self.LAMBDA_X, self.LAMBDA_Y)
 
     def _outputs(self) -> StepOutputs:
-        return StepOutputs(self.sums, self.B * 3 * 64 * 64, self.B * self.N_ATTRS, self.kl_lambda / self.B, self.LAMBDA_X, self.LAMBDA_Y)
+        passes, lx, ly = self._last
+        return StepOutputs(self.sums, self.B * 3 * 64 * 64, self.B * self.N_ATTRS, self.kl_lambda / self.B, lx, ly, passes)
 
     def forward_backward(self, image, attrs, training=True, backward=True, eps=None, enc_mask=None, recon_image=None,
-                         recon_attrs=None, mu=None, logvar=None) -> StepOutputs:
+                         recon_attrs=None, mu=None, logvar=None, passes=None, lambda_x=None, lambda_y=None) -> StepOutputs:
         assert image.is_contiguous() and attrs.is_contiguous() and image.dtype == torch.float32 and attrs.dtype == torch.float32
         assert image.shape == (self.B, 3, 64, 64) and attrs.shape == (self.B, self.N_ATTRS)
         io = _lib.CelebaStepIO()
@@ -305,8 +334,7 @@ class FusedCelebaStep(_FusedStepBase):
             setattr(io, k, None if t is None else t.data_ptr())
         io.enc_dropout = int(self.enc_dropout)
         io.kl_lambda = self.kl_lambda
-        io.lambda_x = (C.c_float * 3)(*self.LAMBDA_X)
-        io.lambda_y = (C.c_float * 3)(*self.LAMBDA_Y)
+        self._pass_config(io, passes, lambda_x, lambda_y, "lambda_x", "lambda_y")
         io.seed = self.seed
         io.sums = self.sums.data_ptr()
         call("mmvae_celeba_step", self.h, C.byref(io), int(training), int(backward), _stream())

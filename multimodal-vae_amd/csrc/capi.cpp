@@ -168,6 +168,7 @@ int mmvae_mm_step(mmvae_mm_t* p, const mmvae_mm_step_io* io, int training, int d
     for (int k = 0; k < 3; ++k) { s.lambda_xy[k] = io->lambda_xy[k]; s.lambda_yx[k] = io->lambda_yx[k]; }
     s.seed = io->seed; s.sums = io->sums; s.recon_image = io->recon_image; s.recon_text = io->recon_text;
     s.mu = io->mu; s.logvar = io->logvar; s.tokens = io->tokens;
+    for (int k = 0; k < 3; ++k) s.pass_skip[k] = io->pass_skip[k];
     return mm_step_fwd_bwd(p, s, training, do_backward, S(stream));
     API_GUARD_END
 }
@@ -236,6 +237,7 @@ int mmvae_mnist_step(mmvae_mnist_t* p, const mmvae_mnist_step_io* io, int traini
     for (int k = 0; k < 3; ++k) { s.lambda_xy[k] = io->lambda_xy[k]; s.lambda_yx[k] = io->lambda_yx[k]; }
     s.kl_coef = io->kl_coef; s.seed = io->seed; s.sums = io->sums; s.recon_image = io->recon_image; s.recon_text = io->recon_text;
     s.mu = io->mu; s.logvar = io->logvar;
+    for (int k = 0; k < 3; ++k) s.pass_skip[k] = io->pass_skip[k];
     return mnist_step(p, s, training, do_backward, S(stream));
     API_GUARD_END
 }
@@ -286,6 +288,7 @@ int mmvae_celeba_step(mmvae_celeba_t* p, const mmvae_celeba_step_io* io, int tra
     for (int k = 0; k < 3; ++k) { s.lambda_x[k] = io->lambda_x[k]; s.lambda_y[k] = io->lambda_y[k]; }
     s.seed = io->seed; s.sums = io->sums; s.recon_image = io->recon_image; s.recon_attrs = io->recon_attrs;
     s.mu = io->mu; s.logvar = io->logvar;
+    for (int k = 0; k < 3; ++k) s.pass_skip[k] = io->pass_skip[k];
     return celeba_step(p, s, training, do_backward, S(stream));
     API_GUARD_END
 }

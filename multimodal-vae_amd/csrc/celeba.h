@@ -21,6 +21,7 @@ struct CelebaStepIO {
     float* recon_image = nullptr;       // [3][B][3][64][64] or null
     float* recon_attrs = nullptr;       // [3][B][18] or null
     float* mu = nullptr; float* logvar = nullptr;   // [3][B][D] or null
+    int pass_skip[3] = {0, 0, 0};       // 1: pass k is absent from this step
 };
 
 struct CelebaPlan;

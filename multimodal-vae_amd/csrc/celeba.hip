@@ -400,6 +400,7 @@ int use_ws(CelebaPlan* P, void* ws, size_t bytes) {
     Workspace w(ws, bytes);
     carve(*P, w);
     P->wgrad_forked = false;
+    P->dec_skip_mask = 0;
     return MMVAE_OK;
 }
 int unpack(CelebaPlan& P, hipStream_t s) {
@@ -443,15 +444,17 @@ int celeba_step(CelebaPlan* Pp, const CelebaStepIO& io, int training, int do_bac
     if (do_backward && P.nparams % 4 != 0)
         MMVAE_TRY(launch_fill_zero(P.buf.grads + (P.nparams / 4) * 4, (size_t)(P.nparams % 4) * sizeof(float), s));
     const int enc_drop = training && io.enc_dropout;
+    const int sk[3] = {io.pass_skip[0] != 0, io.pass_skip[1] != 0, io.pass_skip[2] != 0};
+    P.dec_skip_mask = (unsigned)(sk[0] | (sk[1] << 1) | (sk[2] << 2));
     MMVAE_TRY(ensure_streams(P));
     static const bool serial = getenv("MMVAE_SERIAL") != nullptr;
     hipStream_t T = serial ? s : P.st_text;
     // ---- encoders: attribute MLP on the side stream, image encoder on main
     MMVAE_TRY(edge(P, s, T));
     P.no_splitk = !serial;
-    MMVAE_TRY(att_enc_fwd(P, io.attrs, training, 2, w.attout, T));
+    MMVAE_TRY(att_enc_fwd(P, io.attrs, training, 2 - sk[0] - sk[2], w.attout, T));
     P.no_splitk = false;
-    MMVAE_TRY(enc_fwd(P, io.image, 2, m1, enc_drop, training, 2, w.encout, s));
+    MMVAE_TRY(enc_fwd(P, io.image, 2, m1, enc_drop, training, 2 - sk[0] - sk[1], w.encout, s));
     MMVAE_TRY(edge(P, T, s));
     Latent3Args la{};
     la.B = B; la.D = D; la.img_out = w.encout; la.txt_out = w.attout; la.eps = eps;
@@ -467,7 +470,7 @@ int celeba_step(CelebaPlan* Pp, const CelebaStepIO& io, int training, int do_bac
         bc.logits = w.alogits; bc.ldl = NA; bc.target = io.attrs; bc.G = 3; bc.B = B; bc.C = NA; bc.H = 1; bc.W = 1;
         bc.recon = io.recon_attrs ? io.recon_attrs : w.arecon; bc.dlogit = do_backward ? w.dalogit : nullptr; bc.loss_sum = w.sums + 4;
         // celeba/train.py:69-73: mean over the batch per attribute, averaged over the 18 attributes
-        for (int k = 0; k < 3; ++k) bc.coef[k] = io.lambda_y[k] / (float)(B * NA);
+        for (int k = 0; k < 3; ++k) bc.coef[k] = sk[k] ? 0.f : io.lambda_y[k] / (float)(B * NA);
         MMVAE_TRY(launch_sigmoid_bce(bc, T));
     }
     if (do_backward) {
@@ -477,7 +480,7 @@ int celeba_step(CelebaPlan* Pp, const CelebaStepIO& io, int training, int do_bac
     P.no_splitk = false;
     ConvTLastFwdArgs last{};
     last.target = io.image; last.recon = io.recon_image; last.dlogit = do_backward ? w.dlogit : nullptr; last.loss_sum = w.sums;
-    for (int k = 0; k < 3; ++k) last.coef[k] = io.lambda_x[k] / (float)(B * NPIX);
+    for (int k = 0; k < 3; ++k) last.coef[k] = sk[k] ? 0.f : io.lambda_x[k] / (float)(B * NPIX);
     MMVAE_TRY(dec_fwd(P, 3, training, &last, s));
     if (!do_backward) {
         MMVAE_TRY(edge(P, T, s));
@@ -487,13 +490,13 @@ int celeba_step(CelebaPlan* Pp, const CelebaStepIO& io, int training, int do_bac
     // =============================== backward ===============================
     P.wgrad_forked = true;
     int img_groups = 3;
-    while (img_groups > 0 && io.lambda_x[img_groups - 1] == 0.f) --img_groups;
+    while (img_groups > 0 && (io.lambda_x[img_groups - 1] == 0.f || sk[img_groups - 1])) --img_groups;
     int rc = MMVAE_OK;
     if (img_groups > 0) rc = dec_bwd(P, w.dlogit, img_groups, w.dz_img, s);
     if (rc == MMVAE_OK) rc = edge(P, T, s);          // dz of the attribute decoder
     Latent3BwdArgs lb{};
     lb.f = la; lb.dz_a = w.dz_img; lb.dz_b = w.dz_att;
-    for (int k = 0; k < 3; ++k) lb.kl_coef[k] = io.kl_lambda / (float)B;
+    for (int k = 0; k < 3; ++k) lb.kl_coef[k] = sk[k] ? 0.f : io.kl_lambda / (float)B;
     lb.d_img_out_bf = w.d_encout; lb.d_img_bias = P.buf.grads + P.fc2.b_off;
     lb.d_txt_out = nullptr; lb.d_txt_out_bf = w.d_attout_bf; lb.d_txt_bias = P.buf.grads + P.ae[1].b_off;
     if (rc == MMVAE_OK) rc = launch_latent3_bwd(lb, s);

@@ -35,6 +35,8 @@ struct BnFinalizeArgs {
     const float* gamma; const float* beta;
     float* running_mean; float* running_var; long long* num_batches_tracked;   // may be null (no update)
     int updates_per_group;   // how many forward calls each group's statistics stand for (encoder dedup: 2)
+    unsigned skip_update_mask;   // bit g set: group g's forward does not exist in the reference step (weak-supervision pass masks):
+                             // its statistics normalise the (unused) rows but do not touch the running buffers
     float2* affine;          // [G][C] (scale, shift):  y = x*scale + shift
     float2* meanrstd;        // [G][C]
     float eps, momentum;

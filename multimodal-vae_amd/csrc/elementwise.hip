@@ -165,13 +165,15 @@ __global__ void bn_finalize_kernel(const BnFinalizeArgs a) {
         a.affine[g * a.C + c] = make_float2(gamma * rstd, beta - mean * gamma * rstd);
         a.meanrstd[g * a.C + c] = make_float2(mean, rstd);
         float unbiased = var * a.count / (a.count - 1.f);
-        for (int u = 0; u < a.updates_per_group; ++u) {
+        const int nu = ((a.skip_update_mask >> g) & 1u) ? 0 : a.updates_per_group;
+        for (int u = 0; u < nu; ++u) {
             rm = (1.f - a.momentum) * rm + a.momentum * mean;
             rv = (1.f - a.momentum) * rv + a.momentum * unbiased;
         }
     }
     if (a.running_mean) { a.running_mean[c] = rm; a.running_var[c] = rv; }
-    if (c == 0 && a.num_batches_tracked) *a.num_batches_tracked += (long long)a.G * a.updates_per_group;
+    if (c == 0 && a.num_batches_tracked)
+        *a.num_batches_tracked += (long long)(a.G - __popc(a.skip_update_mask & ((1u << a.G) - 1u))) * a.updates_per_group;
 }
 
 // ------------------------------------------------------------------ BatchNorm finalize + normalise + activation
@@ -217,14 +219,16 @@ __global__ __launch_bounds__(TPB) void bn_act_kernel(const BnActArgs a) {
                 float mean = s.x / f.count;
                 float var = fmaxf(s.y / f.count - mean * mean, 0.f);
                 float unbiased = var * f.count / (f.count - 1.f);
-                for (int u = 0; u < f.updates_per_group; ++u) {
+                const int nu = ((f.skip_update_mask >> g) & 1u) ? 0 : f.updates_per_group;
+                for (int u = 0; u < nu; ++u) {
                     rm = (1.f - f.momentum) * rm + f.momentum * mean;
                     rv = (1.f - f.momentum) * rv + f.momentum * unbiased;
                 }
             }
             f.running_mean[c] = rm; f.running_var[c] = rv;
         }
-        if (threadIdx.x == 0 && f.num_batches_tracked) *f.num_batches_tracked += (long long)a.G * f.updates_per_group;
+        if (threadIdx.x == 0 && f.num_batches_tracked)
+            *f.num_batches_tracked += (long long)(a.G - __popc(f.skip_update_mask & ((1u << a.G) - 1u))) * f.updates_per_group;
     }
     __syncthreads();
     const int vpr = (a.C + 7) / 8;           // C need not be a multiple of 8: pad columns (< ld) are written as zero

@@ -19,6 +19,7 @@ struct MnistStepIO {
     float* recon_image = nullptr;       // [3][B][784] or null
     float* recon_text = nullptr;        // [3][B][10] log-probs or null
     float* mu = nullptr; float* logvar = nullptr;   // [3][B][D] or null
+    int pass_skip[3] = {0, 0, 0};       // 1: pass k is absent from this step (mnist/paired_weak.py, mnist/modal_weak.py)
 };
 
 struct MnistPlan;

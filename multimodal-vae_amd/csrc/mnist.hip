@@ -157,16 +157,19 @@ int mnist_step(MnistPlan* Pp, const MnistStepIO& io, int training, int do_backwa
         MMVAE_TRY(launch_fill_zero(P.buf.grads + (P.nparams / 4) * 4, (size_t)(P.nparams % 4) * sizeof(float), s));
     MMVAE_TRY(ensure_streams(P));
     P.wgrad_forked = false;
+    const int sk[3] = {io.pass_skip[0] != 0, io.pass_skip[1] != 0, io.pass_skip[2] != 0};
+    P.dec_skip_mask = (unsigned)(sk[0] | (sk[1] << 1) | (sk[2] << 2));
+    const int img_updates = 2 - sk[0] - sk[1], txt_updates = 2 - sk[0] - sk[2];
     // ---- image encoder (mnist/model.py:99-118), once for passes 1 and 2
     MMVAE_TRY(launch_cast_bf16(io.image, (long long)B * 784, w.x_bf, s));
     MMVAE_TRY(lin_fwd(P, P.ie[0], w.x_bf, B, 1, w.r_ie[0], nullptr, training ? w.st[0] : nullptr, s));
-    MMVAE_TRY(mn_bn_act(P, 0, w.r_ie[0], w.a_ie[0], B, 1, 400, 2, training, s));
+    MMVAE_TRY(mn_bn_act(P, 0, w.r_ie[0], w.a_ie[0], B, 1, 400, img_updates, training, s));
     MMVAE_TRY(lin_fwd(P, P.ie[1], w.a_ie[0], B, 1, w.r_ie[1], nullptr, training ? w.st[1] : nullptr, s));
-    MMVAE_TRY(mn_bn_act(P, 1, w.r_ie[1], w.a_ie[1], B, 1, 200, 2, training, s));
+    MMVAE_TRY(mn_bn_act(P, 1, w.r_ie[1], w.a_ie[1], B, 1, 200, img_updates, training, s));
     MMVAE_TRY(lin_fwd(P, P.ie[2], w.a_ie[1], B, 1, nullptr, w.encout, nullptr, s));
     // ---- label encoder (mnist/model.py:136-153), once for passes 1 and 3
     MMVAE_TRY(launch_embed_gather_stats(P.buf.params + P.emb_off, 50, io.label, B, B, B, w.r_te, 56, training ? w.st[4] : nullptr, s));
-    MMVAE_TRY(mn_bn_act(P, 4, w.r_te, w.a_te, B, 1, 56, 2, training, s));
+    MMVAE_TRY(mn_bn_act(P, 4, w.r_te, w.a_te, B, 1, 56, txt_updates, training, s));
     MMVAE_TRY(lin_fwd(P, P.te_lin, w.a_te, B, 1, nullptr, w.txtout, nullptr, s));
     // ---- product of experts, reparametrisation, KL
     Latent3Args la{};
@@ -183,7 +186,7 @@ int mnist_step(MnistPlan* Pp, const MnistStepIO& io, int training, int do_backwa
     BceArgs bc{};
     bc.logits = w.logits; bc.ldl = 1; bc.target = io.image; bc.G = 3; bc.B = B; bc.C = 1; bc.H = 28; bc.W = 28;
     bc.recon = io.recon_image; bc.dlogit = do_backward ? w.dlogit : nullptr; bc.loss_sum = w.sums;
-    for (int k = 0; k < 3; ++k) bc.coef[k] = io.lambda_xy[k] / (float)(B * 784);
+    for (int k = 0; k < 3; ++k) bc.coef[k] = sk[k] ? 0.f : io.lambda_xy[k] / (float)(B * 784);
     MMVAE_TRY(launch_sigmoid_bce(bc, s));
     // ---- label decoder (mnist/model.py:156-170) + NLL
     MMVAE_TRY(lin_fwd(P, P.td[0], w.z_bf, B3, 3, w.r_td, nullptr, training ? w.st[5] : nullptr, s));
@@ -193,7 +196,7 @@ int mnist_step(MnistPlan* Pp, const MnistStepIO& io, int training, int do_backwa
     ls.logits = w.tlogits; ls.rows = B3; ls.classes = 10; ls.words = io.recon_text ? io.recon_text : w.words;
     ls.target = io.label; ls.target_rows = B; ls.rows_per_group = B; ls.nll_sum = w.sums + 4;
     ls.dlogits = do_backward ? w.dtl : nullptr; ls.ld_d = 16;
-    for (int k = 0; k < 3; ++k) ls.coef[k] = io.lambda_yx[k] / (float)B;
+    for (int k = 0; k < 3; ++k) ls.coef[k] = sk[k] ? 0.f : io.lambda_yx[k] / (float)B;
     MMVAE_TRY(launch_logsoftmax_nll(ls, s));
     hipLaunchKernelGGL(sum_slots_kernel, dim3(1), dim3(64), 0, s, w.sums, io.sums);
     MMVAE_TRY(mmvae_check_launch("sum_slots"));
@@ -225,7 +228,7 @@ int mnist_step(MnistPlan* Pp, const MnistStepIO& io, int training, int do_backwa
     // latent block
     Latent3BwdArgs lb{};
     lb.f = la; lb.dz_a = w.dz_img; lb.dz_b = w.dz_txt;
-    for (int k = 0; k < 3; ++k) lb.kl_coef[k] = io.kl_coef;
+    for (int k = 0; k < 3; ++k) lb.kl_coef[k] = sk[k] ? 0.f : io.kl_coef;
     lb.d_img_out_bf = w.d_encout; lb.sum_img_variants = 1; lb.d_img_bias = G + P.ie[2].b_off;
     lb.d_txt_out = nullptr; lb.d_txt_out_bf = w.d_txtout_bf; lb.d_txt_bias = G + P.te_lin.b_off;
     TRY(launch_latent3_bwd(lb, s));
@@ -259,6 +262,7 @@ int mn_use_ws(MnistPlan* P, void* ws, size_t bytes) {
     Workspace w(ws, bytes);
     carve(*P, w);
     P->wgrad_forked = false;
+    P->dec_skip_mask = 0;
     return MMVAE_OK;
 }
 int mn_zero(MnistPlan& P, bool backward, hipStream_t s) {

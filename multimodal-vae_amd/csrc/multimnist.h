@@ -28,6 +28,7 @@ struct MMStepIO {
     float* recon_text = nullptr;        // [3][B][4][12] or null
     float* mu = nullptr; float* logvar = nullptr;   // [3][B][D] or null
     long long* tokens = nullptr;        // [3][B][4] or null
+    int pass_skip[3] = {0, 0, 0};       // 1: pass k is absent from this step (paired_weak.py / modal_weak.py)
 };
 
 struct MMPlan;

@@ -584,6 +584,7 @@ static int use_ws(MMPlan* P, void* ws, size_t bytes) {
     MMVAE_REQUIRE(ws != nullptr && bytes >= P->ws_bytes, "workspace too small (%zu < %zu)", bytes, P->ws_bytes);
     Workspace w(ws, bytes);
     carve(*P, w);
+    P->dec_skip_mask = 0;
     return MMVAE_OK;
 }
 
@@ -624,6 +625,11 @@ int mm_step_fwd_bwd(MMPlan* Pp, const MMStepIO& io, int training, int do_backwar
     if (do_backward && P.nparams % 4 != 0)
         MMVAE_TRY(launch_fill_zero(P.buf.grads + (P.nparams / 4) * 4, (size_t)(P.nparams % 4) * sizeof(float), s));
     const int enc_drop = training && io.enc_dropout;
+    // weak-supervision variants (multimnist/paired_weak.py:84-117, modal_weak.py:87-117): an absent pass contributes no
+    // loss, no gradient and no BatchNorm running-statistics update; its rows are still computed (batched with the others)
+    const int sk[3] = {io.pass_skip[0] != 0, io.pass_skip[1] != 0, io.pass_skip[2] != 0};
+    P.dec_skip_mask = (unsigned)(sk[0] | (sk[1] << 1) | (sk[2] << 2));
+    const int enc_updates = 2 - sk[0] - sk[1];
     MMVAE_TRY(ensure_streams(P));
     static const bool serial = getenv("MMVAE_SERIAL") != nullptr;      // profiling aid: one stream, no overlap
     hipStream_t T = serial ? s : P.st_text;
@@ -633,7 +639,7 @@ int mm_step_fwd_bwd(MMPlan* Pp, const MMStepIO& io, int training, int do_backwar
         TextEncArgs a = te_args(P, io.text, w.txtout, do_backward);
         MMVAE_TRY(launch_text_encoder_fwd(a, T));
     }
-    MMVAE_TRY(enc_fwd(P, io.image, 2, m1, m2, enc_drop, training, 2, w.encout, s));
+    MMVAE_TRY(enc_fwd(P, io.image, 2, m1, m2, enc_drop, training, enc_updates, w.encout, s));
     MMVAE_TRY(edge(P, T, s));
     // ---- product of experts + reparametrisation + KL for the three passes
     Latent3Args la{};
@@ -649,13 +655,13 @@ int mm_step_fwd_bwd(MMPlan* Pp, const MMStepIO& io, int training, int do_backwar
     if (io.recon_text) td.words = io.recon_text;
     if (io.tokens) td.tokens_out = io.tokens;
     td.target = io.text; td.nll_sum = w.sums + 4; td.dwords = do_backward ? w.dwords : nullptr;
-    for (int k = 0; k < 3; ++k) td.nll_coef[k] = io.lambda_yx[k] / (float)(B * TXT_T);
+    for (int k = 0; k < 3; ++k) td.nll_coef[k] = sk[k] ? 0.f : io.lambda_yx[k] / (float)(B * TXT_T);
     MMVAE_TRY(launch_text_decoder_fwd(td, T));
     if (do_backward) MMVAE_TRY(txt_dec_bwd(P, td, w.dwords, w.dz_txt, T));
     // decoders on 3B rows, BatchNorm statistics per pass; last layer fused with sigmoid + BCE (+ gradient)
     ConvTLastFwdArgs last{};
     last.target = io.image; last.recon = io.recon_image; last.dlogit = do_backward ? w.dlogit : nullptr; last.loss_sum = w.sums;
-    for (int k = 0; k < 3; ++k) last.coef[k] = io.lambda_xy[k] / (float)(B * NPIX);
+    for (int k = 0; k < 3; ++k) last.coef[k] = sk[k] ? 0.f : io.lambda_xy[k] / (float)(B * NPIX);
     MMVAE_TRY(dec_fwd(P, 3, training, &last, s));
     if (!do_backward) {
         MMVAE_TRY(edge(P, T, s));
@@ -667,13 +673,13 @@ int mm_step_fwd_bwd(MMPlan* Pp, const MMStepIO& io, int training, int do_backwar
     P.wgrad_forked = true;
     // image decoder: a pass with lambda_xy = 0 (text-only) has exactly zero gradient: only the leading groups run
     int img_groups = 3;
-    while (img_groups > 0 && io.lambda_xy[img_groups - 1] == 0.f) --img_groups;
+    while (img_groups > 0 && (io.lambda_xy[img_groups - 1] == 0.f || sk[img_groups - 1])) --img_groups;
     int rc = MMVAE_OK;
     if (img_groups > 0) rc = dec_bwd(P, w.dlogit, img_groups, w.dz_img, s);
     if (rc == MMVAE_OK) rc = edge(P, T, s);          // dz of the text decoder
     Latent3BwdArgs lb{};
     lb.f = la; lb.dz_a = w.dz_img; lb.dz_b = w.dz_txt;
-    for (int k = 0; k < 3; ++k) lb.kl_coef[k] = io.kl_lambda / (float)B;
+    for (int k = 0; k < 3; ++k) lb.kl_coef[k] = sk[k] ? 0.f : io.kl_lambda / (float)B;
     lb.d_img_out_bf = w.d_encout; lb.d_img_bias = P.buf.grads + P.fc[2].b_off; lb.d_txt_out = w.d_txtout;
     if (rc == MMVAE_OK) rc = launch_latent3_bwd(lb, s);
     if (rc == MMVAE_OK) rc = edge(P, s, T);

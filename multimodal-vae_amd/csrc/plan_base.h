@@ -53,6 +53,8 @@ struct PlanBase {
     std::vector<hipEvent_t> events;
     size_t next_event = 0;
     bool wgrad_forked = false;
+    unsigned dec_skip_mask = 0;     // bit k: pass k is absent from this step (weak-supervision variants): its decoder BatchNorm
+                                    // group leaves the running statistics alone
     bool no_splitk = false;         // set while enqueueing on a side stream: the split-K slabs belong to the main chain
     // split-K partial slabs (carved from the caller's workspace)
     float* sk_buf = nullptr; size_t sk_floats = 0; unsigned* sk_cnt = nullptr;
@@ -211,6 +213,7 @@ inline int bn_act(PlanBase& P, const BnL& b, const bf16* r, bf16* a, int rows, i
     f.running_mean = P.buf.bn_stats + b.stat_off; f.running_var = P.buf.bn_stats + b.stat_off + b.C;
     f.num_batches_tracked = P.buf.bn_nbt + b.idx;
     f.updates_per_group = updates; f.affine = aff; f.meanrstd = mr; f.eps = BN_EPS; f.momentum = BN_MOM; f.training = training;
+    f.skip_update_mask = G > 1 ? P.dec_skip_mask : 0u;
     return launch_bn_act(x, s);
 }
 
@@ -272,6 +275,7 @@ inline int bn1d_act(PlanBase& P, const BnL& b, const BnTabs& t, const bf16* r, b
     f.running_mean = P.buf.bn_stats + b.stat_off; f.running_var = P.buf.bn_stats + b.stat_off + b.C;
     f.num_batches_tracked = P.buf.bn_nbt + b.idx;
     f.updates_per_group = updates; f.affine = t.aff; f.meanrstd = t.mr; f.eps = BN_EPS; f.momentum = BN_MOM; f.training = training;
+    f.skip_update_mask = groups > 1 ? P.dec_skip_mask : 0u;
     return launch_bn_act(x, s);
 }
 inline int bn1d_bwd(PlanBase& P, const BnL& b, const BnTabs& t, bf16* d, const bf16* r, int rows, int groups, int ld, hipStream_t s) {
