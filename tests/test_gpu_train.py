@@ -54,3 +54,45 @@ def test_driver_trains_and_writes_reference_checkpoints(tmp_path):
     opt.load_state_dict(ck["optimizer"])                         # the flat Adam moments load into torch.optim.Adam
     assert len(opt.state_dict()["state"]) == 52
     assert os.path.exists(tmp_path / "res" / "sample_text_epoch3.txt")
+
+
+def test_eval_consumers_match_oracle():
+    """compute_nll (multimnist/loglikelihood.py:20-69) and test_multimnist (multimnist/test.py:23-59) on the HIP modules."""
+    from multimodal_vae_amd import multimnist as M
+    from multimodal_vae_amd.evaluate import compute_nll, test_multimnist
+    from oracle import mmvae_ref as R
+    import torch.nn.functional as F
+    dev = _dev()
+    D, B = 100, 16
+    P = R.formula_params("multimnist", D)
+    vae = M.MultimodalVAE(D, use_cuda=True)
+    vae.load_state_dict({k: v.clone() for k, v in P.items()}, strict=True)
+    vae.cuda()
+    image, text = R.formula_inputs("multimnist", 2 * B)
+    loader = [(image[:B], text[:B]), (image[B:], text[B:])]
+    for kw in (dict(), dict(image_only=True), dict(text_only=True)):
+        torch.manual_seed(11)
+        got = compute_nll(vae, loader, n_samples=2, use_cuda=True, **kw)
+        torch.manual_seed(11)
+        wi, wt = 0.0, 0.0
+        with torch.no_grad():
+            for im, tx in loader:
+                a = None if kw.get("text_only") else im
+                b = None if kw.get("image_only") else tx
+                _, _, mu, lv, _ = R.multimnist_forward(P, a, b, False)
+                sample = torch.randn(2, D)
+                z = sample.unsqueeze(0) * lv.mul(0.5).exp().unsqueeze(1) + mu.unsqueeze(1)
+                for i in range(2):
+                    ri = R.multimnist_image_decoder(P, z[:, i], False)
+                    rt, _ = R.multimnist_text_decoder(P, z[:, i], False)
+                    wi += F.binary_cross_entropy(ri, im, reduction="sum").item() / 2
+                    wt += F.nll_loss(rt.reshape(-1, 12), tx.reshape(-1), reduction="sum").item() / 2
+        np.testing.assert_allclose(got, (wi / (2 * B), wt / (2 * B)), rtol=1e-2)
+    acc = test_multimnist(vae, loader, use_cuda=True, verbose=False)
+    with torch.no_grad():
+        cc = lc = 0.0
+        for im, tx in loader:
+            _, rt, _, _, _ = R.multimnist_forward(P, im, None, False)
+            pred = rt.argmax(2).numpy(); gt = tx.numpy()
+            cc += (pred == gt).sum(); lc += ((pred == 11).sum(1) == (gt == 11).sum(1)).sum()
+    assert abs(acc[0] - cc / (2 * B * 4)) <= 0.05 and abs(acc[1] - lc / (2 * B)) <= 0.1      # bf16 near-ties may flip an argmax
