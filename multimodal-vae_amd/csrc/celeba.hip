@@ -305,13 +305,17 @@ int dec_bwd(CelebaPlan& P, const float* dlogit, int groups, float* dz, hipStream
     bf16* q[4] = {w.u, w.q1, w.q2, w.q3};
     bf16* aq[4] = {w.au, w.aq1, w.aq2, w.aq3};
     bf16* dq[4] = {w.du, w.d1, w.d2, w.d3};
-    {   // last transposed conv (32 -> 3): direct dgrad kernel; wgrad through im2col patches of dlogit
+    {   // last transposed conv (32 -> 3): both gradients go through the im2col patches of dlogit (K = 16 taps x 3):
+        // input gradient = dense GEMM patches x W with d-Swish + BatchNorm-backward sums in the epilogue
         const ConvL& L = P.convT[3];
-        ConvTLastDgradArgs x{};
-        x.dlogit = dlogit; x.w = P.buf.params + L.w_off; x.G = groups; x.B = B; x.IH = 32; x.IW = 32; x.Cin = 32; x.Cout = 3;
-        x.r = w.q3; x.affine = w.aff_d[2]; x.meanrstd = w.mr_d[2]; x.act = ACT_SWISH; x.db = w.d3; x.red = w.red_d[2];
-        MMVAE_TRY(launch_convt_last_dgrad(x, s));
         MMVAE_TRY(launch_im2col_small(dlogit, rows, 3, IMG, IMG, 4, 4, 2, 1, 32, 32, w.patches4, 48, s));
+        {
+            GatherPlan pd = dense_plan(B * 1024, 48, 48, 32);
+            GemmParams d = gemm_of(P, pd, L.pk_dgrad, groups, B * 1024);
+            d.c.A = w.patches4; d.out_bf = w.d3; d.ldo = 32;
+            d.d_r = w.q3; d.d_ld = 32; d.d_act = ACT_SWISH; d.d_affine = w.aff_d[2]; d.d_meanrstd = w.mr_d[2]; d.d_red = w.red_d[2];
+            MMVAE_TRY(launch_gemm_gather(d, s));
+        }
         GatherPlan pl = plan_fwdform(1, 1, 32, 32, 48, 1, 1, 1, 0, 32, groups, B);   // rows (n, iy, ix), dense K=48
         WgradParams g = wgrad_of(P, pl, L.gk, groups, B);
         g.c.A = w.patches4; g.c.AH = 32; g.c.AW = 32; g.c.sy = g.c.sx = 1;

@@ -1,0 +1,5 @@
+#!/bin/bash
+# usage: scratch/prof_model.sh <tag> <model> <batch>   (run on the GPU box via gpurun)
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$1 -- python3 $GRAFT_REPO_ROOT/scratch/time_models.py $2 $3 12 > $GRAFT_REPO_ROOT/gpurun_out/prof_$1.log 2>&1
+cd $GRAFT_REPO_ROOT && python3 scratch/trace_step.py gpurun_out/prof_$1 > gpurun_out/prof_$1.txt
