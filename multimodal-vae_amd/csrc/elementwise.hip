@@ -107,33 +107,46 @@ int table_blocks(const PackDesc* host, int nd) {
 }
 
 // ------------------------------------------------------------------ im2col for thin (1/3-channel) inputs
+// q = r / d, rem = r % d for 0 <= r < 2^23 with inv = 1.0f/d (one correction step each way)
+__device__ __forceinline__ int fast_divmod_ew(int r, int d, float inv, int& rem) {
+    int q = (int)((float)r * inv);
+    rem = r - q * d;
+    if (rem < 0) { --q; rem += d; }
+    else if (rem >= d) { ++q; rem -= d; }
+    return q;
+}
+// one thread = one 8-wide vector of one patch row; 32-bit index math, reciprocal divisions, (tap, channel) walked
+// incrementally over the 8 elements (the first version's 64-bit and per-element integer divisions made this
+// streaming kernel 5x slower than its memory traffic)
 __global__ __launch_bounds__(TPB) void im2col_small_kernel(const float* __restrict__ src, int Nimg, int Cin, int H, int W,
                                                            int KH, int KW, int stride, int pad, int OH, int OW,
                                                            bf16* __restrict__ dst, int ld) {
-    const long long nvec = (long long)Nimg * OH * OW * (ld / 8);
-    const int K = KH * KW * Cin;
-    for (long long v = (long long)blockIdx.x * TPB + threadIdx.x; v < nvec; v += (long long)gridDim.x * TPB) {
-        const int vpr = ld / 8;
-        const long long row = v / vpr;
-        const int k0 = (int)(v - row * vpr) * 8;
-        const int n = (int)(row / (OH * OW));
-        const int rem = (int)(row - (long long)n * OH * OW);
-        const int oy = rem / OW, ox = rem - oy * OW;
+    const int vpr = ld / 8, rpb = TPB / vpr;                 // vectors per row, rows per block
+    const int rl = threadIdx.x / vpr, kv = threadIdx.x - rl * vpr;
+    if (rl >= rpb) return;
+    const int nrows = Nimg * OH * OW;
+    const int K = KH * KW * Cin, pix = OH * OW;
+    const float inv_pix = 1.0f / (float)pix, inv_ow = 1.0f / (float)OW, inv_c = 1.0f / (float)Cin, inv_kw = 1.0f / (float)KW;
+    for (int row = blockIdx.x * rpb + rl; row < nrows; row += gridDim.x * rpb) {
+        int rem, ox;
+        const int n = fast_divmod_ew(row, pix, inv_pix, rem);
+        const int oy = fast_divmod_ew(rem, OW, inv_ow, ox);
+        const int y0 = oy * stride - pad, x0 = ox * stride - pad;
+        const int k0 = kv * 8;
+        int ci, kw;
+        int tap = fast_divmod_ew(k0, Cin, inv_c, ci);
+        int kh = fast_divmod_ew(tap, KW, inv_kw, kw);
+        const float* img = src + (size_t)n * Cin * H * W;
         bf16x8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int k = k0 + j;
             float val = 0.f;
-            if (k < K) {
-                int tap = k / Cin, ci = k - tap * Cin;
-                int kh = tap / KW, kw = tap - kh * KW;
-                int y = oy * stride - pad + kh, x = ox * stride - pad + kw;
-                if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
-                    val = src[((long long)(n * Cin + ci) * H + y) * W + x];
-            }
+            const int y = y0 + kh, x = x0 + kw;
+            if (k0 + j < K && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) val = img[(ci * H + y) * W + x];
             o[j] = (bf16)val;
+            if (++ci == Cin) { ci = 0; if (++kw == KW) { kw = 0; ++kh; } }
         }
-        *reinterpret_cast<bf16x8*>(dst + row * ld + k0) = o;
+        *reinterpret_cast<bf16x8*>(dst + (size_t)row * ld + k0) = o;
     }
 }
 
@@ -796,9 +809,12 @@ int launch_unpack_grads(const PackDesc* table_dev, const PackDesc* table_host, i
 }
 int launch_im2col_small(const float* src, int Nimg, int Cin, int H, int W, int KH, int KW, int stride, int pad, int OH, int OW,
                         bf16* dst, int ld, hipStream_t s) {
-    MMVAE_REQUIRE(ld % 8 == 0 && ld >= KH * KW * Cin, "im2col: ld=%d", ld);
-    long long nvec = (long long)Nimg * OH * OW * (ld / 8);
-    hipLaunchKernelGGL(im2col_small_kernel, dim3(nblocks(nvec)), dim3(TPB), 0, s, src, Nimg, Cin, H, W, KH, KW, stride, pad, OH, OW, dst, ld);
+    MMVAE_REQUIRE(ld % 8 == 0 && ld >= KH * KW * Cin && ld / 8 <= TPB, "im2col: ld=%d", ld);
+    MMVAE_REQUIRE((long long)Nimg * OH * OW < (1 << 23) && (long long)Cin * H * W < (1ll << 31), "im2col: too many rows");
+    const int rpb = TPB / (ld / 8);
+    const long long nrows = (long long)Nimg * OH * OW;
+    hipLaunchKernelGGL(im2col_small_kernel, dim3((unsigned)min((nrows + rpb - 1) / rpb, (long long)65536)), dim3(TPB), 0, s, src, Nimg, Cin, H, W,
+                       KH, KW, stride, pad, OH, OW, dst, ld);
     return mmvae_check_launch("im2col_small");
 }
 int launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t s) {
