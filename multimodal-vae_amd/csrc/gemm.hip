@@ -192,9 +192,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const GatherC
 #pragma unroll
         for (int j = 0; j < 8; ++j) red[(tid / VPR) * BN + cv * 8 + j] = make_float2(s1[j], s2[j]);
         __syncthreads();
+        // two-level column sum: all 256 threads fold RPP rows down to PARTS partial rows, then BN threads finish
+        // (a single pass left BN threads walking RPP = 64 rows for the narrow tiles while 7/8 of the workgroup idled)
+        constexpr int PARTS = 256 / BN;
+        {
+            const int col = tid % BN, part = tid / BN;
+            float a = 0.f, b = 0.f;
+            for (int q = part; q < RPP; q += PARTS) { a += red[q * BN + col].x; b += red[q * BN + col].y; }
+            __syncthreads();
+            red[part * BN + col] = make_float2(a, b);
+        }
+        __syncthreads();
         if (tid < BN && n0 + tid < c.N) {
             float a = 0.f, b = 0.f;
-            for (int q = 0; q < RPP; ++q) { a += red[q * BN + tid].x; b += red[q * BN + tid].y; }
+#pragma unroll
+            for (int q = 0; q < PARTS; ++q) { a += red[q * BN + tid].x; b += red[q * BN + tid].y; }
             float2* dst = want_stats ? p.colstats : p.d_red;      // [groups][SLOTS][N]
             if (dst) {
                 const bool cm = !want_stats && p.d_cmod > 0;

@@ -26,3 +26,14 @@ for _ in range(steps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 print(f"{which} B={B}: {dt*1e3:.3f} ms/step  {1/dt:.1f} steps/s  {B/dt:.0f} samples/s  losses {out.losses().cpu().numpy()}")
+if os.environ.get("TRY_GRAPH"):
+    eng.capture(a, b)
+    for _ in range(5):
+        eng.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = eng.replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    print(f"{which} B={B} GRAPH: {dt*1e3:.3f} ms/step  {1/dt:.1f} steps/s  losses {out.losses().cpu().numpy()}")
