@@ -35,6 +35,14 @@ def synthetic_batch(B, seed):
     return torch.from_numpy(img), torch.from_numpy(text)
 
 
+# HBM-side bytes per launch of the roofline kernel from rocprofv3 PMC passes (one pass per counter, no trace domains):
+# FETCH_SIZE 30,725 KB x 2 (gfx950 tallies the 128-B requests of 16-B/lane reads at 64 B: MI355X_MICROARCH "HBM") +
+# WRITE_SIZE 32,802 KB.  Raw rows: profiles/r01_pmc_{fetch,write}_size_dec_convT3.csv.  Algorithmic bytes of the
+# layer: 14.2 MB activations in + 30.7 MB raw output = 44.9 MB; the extra reads are the 8 per-XCD L2s each fetching
+# their own copy of input rows (the kernel is MFMA/issue-bound, not HBM-bound: 94 MB / 57 us = 1.6 TB/s).
+MEASURED_TRAFFIC = {("dec_convT3", 256, 100): 2 * 30725e3 + 32802e3}
+
+
 def cpu_baseline(B, D, image, text, budget_s=20.0):
     """The oracle (CPU restatement pinned to the reference) timed on this host's cores: reported, not the target."""
     from oracle import mmvae_ref as R
@@ -186,7 +194,8 @@ def main():
         result["roofline"] = {"kernel": "gemm_gather_kernel (%s)" % args.roofline_layer, "bound": "mfma",
                               "achieved": flops / (us * 1e-6) / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                               "frac": flops / (us * 1e-6) / 1e12 / PEAK_BF16_TFLOPS, "us_per_launch": us,
-                              "flops_per_launch": flops, "traffic": None}
+                              "flops_per_launch": flops,
+                              "traffic": MEASURED_TRAFFIC.get((args.roofline_layer, B, D))}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(B, D, image, text)
             result["speedup_vs_cpu_baseline"] = steps_per_s / result["cpu_baseline"]["value"]
