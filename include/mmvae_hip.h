@@ -108,6 +108,11 @@ long long mmvae_mm_debug_offset(mmvae_mm_t*, const char* name);
  * The plan/query/bind/pack functions have the same meaning as their mmvae_mm_* counterparts above. */
 typedef struct MnistPlan mmvae_mnist_t;
 mmvae_mnist_t* mmvae_mnist_create(int n_latents, int batch);      /* MultimodalVAE(n_latents) mnist/model.py:14-20 */
+/* precision 0 (default of mmvae_mnist_create): fp32 operands on fp32 MFMA, fp32 activations -- the reference's own
+ * arithmetic (this model is Linear->BatchNorm1d->ReLU: bf16 operand rounding flips ReLU decisions and moves gradients by
+ * 10-30 %); precision 1: bf16 MFMA operands like the conv models.  -1: environment MMVAE_MNIST_PRECISION=fp32|bf16 */
+mmvae_mnist_t* mmvae_mnist_create_p(int n_latents, int batch, int precision);
+int mmvae_mnist_precision(const mmvae_mnist_t*);
 void mmvae_mnist_destroy(mmvae_mnist_t*);
 long long mmvae_mnist_param_count(const mmvae_mnist_t*);
 int mmvae_mnist_num_params(const mmvae_mnist_t*);

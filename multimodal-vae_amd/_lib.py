@@ -137,6 +137,8 @@ def _plan_api(pfx):
 
 
 SIGNATURES.update(_plan_api("mnist"))
+SIGNATURES["mmvae_mnist_create_p"] = (_P, [_I, _I, _I])
+SIGNATURES["mmvae_mnist_precision"] = (_I, [_P])
 SIGNATURES["mmvae_mnist_step"] = (_I, [_P, C.POINTER(MnistStepIO), _I, _I, _P])
 for _m in ("image_encoder", "image_decoder", "text_encoder", "text_decoder"):
     SIGNATURES["mmvae_mnist_%s_fwd" % _m] = (_I, [_P, _P, _SZ, _P, _I, _P, _P])
@@ -154,7 +156,7 @@ SIGNATURES["mmvae_celeba_attrs_encoder_fwd"] = (_I, [_P, _P, _SZ, _P, _I, _P, _P
 SIGNATURES["mmvae_celeba_attrs_encoder_bwd"] = (_I, [_P, _P, _SZ, _P, _P])
 SIGNATURES["mmvae_celeba_attrs_decoder_fwd"] = (_I, [_P, _P, _SZ, _P, _I, _P, _P])
 SIGNATURES["mmvae_celeba_attrs_decoder_bwd"] = (_I, [_P, _P, _SZ, _P, _P, _P, _P])
-_STATUS = {n for n, (r, _) in SIGNATURES.items() if r is _I and not n.endswith(("_num_params", "_num_bn"))}
+_STATUS = {n for n, (r, _) in SIGNATURES.items() if r is _I and not n.endswith(("_num_params", "_num_bn", "_precision"))}
 
 _lib = None
 _inited = set()

@@ -124,8 +124,19 @@ class MultimnistState(PlanState):
 
 
 class MnistState(PlanState):
-    """mnist/model.py MultimodalVAE"""
+    """mnist/model.py MultimodalVAE.  ``precision``: "fp32" (default: the reference's own arithmetic on fp32 MFMA) or
+    "bf16" (bf16 MFMA operands like the conv models)."""
     API = "mnist"
+
+    def __init__(self, n_latents: int, device: torch.device, precision: str = "fp32"):
+        assert precision in ("fp32", "bf16")
+        self.precision = precision
+        super().__init__(n_latents, device)
+
+    def _c(self, fn, *args):
+        if fn == "create":
+            return call("mmvae_mnist_create_p", *args, 0 if self.precision == "fp32" else 1)
+        return super()._c(fn, *args)
 
 
 class CelebaState(PlanState):

@@ -51,6 +51,7 @@ static int pb_bind(PlanBase* P, float* params, float* grads, float* bn_stats, lo
 }
 static int pb_pack(PlanBase* P, hipStream_t s) {
     MMVAE_TRY(check_bound(P));
+    if (P->no_pack) return MMVAE_OK;
     return launch_pack(P->buf.desc_dev, P->pk.d.data(), (int)P->pk.d.size(), P->buf.params, P->buf.packed, P->buf.packed_vec, s);
 }
 #define MMVAE_PLAN_API(pfx, T, BASE)                                                                                      \
@@ -227,6 +228,10 @@ long long mmvae_mm_debug_offset(mmvae_mm_t* p, const char* name) { return mm_deb
 mmvae_mnist_t* mmvae_mnist_create(int n_latents, int batch) {
     try { return mnist_create(n_latents, batch); } catch (...) { mmvae_set_error("mnist_create failed"); return nullptr; }
 }
+mmvae_mnist_t* mmvae_mnist_create_p(int n_latents, int batch, int precision) {
+    try { return mnist_create(n_latents, batch, precision); } catch (...) { mmvae_set_error("mnist_create failed"); return nullptr; }
+}
+int mmvae_mnist_precision(const mmvae_mnist_t* p) { return mnist_is_f32(p) ? 0 : 1; }
 void mmvae_mnist_destroy(mmvae_mnist_t* p) { mnist_destroy(p); }
 MMVAE_PLAN_API(mnist, mmvae_mnist_t, mnist_b)
 int mmvae_mnist_step(mmvae_mnist_t* p, const mmvae_mnist_step_io* io, int training, int do_backward, void* stream) {

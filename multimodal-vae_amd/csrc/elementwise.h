@@ -120,6 +120,7 @@ struct Latent3BwdArgs {
     int sum_img_variants;    // 1: d_img_out_bf is [B][2D] = pass-1 + pass-2 gradient
     bf16* d_txt_out_bf;      // optional bf16 copy [B][2D]
     float* d_txt_bias;       // optional [2D] += column sums of the text-encoder output gradient
+    float* d_img_out_f32;    // optional fp32 [B][2D] = pass-1 + pass-2 gradient (then d_img_out_bf is not written)
 };
 int launch_latent3_bwd(const Latent3BwdArgs& a, hipStream_t s);
 
@@ -162,6 +163,7 @@ struct LogSoftmaxNllArgs {
     const long long* target; int target_rows; int rows_per_group;
     float* nll_sum;                    // [MMVAE_LOSS_SLOTS][16] column g, or null
     bf16* dlogits; int ld_d;           // or null
+    float* dlogits_f32;                // optional fp32 copy [rows][classes]
     float coef[4];
 };
 int launch_logsoftmax_nll(const LogSoftmaxNllArgs& a, hipStream_t s);

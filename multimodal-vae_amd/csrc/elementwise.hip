@@ -602,7 +602,10 @@ __global__ __launch_bounds__(TPB) void latent3_bwd_kernel(const Latent3BwdArgs a
         poe_bwd_m<1>(m, l, gmu[2], glv[2], dm, dl);
         d_tm += dm[0]; d_tl += dl[0];
     }
-    if (a.sum_img_variants) {       // the two variants share one encoder forward: its backward needs the summed gradient
+    if (a.d_img_out_f32) {          // fp32 model path (MNIST): summed gradient of the two passes that share the encoder
+        a.d_img_out_f32[(size_t)b * D2 + d] = d_im0 + d_im1;
+        a.d_img_out_f32[(size_t)b * D2 + f.D + d] = d_il0 + d_il1;
+    } else if (a.sum_img_variants) {       // the two variants share one encoder forward: its backward needs the summed gradient
         a.d_img_out_bf[(size_t)b * D2 + d] = (bf16)(d_im0 + d_im1);
         a.d_img_out_bf[(size_t)b * D2 + f.D + d] = (bf16)(d_il0 + d_il1);
     } else {
@@ -729,6 +732,7 @@ __global__ __launch_bounds__(TPB) void logsoftmax_nll_kernel(const LogSoftmaxNll
             a.words[(size_t)r * a.classes + c] = lp;
             if (c == tg) nll = -lp;
             if (a.dlogits) a.dlogits[(size_t)r * a.ld_d + c] = (bf16)(a.coef[g & 3] * (expf(lp) - (c == tg ? 1.f : 0.f)));
+            if (a.dlogits_f32) a.dlogits_f32[(size_t)r * a.classes + c] = a.coef[g & 3] * (expf(lp) - (c == tg ? 1.f : 0.f));
         }
         if (a.dlogits)
             for (int c = a.classes; c < a.ld_d; ++c) a.dlogits[(size_t)r * a.ld_d + c] = (bf16)0.f;

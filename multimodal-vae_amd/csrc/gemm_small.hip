@@ -15,6 +15,7 @@
 //     BatchNorm statistics, d-activation with BatchNorm-backward sums, bias-gradient column sums) runs from registers
 //     with 8/16-byte accesses.
 #include "gemm.h"
+#include <cstdlib>
 
 namespace {
 
@@ -328,7 +329,8 @@ int try_launch_gemm_small(const GemmParams& pin, hipStream_t stream) {
     (void)tiles44;
     if (tiles22 > 1536) return 0;                                                  // enough work for the tile kernels
     if (p.d_r == nullptr && (p.d_mask || p.d_red || p.d_colsum)) return 0;
-    const int ks = (int)min((long long)min(4, max(1, min_nch / 2)), max(1ll, 1024 / max(tiles22, 1ll)));
+    static const long long wave_target = getenv("MMVAE_SMALL_WAVES") ? atoll(getenv("MMVAE_SMALL_WAVES")) : 1024;
+    const int ks = (int)min((long long)min(4, max(1, min_nch / 2)), max(1ll, wave_target / max(tiles22, 1ll)));
     const int rc = p.d_r ? launch_small_ks<2, 2, true>(p, ks, stream) : launch_small_ks<2, 2, false>(p, ks, stream);
     return rc == MMVAE_OK ? 1 : rc;
 }

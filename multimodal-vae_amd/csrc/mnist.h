@@ -23,7 +23,8 @@ struct MnistStepIO {
 };
 
 struct MnistPlan;
-MnistPlan* mnist_create(int D, int B);
+MnistPlan* mnist_create(int D, int B, int precision = -1);   // 0 fp32 (default), 1 bf16 operands, -1: env MMVAE_MNIST_PRECISION
+int mnist_is_f32(const MnistPlan*);
 void mnist_destroy(MnistPlan*);
 PlanBase* mnist_base(MnistPlan*);
 int mnist_step(MnistPlan*, const MnistStepIO&, int training, int do_backward, hipStream_t);

@@ -9,26 +9,9 @@
 #include "mnist.h"
 #include "plan_base.h"
 #include <cstring>
+#include <algorithm>
 
-struct MnistPlan : PlanBase {
-    int ldz;
-    MlpLin ie[3], id[3], te_lin, td[2];
-    BnL bn[6];
-    long long emb_off;
-    struct W {
-        char* zero_begin; size_t zero_bytes;
-        float2* st[6]; float2* red[6];
-        float* sums; float* dz_img; float* dz_txt;
-        float2* aff[6]; float2* mr[6];
-        bf16 *x_bf, *r_ie[2], *a_ie[2]; float* encout;
-        bf16 *r_te, *a_te; float* txtout;
-        float *eps, *mu, *logvar, *z_f32; bf16* z_bf;
-        bf16 *r_id[2], *a_id[2]; float *logits, *dlogit; bf16* dlogit_bf;
-        bf16 *r_td, *a_td; float *tlogits, *words; bf16* dtl;
-        bf16 *d_id[2], *d_td;
-        bf16 *d_encout, *d_txtout_bf, *d_ie[2], *d_te;
-    } w;
-};
+#include "mnist_plan.h"
 
 namespace {
 
@@ -121,22 +104,28 @@ int mn_bn_bwd(MnistPlan& P, int bi, bf16* d, const bf16* r, int rows, int groups
 
 }  // namespace
 
-MnistPlan* mnist_create(int D, int B) {
+MnistPlan* mnist_create(int D, int B, int precision) {
     if (D < 4 || D > 124 || D % 4 != 0 || B < 1) { mmvae_set_error("mnist_create: need n_latents in 4..124, a multiple of 4, and batch >= 1"); return nullptr; }
     MnistPlan* P = new MnistPlan();
     P->D = D; P->B = B;
+    // precision: 0 = fp32 (the reference's own arithmetic; default), 1 = bf16 MFMA operands (the engine's conv path)
+    if (precision < 0) { const char* e = getenv("MMVAE_MNIST_PRECISION"); precision = (e && !strcmp(e, "bf16")) ? 1 : 0; }
+    P->f32 = precision == 0;
+    P->no_pack = P->f32;
     build(*P);
     Workspace ws(nullptr, 0);
     carve(*P, ws);
-    P->ws_bytes = ws.used();
+    P->ws_bytes = std::max(ws.used(), mnist_f32_workspace_bytes(*P));
     return P;
 }
 void mnist_destroy(MnistPlan* P) { delete P; }
+int mnist_is_f32(const MnistPlan* P) { return P->f32 ? 1 : 0; }
 PlanBase* mnist_base(MnistPlan* P) { return P; }
 
 int mnist_step(MnistPlan* Pp, const MnistStepIO& io, int training, int do_backward, hipStream_t s) {
     MMVAE_TRY(check_bound(Pp));
     MnistPlan& P = *Pp;
+    if (P.f32) return mnist_f32_step(P, io, training, do_backward, s);
     MMVAE_REQUIRE(io.ws && io.ws_bytes >= P.ws_bytes, "mnist step: workspace too small");
     MMVAE_REQUIRE(io.image && io.label && io.sums, "mnist step: image/label/sums must be given");
     Workspace wsp(io.ws, io.ws_bytes);
@@ -287,6 +276,7 @@ __global__ void logsoftmax_bwd_kernel(const float* d_logp, const float* logp, in
 }  // namespace
 
 int mnist_image_encoder_fwd(MnistPlan* Pp, void* ws, size_t wsb, const float* image, int training, float* out, hipStream_t s) {
+    if (Pp && Pp->f32) { MMVAE_TRY(check_bound(Pp)); return mnist_f32_image_encoder_fwd(*Pp, ws, wsb, image, training, out, s); }
     MMVAE_TRY(mn_use_ws(Pp, ws, wsb));
     MnistPlan& P = *Pp; MnistPlan::W& w = P.w; const int B = P.B;
     MMVAE_TRY(mn_zero(P, false, s));
@@ -298,6 +288,7 @@ int mnist_image_encoder_fwd(MnistPlan* Pp, void* ws, size_t wsb, const float* im
     return lin_fwd(P, P.ie[2], w.a_ie[1], B, 1, nullptr, out, nullptr, s);
 }
 int mnist_image_encoder_bwd(MnistPlan* Pp, void* ws, size_t wsb, const float* d_out, hipStream_t s) {
+    if (Pp && Pp->f32) { MMVAE_TRY(check_bound(Pp)); return mnist_f32_image_encoder_bwd(*Pp, ws, wsb, d_out, s); }
     MMVAE_TRY(mn_use_ws(Pp, ws, wsb));
     MnistPlan& P = *Pp; MnistPlan::W& w = P.w; const int B = P.B, D2 = 2 * P.D;
     MMVAE_TRY(launch_fill_zero(P.buf.gpk, (size_t)P.gk.mat_elems * sizeof(float), s));
@@ -313,6 +304,7 @@ int mnist_image_encoder_bwd(MnistPlan* Pp, void* ws, size_t wsb, const float* d_
     return mn_unpack(P, s);
 }
 int mnist_image_decoder_fwd(MnistPlan* Pp, void* ws, size_t wsb, const float* z, int training, float* recon, hipStream_t s) {
+    if (Pp && Pp->f32) { MMVAE_TRY(check_bound(Pp)); return mnist_f32_image_decoder_fwd(*Pp, ws, wsb, z, training, recon, s); }
     MMVAE_TRY(mn_use_ws(Pp, ws, wsb));
     MnistPlan& P = *Pp; MnistPlan::W& w = P.w; const int B = P.B;
     MMVAE_TRY(mn_zero(P, false, s));
@@ -328,6 +320,7 @@ int mnist_image_decoder_fwd(MnistPlan* Pp, void* ws, size_t wsb, const float* z,
     return mmvae_check_launch("sigmoid");
 }
 int mnist_image_decoder_bwd(MnistPlan* Pp, void* ws, size_t wsb, const float* d_recon, const float* recon, float* dz, hipStream_t s) {
+    if (Pp && Pp->f32) { MMVAE_TRY(check_bound(Pp)); return mnist_f32_image_decoder_bwd(*Pp, ws, wsb, d_recon, recon, dz, s); }
     MMVAE_TRY(mn_use_ws(Pp, ws, wsb));
     MnistPlan& P = *Pp; MnistPlan::W& w = P.w; const int B = P.B;
     MMVAE_TRY(launch_fill_zero(P.buf.gpk, (size_t)P.gk.mat_elems * sizeof(float), s));
@@ -347,6 +340,7 @@ int mnist_image_decoder_bwd(MnistPlan* Pp, void* ws, size_t wsb, const float* d_
     return mn_unpack(P, s);
 }
 int mnist_text_encoder_fwd(MnistPlan* Pp, void* ws, size_t wsb, const long long* label, int training, float* out, hipStream_t s) {
+    if (Pp && Pp->f32) { MMVAE_TRY(check_bound(Pp)); return mnist_f32_text_encoder_fwd(*Pp, ws, wsb, label, training, out, s); }
     MMVAE_TRY(mn_use_ws(Pp, ws, wsb));
     MnistPlan& P = *Pp; MnistPlan::W& w = P.w; const int B = P.B;
     MMVAE_TRY(mn_zero(P, false, s));
@@ -355,6 +349,7 @@ int mnist_text_encoder_fwd(MnistPlan* Pp, void* ws, size_t wsb, const long long*
     return lin_fwd(P, P.te_lin, w.a_te, B, 1, nullptr, out, nullptr, s);
 }
 int mnist_text_encoder_bwd(MnistPlan* Pp, void* ws, size_t wsb, const long long* label, const float* d_out, hipStream_t s) {
+    if (Pp && Pp->f32) { MMVAE_TRY(check_bound(Pp)); return mnist_f32_text_encoder_bwd(*Pp, ws, wsb, label, d_out, s); }
     MMVAE_TRY(mn_use_ws(Pp, ws, wsb));
     MnistPlan& P = *Pp; MnistPlan::W& w = P.w; const int B = P.B, D2 = 2 * P.D;
     MMVAE_TRY(launch_fill_zero(P.buf.gpk, (size_t)P.gk.mat_elems * sizeof(float), s));
@@ -367,6 +362,7 @@ int mnist_text_encoder_bwd(MnistPlan* Pp, void* ws, size_t wsb, const long long*
     return mn_unpack(P, s);
 }
 int mnist_text_decoder_fwd(MnistPlan* Pp, void* ws, size_t wsb, const float* z, int training, float* logp, hipStream_t s) {
+    if (Pp && Pp->f32) { MMVAE_TRY(check_bound(Pp)); return mnist_f32_text_decoder_fwd(*Pp, ws, wsb, z, training, logp, s); }
     MMVAE_TRY(mn_use_ws(Pp, ws, wsb));
     MnistPlan& P = *Pp; MnistPlan::W& w = P.w; const int B = P.B;
     MMVAE_TRY(mn_zero(P, false, s));
@@ -380,6 +376,7 @@ int mnist_text_decoder_fwd(MnistPlan* Pp, void* ws, size_t wsb, const float* z, 
     return launch_logsoftmax_nll(ls, s);
 }
 int mnist_text_decoder_bwd(MnistPlan* Pp, void* ws, size_t wsb, const float* d_logp, const float* logp, float* dz, hipStream_t s) {
+    if (Pp && Pp->f32) { MMVAE_TRY(check_bound(Pp)); return mnist_f32_text_decoder_bwd(*Pp, ws, wsb, d_logp, logp, dz, s); }
     MMVAE_TRY(mn_use_ws(Pp, ws, wsb));
     MnistPlan& P = *Pp; MnistPlan::W& w = P.w; const int B = P.B;
     MMVAE_TRY(launch_fill_zero(P.buf.gpk, (size_t)P.gk.mat_elems * sizeof(float), s));

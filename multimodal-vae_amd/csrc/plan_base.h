@@ -55,6 +55,7 @@ struct PlanBase {
     bool wgrad_forked = false;
     unsigned dec_skip_mask = 0;     // bit k: pass k is absent from this step (weak-supervision variants): its decoder BatchNorm
                                     // group leaves the running statistics alone
+    bool no_pack = false;           // the plan never reads the packed bf16 weights (fp32 MNIST path): pack_weights is a no-op
     bool no_splitk = false;         // set while enqueueing on a side stream: the split-K slabs belong to the main chain
     // split-K partial slabs (carved from the caller's workspace)
     float* sk_buf = nullptr; size_t sk_floats = 0; unsigned* sk_cnt = nullptr;

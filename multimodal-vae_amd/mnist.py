@@ -127,7 +127,8 @@ class TextDecoder(nn.Module):
 class MultimodalVAE(nn.Module):
     """mnist/model.py:14-96"""
 
-    def __init__(self, n_latents=20):
+    def __init__(self, n_latents=20, precision="fp32"):
+        """``precision``: "fp32" (default; the reference's own arithmetic, fp32 MFMA) or "bf16" (bf16 MFMA operands)."""
         super().__init__()
         self.image_encoder = ImageEncoder(n_latents)
         self.image_decoder = ImageDecoder(n_latents)
@@ -135,7 +136,8 @@ class MultimodalVAE(nn.Module):
         self.text_decoder = TextDecoder(n_latents)
         self.experts = ProductOfExperts()
         self.n_latents = n_latents
-        self._core = _Core(self, "", n_latents, MnistState)
+        self.precision = precision
+        self._core = _Core(self, "", n_latents, lambda n, d: MnistState(n, d, precision))
         for m in (self.image_encoder, self.image_decoder, self.text_encoder, self.text_decoder):
             object.__setattr__(m, "_mmvae_root", weakref.ref(self))
 

@@ -93,16 +93,15 @@ def test_mnist_unpaired_step():
     cfg = dict(passes=(False, True, True), lambda_xy=(0.0, 1.0, 0.0), lambda_yx=(0.0, 0.0, 1.0))     # mnist/paired_weak.py unpaired branch
     out = eng.forward_backward(image.reshape(B, 784).to(dev).contiguous(), label.to(dev), True, True,
                                eps=torch.stack(eps).to(dev).contiguous(), **cfg)
-    with R.bf16_contract():
-        ri, rt, mu, lv = R.mnist_forward(P, image, None, True, eps[1])
-        l2 = R.mnist_loss(mu, lv, ri, image, None, None)
-        ri, rt, mu, lv = R.mnist_forward(P, None, label, True, eps[2])
-        l3 = R.mnist_loss(mu, lv, None, None, rt, label)
+    ri, rt, mu, lv = R.mnist_forward(P, image, None, True, eps[1])          # default MNIST plan is fp32: fp32 tolerances
+    l2 = R.mnist_loss(mu, lv, ri, image, None, None)
+    ri, rt, mu, lv = R.mnist_forward(P, None, label, True, eps[2])
+    l3 = R.mnist_loss(mu, lv, None, None, rt, label)
     (l2 + l3).backward()
-    np.testing.assert_allclose(out.losses().cpu().numpy(), np.array([0.0, l2.item(), l3.item()]), rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(out.losses().cpu().numpy(), np.array([0.0, l2.item(), l3.item()]), rtol=2e-5, atol=1e-7)
     g = st.grads.cpu()
     tot = torch.sqrt(sum(p.grad.double().pow(2).sum() for p in P.values() if p.grad is not None)).item()
-    np.testing.assert_allclose(g.double().norm().item(), tot, rtol=3e-2)
+    np.testing.assert_allclose(g.double().norm().item(), tot, rtol=1e-4)
     for i, (pre, c, off) in enumerate(st.bn_table):
         assert int(st.bn_nbt[i].item()) == int(P[pre + ".num_batches_tracked"].item()), pre
-        np.testing.assert_allclose(st.bn_stats[off:off + c].cpu().numpy(), P[pre + ".running_mean"].numpy(), atol=3e-3)
+        np.testing.assert_allclose(st.bn_stats[off:off + c].cpu().numpy(), P[pre + ".running_mean"].numpy(), atol=1e-5)
