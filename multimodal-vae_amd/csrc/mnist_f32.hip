@@ -26,10 +26,15 @@ struct F32Gemm {
     const float* bias;                         // [N] or null
 };
 
-// one wave per 32x32 output tile: 2x2 tiles of v_mfma_f32_16x16x4_f32 (operand fragment: lane -> index lane%16,
-// k = lane/16; accumulator: lane -> column lane%16, rows 4*(lane/16)..+3)
-__global__ __launch_bounds__(64) void gemm_f32_kernel(const F32Gemm g) {
-    const int lane = threadIdx.x, fr = lane & 15, fq = lane >> 4;
+// one 32x32 output tile per workgroup: 2x2 tiles of v_mfma_f32_16x16x4_f32 (operand fragment: lane -> index lane%16,
+// one k per lane group lane/16; accumulator: lane -> column lane%16, rows 4*(lane/16)..+3).  The KS waves of the
+// workgroup split K (these GEMMs have 10..400 tiles: the K chain is the latency) and are summed through LDS.
+// Within a 16-deep step, MFMA s of lane group q consumes k = k0 + 4q + s: an operand that is contiguous along k is
+// then ONE 16-byte load per lane per step, a strided one four 4-byte loads of the same k's.
+template <int KS, bool AV, bool BV>
+__global__ __launch_bounds__(KS * 64) void gemm_f32_kernel(const F32Gemm g) {
+    __shared__ float red[KS > 1 ? (KS - 1) * 16 * 64 : 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
     const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
     f32x4 acc[2][2];
 #pragma unroll
@@ -45,27 +50,65 @@ __global__ __launch_bounds__(64) void gemm_f32_kernel(const F32Gemm g) {
         ap[t] = g.A + (long long)(aok[t] ? m : 0) * g.a_rs;
         bp[t] = g.B + (long long)(bok[t] ? n : 0) * g.b_cs;
     }
-    for (int k0 = 0; k0 < g.K; k0 += 16) {
+    const int nst = (g.K + 15) / 16;
+    const int st0 = nst * wave / KS, st1 = nst * (wave + 1) / KS;
+    for (int st = st0; st < st1; ++st) {
+        const int kb = st * 16 + fq * 4;                   // this lane group's 4 consecutive k
         float av[4][2], bv[4][2];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int k = k0 + s * 4 + fq;
-            const bool kin = k < g.K;
-            const long long kk = kin ? k : 0;
+        for (int t = 0; t < 2; ++t) {
+            if (AV && kb + 4 <= g.K) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(ap[t] + kb);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const float a = ap[t][kk * g.a_cs], b = bp[t][kk * g.b_rs];
-                av[s][t] = (kin && aok[t]) ? a : 0.f;
-                bv[s][t] = (kin && bok[t]) ? b : 0.f;
+                for (int q = 0; q < 4; ++q) av[q][t] = aok[t] ? v[q] : 0.f;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool kin = kb + q < g.K;
+                    const float v = ap[t][(long long)(kin ? kb + q : 0) * g.a_cs];
+                    av[q][t] = (kin && aok[t]) ? v : 0.f;
+                }
+            }
+            if (BV && kb + 4 <= g.K) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(bp[t] + kb);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bv[q][t] = bok[t] ? v[q] : 0.f;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool kin = kb + q < g.K;
+                    const float v = bp[t][(long long)(kin ? kb + q : 0) * g.b_rs];
+                    bv[q][t] = (kin && bok[t]) ? v : 0.f;
+                }
             }
         }
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][i], bv[s][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][i], bv[q][j], acc[i][j], 0, 0, 0);
+    }
+    if (KS > 1) {
+        if (wave > 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[((wave - 1) * 16 + (i * 2 + j) * 4 + r) * 64 + lane] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 0; w < KS - 1; ++w)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] += red[(w * 16 + (i * 2 + j) * 4 + r) * 64 + lane];
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -81,10 +124,24 @@ __global__ __launch_bounds__(64) void gemm_f32_kernel(const F32Gemm g) {
             }
         }
 }
+template <int KS>
+int gemm_f32_ks(const F32Gemm& g, bool av, bool bv, hipStream_t s) {
+    dim3 grid(ceil_div(g.M, 32), ceil_div(g.N, 32)), block(KS * 64);
+    if (av && bv) hipLaunchKernelGGL((gemm_f32_kernel<KS, true, true>), grid, block, 0, s, g);
+    else if (av) hipLaunchKernelGGL((gemm_f32_kernel<KS, true, false>), grid, block, 0, s, g);
+    else if (bv) hipLaunchKernelGGL((gemm_f32_kernel<KS, false, true>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<KS, false, false>), grid, block, 0, s, g);
+    return mmvae_check_launch("gemm_f32");
+}
 int gemm_f32(const F32Gemm& g, hipStream_t s) {
     MMVAE_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.A && g.B && g.C, "gemm_f32: bad arguments");
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3(ceil_div(g.M, 32), ceil_div(g.N, 32)), dim3(64), 0, s, g);
-    return mmvae_check_launch("gemm_f32");
+    // 16-byte loads along k need a unit k stride, rows that start 16-byte aligned
+    const bool av = g.a_cs == 1 && g.a_rs % 4 == 0 && (reinterpret_cast<uintptr_t>(g.A) & 15) == 0;
+    const bool bv = g.b_rs == 1 && g.b_cs % 4 == 0 && (reinterpret_cast<uintptr_t>(g.B) & 15) == 0;
+    const int tiles = ceil_div(g.M, 32) * ceil_div(g.N, 32), nst = ceil_div(g.K, 16);
+    if (tiles <= 256 && nst >= 8) return gemm_f32_ks<4>(g, av, bv, s);
+    if (tiles <= 512 && nst >= 4) return gemm_f32_ks<2>(g, av, bv, s);
+    return gemm_f32_ks<1>(g, av, bv, s);
 }
 // y[rows][N] = x[rows][K] W[N][K]^T + b
 int lin_fwd32(MnistPlan& P, const MlpLin& L, const float* x, int ldx, int rows, float* y, hipStream_t s) {
@@ -117,22 +174,36 @@ struct Bn32 {
     float2* mr;                          // [G][C] (mean, rstd) out
     int updates; unsigned skip_mask; int training; int relu;
 };
-__global__ __launch_bounds__(64) void bn1d_fwd32_kernel(const Bn32 a) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= a.C) return;
-    const float gamma = a.gamma[c], beta = a.beta[c];
-    float rm = a.running_mean[c], rv = a.running_var[c];
+// workgroup = 64 channels x 16 row lanes (1024 threads): every pass over a group's rows is rpg/16 coalesced steps
+constexpr int BN_RL = 16;
+__device__ __forceinline__ float bn_block_sum(float v, float (*sh)[64], int cl, int rl) {
+    __syncthreads();
+    sh[rl][cl] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < BN_RL; ++q) s += sh[q][cl];
+    return s;
+}
+__global__ __launch_bounds__(64 * BN_RL) void bn1d_fwd32_kernel(const Bn32 a) {
+    __shared__ float sh[BN_RL][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const bool cok = c < a.C;
+    const int cc = cok ? c : 0;
+    const float gamma = a.gamma[cc], beta = a.beta[cc];
+    float rm = a.running_mean[cc], rv = a.running_var[cc];
     for (int g = 0; g < a.G; ++g) {
-        const float* x = a.x + (size_t)g * a.rpg * a.C + c;
-        float* y = a.y + (size_t)g * a.rpg * a.C + c;
+        const float* x = a.x + (size_t)g * a.rpg * a.C + cc;
+        float* y = a.y + (size_t)g * a.rpg * a.C + cc;
         float mean, rstd;
         if (a.training) {
             float s = 0.f;
-            for (int r = 0; r < a.rpg; ++r) s += x[(size_t)r * a.C];
-            mean = s / (float)a.rpg;
+            for (int r = rl; r < a.rpg; r += BN_RL) s += x[(size_t)r * a.C];
+            mean = bn_block_sum(s, sh, cl, rl) / (float)a.rpg;
             float v = 0.f;
-            for (int r = 0; r < a.rpg; ++r) { const float d = x[(size_t)r * a.C] - mean; v += d * d; }
-            const float var = v / (float)a.rpg;                      // biased, like nn.BatchNorm1d's normalisation
+            for (int r = rl; r < a.rpg; r += BN_RL) { const float d = x[(size_t)r * a.C] - mean; v += d * d; }
+            const float var = bn_block_sum(v, sh, cl, rl) / (float)a.rpg;       // biased, like nn.BatchNorm1d's normalisation
             rstd = rsqrtf(var + BN_EPS);
             const int nu = ((a.skip_mask >> g) & 1u) ? 0 : a.updates;
             const float unbiased = var * (float)a.rpg / (float)(a.rpg - 1);
@@ -143,14 +214,15 @@ __global__ __launch_bounds__(64) void bn1d_fwd32_kernel(const Bn32 a) {
         } else {
             mean = rm; rstd = rsqrtf(rv + BN_EPS);
         }
-        a.mr[g * a.C + c] = make_float2(mean, rstd);
-        for (int r = 0; r < a.rpg; ++r) {
-            float o = (x[(size_t)r * a.C] - mean) * rstd * gamma + beta;
-            if (a.relu) o = fmaxf(o, 0.f);
-            y[(size_t)r * a.C] = o;
-        }
+        if (cok && rl == 0) a.mr[g * a.C + c] = make_float2(mean, rstd);
+        if (cok)
+            for (int r = rl; r < a.rpg; r += BN_RL) {
+                float o = (x[(size_t)r * a.C] - mean) * rstd * gamma + beta;
+                if (a.relu) o = fmaxf(o, 0.f);
+                y[(size_t)r * a.C] = o;
+            }
     }
-    if (a.training) {
+    if (a.training && cok && rl == 0) {
         a.running_mean[c] = rm; a.running_var[c] = rv;
         if (c == 0) *a.nbt += (long long)(a.G - __popc(a.skip_mask & ((1u << a.G) - 1u))) * a.updates;
     }
@@ -163,7 +235,7 @@ int bn_fwd32(MnistPlan& P, int bi, const float* x, float* y, int rows, int group
     a.gamma = P.buf.params + b.w_off; a.beta = P.buf.params + b.b_off;
     a.running_mean = P.buf.bn_stats + b.stat_off; a.running_var = P.buf.bn_stats + b.stat_off + b.C; a.nbt = P.buf.bn_nbt + b.idx;
     a.mr = mr; a.updates = updates; a.skip_mask = groups > 1 ? P.dec_skip_mask : 0u; a.training = training; a.relu = 1;
-    hipLaunchKernelGGL(bn1d_fwd32_kernel, dim3(ceil_div(b.C, 64)), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(bn1d_fwd32_kernel, dim3(ceil_div(b.C, 64)), dim3(64 * BN_RL), 0, s, a);
     return mmvae_check_launch("bn1d_fwd32");
 }
 // d: grad wrt the activated output (in), grad wrt the raw input (out, in place)
@@ -172,30 +244,36 @@ struct BnB32 {
     const float* gamma; const float* beta; const float2* mr;
     float* dgamma; float* dbeta; int training;
 };
-__global__ __launch_bounds__(64) void bn1d_bwd32_kernel(const BnB32 a) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= a.C) return;
-    const float gamma = a.gamma[c], beta = a.beta[c];
+__global__ __launch_bounds__(64 * BN_RL) void bn1d_bwd32_kernel(const BnB32 a) {
+    __shared__ float sh[BN_RL][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const bool cok = c < a.C;
+    const int cc = cok ? c : 0;
+    const float gamma = a.gamma[cc], beta = a.beta[cc];
     float dg = 0.f, db = 0.f;
     for (int g = 0; g < a.G; ++g) {
-        const float2 m = a.mr[g * a.C + c];
-        const float* x = a.x + (size_t)g * a.rpg * a.C + c;
-        float* d = a.d + (size_t)g * a.rpg * a.C + c;
-        float s1 = 0.f, s2 = 0.f;
-        for (int r = 0; r < a.rpg; ++r) {
+        const float2 m = a.mr[g * a.C + cc];
+        const float* x = a.x + (size_t)g * a.rpg * a.C + cc;
+        float* d = a.d + (size_t)g * a.rpg * a.C + cc;
+        float p1 = 0.f, p2 = 0.f;
+        for (int r = rl; r < a.rpg; r += BN_RL) {
             const float xh = (x[(size_t)r * a.C] - m.x) * m.y;
             const float dy = (xh * gamma + beta > 0.f) ? d[(size_t)r * a.C] : 0.f;     // ReLU backward
-            s1 += dy; s2 += dy * xh;
+            p1 += dy; p2 += dy * xh;
         }
+        const float s1 = bn_block_sum(p1, sh, cl, rl);
+        const float s2 = bn_block_sum(p2, sh, cl, rl);
         dg += s2; db += s1;
         const float inv = 1.f / (float)a.rpg;
-        for (int r = 0; r < a.rpg; ++r) {
-            const float xh = (x[(size_t)r * a.C] - m.x) * m.y;
-            const float dy = (xh * gamma + beta > 0.f) ? d[(size_t)r * a.C] : 0.f;
-            d[(size_t)r * a.C] = a.training ? gamma * m.y * (dy - s1 * inv - xh * s2 * inv) : gamma * m.y * dy;
-        }
+        if (cok)
+            for (int r = rl; r < a.rpg; r += BN_RL) {
+                const float xh = (x[(size_t)r * a.C] - m.x) * m.y;
+                const float dy = (xh * gamma + beta > 0.f) ? d[(size_t)r * a.C] : 0.f;
+                d[(size_t)r * a.C] = a.training ? gamma * m.y * (dy - s1 * inv - xh * s2 * inv) : gamma * m.y * dy;
+            }
     }
-    a.dgamma[c] += dg; a.dbeta[c] += db;
+    if (cok && rl == 0) { a.dgamma[c] += dg; a.dbeta[c] += db; }
 }
 int bn_bwd32(MnistPlan& P, int bi, float* d, const float* x, int rows, int groups, const float2* mr, hipStream_t s) {
     const BnL& b = P.bn[bi];
@@ -203,7 +281,7 @@ int bn_bwd32(MnistPlan& P, int bi, float* d, const float* x, int rows, int group
     a.d = d; a.x = x; a.C = b.C; a.G = groups; a.rpg = rows / groups;
     a.gamma = P.buf.params + b.w_off; a.beta = P.buf.params + b.b_off; a.mr = mr;
     a.dgamma = P.buf.grads + b.w_off; a.dbeta = P.buf.grads + b.b_off; a.training = 1;
-    hipLaunchKernelGGL(bn1d_bwd32_kernel, dim3(ceil_div(b.C, 64)), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(bn1d_bwd32_kernel, dim3(ceil_div(b.C, 64)), dim3(64 * BN_RL), 0, s, a);
     return mmvae_check_launch("bn1d_bwd32");
 }
 
