@@ -245,6 +245,9 @@ int mmvae_nll_bwd(const long long* target, int rows, int classes, float coef, fl
 int mmvae_normal(float* out, long long n, unsigned long long seed, const long long* step_counter, unsigned stream_id, void* stream);
 int mmvae_keep_mask(uint8_t* out, long long n, float p, unsigned long long seed, const long long* step_counter,
                     unsigned stream_id, void* stream);
+/* F.mse_loss of the COCO loss variant (coco/train.py:75): out[0] += sum (a-b)^2 ; bwd: d_a = coef * 2 (a-b) */
+int mmvae_mse_fwd(const float* a, const float* b, long long n, float* out_sum, void* stream);
+int mmvae_mse_bwd(const float* a, const float* b, long long n, float coef, float* d_a, void* stream);
 /* Input pipeline: the ToTensor() transform of the reference's loaders (multimnist/train.py:113-121; dataset tensors are
  * uint8 (N,50,50), multimnist/datasets.py:180-181) done on the device: dst[i] = src[i] / denom (denom = 255, IEEE division: bit-equal to ToTensor) */
 int mmvae_u8_to_f32(const uint8_t* src, long long n, float denom, float* dst, void* stream);

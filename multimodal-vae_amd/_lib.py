@@ -108,6 +108,8 @@ SIGNATURES = {
     "mmvae_nll_bwd": (_I, [_P, _I, _I, _F, _P, _P]),
     "mmvae_normal": (_I, [_P, _LL, _ULL, _P, _U, _P]),
     "mmvae_keep_mask": (_I, [_P, _LL, _F, _ULL, _P, _U, _P]),
+    "mmvae_mse_fwd": (_I, [_P, _P, _LL, _P, _P]),
+    "mmvae_mse_bwd": (_I, [_P, _P, _LL, _F, _P, _P]),
     "mmvae_u8_to_f32": (_I, [_P, _LL, _F, _P, _P]),
     "mmvae_adam_step": (_I, [_P, _P, _P, _P, _LL, _P, _F, _F, _F, _F, _F, _P]),
 }

@@ -356,6 +356,8 @@ int mmvae_normal(float* out, long long n, unsigned long long seed, const long lo
 int mmvae_keep_mask(uint8_t* out, long long n, float p, unsigned long long seed, const long long* ctr, unsigned sid, void* s) {
     return launch_keep_mask(out, n, p, seed, ctr, sid, S(s));
 }
+int mmvae_mse_fwd(const float* a, const float* b, long long n, float* out, void* s) { return launch_mse_fwd(a, b, n, out, S(s)); }
+int mmvae_mse_bwd(const float* a, const float* b, long long n, float coef, float* da, void* s) { return launch_mse_bwd(a, b, n, coef, da, S(s)); }
 int mmvae_u8_to_f32(const uint8_t* src, long long n, float denom, float* dst, void* s) { return launch_u8_to_f32(src, n, denom, dst, S(s)); }
 int mmvae_adam_step(float* p, const float* g, float* m, float* v, long long n, long long* state, float lr, float b1, float b2,
                     float eps, float grad_scale, void* s) {

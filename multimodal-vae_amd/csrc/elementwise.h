@@ -173,3 +173,6 @@ int launch_colsum_f32(const float* x, int rows, int cols, float* out, hipStream_
 int launch_colsum_bf16(const bf16* x, int ld, int rows, int cols, float* out, hipStream_t s);
 // input pipeline (multimnist/datasets.py:45-74 + torchvision ToTensor): uint8 pixels -> fp32 / denom
 int launch_u8_to_f32(const uint8_t* src, long long n, float denom, float* dst, hipStream_t s);
+// F.mse_loss pieces of the COCO loss variant (coco/train.py:75)
+int launch_mse_fwd(const float* a, const float* b, long long n, float* out_sum, hipStream_t s);
+int launch_mse_bwd(const float* a, const float* b, long long n, float coef, float* d_a, hipStream_t s);

@@ -758,6 +758,20 @@ __global__ __launch_bounds__(TPB) void cast_bf16_kernel(const float* x, long lon
         for (long long q = i; q < n; ++q) out[q] = (bf16)x[q];
     }
 }
+// F.mse_loss pieces (coco/train.py:75): out += sum (a-b)^2 ; d_a = coef * 2 (a-b)
+__global__ __launch_bounds__(TPB) void mse_fwd_kernel(const float* a, const float* b, long long n, float* out) {
+    float acc = 0.f;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long long)gridDim.x * TPB) {
+        const float d = a[i] - b[i];
+        acc += d * d;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+__global__ __launch_bounds__(TPB) void mse_bwd_kernel(const float* a, const float* b, long long n, float coef, float* da) {
+    const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+    if (i < n) da[i] = coef * 2.f * (a[i] - b[i]);
+}
 // torchvision ToTensor on the device: uint8 pixels -> fp32 / denom (255; a true division, bit-equal to .div(255)), 16 pixels per thread
 __global__ __launch_bounds__(TPB) void u8_to_f32_kernel(const uint8_t* __restrict__ src, long long n, float denom, float* __restrict__ dst) {
     const long long i = ((long long)blockIdx.x * TPB + threadIdx.x) * 16;
@@ -793,6 +807,14 @@ __global__ __launch_bounds__(TPB) void colsum_kernel_t(const T* x, int ld, int r
 
 }  // namespace
 
+int launch_mse_fwd(const float* a, const float* b, long long n, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(mse_fwd_kernel, dim3(nblocks(n, TPB * 4, 256)), dim3(TPB), 0, s, a, b, n, out);
+    return mmvae_check_launch("mse_fwd");
+}
+int launch_mse_bwd(const float* a, const float* b, long long n, float coef, float* da, hipStream_t s) {
+    hipLaunchKernelGGL(mse_bwd_kernel, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, s, a, b, n, coef, da);
+    return mmvae_check_launch("mse_bwd");
+}
 int launch_u8_to_f32(const uint8_t* src, long long n, float denom, float* dst, hipStream_t s) {
     MMVAE_REQUIRE(src && dst && n >= 0, "u8_to_f32: null argument");
     if (n == 0) return MMVAE_OK;

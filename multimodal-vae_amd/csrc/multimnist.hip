@@ -681,6 +681,9 @@ int mm_step_fwd_bwd(MMPlan* Pp, const MMStepIO& io, int training, int do_backwar
     int img_groups = 3;
     while (img_groups > 0 && (io.lambda_xy[img_groups - 1] == 0.f || sk[img_groups - 1])) --img_groups;
     int rc = MMVAE_OK;
+    static const bool defer = getenv("MMVAE_DEFER_WGRAD") != nullptr;
+    P.deferred.clear();
+    P.defer_wgrad = defer && !serial;
     if (img_groups > 0) rc = dec_bwd(P, w.dlogit, img_groups, w.dz_img, s);
     if (rc == MMVAE_OK) rc = edge(P, T, s);          // dz of the text decoder
     Latent3BwdArgs lb{};
@@ -688,6 +691,7 @@ int mm_step_fwd_bwd(MMPlan* Pp, const MMStepIO& io, int training, int do_backwar
     for (int k = 0; k < 3; ++k) lb.kl_coef[k] = sk[k] ? 0.f : io.kl_lambda / (float)B;
     lb.d_img_out_bf = w.d_encout; lb.d_img_bias = P.buf.grads + P.fc[2].b_off; lb.d_txt_out = w.d_txtout;
     if (rc == MMVAE_OK) rc = launch_latent3_bwd(lb, s);
+    if (rc == MMVAE_OK) rc = flush_wgrads(P, s);
     if (rc == MMVAE_OK) rc = edge(P, s, T);
     if (rc == MMVAE_OK) rc = txt_enc_bwd(P, io.text, w.d_txtout, T);
     if (rc == MMVAE_OK) rc = enc_bwd(P, w.d_encout, 2, m1, m2, enc_drop, s);

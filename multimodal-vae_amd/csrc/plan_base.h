@@ -50,6 +50,8 @@ struct PlanBase {
     // chain; forks/joins are event edges, so nothing syncs the host (and a captured HIP graph gets parallel branches)
     hipStream_t st_text = nullptr, st_wgrad = nullptr, st_wgrad2 = nullptr;
     int wgrad_rr = 0;               // weight gradients alternate between the two side streams
+    bool defer_wgrad = false;       // collect weight-gradient launches instead of issuing them (flush_wgrads)
+    std::vector<WgradParams> deferred;
     std::vector<hipEvent_t> events;
     size_t next_event = 0;
     bool wgrad_forked = false;
@@ -73,9 +75,22 @@ inline int edge(PlanBase& P, hipStream_t from, hipStream_t to);
 inline int wgrad_async(PlanBase& P, const WgradParams& g, hipStream_t s) {
     static const bool serial = getenv("MMVAE_SERIAL") != nullptr;
     if (!P.wgrad_forked || serial) return launch_wgrad(g, s);
+    if (P.defer_wgrad) { P.deferred.push_back(g); return MMVAE_OK; }
     hipStream_t w = (P.wgrad_rr++ & 1) ? P.st_wgrad2 : P.st_wgrad;
     MMVAE_TRY(edge(P, s, w));
     return launch_wgrad(g, w);
+}
+
+// issue the weight gradients collected while defer_wgrad was set (their operands are complete on `s` by now)
+inline int flush_wgrads(PlanBase& P, hipStream_t s) {
+    P.defer_wgrad = false;
+    for (const WgradParams& g : P.deferred) {
+        hipStream_t w = (P.wgrad_rr++ & 1) ? P.st_wgrad2 : P.st_wgrad;
+        MMVAE_TRY(edge(P, s, w));
+        MMVAE_TRY(launch_wgrad(g, w));
+    }
+    P.deferred.clear();
+    return MMVAE_OK;
 }
 
 inline void add_param(PlanBase& P, const std::string& name, std::initializer_list<int> shape) {

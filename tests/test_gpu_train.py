@@ -96,3 +96,28 @@ def test_eval_consumers_match_oracle():
             pred = rt.argmax(2).numpy(); gt = tx.numpy()
             cc += (pred == gt).sum(); lc += ((pred == 11).sum(1) == (gt == 11).sum(1)).sum()
     assert abs(acc[0] - cc / (2 * B * 4)) <= 0.05 and abs(acc[1] - lc / (2 * B)) <= 0.1      # bf16 near-ties may flip an argmax
+
+
+def test_coco_loss_variant_matches_torch():
+    """coco/train.py:66-84: image BCE over 3*32*32 + F.mse_loss on the caption embeddings + KL/B*kl_lambda."""
+    import torch.nn.functional as F
+    from multimodal_vae_amd import coco as C
+    dev = _dev()
+    g = torch.Generator().manual_seed(4)
+    B, D = 6, 100
+    mu = torch.randn(B, D, generator=g); lv = 0.3 * torch.randn(B, D, generator=g)
+    ri = torch.rand(B, 3, 32, 32, generator=g).clamp(1e-4, 1 - 1e-4); im = torch.rand(B, 3, 32, 32, generator=g)
+    rt = torch.randn(B, 102, 300, generator=g); tx = 0.4 * torch.randn(B, 102, 300, generator=g)
+    ref_in = [t.clone().requires_grad_(True) for t in (mu, lv, ri, rt)]
+    ref = (0.7 * F.binary_cross_entropy(ref_in[2].view(-1, 3072), im.view(-1, 3072)) + 1.3 * F.mse_loss(ref_in[3], tx)
+           + (-0.5 * torch.sum(1 + ref_in[1] - ref_in[0].pow(2) - ref_in[1].exp())) / B * 1e-2)
+    ref.backward()
+    got_in = [t.clone().to(dev).requires_grad_(True) for t in (mu, lv, ri, rt)]
+    got = C.loss_function(got_in[0], got_in[1], recon_image=got_in[2], image=im.to(dev), recon_text=got_in[3], text=tx.to(dev),
+                          kl_lambda=1e-2, lambda_xy=0.7, lambda_yx=1.3)
+    got.backward()
+    np.testing.assert_allclose(got.item(), ref.item(), rtol=1e-5)
+    for a, b in zip(got_in, ref_in):
+        np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.numpy(), rtol=1e-4, atol=1e-8)
+    with pytest.raises(C.MMVAEError):
+        C.MultimodalVAE(100)
