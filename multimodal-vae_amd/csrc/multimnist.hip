@@ -358,11 +358,12 @@ int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const
             MMVAE_TRY(launch_gemm_gather(d, s));
         }
     }
-    {   // conv1 wgrad over the im2col patches
+    {   // conv1 wgrad over the im2col patches: the LAST kernel of the backward chain -- it stays on the main stream (a hop
+        // to a side stream and back would put two event latencies on the critical path)
         GatherPlan pl = dense_plan(B * 625, 16, 16, 32);
         WgradParams g = wgrad_of(P, pl, P.conv[0].gk, 1, B * 625);
         g.c.A = w.patches1; g.P = w.d1e; g.ldp = 32;
-        MMVAE_TRY(wgrad_async(P, g, s));
+        MMVAE_TRY(launch_wgrad(g, s));
     }
     return MMVAE_OK;
 }
@@ -370,7 +371,7 @@ int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const
 // ================================================================== image decoder (multimnist/model.py:211-216)
 // z_bf: [groups*B][ldz] with column D == 1.0 (folded bias).  The last layer is the fused direct kernel
 // ConvTranspose2d(32,1) + sigmoid (+ BCE and its gradient when `bce` is given).
-int dec_fwd(MMPlan& P, int groups, int training, ConvTLastFwdArgs* last, hipStream_t s) {
+int dec_fwd(MMPlan& P, int groups, int training, ConvTLastFwdArgs* last, hipStream_t s, int last_groups = -1) {
     MMPlan::W& w = P.w;
     const int B = P.B, rows = groups * B;
     {
@@ -392,7 +393,7 @@ int dec_fwd(MMPlan& P, int groups, int training, ConvTLastFwdArgs* last, hipStre
         MMVAE_TRY(bn_act(P, P.bn[L.bn], q[l + 1], aq[l + 1], groups * rpg, rpg, groups, w.st_d[l], 1, w.aff_d[l], w.mr_d[l], training, s));
     }
     ConvTLastFwdArgs x = *last;
-    x.act = w.aq3; x.w = P.buf.params + P.convT[3].w_off; x.G = groups; x.B = B; x.IH = 25; x.IW = 25; x.Cin = 32; x.Cout = 1;
+    x.act = w.aq3; x.w = P.buf.params + P.convT[3].w_off; x.G = last_groups > 0 ? last_groups : groups; x.B = B; x.IH = 25; x.IW = 25; x.Cin = 32; x.Cout = 1;
     return launch_convt_last_fwd(x, s);
 }
 
@@ -668,7 +669,12 @@ int mm_step_fwd_bwd(MMPlan* Pp, const MMStepIO& io, int training, int do_backwar
     ConvTLastFwdArgs last{};
     last.target = io.image; last.recon = io.recon_image; last.dlogit = do_backward ? w.dlogit : nullptr; last.loss_sum = w.sums;
     for (int k = 0; k < 3; ++k) last.coef[k] = sk[k] ? 0.f : io.lambda_xy[k] / (float)(B * NPIX);
-    MMVAE_TRY(dec_fwd(P, 3, training, &last, s));
+    // the last layer (no BatchNorm after it) of a trailing pass whose image term has weight 0 and whose reconstruction is
+    // not asked for feeds nothing: multimnist/train.py:164-166 multiplies that pass's BCE by lambda_xy = 0
+    int last_groups = 3;
+    if (!io.recon_image)
+        while (last_groups > 1 && last.coef[last_groups - 1] == 0.f) --last_groups;
+    MMVAE_TRY(dec_fwd(P, 3, training, &last, s, last_groups));
     if (!do_backward) {
         MMVAE_TRY(edge(P, T, s));
         hipLaunchKernelGGL(sum_slots_kernel, dim3(1), dim3(64), 0, s, w.sums, io.sums);
@@ -691,6 +697,10 @@ int mm_step_fwd_bwd(MMPlan* Pp, const MMStepIO& io, int training, int do_backwar
     for (int k = 0; k < 3; ++k) lb.kl_coef[k] = sk[k] ? 0.f : io.kl_lambda / (float)B;
     lb.d_img_out_bf = w.d_encout; lb.d_img_bias = P.buf.grads + P.fc[2].b_off; lb.d_txt_out = w.d_txtout;
     if (rc == MMVAE_OK) rc = launch_latent3_bwd(lb, s);
+    if (rc == MMVAE_OK) {       // every loss term is final here (text-decoder NLL joined above): keep this off the tail
+        hipLaunchKernelGGL(sum_slots_kernel, dim3(1), dim3(64), 0, s, w.sums, io.sums);
+        rc = mmvae_check_launch("sum_slots");
+    }
     if (rc == MMVAE_OK) rc = flush_wgrads(P, s);
     if (rc == MMVAE_OK) rc = edge(P, s, T);
     if (rc == MMVAE_OK) rc = txt_enc_bwd(P, io.text, w.d_txtout, T);
@@ -700,8 +710,6 @@ int mm_step_fwd_bwd(MMPlan* Pp, const MMStepIO& io, int training, int do_backwar
     MMVAE_TRY(edge(P, T, s));
     MMVAE_TRY(edge(P, P.st_wgrad, s));
     if (P.st_wgrad2 != P.st_wgrad) MMVAE_TRY(edge(P, P.st_wgrad2, s));
-    hipLaunchKernelGGL(sum_slots_kernel, dim3(1), dim3(64), 0, s, w.sums, io.sums);
-    MMVAE_TRY(mmvae_check_launch("sum_slots"));
     MMVAE_TRY(mm_unpack_grads(Pp, s));
     return MMVAE_OK;
 }
