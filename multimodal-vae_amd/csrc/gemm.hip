@@ -470,6 +470,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave / WK, wk = wave % WK;
     const int pix_per_img = k.OY * k.OX;
+    const float inv_rpg = 1.0f / (float)k.rows_per_group, inv_pix = 1.0f / (float)pix_per_img, inv_ox = 1.0f / (float)k.OX;
     const int row_l = tid >> 2, sub = tid & 3;
 
     int g_dy[NGV], g_dx[NGV], g_c[NGV];
@@ -499,12 +500,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
         const int rq = rb + row_l;
         const bool rin = rq < r_end;
         const int r = rin ? rq : r_end - 1;                  // clamped: loads are unconditional, results masked
-        const int g = r / k.rows_per_group;
-        const int rg = r - g * k.rows_per_group;
-        const int img = rg / pix_per_img;
-        const int rem = rg - img * pix_per_img;
-        const int oy = rem / k.OX;
-        const int ox = rem - oy * k.OX;
+        int rg, rem, ox;                                     // reciprocal divisions: this runs once per 64-row iteration
+        const int g = fast_divmod(r, k.rows_per_group, inv_rpg, rg);
+        const int img = fast_divmod(rg, pix_per_img, inv_pix, rem);
+        const int oy = fast_divmod(rem, k.OX, inv_ox, ox);
         const int n = g * c.group_n + img;
         const int an = c.a_bcast_n > 0 ? n % c.a_bcast_n : n;
         const size_t ppix = (size_t)(n * c.OH + oy * c.osy + k.ooy) * c.OW + ox * c.osx + k.oox;
@@ -918,6 +917,7 @@ int launch_wgrad(const WgradParams& p, hipStream_t stream) {
         const GatherClass& k = p.cls[i];
         MMVAE_REQUIRE(k.Kpad >= k.K && k.K == k.TH * k.TW * c.C, "wgrad: class %d K=%d Kpad=%d", i, k.K, k.Kpad);
         MMVAE_REQUIRE(k.rows_per_group == c.group_n * k.OY * k.OX && k.dWp != nullptr, "wgrad: class %d", i);
+        MMVAE_REQUIRE((long long)c.groups * k.rows_per_group < (1 << 23), "wgrad: more than 2^23 rows");
         max_k = max(max_k, k.K);
     }
     // tile shape by problem shape: thin outputs get a wide K tile so each staged pixel row feeds more MFMAs
