@@ -21,6 +21,14 @@ __device__ __forceinline__ int find_desc(const PackDesc* t, int nd, int block) {
     }
     return lo;
 }
+// q = r / d, rem = r % d for 0 <= r < 2^23 with inv = 1.0f/d (one correction step each way)
+__device__ __forceinline__ int fast_divmod_ew(int r, int d, float inv, int& rem) {
+    int q = (int)((float)r * inv);
+    rem = r - q * d;
+    if (rem < 0) { --q; rem += d; }
+    else if (rem >= d) { ++q; rem -= d; }
+    return q;
+}
 __device__ __forceinline__ long long pack_src(const PackDesc& d, int n, int k) {
     int nhi = n / d.NL, nlo = n - nhi * d.NL;
     int tap = k / d.C, c = k - tap * d.C;
@@ -34,19 +42,24 @@ __global__ __launch_bounds__(TPB) void pack_kernel(const PackDesc* __restrict__ 
                                                    bf16* __restrict__ packed_bf, float* __restrict__ packed_f32) {
     const int di = find_desc(table, nd, blockIdx.x);
     const PackDesc d = table[di];
-    const long long v = (long long)(blockIdx.x - d.first_block) * TPB + threadIdx.x;
+    // 32-bit index math with reciprocal divisions (packed matrices have < 2^23 vectors; launch_pack checks)
+    const int v = (int)(blockIdx.x - d.first_block) * TPB + threadIdx.x;
     const int vpr = d.Kpad / 8;
-    if (v >= (long long)d.Npad * vpr) return;
-    const int n = (int)(v / vpr), k0 = (int)(v - (long long)n * vpr) * 8;
+    if (v >= d.Npad * vpr) return;
+    int kv;
+    const int n = fast_divmod_ew(v, vpr, 1.0f / (float)vpr, kv);
+    const int k0 = kv * 8;
     float val[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) val[j] = 0.f;
     if (n < d.N) {
-        const int nhi = n / d.NL, nlo = n - nhi * d.NL;
+        int nlo;
+        const int nhi = fast_divmod_ew(n, d.NL, 1.0f / (float)d.NL, nlo);
         const long long rowbase = d.src_off + (long long)nhi * d.s_nhi + (long long)nlo * d.s_nlo;
         if (d.C % 8 == 0 && k0 + 8 <= d.K) {              // the 8 columns share one tap
-            const int tap = k0 / d.C, c = k0 - tap * d.C;
-            const int ty = tap / d.TW, tx = tap - ty * d.TW;
+            int c, tx;
+            const int tap = fast_divmod_ew(k0, d.C, 1.0f / (float)d.C, c);
+            const int ty = fast_divmod_ew(tap, d.TW, 1.0f / (float)d.TW, tx);
             const long long b = rowbase + (long long)(d.o_ty + ty * d.step_t) * d.s_ty + (long long)(d.o_tx + tx * d.step_t) * d.s_tx + (long long)c * d.s_c;
 #pragma unroll
             for (int j = 0; j < 8; ++j) val[j] = params[b + (long long)j * d.s_c];
@@ -75,19 +88,22 @@ __global__ __launch_bounds__(TPB) void unpack_kernel(const PackDesc* __restrict_
                                                      const float* __restrict__ gvec, float* __restrict__ grads) {
     const int di = find_desc(table, nd, blockIdx.x);
     const PackDesc d = table[di];
-    const long long v = (long long)(blockIdx.x - d.first_block) * TPB + threadIdx.x;
+    const int v = (int)(blockIdx.x - d.first_block) * TPB + threadIdx.x;
     const int vpr = d.Kpad / 8;
-    if (v >= (long long)d.N * vpr) return;
-    const int n = (int)(v / vpr), k0 = (int)(v - (long long)n * vpr) * 8;
+    if (v >= d.N * vpr) return;
+    int kv, nlo;
+    const int n = fast_divmod_ew(v, vpr, 1.0f / (float)vpr, kv);
+    const int k0 = kv * 8;
     if (k0 > d.K) return;
-    const int nhi = n / d.NL, nlo = n - nhi * d.NL;
+    const int nhi = fast_divmod_ew(n, d.NL, 1.0f / (float)d.NL, nlo);
     const float* src = (d.is_f32 ? gvec : gmat) + d.dst_off + (long long)n * d.Kpad + k0;
     const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
     const float val[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     if (d.C % 8 == 0 && k0 + 8 <= d.K) {
         const long long rowbase = d.src_off + (long long)nhi * d.s_nhi + (long long)nlo * d.s_nlo;
-        const int tap = k0 / d.C, c = k0 - tap * d.C;
-        const int ty = tap / d.TW, tx = tap - ty * d.TW;
+        int c, tx;
+        const int tap = fast_divmod_ew(k0, d.C, 1.0f / (float)d.C, c);
+        const int ty = fast_divmod_ew(tap, d.TW, 1.0f / (float)d.TW, tx);
         const long long b = rowbase + (long long)(d.o_ty + ty * d.step_t) * d.s_ty + (long long)(d.o_tx + tx * d.step_t) * d.s_tx + (long long)c * d.s_c;
 #pragma unroll
         for (int j = 0; j < 8; ++j) grads[b + (long long)j * d.s_c] += val[j];
@@ -107,14 +123,6 @@ int table_blocks(const PackDesc* host, int nd) {
 }
 
 // ------------------------------------------------------------------ im2col for thin (1/3-channel) inputs
-// q = r / d, rem = r % d for 0 <= r < 2^23 with inv = 1.0f/d (one correction step each way)
-__device__ __forceinline__ int fast_divmod_ew(int r, int d, float inv, int& rem) {
-    int q = (int)((float)r * inv);
-    rem = r - q * d;
-    if (rem < 0) { --q; rem += d; }
-    else if (rem >= d) { ++q; rem -= d; }
-    return q;
-}
 // one thread = one 8-wide vector of one patch row; 32-bit index math, reciprocal divisions, (tap, channel) walked
 // incrementally over the 8 elements (the first version's 64-bit and per-element integer divisions made this
 // streaming kernel 5x slower than its memory traffic)
@@ -824,12 +832,16 @@ int launch_u8_to_f32(const uint8_t* src, long long n, float denom, float* dst, h
 int launch_pack(const PackDesc* table_dev, const PackDesc* table_host, int nd, const float* params, bf16* packed_bf,
                 float* packed_f32, hipStream_t s) {
     MMVAE_REQUIRE(nd > 0, "pack: empty table");
+    for (int i = 0; i < nd; ++i)
+        MMVAE_REQUIRE((long long)table_host[i].Npad * (table_host[i].Kpad / 8) < (1 << 23), "pack: matrix %d too large for 32-bit index math", i);
     hipLaunchKernelGGL(pack_kernel, dim3(table_blocks(table_host, nd)), dim3(TPB), 0, s, table_dev, nd, params, packed_bf, packed_f32);
     return mmvae_check_launch("pack");
 }
 int launch_unpack_grads(const PackDesc* table_dev, const PackDesc* table_host, int nd, const float* gmat, const float* gvec,
                         float* grads, hipStream_t s) {
     MMVAE_REQUIRE(nd > 0, "unpack: empty table");
+    for (int i = 0; i < nd; ++i)
+        MMVAE_REQUIRE((long long)table_host[i].Npad * (table_host[i].Kpad / 8) < (1 << 23), "unpack: matrix %d too large for 32-bit index math", i);
     hipLaunchKernelGGL(unpack_kernel, dim3(table_blocks(table_host, nd)), dim3(TPB), 0, s, table_dev, nd, gmat, gvec, grads);
     return mmvae_check_launch("unpack_grads");
 }
