@@ -177,6 +177,17 @@ def main():
         "step_mfma_frac": steps_per_s / world * B * FLOP_PER_SAMPLE / (PEAK_BF16_TFLOPS * 1e12),
     }
 
+    # ---- per-step distribution: HIP events around single steps, outside the timed region
+    n_ev = min(100, args.steps)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev + 1)]
+    evs[0].record()
+    for i in range(n_ev):
+        run()
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n_ev))
+    result["ms_per_step_p10_p50_p90"] = [per[int(0.1 * (n_ev - 1))], per[(n_ev - 1) // 2], per[int(0.9 * (n_ev - 1))]]
+
     if rank == 0:
         # ---- roofline of the dominant GEMM kernel, timed live with HIP events on its own stream
         layer = args.roofline_layer.encode()
