@@ -27,6 +27,12 @@ extern "C" {
 int mmvae_init(int device);                 /* checks the device is gfx950, makes it current */
 const char* mmvae_last_error(void);
 const char* mmvae_version(void);
+/* Priority policy of the engine's three side streams (second-modality path, weight gradients); call before the first
+ * step of the process.  0 (default): lowest priority, they fill CUs the main chain leaves idle.  1: default priority --
+ * REQUIRED when another library enqueues on a stream of its own next to the step (RCCL under torch.distributed in the
+ * data-parallel path of multimnist/train.py's loop): mixed priorities then slow every kernel down several-fold.
+ * MMVAE_ESTATE if the side streams already exist with the other policy. */
+int mmvae_set_stream_policy(int flat);
 
 /* ---------------------------------------------------------------- MultiMNIST plan (multimnist/model.py:21-93) */
 typedef struct MMPlan mmvae_mm_t;

@@ -67,6 +67,7 @@ SIGNATURES = {
     "mmvae_init": (_I, [_I]),
     "mmvae_last_error": (C.c_char_p, []),
     "mmvae_version": (C.c_char_p, []),
+    "mmvae_set_stream_policy": (_I, [_I]),
     "mmvae_mm_create": (_P, [_I, _I]),
     "mmvae_mm_destroy": (None, [_P]),
     "mmvae_mm_param_count": (_LL, [_P]),

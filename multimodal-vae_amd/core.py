@@ -177,6 +177,10 @@ class _FusedStepBase:
         self.state, self.B, self.D = state, int(batch), state.n_latents
         self.lr, self.betas, self.eps, self.seed = lr, betas, eps, seed
         self.world_size, self.all_reduce = world_size, all_reduce
+        if all_reduce is not None and world_size > 1:
+            # the collective library may enqueue on a stream of its own: mixed stream priorities then slow the whole
+            # process down (include/mmvae_hip.h: mmvae_set_stream_policy)
+            call("mmvae_set_stream_policy", 1)
         dev = state.device
         self.h = state.plan(batch)
         self.ws = torch.empty(state.workspace_bytes(batch), dtype=torch.uint8, device=dev)

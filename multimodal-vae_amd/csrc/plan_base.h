@@ -5,6 +5,7 @@
 #pragma once
 #include "layers.h"
 #include <map>
+#include <mutex>
 #include <cstdlib>
 
 constexpr float BN_EPS = 1e-5f, BN_MOM = 0.1f, DROP_P = 0.1f;
@@ -322,17 +323,32 @@ inline int edge(PlanBase& P, hipStream_t from, hipStream_t to) {
 inline int ensure_streams(PlanBase& P) {
     if (!P.st_text) {
         // side work (second-modality path, weight gradients) only feeds the optimizer at the end of the step: it runs at
-        // the LOWEST stream priority so that its workgroups fill CUs the main chain leaves idle instead of sharing them
-        int least = 0, greatest = 0;
-        hipDeviceGetStreamPriorityRange(&least, &greatest);
-        static const bool flat = getenv("MMVAE_FLAT_PRIORITY") != nullptr;     // A/B aid
-        const int prio = flat ? 0 : least;
-        if (hipStreamCreateWithPriority(&P.st_text, hipStreamNonBlocking, prio) != hipSuccess ||
-            hipStreamCreateWithPriority(&P.st_wgrad, hipStreamNonBlocking, prio) != hipSuccess ||
-            hipStreamCreateWithPriority(&P.st_wgrad2, hipStreamNonBlocking, prio) != hipSuccess) {
-            mmvae_set_error("hipStreamCreate failed");
-            return MMVAE_EHIP;
+        // the LOWEST stream priority so that its workgroups fill CUs the main chain leaves idle instead of sharing them.
+        // The three side streams are shared by every plan of the process: ROCm gives a process 4 hardware queues, and
+        // once more streams than that carry work they are time-sliced onto shared queues and every kernel slows down
+        // several-fold (measured: 0.98 -> 2.78 ms per step with 7 streams).  Plans enqueue behind event edges, so sharing
+        // streams between plans only serialises what would have been serialised anyway.
+        static std::mutex mu;
+        static hipStream_t shared[3] = {nullptr, nullptr, nullptr};
+        std::lock_guard<std::mutex> g(mu);
+        if (!shared[0]) {
+            int least = 0, greatest = 0;
+            hipDeviceGetStreamPriorityRange(&least, &greatest);
+            // policy 1 (mmvae_set_stream_policy; the data-parallel host sets it): every stream at the default priority.
+            // Measured on MI355X / ROCm 7: as soon as ANOTHER default-priority stream carries work next to the main one
+            // (a collective library's internal stream), lowest-priority side streams make every kernel of the process
+            // run several times slower (0.98 -> 2.63 ms per step); with flat priorities the same mix costs 2 %.
+            const bool flat = getenv("MMVAE_FLAT_PRIORITY") != nullptr || mmvae_stream_policy() == 1;
+            mmvae_stream_policy_freeze();
+            const int prio = flat ? 0 : least;
+            for (int i = 0; i < 3; ++i)
+                if (hipStreamCreateWithPriority(&shared[i], hipStreamNonBlocking, prio) != hipSuccess) {
+                    mmvae_set_error("hipStreamCreate failed");
+                    shared[0] = nullptr;
+                    return MMVAE_EHIP;
+                }
         }
+        P.st_text = shared[0]; P.st_wgrad = shared[1]; P.st_wgrad2 = shared[2];
     }
     static const bool one_side = getenv("MMVAE_ONE_SIDE") != nullptr;   // experiment: text path and wgrads share a stream
     static const bool one_wgrad = getenv("MMVAE_ONE_WGRAD") != nullptr; // experiment: a single weight-gradient stream

@@ -21,3 +21,23 @@ int mmvae_check_launch(const char* what) {
     }
     return MMVAE_OK;
 }
+
+// ---- side-stream priority policy
+#include <atomic>
+static std::atomic<int> g_policy{-1};
+static std::atomic<bool> g_policy_frozen{false};
+int mmvae_stream_policy() { return g_policy.load(); }
+void mmvae_stream_policy_freeze() { g_policy_frozen.store(true); }
+extern "C" int mmvae_set_stream_policy(int flat) {
+    const int want = flat ? 1 : 0;
+    if (g_policy_frozen.load()) {
+        const int have = g_policy.load() == 1 ? 1 : 0;
+        if (have != want) {
+            mmvae_set_error("stream policy: the side streams already exist with policy %d", have);
+            return MMVAE_ESTATE;
+        }
+        return MMVAE_OK;
+    }
+    g_policy.store(want);
+    return MMVAE_OK;
+}
