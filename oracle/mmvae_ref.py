@@ -474,6 +474,147 @@ def celeba_step_losses(p: Params, image: Tensor, attrs: Tensor, training: bool =
 
 
 # ----------------------------------------------------------------------------
+# COCO  (coco/model.py:22-90,147-312 ; coco/train.py:66-84,146-164)
+# ----------------------------------------------------------------------------
+COCO_MAX_WORDS = 102   # coco/utils.py:12-15 (100 words + SOS + EOS)
+COCO_EMB = 300         # GloVe-840B vectors
+COCO_HID = 200
+COCO_LAMBDAS = ((1.0, 1.0), (1.0, 1.0), (0.0, 1.0))    # coco/train.py:152-164 (lambda_xy, lambda_yx)
+
+
+def coco_image_encoder(p: Params, x: Tensor, training: bool, masks=None,
+                       pre: str = "image_encoder.", drop_p: float = DROP_P) -> Tensor:
+    """coco/model.py:155-187: 3x32x32, four k4 s2 p1 convolutions, classifier 2048-1024-256-2D with two Dropouts."""
+    m1, m2 = masks if masks is not None else (None, None)
+    x = swish(F.conv2d(x, p[pre + "features.0.weight"], None, 2, 1))
+    x = F.conv2d(x, p[pre + "features.2.weight"], None, 2, 1)
+    x = swish(batch_norm(x, p, pre + "features.3", training))
+    x = F.conv2d(x, p[pre + "features.5.weight"], None, 2, 1)
+    x = swish(batch_norm(x, p, pre + "features.6", training))
+    x = F.conv2d(x, p[pre + "features.8.weight"], None, 2, 1)
+    x = swish(batch_norm(x, p, pre + "features.9", training))
+    x = x.reshape(-1, 512 * 2 * 2)
+    x = dropout(swish(F.linear(x, p[pre + "classifier.0.weight"], p[pre + "classifier.0.bias"])), training, m1, drop_p)
+    x = dropout(swish(F.linear(x, p[pre + "classifier.3.weight"], p[pre + "classifier.3.bias"])), training, m2, drop_p)
+    return F.linear(x, p[pre + "classifier.6.weight"], p[pre + "classifier.6.bias"])
+
+
+def coco_image_decoder(p: Params, z: Tensor, training: bool, pre: str = "image_decoder.") -> Tensor:
+    """coco/model.py:190-216"""
+    x = swish(F.linear(z, p[pre + "upsample.0.weight"], p[pre + "upsample.0.bias"]))
+    x = x.view(-1, 512, 2, 2)
+    x = F.conv_transpose2d(x, p[pre + "hallucinate.0.weight"], None, 2, 1)
+    x = swish(batch_norm(x, p, pre + "hallucinate.1", training))
+    x = F.conv_transpose2d(x, p[pre + "hallucinate.3.weight"], None, 2, 1)
+    x = swish(batch_norm(x, p, pre + "hallucinate.4", training))
+    x = F.conv_transpose2d(x, p[pre + "hallucinate.6.weight"], None, 2, 1)
+    x = swish(batch_norm(x, p, pre + "hallucinate.7", training))
+    return torch.sigmoid(F.conv_transpose2d(x, p[pre + "hallucinate.9.weight"], None, 2, 1))
+
+
+def coco_text_encoder(p: Params, text: Tensor, pre: str = "text_encoder.") -> Tensor:
+    """coco/model.py:219-245: (B, T, 300) GloVe vectors -> (B, 2D).
+
+    Bidirectional 1-layer GRU(300 -> 200); ``x[-1]`` is the LAST time step of both directions, so the reverse direction
+    has seen only vector T-1 from h = 0 (same quirk as multimnist/model.py:242-245).  dropout=0.1 on a single-layer GRU
+    is a no-op."""
+    B, T, _ = text.shape
+    h = text.new_zeros(B, COCO_HID)
+    for t in range(T):
+        h = gru_cell(text[:, t], h, p[pre + "gru.weight_ih_l0"], p[pre + "gru.weight_hh_l0"],
+                     p[pre + "gru.bias_ih_l0"], p[pre + "gru.bias_hh_l0"])
+    hb = gru_cell(text[:, T - 1], text.new_zeros(B, COCO_HID),
+                  p[pre + "gru.weight_ih_l0_reverse"], p[pre + "gru.weight_hh_l0_reverse"],
+                  p[pre + "gru.bias_ih_l0_reverse"], p[pre + "gru.bias_hh_l0_reverse"])
+    return F.linear(h + hb, p[pre + "h2p.weight"], p[pre + "h2p.bias"])
+
+
+def coco_text_decoder(p: Params, z: Tensor, training: bool, sos: Tensor, steps: int = COCO_MAX_WORDS,
+                      gru_masks: Optional[Sequence[Optional[Tensor]]] = None,
+                      pre: str = "text_decoder.", drop_p: float = DROP_P) -> Tensor:
+    """coco/model.py:256-312 -> sentence (B, steps, 300).
+
+    ``h = z2h(z)`` repeated for the 2 GRU layers; the first input is the GloVe vector of '<s>' (``sos``, a constant of
+    the module, coco/model.py:271-272); every later input is the PREVIOUS OUTPUT VECTOR itself (:286) -- a differentiable
+    feedback, unlike the argmax of the character models.  Each step: GRU(300+D -> 200, 2 layers, inter-layer dropout 0.1
+    in train) on ``w_in || z``, then Linear(200+D -> 300) on ``h_top || z``.  The EOS pre-fill of ``sentence`` (:275-277)
+    is overwritten at every position."""
+    B = z.shape[0]
+    w_in = sos.to(z.dtype).reshape(1, COCO_EMB).expand(B, COCO_EMB)
+    h0 = F.linear(z, p[pre + "z2h.weight"], p[pre + "z2h.bias"])
+    h = [h0, h0]
+    out = []
+    for i in range(steps):
+        x = torch.cat((w_in, z), dim=1)
+        h[0] = gru_cell(x, h[0], p[pre + "gru.weight_ih_l0"], p[pre + "gru.weight_hh_l0"],
+                        p[pre + "gru.bias_ih_l0"], p[pre + "gru.bias_hh_l0"])
+        mid = h[0]
+        if training:
+            mid = dropout(mid, True, None if gru_masks is None else gru_masks[i], drop_p)
+        h[1] = gru_cell(mid, h[1], p[pre + "gru.weight_ih_l1"], p[pre + "gru.weight_hh_l1"],
+                        p[pre + "gru.bias_ih_l1"], p[pre + "gru.bias_hh_l1"])
+        w_out = F.linear(torch.cat((h[1], z), dim=1), p[pre + "h2o.weight"], p[pre + "h2o.bias"])
+        out.append(w_out)
+        w_in = w_out
+    return torch.stack(out, dim=1)
+
+
+def coco_forward(p: Params, image: Optional[Tensor], text: Optional[Tensor], training: bool, sos: Tensor,
+                 eps: Optional[Tensor] = None, enc_masks=None, gru_masks=None,
+                 enc_drop_p: float = DROP_P, gru_drop_p: float = DROP_P, steps: int = COCO_MAX_WORDS):
+    """coco/model.py:60-90 -> (image_recon, text_recon, mu, logvar)."""
+    assert image is not None or text is not None
+    D = p["image_decoder.upsample.0.weight"].shape[1]
+    mus, lvs = [], []
+    if image is not None:
+        o = coco_image_encoder(p, image, training, enc_masks, drop_p=enc_drop_p)
+        mus.append(o[:, :D]); lvs.append(o[:, D:])
+    if text is not None:
+        o = coco_text_encoder(p, text)
+        mus.append(o[:, :D]); lvs.append(o[:, D:])
+    mu, logvar = product_of_experts(torch.stack(mus, 0), torch.stack(lvs, 0))
+    z = reparametrize(mu, logvar, training, eps)
+    return (coco_image_decoder(p, z, training),
+            coco_text_decoder(p, z, training, sos, steps, gru_masks, drop_p=gru_drop_p), mu, logvar)
+
+
+def coco_loss(mu, logvar, recon_image=None, image=None, recon_text=None, text=None,
+              kl_lambda=1e-3, lambda_xy=1., lambda_yx=1.):
+    """coco/train.py:66-84: BCE mean over B*3*32*32, MSE mean over B*T*300, KL/B*kl_lambda."""
+    B = mu.shape[0]
+    image_bce, text_mse = 0, 0
+    if recon_image is not None and image is not None:
+        image_bce = lambda_xy * F.binary_cross_entropy(recon_image.reshape(-1, 3 * 32 * 32), image.reshape(-1, 3 * 32 * 32))
+    if recon_text is not None and text is not None:
+        text_mse = lambda_yx * F.mse_loss(recon_text, text)
+    return image_bce + text_mse + kl_sum(mu, logvar) / B * kl_lambda
+
+
+def coco_step_losses(p: Params, image: Tensor, text: Tensor, sos: Tensor, training: bool = True, kl_lambda: float = 1e-3,
+                     eps: Optional[Sequence[Tensor]] = None, enc_masks=None, gru_masks=None,
+                     enc_drop_p: float = DROP_P, gru_drop_p: float = DROP_P):
+    """coco/train.py:146-165: passes (image,text), (image), (text) with COCO_LAMBDAS."""
+    e = eps if eps is not None else (None, None, None)
+    em = enc_masks if enc_masks is not None else (None, None, None)
+    gm = gru_masks if gru_masks is not None else (None, None, None)
+    args = ((image, text), (image, None), (None, text))
+    T = text.shape[1]
+    losses, outs = [], []
+    for k in range(3):
+        ri, rt, mu, lv = coco_forward(p, args[k][0], args[k][1], training, sos, e[k], em[k], gm[k],
+                                      enc_drop_p, gru_drop_p, steps=T)
+        losses.append(coco_loss(mu, lv, ri, image, rt, text, kl_lambda, COCO_LAMBDAS[k][0], COCO_LAMBDAS[k][1]))
+        outs.append((ri, rt, mu, lv))
+    return losses, outs
+
+
+def formula_sos() -> Tensor:
+    """Stand-in for GloVe('<s>') (the 2 GB GloVe file is not available anywhere in this build): a fixed 300-vector of
+    GloVe-like scale.  The golden generator hands the same vector to the reference through its stubbed ``GloVe``."""
+    return (0.4 * _hash_uniform(COCO_EMB, 999)).to(torch.float32)
+
+
+# ----------------------------------------------------------------------------
 # parameter tables (state_dict order and shapes, SURVEY 8 a14 [probed])
 # ----------------------------------------------------------------------------
 def _bn(name: str, c: int):
@@ -540,6 +681,25 @@ def param_table(model: str, D: int) -> List[Tuple[str, Tuple[int, ...]]]:
         t += [("attrs_decoder.net.0.weight", (64, D)), ("attrs_decoder.net.0.bias", (64,))] + _bn("attrs_decoder.net.1", 64)
         t += [("attrs_decoder.net.3.weight", (N_ATTRS, 64)), ("attrs_decoder.net.3.bias", (N_ATTRS,))]
         return t
+    if model == "coco":
+        t = [("image_encoder.features.0.weight", (64, 3, 4, 4)),
+             ("image_encoder.features.2.weight", (128, 64, 4, 4))] + _bn("image_encoder.features.3", 128)
+        t += [("image_encoder.features.5.weight", (256, 128, 4, 4))] + _bn("image_encoder.features.6", 256)
+        t += [("image_encoder.features.8.weight", (512, 256, 4, 4))] + _bn("image_encoder.features.9", 512)
+        t += [("image_encoder.classifier.0.weight", (1024, 2048)), ("image_encoder.classifier.0.bias", (1024,)),
+              ("image_encoder.classifier.3.weight", (256, 1024)), ("image_encoder.classifier.3.bias", (256,)),
+              ("image_encoder.classifier.6.weight", (2 * D, 256)), ("image_encoder.classifier.6.bias", (2 * D,))]
+        t += [("image_decoder.upsample.0.weight", (2048, D)), ("image_decoder.upsample.0.bias", (2048,)),
+              ("image_decoder.hallucinate.0.weight", (512, 256, 4, 4))] + _bn("image_decoder.hallucinate.1", 256)
+        t += [("image_decoder.hallucinate.3.weight", (256, 128, 4, 4))] + _bn("image_decoder.hallucinate.4", 128)
+        t += [("image_decoder.hallucinate.6.weight", (128, 64, 4, 4))] + _bn("image_decoder.hallucinate.7", 64)
+        t += [("image_decoder.hallucinate.9.weight", (64, 3, 4, 4))]
+        t += _gru("text_encoder.gru", COCO_EMB, COCO_HID, ("l0", "l0_reverse"))
+        t += [("text_encoder.h2p.weight", (2 * D, COCO_HID)), ("text_encoder.h2p.bias", (2 * D,))]
+        t += [("text_decoder.z2h.weight", (COCO_HID, D)), ("text_decoder.z2h.bias", (COCO_HID,))]
+        t += _gru("text_decoder.gru", COCO_EMB + D, COCO_HID, ("l0", "l1"))
+        t += [("text_decoder.h2o.weight", (COCO_EMB, COCO_HID + D)), ("text_decoder.h2o.bias", (COCO_EMB,))]
+        return t
     raise ValueError(model)
 
 
@@ -581,7 +741,7 @@ def formula_params(model: str, D: int, requires_grad: bool = False) -> Params:
         elif "embed" in name or (model == "mnist" and name == "text_encoder.net.0.weight"):
             v = 1.7 * u                                          # ~unit variance like N(0,1)
         elif "gru" in name:
-            v = u * 0.1                                          # U(+-1/sqrt(hidden=100))
+            v = u * (1.0 / math.sqrt(COCO_HID) if model == "coco" else 0.1)    # U(+-1/sqrt(hidden))
         elif len(shape) == 1:
             v = 0.05 * u
         else:
@@ -624,6 +784,16 @@ def formula_inputs(model: str, B: int, seed: int = 0):
         img = (0.5 + 0.5 * torch.sin(0.0031 * i + seed)).clamp(0, 1)
         attrs = (lcg(B * N_ATTRS, 10, 4) < 3).to(torch.float32).view(B, N_ATTRS)
         return img.to(torch.float32).view(B, 3, 64, 64), attrs
+    if model == "coco":
+        i = torch.arange(B * 3 * 32 * 32, dtype=torch.float64)
+        img = (0.5 + 0.5 * torch.sin(0.0071 * i + seed)).clamp(0, 1)
+        # caption tensors (coco/utils.py:36-47): GloVe-like vectors for the first `len` positions, zeros after
+        j = torch.arange(B * COCO_MAX_WORDS * COCO_EMB, dtype=torch.float64)
+        txt = (0.4 * (torch.sin(0.37 * j + 0.11 * seed) + 0.5 * torch.cos(0.0131 * j))).view(B, COCO_MAX_WORDS, COCO_EMB)
+        lens = 8 + lcg(B, 40, 5)
+        for b in range(B):
+            txt[b, int(lens[b]):] = 0.0
+        return img.to(torch.float32).view(B, 3, 32, 32), txt.to(torch.float32)
     raise ValueError(model)
 
 
