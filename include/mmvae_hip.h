@@ -230,6 +230,71 @@ int mmvae_celeba_attrs_decoder_fwd(mmvae_celeba_t*, void* ws, size_t ws_bytes, c
 int mmvae_celeba_attrs_decoder_bwd(mmvae_celeba_t*, void* ws, size_t ws_bytes, const float* d_recon, const float* recon,
                                    float* dz, void* stream);
 
+/* ---------------------------------------------------------------- COCO (coco/model.py, coco/train.py)
+ * MultimodalVAE of coco/model.py:22-90: conv ImageEncoder :147-187 / ImageDecoder :190-216 on 3x32x32 images (the code's
+ * size: Scale(32), coco/train.py:107-112), TextEncoder :219-245 (biGRU over `steps` 300-d GloVe vectors) / TextDecoder
+ * :248-312 (2-layer GRU regressing one 300-d vector per step, fed back as the next input), loss_function
+ * coco/train.py:66-84 (BCE + MSE + KL).  Plan/query/bind/pack functions as for mmvae_mm_*. */
+typedef struct CocoPlan mmvae_coco_t;
+mmvae_coco_t* mmvae_coco_create(int n_latents, int batch);        /* MultimodalVAE(n_latents), steps = 102 (coco/utils.py:12-15) */
+mmvae_coco_t* mmvae_coco_create_t(int n_latents, int batch, int steps);   /* other caption lengths (tests) */
+void mmvae_coco_destroy(mmvae_coco_t*);
+int mmvae_coco_steps(const mmvae_coco_t*);
+long long mmvae_coco_param_count(const mmvae_coco_t*);
+int mmvae_coco_num_params(const mmvae_coco_t*);
+int mmvae_coco_param_info(const mmvae_coco_t*, int i, char* name128, int* ndim, int* shape4, long long* offset);
+long long mmvae_coco_bn_floats(const mmvae_coco_t*);
+int mmvae_coco_num_bn(const mmvae_coco_t*);
+int mmvae_coco_bn_info(const mmvae_coco_t*, int i, char* prefix128, int* channels, long long* offset);
+long long mmvae_coco_packed_elems(const mmvae_coco_t*);
+long long mmvae_coco_packed_vec_elems(const mmvae_coco_t*);
+long long mmvae_coco_gpk_elems(const mmvae_coco_t*);
+long long mmvae_coco_gpk_vec_elems(const mmvae_coco_t*);
+size_t mmvae_coco_desc_bytes(const mmvae_coco_t*, int which);
+int mmvae_coco_desc_copy(const mmvae_coco_t*, int which, void* host_out);
+size_t mmvae_coco_workspace_bytes(const mmvae_coco_t*);
+int mmvae_coco_bind(mmvae_coco_t*, float* params, float* grads, float* bn_stats, long long* num_batches_tracked,
+                    void* packed, float* packed_vec, float* gpk, float* gpk_vec, void* desc_dev, void* gdesc_dev);
+int mmvae_coco_pack_weights(mmvae_coco_t*, void* stream);
+/* The train() closure body of coco/train.py:138-173 (3 passes, 3 losses, backward) */
+typedef struct {
+    void* ws; size_t ws_bytes;
+    const long long* step_counter;          /* device int64 keying the Philox streams, or NULL */
+    const float* image;                     /* [B][3][32][32] fp32 */
+    const float* text;                      /* [B][steps][300] fp32 GloVe vectors (coco/utils.py:36-47) */
+    const float* sos;                       /* [300] GloVe('<s>') (coco/model.py:271-272) */
+    const float* eps;                       /* [3][B][D] or NULL (drawn on device) */
+    const uint8_t* enc_mask1;               /* [2][B][1024] keep flags of classifier Dropout 1 or NULL (drawn) */
+    const uint8_t* enc_mask2;               /* [2][B][256] */
+    const uint8_t* gru_keep;                /* [steps][3B][200] keep flags of the decoder GRU's inter-layer dropout or NULL */
+    int enc_dropout; int gru_dropout;       /* 0: no dropout */
+    float kl_lambda;                        /* coco/train.py:67 (1e-3) */
+    float lambda_xy[3]; float lambda_yx[3]; /* coco/train.py:152-164: (1,1,0) and (1,1,1) */
+    unsigned long long seed;
+    float* sums;                            /* out [16]: image bce_sum[0..2], text squared-error sum[4..6], kl_sum[8..10] */
+    float* recon_image;                     /* out [3][B][3][32][32] or NULL */
+    float* recon_text;                      /* out [3][B][steps][300] or NULL */
+    float* mu; float* logvar;               /* out [3][B][D] or NULL */
+    int pass_skip[3];                       /* 1: pass k absent from this step */
+} mmvae_coco_step_io;
+int mmvae_coco_step(mmvae_coco_t*, const mmvae_coco_step_io*, int training, int do_backward, void* stream);
+/* Granular modules (forward + autograd backward), workspace rules as for mmvae_mm_*_fwd/bwd */
+int mmvae_coco_image_encoder_fwd(mmvae_coco_t*, void* ws, size_t ws_bytes, const float* image, const uint8_t* mask1,
+                                 const uint8_t* mask2, int training, float* out_mu_logvar, void* stream);  /* coco/model.py:182-187 */
+int mmvae_coco_image_encoder_bwd(mmvae_coco_t*, void* ws, size_t ws_bytes, const float* d_out, const uint8_t* mask1,
+                                 const uint8_t* mask2, void* stream);
+int mmvae_coco_image_decoder_fwd(mmvae_coco_t*, void* ws, size_t ws_bytes, const float* z, int training, float* recon,
+                                 void* stream);                                                  /* coco/model.py:211-216 */
+int mmvae_coco_image_decoder_bwd(mmvae_coco_t*, void* ws, size_t ws_bytes, const float* d_recon, const float* recon,
+                                 float* dz, void* stream);
+int mmvae_coco_text_encoder_fwd(mmvae_coco_t*, void* ws, size_t ws_bytes, const float* text, float* out_mu_logvar,
+                                void* stream);                                                   /* coco/model.py:236-245 */
+int mmvae_coco_text_encoder_bwd(mmvae_coco_t*, void* ws, size_t ws_bytes, const float* text, const float* d_out, void* stream);
+int mmvae_coco_text_decoder_fwd(mmvae_coco_t*, void* ws, size_t ws_bytes, const float* z, const float* sos,
+                                const uint8_t* keep, int training, float* sentence, void* stream);  /* coco/model.py:266-288 */
+int mmvae_coco_text_decoder_bwd(mmvae_coco_t*, void* ws, size_t ws_bytes, const float* z, const float* sos,
+                                const uint8_t* keep, const float* sentence, const float* d_sentence, float* dz, void* stream);
+
 /* ---------------------------------------------------------------- dataset-independent ops */
 /* ProductOfExperts.forward (multimnist/model.py:355-360) over M stacked experts of n scalars each */
 int mmvae_poe_fwd(const float* mu, const float* logvar, int M, int n, float* out_mu, float* out_logvar, void* stream);

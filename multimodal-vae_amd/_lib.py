@@ -44,6 +44,23 @@ class MnistStepIO(C.Structure):
     ]
 
 
+class CocoStepIO(C.Structure):
+    """mmvae_coco_step_io"""
+    _fields_ = [
+        ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
+        ("step_counter", C.c_void_p),
+        ("image", C.c_void_p), ("text", C.c_void_p), ("sos", C.c_void_p), ("eps", C.c_void_p),
+        ("enc_mask1", C.c_void_p), ("enc_mask2", C.c_void_p), ("gru_keep", C.c_void_p),
+        ("enc_dropout", C.c_int), ("gru_dropout", C.c_int),
+        ("kl_lambda", C.c_float),
+        ("lambda_xy", C.c_float * 3), ("lambda_yx", C.c_float * 3),
+        ("seed", C.c_ulonglong),
+        ("sums", C.c_void_p), ("recon_image", C.c_void_p), ("recon_text", C.c_void_p),
+        ("mu", C.c_void_p), ("logvar", C.c_void_p),
+        ("pass_skip", C.c_int * 3),
+    ]
+
+
 class CelebaStepIO(C.Structure):
     """mmvae_celeba_step_io"""
     _fields_ = [
@@ -159,7 +176,19 @@ SIGNATURES["mmvae_celeba_attrs_encoder_fwd"] = (_I, [_P, _P, _SZ, _P, _I, _P, _P
 SIGNATURES["mmvae_celeba_attrs_encoder_bwd"] = (_I, [_P, _P, _SZ, _P, _P])
 SIGNATURES["mmvae_celeba_attrs_decoder_fwd"] = (_I, [_P, _P, _SZ, _P, _I, _P, _P])
 SIGNATURES["mmvae_celeba_attrs_decoder_bwd"] = (_I, [_P, _P, _SZ, _P, _P, _P, _P])
-_STATUS = {n for n, (r, _) in SIGNATURES.items() if r is _I and not n.endswith(("_num_params", "_num_bn", "_precision"))}
+SIGNATURES.update(_plan_api("coco"))
+SIGNATURES["mmvae_coco_create_t"] = (_P, [_I, _I, _I])
+SIGNATURES["mmvae_coco_steps"] = (_I, [_P])
+SIGNATURES["mmvae_coco_step"] = (_I, [_P, C.POINTER(CocoStepIO), _I, _I, _P])
+SIGNATURES["mmvae_coco_image_encoder_fwd"] = (_I, [_P, _P, _SZ, _P, _P, _P, _I, _P, _P])
+SIGNATURES["mmvae_coco_image_encoder_bwd"] = (_I, [_P, _P, _SZ, _P, _P, _P, _P])
+SIGNATURES["mmvae_coco_image_decoder_fwd"] = (_I, [_P, _P, _SZ, _P, _I, _P, _P])
+SIGNATURES["mmvae_coco_image_decoder_bwd"] = (_I, [_P, _P, _SZ, _P, _P, _P, _P])
+SIGNATURES["mmvae_coco_text_encoder_fwd"] = (_I, [_P, _P, _SZ, _P, _P, _P])
+SIGNATURES["mmvae_coco_text_encoder_bwd"] = (_I, [_P, _P, _SZ, _P, _P, _P])
+SIGNATURES["mmvae_coco_text_decoder_fwd"] = (_I, [_P, _P, _SZ, _P, _P, _P, _I, _P, _P])
+SIGNATURES["mmvae_coco_text_decoder_bwd"] = (_I, [_P, _P, _SZ, _P, _P, _P, _P, _P, _P, _P])
+_STATUS = {n for n, (r, _) in SIGNATURES.items() if r is _I and not n.endswith(("_num_params", "_num_bn", "_precision", "_coco_steps"))}
 
 _lib = None
 _inited = set()

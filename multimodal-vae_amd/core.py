@@ -144,6 +144,20 @@ class CelebaState(PlanState):
     API = "celeba"
 
 
+class CocoState(PlanState):
+    """coco/model.py MultimodalVAE.  ``steps``: caption length (coco/utils.py:12-15: 102)."""
+    API = "coco"
+
+    def __init__(self, n_latents: int, device: torch.device, steps: int = 102):
+        self.steps = int(steps)
+        super().__init__(n_latents, device)
+
+    def _c(self, fn, *args):
+        if fn == "create":
+            return call("mmvae_coco_create_t", *args, self.steps)
+        return super()._c(fn, *args)
+
+
 class StepOutputs:
     """Lazy view of the loss sums of one fused step (no host sync until a value is read)."""
 
@@ -353,4 +367,46 @@ class FusedCelebaStep(_FusedStepBase):
         io.seed = self.seed
         io.sums = self.sums.data_ptr()
         call("mmvae_celeba_step", self.h, C.byref(io), int(training), int(backward), _stream())
+        return self._outputs()
+
+
+class FusedCocoStep(_FusedStepBase):
+    """The 3-pass step of coco/train.py:138-173 (lambda_xy = (1,1,0), lambda_yx = (1,1,1), kl_lambda 1e-3)."""
+
+    LAMBDA_XY = (1.0, 1.0, 0.0)
+    LAMBDA_YX = (1.0, 1.0, 1.0)
+    EMB = 300
+
+    def __init__(self, state: PlanState, batch: int, sos: torch.Tensor, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
+                 kl_lambda: float = 1e-3, seed: int = 1234, world_size: int = 1, all_reduce=None):
+        super().__init__(state, batch, lr, betas, eps, seed, world_size, all_reduce)
+        self.kl_lambda = kl_lambda
+        self.T = state.steps
+        self.sos = sos.to(device=state.device, dtype=torch.float32).contiguous().reshape(self.EMB)
+        self.enc_dropout = self.gru_dropout = True
+        self._LA, self._LB = self.LAMBDA_XY, self.LAMBDA_YX
+        self._last = ((True, True, True), self.LAMBDA_XY, self.LAMBDA_YX)
+
+    def _outputs(self) -> StepOutputs:
+        passes, lxy, lyx = self._last
+        return StepOutputs(self.sums, self.B * 3 * 32 * 32, self.B * self.T * self.EMB, self.kl_lambda / self.B, lxy, lyx, passes)
+
+    def forward_backward(self, image, text, training=True, backward=True, eps=None, enc_mask1=None, enc_mask2=None,
+                         gru_keep=None, recon_image=None, recon_text=None, mu=None, logvar=None, passes=None,
+                         lambda_xy=None, lambda_yx=None) -> StepOutputs:
+        assert image.is_contiguous() and text.is_contiguous() and image.dtype == torch.float32 and text.dtype == torch.float32
+        assert image.shape == (self.B, 3, 32, 32) and text.shape == (self.B, self.T, self.EMB)
+        io = _lib.CocoStepIO()
+        io.ws, io.ws_bytes = self.ws.data_ptr(), self.ws.numel()
+        io.step_counter = self.adam_state.data_ptr()
+        io.image, io.text, io.sos = image.data_ptr(), text.data_ptr(), self.sos.data_ptr()
+        for k, t in (("eps", eps), ("enc_mask1", enc_mask1), ("enc_mask2", enc_mask2), ("gru_keep", gru_keep),
+                     ("recon_image", recon_image), ("recon_text", recon_text), ("mu", mu), ("logvar", logvar)):
+            setattr(io, k, None if t is None else t.data_ptr())
+        io.enc_dropout, io.gru_dropout = int(self.enc_dropout), int(self.gru_dropout)
+        io.kl_lambda = self.kl_lambda
+        self._pass_config(io, passes, lambda_xy, lambda_yx, "lambda_xy", "lambda_yx")
+        io.seed = self.seed
+        io.sums = self.sums.data_ptr()
+        call("mmvae_coco_step", self.h, C.byref(io), int(training), int(backward), _stream())
         return self._outputs()

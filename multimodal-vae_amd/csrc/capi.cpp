@@ -3,6 +3,7 @@
 #include "multimnist.h"
 #include "mnist.h"
 #include "celeba.h"
+#include "coco.h"
 #include "plan_base.h"
 #include <cstring>
 #include <exception>
@@ -90,6 +91,7 @@ static int pb_pack(PlanBase* P, hipStream_t s) {
     }
 static inline PlanBase* mnist_b(const mmvae_mnist_t* p) { return mnist_base(const_cast<mmvae_mnist_t*>(p)); }
 static inline PlanBase* celeba_b(const mmvae_celeba_t* p) { return celeba_base(const_cast<mmvae_celeba_t*>(p)); }
+static inline PlanBase* coco_b(const mmvae_coco_t* p) { return coco_base(const_cast<mmvae_coco_t*>(p)); }
 
 extern "C" {
 
@@ -337,6 +339,70 @@ int mmvae_celeba_attrs_decoder_bwd(mmvae_celeba_t* p, void* ws, size_t wsb, cons
     return celeba_attrs_decoder_bwd(p, ws, wsb, d_recon, recon, dz, S(st));
     API_GUARD_END
 }
+
+// ---- COCO (coco/model.py, coco/train.py)
+mmvae_coco_t* mmvae_coco_create_t(int n_latents, int batch, int steps) {
+    try { return coco_create(n_latents, batch, steps); } catch (...) { mmvae_set_error("coco_create failed"); return nullptr; }
+}
+mmvae_coco_t* mmvae_coco_create(int n_latents, int batch) { return mmvae_coco_create_t(n_latents, batch, 102); }
+void mmvae_coco_destroy(mmvae_coco_t* p) { coco_destroy(p); }
+int mmvae_coco_steps(const mmvae_coco_t* p) { return p ? coco_steps(p) : 0; }
+MMVAE_PLAN_API(coco, mmvae_coco_t, coco_b)
+int mmvae_coco_step(mmvae_coco_t* p, const mmvae_coco_step_io* io, int training, int do_backward, void* stream) {
+    API_GUARD_BEGIN
+    MMVAE_REQUIRE(p && io, "mmvae_coco_step: null argument");
+    CocoStepIO s;
+    s.ws = io->ws; s.ws_bytes = io->ws_bytes; s.step_ctr = io->step_counter; s.image = io->image; s.text = io->text; s.sos = io->sos;
+    s.eps = io->eps; s.enc_mask1 = io->enc_mask1; s.enc_mask2 = io->enc_mask2; s.gru_keep = io->gru_keep;
+    s.enc_dropout = io->enc_dropout; s.gru_dropout = io->gru_dropout; s.kl_lambda = io->kl_lambda;
+    for (int k = 0; k < 3; ++k) { s.lambda_xy[k] = io->lambda_xy[k]; s.lambda_yx[k] = io->lambda_yx[k]; }
+    s.seed = io->seed; s.sums = io->sums; s.recon_image = io->recon_image; s.recon_text = io->recon_text;
+    s.mu = io->mu; s.logvar = io->logvar;
+    for (int k = 0; k < 3; ++k) s.pass_skip[k] = io->pass_skip[k];
+    return coco_step(p, s, training, do_backward, S(stream));
+    API_GUARD_END
+}
+int mmvae_coco_image_encoder_fwd(mmvae_coco_t* p, void* ws, size_t wsb, const float* image, const uint8_t* m1, const uint8_t* m2, int training, float* out, void* st) {
+    API_GUARD_BEGIN
+    return coco_image_encoder_fwd(p, ws, wsb, image, m1, m2, training, out, S(st));
+    API_GUARD_END
+}
+int mmvae_coco_image_encoder_bwd(mmvae_coco_t* p, void* ws, size_t wsb, const float* d_out, const uint8_t* m1, const uint8_t* m2, void* st) {
+    API_GUARD_BEGIN
+    return coco_image_encoder_bwd(p, ws, wsb, d_out, m1, m2, S(st));
+    API_GUARD_END
+}
+int mmvae_coco_image_decoder_fwd(mmvae_coco_t* p, void* ws, size_t wsb, const float* z, int training, float* recon, void* st) {
+    API_GUARD_BEGIN
+    return coco_image_decoder_fwd(p, ws, wsb, z, training, recon, S(st));
+    API_GUARD_END
+}
+int mmvae_coco_image_decoder_bwd(mmvae_coco_t* p, void* ws, size_t wsb, const float* d_recon, const float* recon, float* dz, void* st) {
+    API_GUARD_BEGIN
+    return coco_image_decoder_bwd(p, ws, wsb, d_recon, recon, dz, S(st));
+    API_GUARD_END
+}
+int mmvae_coco_text_encoder_fwd(mmvae_coco_t* p, void* ws, size_t wsb, const float* text, float* out, void* st) {
+    API_GUARD_BEGIN
+    return coco_text_encoder_fwd(p, ws, wsb, text, out, S(st));
+    API_GUARD_END
+}
+int mmvae_coco_text_encoder_bwd(mmvae_coco_t* p, void* ws, size_t wsb, const float* text, const float* d_out, void* st) {
+    API_GUARD_BEGIN
+    return coco_text_encoder_bwd(p, ws, wsb, text, d_out, S(st));
+    API_GUARD_END
+}
+int mmvae_coco_text_decoder_fwd(mmvae_coco_t* p, void* ws, size_t wsb, const float* z, const float* sos, const uint8_t* keep, int training, float* sentence, void* st) {
+    API_GUARD_BEGIN
+    return coco_text_decoder_fwd(p, ws, wsb, z, sos, keep, training, sentence, S(st));
+    API_GUARD_END
+}
+int mmvae_coco_text_decoder_bwd(mmvae_coco_t* p, void* ws, size_t wsb, const float* z, const float* sos, const uint8_t* keep, const float* sentence, const float* d_sentence, float* dz, void* st) {
+    API_GUARD_BEGIN
+    return coco_text_decoder_bwd(p, ws, wsb, z, sos, keep, sentence, d_sentence, dz, S(st));
+    API_GUARD_END
+}
+
 
 int mmvae_poe_fwd(const float* mu, const float* lv, int M, int n, float* omu, float* olv, void* s) { return launch_poe_fwd(mu, lv, M, n, omu, olv, S(s)); }
 int mmvae_poe_bwd(const float* mu, const float* lv, int M, int n, const float* gmu, const float* glv, float* dmu, float* dlv, void* s) {

@@ -1,0 +1,359 @@
+// Caption half of the COCO MMVAE (coco/model.py:219-312), fp32 on the fp32 MFMA GEMM of gemm_f32.hip.
+//
+// TextEncoder: bidirectional GRU(300 -> 200) over T = 102 GloVe vectors, last time step of both directions (the reverse
+// direction has then seen only vector T-1 from h = 0), summed, Linear(200, 2D).
+// TextDecoder: h = z2h(z) for both layers of a GRU(300+D -> 200, 2 layers, inter-layer dropout 0.1); the first input is
+// GloVe('<s>'), every later input is the previous OUTPUT VECTOR (a differentiable feedback: backpropagation through time
+// runs through the outputs as well as through the hidden states); output Linear(200+D -> 300).
+//
+// Why fp32: 102 dependent steps amplify operand rounding, and the reference's numbers are the parity target; the
+// per-step GEMMs (3B x 600 x 400 at most) are latency-sized either way.  What is restructured, not approximated:
+//   * the z-columns of the layer-0 input projection and of the output projection do not depend on the time step: they are
+//     computed once per step of the optimizer (zi0 = z Wih0[:,300:]^T + b, zo = z Who[:,200:]^T + b) and added in the
+//     GEMM epilogues; their gradients are one GEMM over the time-summed gate gradients;
+//   * the encoder's input projection for all T steps is ONE GEMM (B*T rows);
+//   * weight gradients whose operands share a [t][row] layout are ONE GEMM over K = T*rows (split-K over the grid).
+// Saved per step for the backward pass: gates (r, z, n, W_hn h + b_hn) and hidden states.
+#include "coco_plan.h"
+#include "gemm_f32.h"
+
+namespace {
+
+constexpr int H = COCO_H, G = COCO_G, E = COCO_E, TPBT = 256;
+
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+struct GruFwd {
+    const float* gi; long long ldgi;     // [rows][3H] input projection (+ bias), row stride ldgi
+    const float* gh;                     // [rows][3H] hidden projection (+ bias), dense
+    const float* hprev;                  // [rows][H]
+    float* h;                            // [rows][H]
+    float* sav;                          // [rows][4H] (r | z | n | gh_n) or null
+    const uint8_t* keep; float scale;    // inter-layer dropout keep flags [rows][H] or null
+    float* mid;                          // [rows][H] = dropout(h) or null
+    int rows;
+};
+__global__ __launch_bounds__(TPBT) void gru_fwd_kernel(const GruFwd a) {
+    const int i = blockIdx.x * TPBT + threadIdx.x;
+    if (i >= a.rows * H) return;
+    const int r = i / H, j = i - r * H;
+    const float* gi = a.gi + (size_t)r * a.ldgi;
+    const float* gh = a.gh + (size_t)r * G;
+    const float rr = sigm(gi[j] + gh[j]);
+    const float zz = sigm(gi[H + j] + gh[H + j]);
+    const float ghn = gh[2 * H + j];
+    const float nn = tanhf(gi[2 * H + j] + rr * ghn);
+    const float hh = (1.0f - zz) * nn + zz * a.hprev[i];
+    a.h[i] = hh;
+    if (a.sav) {
+        float* s = a.sav + (size_t)r * 4 * H;
+        s[j] = rr; s[H + j] = zz; s[2 * H + j] = nn; s[3 * H + j] = ghn;
+    }
+    if (a.mid) a.mid[i] = a.keep ? hh * (float)a.keep[i] * a.scale : hh;
+}
+int gru_fwd(const GruFwd& a, hipStream_t s) {
+    hipLaunchKernelGGL(gru_fwd_kernel, dim3(ceil_div(a.rows * H, TPBT)), dim3(TPBT), 0, s, a);
+    return mmvae_check_launch("gru_fwd");
+}
+
+struct GruBwd {
+    const float* dh;                     // [rows][H] gradient wrt this step's h
+    const float* dh2;                    // optional second addend (gradient wrt dropout(h) of the layer above)
+    const uint8_t* keep; float scale;    // its dropout keep flags, or null
+    const float* sav; const float* hprev;
+    float* dgi; long long lddgi;         // [rows][3H] gradient wrt the input projection, row stride lddgi
+    float* dgh;                          // [rows][3H] gradient wrt the hidden projection, dense
+    float* dh_out;                       // [rows][H] = dh * z (the direct path to h_prev; may alias dh)
+    int rows;
+};
+__global__ __launch_bounds__(TPBT) void gru_bwd_kernel(const GruBwd a) {
+    const int i = blockIdx.x * TPBT + threadIdx.x;
+    if (i >= a.rows * H) return;
+    const int r = i / H, j = i - r * H;
+    float d = a.dh[i];
+    if (a.dh2) d += a.keep ? a.dh2[i] * (float)a.keep[i] * a.scale : a.dh2[i];
+    const float* s = a.sav + (size_t)r * 4 * H;
+    const float rr = s[j], zz = s[H + j], nn = s[2 * H + j], ghn = s[3 * H + j];
+    const float dn = d * (1.0f - zz);
+    const float dzz = d * (a.hprev[i] - nn);
+    const float dpn = dn * (1.0f - nn * nn);
+    const float dpz = dzz * zz * (1.0f - zz);
+    const float dpr = dpn * ghn * rr * (1.0f - rr);
+    float* gi = a.dgi + (size_t)r * a.lddgi;
+    float* gh = a.dgh + (size_t)r * G;
+    gi[j] = dpr; gi[H + j] = dpz; gi[2 * H + j] = dpn;
+    gh[j] = dpr; gh[H + j] = dpz; gh[2 * H + j] = dpn * rr;
+    a.dh_out[i] = d * zz;
+}
+int gru_bwd(const GruBwd& a, hipStream_t s) {
+    hipLaunchKernelGGL(gru_bwd_kernel, dim3(ceil_div(a.rows * H, TPBT)), dim3(TPBT), 0, s, a);
+    return mmvae_check_launch("gru_bwd");
+}
+
+__global__ __launch_bounds__(TPBT) void add2_kernel(const float* a, const float* b, long long n, float* out) {
+    const long long i = (long long)blockIdx.x * TPBT + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
+int add2(const float* a, const float* b, long long n, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(add2_kernel, dim3((unsigned)((n + TPBT - 1) / TPBT)), dim3(TPBT), 0, s, a, b, n, out);
+    return mmvae_check_launch("add2");
+}
+// out[o][i] = sum_t in[(o*T + t)*inner + i]
+__global__ __launch_bounds__(TPBT) void sum_mid_kernel(const float* in, long long outer, int T, long long inner, float* out) {
+    const long long i = (long long)blockIdx.x * TPBT + threadIdx.x;
+    if (i >= outer * inner) return;
+    const long long o = i / inner, c = i - o * inner;
+    const float* p = in + o * T * inner + c;
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) acc += p[(long long)t * inner];
+    out[i] = acc;
+}
+int sum_mid(const float* in, long long outer, int T, long long inner, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(sum_mid_kernel, dim3((unsigned)((outer * inner + TPBT - 1) / TPBT)), dim3(TPBT), 0, s, in, outer, T, inner, out);
+    return mmvae_check_launch("sum_mid");
+}
+
+// grid.y = group; recon rows of group g compare with the same target
+__global__ __launch_bounds__(TPBT) void mse3_kernel(const float* recon, const float* target, long long per_group, float c0, float c1,
+                                                    float c2, float* loss_sum, float* dw) {
+    const int g = blockIdx.y;
+    const float coef = g == 0 ? c0 : (g == 1 ? c1 : c2);
+    float acc = 0.f;
+    for (long long i = (long long)blockIdx.x * TPBT + threadIdx.x; i < per_group; i += (long long)gridDim.x * TPBT) {
+        const float d = recon[g * per_group + i] - target[i];
+        acc += d * d;
+        if (dw) dw[g * per_group + i] = coef * 2.f * d;
+    }
+    acc = wave_sum(acc);
+    if (loss_sum && (threadIdx.x & 63) == 0) atomicAdd(loss_sum + (blockIdx.x % MMVAE_LOSS_SLOTS) * 16 + 4 + g, acc);
+}
+
+// ---- GEMM shorthands over PyTorch-layout weights W[N][ldw] (a column window [c0, c0+K) of it) -------------------------
+// y[M][N] (ldy) = x[M][K] (ldx) W[:, c0:c0+K]^T (+ bias) (+ addm)
+int lin(const float* x, long long ldx, int M, const float* W, int N, int K, long long ldw, int c0, const float* bias,
+        const float* addm, long long ldadd, float* y, long long ldy, hipStream_t s) {
+    F32Gemm g{};
+    g.A = x; g.a_rs = ldx; g.a_cs = 1; g.B = W + c0; g.b_rs = 1; g.b_cs = ldw;
+    g.M = M; g.N = N; g.K = K; g.C = y; g.ldc = ldy; g.bias = bias; g.addm = addm; g.ldadd = ldadd;
+    return gemm_f32(g, s);
+}
+// dx[M][K] (lddx) (+)= dy[M][N] (lddy) W[:, c0:c0+K]
+int lin_dx(const float* dy, long long lddy, int M, const float* W, int N, int K, long long ldw, int c0, float* dx, long long lddx,
+           int accumulate, hipStream_t s) {
+    F32Gemm g{};
+    g.A = dy; g.a_rs = lddy; g.a_cs = 1; g.B = W + c0; g.b_rs = ldw; g.b_cs = 1;
+    g.M = M; g.N = K; g.K = N; g.C = dx; g.ldc = lddx; g.accumulate = accumulate;
+    return gemm_f32(g, s);
+}
+// dW[:, c0:c0+K] += dy[M][N]^T x[M][K]   (dW is zero at the start of the step; float atomics when K is split)
+int lin_dw(const float* dy, long long lddy, const float* x, long long ldx, int M, float* dW, int N, int K, long long ldw, int c0,
+           hipStream_t s) {
+    F32Gemm g{};
+    g.A = dy; g.a_rs = 1; g.a_cs = lddy; g.B = x; g.b_rs = ldx; g.b_cs = 1;
+    g.M = N; g.N = K; g.K = M; g.C = dW + c0; g.ldc = ldw; g.accumulate = 1;
+    const int tiles = ceil_div(N, 32) * ceil_div(K, 32);
+    int ks = 1;
+    while (tiles * ks < 1024 && M / (ks * 2) >= 512 && ks < 64) ks *= 2;
+    g.ksplit = ks;
+    return gemm_f32(g, s);
+}
+
+}  // namespace
+
+void coco_text_build(CocoPlan& P) {
+    auto gru = [&](CocoGru& g, const std::string& n, const char* sfx) {
+        g.wih = off(P, n + ".weight_ih_" + sfx); g.whh = off(P, n + ".weight_hh_" + sfx);
+        g.bih = off(P, n + ".bias_ih_" + sfx); g.bhh = off(P, n + ".bias_hh_" + sfx);
+    };
+    gru(P.te_f, "text_encoder.gru", "l0"); gru(P.te_r, "text_encoder.gru", "l0_reverse");
+    gru(P.td0, "text_decoder.gru", "l0"); gru(P.td1, "text_decoder.gru", "l1");
+    P.te_h2p_w = off(P, "text_encoder.h2p.weight"); P.te_h2p_b = off(P, "text_encoder.h2p.bias");
+    P.td_z2h_w = off(P, "text_decoder.z2h.weight"); P.td_z2h_b = off(P, "text_decoder.z2h.bias");
+    P.td_h2o_w = off(P, "text_decoder.h2o.weight"); P.td_h2o_b = off(P, "text_decoder.h2o.bias");
+}
+
+void coco_text_carve(CocoPlan& P, Workspace& ws) {
+    CocoPlan::W& w = P.w;
+    const size_t B = P.B, R = 3 * B, T = P.T, D = P.D;
+    w.te_gi = ws.take<float>(B * T * G); w.te_gh = ws.take<float>(B * G); w.te_h = ws.take<float>(T * B * H);
+    w.te_sav = ws.take<float>(T * B * 4 * H); w.te_gi_r = ws.take<float>(B * G); w.te_sav_r = ws.take<float>(B * 4 * H);
+    w.te_hb = ws.take<float>(B * H); w.te_sum = ws.take<float>(B * H); w.txtout = ws.take<float>(B * 2 * D);
+    w.d_txtout = ws.take<float>(B * 2 * D); w.te_dsum = ws.take<float>(B * H); w.te_dh = ws.take<float>(B * H);
+    w.te_dgi = ws.take<float>(B * T * G); w.te_dgh = ws.take<float>(T * B * G); w.te_dgi_r = ws.take<float>(B * G);
+    w.td_zi0 = ws.take<float>(R * G); w.td_zo = ws.take<float>(R * E); w.td_gi = ws.take<float>(R * G); w.td_gh = ws.take<float>(R * G);
+    w.td_h0 = ws.take<float>((T + 1) * R * H); w.td_h1 = ws.take<float>((T + 1) * R * H); w.td_mid = ws.take<float>(T * R * H);
+    w.td_sav0 = ws.take<float>(T * R * 4 * H); w.td_sav1 = ws.take<float>(T * R * 4 * H); w.td_recon = ws.take<float>(R * T * E);
+    w.td_dw = ws.take<float>(R * T * E);
+    w.td_dgi0 = ws.take<float>(T * R * G); w.td_dgh0 = ws.take<float>(T * R * G);
+    w.td_dgi1 = ws.take<float>(T * R * G); w.td_dgh1 = ws.take<float>(T * R * G);
+    w.td_dmid = ws.take<float>(R * H); w.td_dzi0 = ws.take<float>(R * G); w.td_dwsum = ws.take<float>(R * E); w.td_dhinit = ws.take<float>(R * H);
+}
+
+// ================================================================== caption encoder (coco/model.py:236-245)
+int coco_text_enc_fwd(CocoPlan& P, const float* text, int save, float* out, hipStream_t s) {
+    CocoPlan::W& w = P.w;
+    const int B = P.B, T = P.T, D2 = 2 * P.D;
+    const float* p = P.buf.params;
+    // input projection of every time step at once: rows (b, t)
+    MMVAE_TRY(lin(text, E, B * T, p + P.te_f.wih, G, E, E, 0, p + P.te_f.bih, nullptr, 0, w.te_gi, G, s));
+    for (int t = 0; t < T; ++t) {
+        const float* hp = t == 0 ? w.zeros_h : w.te_h + (size_t)(t - 1) * B * H;
+        MMVAE_TRY(lin(hp, H, B, p + P.te_f.whh, G, H, H, 0, p + P.te_f.bhh, nullptr, 0, w.te_gh, G, s));
+        GruFwd a{};
+        a.gi = w.te_gi + (size_t)t * G; a.ldgi = (long long)T * G; a.gh = w.te_gh; a.hprev = hp;
+        a.h = w.te_h + (size_t)t * B * H; a.sav = save ? w.te_sav + (size_t)t * B * 4 * H : nullptr; a.rows = B;
+        MMVAE_TRY(gru_fwd(a, s));
+    }
+    {   // reverse direction: its output at the last position is its FIRST step (input T-1, h = 0)
+        MMVAE_TRY(lin(text + (size_t)(T - 1) * E, (long long)T * E, B, p + P.te_r.wih, G, E, E, 0, p + P.te_r.bih, nullptr, 0, w.te_gi_r, G, s));
+        MMVAE_TRY(lin(w.zeros_h, H, B, p + P.te_r.whh, G, H, H, 0, p + P.te_r.bhh, nullptr, 0, w.te_gh, G, s));
+        GruFwd a{};
+        a.gi = w.te_gi_r; a.ldgi = G; a.gh = w.te_gh; a.hprev = w.zeros_h; a.h = w.te_hb; a.sav = save ? w.te_sav_r : nullptr; a.rows = B;
+        MMVAE_TRY(gru_fwd(a, s));
+    }
+    MMVAE_TRY(add2(w.te_h + (size_t)(T - 1) * B * H, w.te_hb, (long long)B * H, w.te_sum, s));
+    return lin(w.te_sum, H, B, p + P.te_h2p_w, D2, H, H, 0, p + P.te_h2p_b, nullptr, 0, out, D2, s);
+}
+
+int coco_text_enc_bwd(CocoPlan& P, const float* text, const float* d_out, hipStream_t s) {
+    CocoPlan::W& w = P.w;
+    const int B = P.B, T = P.T, D2 = 2 * P.D;
+    const float* p = P.buf.params;
+    float* g = P.buf.grads;
+    MMVAE_TRY(launch_colsum_f32(d_out, B, D2, g + P.te_h2p_b, s));
+    MMVAE_TRY(lin_dw(d_out, D2, w.te_sum, H, B, g + P.te_h2p_w, D2, H, H, 0, s));
+    MMVAE_TRY(lin_dx(d_out, D2, B, p + P.te_h2p_w, D2, H, H, 0, w.te_dsum, H, 0, s));
+    {   // reverse direction (one step from h = 0: no hidden-weight gradient, only its bias)
+        GruBwd a{};
+        a.dh = w.te_dsum; a.sav = w.te_sav_r; a.hprev = w.zeros_h; a.dgi = w.te_dgi_r; a.lddgi = G; a.dgh = w.te_gh; a.dh_out = w.te_dh; a.rows = B;
+        MMVAE_TRY(gru_bwd(a, s));
+        MMVAE_TRY(launch_colsum_f32(w.te_dgi_r, B, G, g + P.te_r.bih, s));
+        MMVAE_TRY(launch_colsum_f32(w.te_gh, B, G, g + P.te_r.bhh, s));
+        MMVAE_TRY(lin_dw(w.te_dgi_r, G, text + (size_t)(T - 1) * E, (long long)T * E, B, g + P.te_r.wih, G, E, E, 0, s));
+    }
+    // forward direction: backpropagation through time
+    hipMemcpyAsync(w.te_dh, w.te_dsum, (size_t)B * H * sizeof(float), hipMemcpyDeviceToDevice, s);
+    for (int t = T - 1; t >= 0; --t) {
+        const float* hp = t == 0 ? w.zeros_h : w.te_h + (size_t)(t - 1) * B * H;
+        GruBwd a{};
+        a.dh = w.te_dh; a.sav = w.te_sav + (size_t)t * B * 4 * H; a.hprev = hp;
+        a.dgi = w.te_dgi + (size_t)t * G; a.lddgi = (long long)T * G; a.dgh = w.te_dgh + (size_t)t * B * G; a.dh_out = w.te_dh; a.rows = B;
+        MMVAE_TRY(gru_bwd(a, s));
+        if (t > 0) MMVAE_TRY(lin_dx(w.te_dgh + (size_t)t * B * G, G, B, p + P.te_f.whh, G, H, H, 0, w.te_dh, H, 1, s));
+    }
+    MMVAE_TRY(lin_dw(w.te_dgi, G, text, E, B * T, g + P.te_f.wih, G, E, E, 0, s));
+    MMVAE_TRY(launch_colsum_f32(w.te_dgi, B * T, G, g + P.te_f.bih, s));
+    MMVAE_TRY(launch_colsum_f32(w.te_dgh, B * T, G, g + P.te_f.bhh, s));
+    if (T > 1)      // pairs (dgh[t], h[t-1]) for t = 1..T-1, both laid out [t][b]
+        MMVAE_TRY(lin_dw(w.te_dgh + (size_t)B * G, G, w.te_h, H, B * (T - 1), g + P.te_f.whh, G, H, H, 0, s));
+    return MMVAE_OK;
+}
+
+// ================================================================== caption decoder (coco/model.py:266-312)
+int coco_text_dec_fwd(CocoPlan& P, const float* z, int groups, const float* sos, const uint8_t* keep, int save, float* sentence,
+                      hipStream_t s) {
+    CocoPlan::W& w = P.w;
+    const int R = groups * P.B, T = P.T, D = P.D, in0 = E + D, ino = H + D;
+    const float* p = P.buf.params;
+    const size_t RH = (size_t)R * H;
+    MMVAE_REQUIRE(sos != nullptr, "coco text decoder: the '<s>' vector must be given");
+    // time-invariant z terms
+    MMVAE_TRY(lin(z, D, R, p + P.td0.wih, G, D, in0, E, p + P.td0.bih, nullptr, 0, w.td_zi0, G, s));
+    MMVAE_TRY(lin(z, D, R, p + P.td_h2o_w, E, D, ino, H, p + P.td_h2o_b, nullptr, 0, w.td_zo, E, s));
+    MMVAE_TRY(lin(z, D, R, p + P.td_z2h_w, H, D, D, 0, p + P.td_z2h_b, nullptr, 0, w.td_h0, H, s));
+    hipMemcpyAsync(w.td_h1, w.td_h0, RH * sizeof(float), hipMemcpyDeviceToDevice, s);
+    const float scale = 1.f / (1.f - DROP_P);
+    for (int t = 0; t < T; ++t) {
+        const float* h0p = w.td_h0 + (size_t)t * RH; float* h0n = w.td_h0 + (size_t)(t + 1) * RH;
+        const float* h1p = w.td_h1 + (size_t)t * RH; float* h1n = w.td_h1 + (size_t)(t + 1) * RH;
+        const float* win = t == 0 ? sos : sentence + (size_t)(t - 1) * E;
+        const long long ldwin = t == 0 ? 0 : (long long)T * E;
+        MMVAE_TRY(lin(win, ldwin, R, p + P.td0.wih, G, E, in0, 0, nullptr, w.td_zi0, G, w.td_gi, G, s));
+        MMVAE_TRY(lin(h0p, H, R, p + P.td0.whh, G, H, H, 0, p + P.td0.bhh, nullptr, 0, w.td_gh, G, s));
+        GruFwd a{};
+        a.gi = w.td_gi; a.ldgi = G; a.gh = w.td_gh; a.hprev = h0p; a.h = h0n; a.rows = R;
+        a.sav = save ? w.td_sav0 + (size_t)t * R * 4 * H : nullptr;
+        const float* mid = h0n;
+        if (keep) { a.keep = keep + (size_t)t * RH; a.scale = scale; a.mid = w.td_mid + (size_t)t * RH; mid = a.mid; }
+        MMVAE_TRY(gru_fwd(a, s));
+        MMVAE_TRY(lin(mid, H, R, p + P.td1.wih, G, H, H, 0, p + P.td1.bih, nullptr, 0, w.td_gi, G, s));
+        MMVAE_TRY(lin(h1p, H, R, p + P.td1.whh, G, H, H, 0, p + P.td1.bhh, nullptr, 0, w.td_gh, G, s));
+        GruFwd b{};
+        b.gi = w.td_gi; b.ldgi = G; b.gh = w.td_gh; b.hprev = h1p; b.h = h1n; b.rows = R;
+        b.sav = save ? w.td_sav1 + (size_t)t * R * 4 * H : nullptr;
+        MMVAE_TRY(gru_fwd(b, s));
+        MMVAE_TRY(lin(h1n, H, R, p + P.td_h2o_w, E, H, ino, 0, nullptr, w.td_zo, E, sentence + (size_t)t * E, (long long)T * E, s));
+    }
+    return MMVAE_OK;
+}
+
+int coco_text_dec_bwd(CocoPlan& P, const float* z, int groups, const float* sos, const uint8_t* keep, const float* sentence, float* dw,
+                      float* dz, hipStream_t s) {
+    CocoPlan::W& w = P.w;
+    const int R = groups * P.B, T = P.T, D = P.D, in0 = E + D, ino = H + D;
+    const float* p = P.buf.params;
+    float* g = P.buf.grads;
+    const size_t RH = (size_t)R * H, RG = (size_t)R * G;
+    const long long ldw = (long long)T * E;
+    const float scale = 1.f / (1.f - DROP_P);
+    // td_dh0 / td_dh1 (carried gradients of the two hidden states) start at zero: the caller zeroes them
+    for (int t = T - 1; t >= 0; --t) {
+        const float* h0p = w.td_h0 + (size_t)t * RH; const float* h1p = w.td_h1 + (size_t)t * RH;
+        const float* h1n = w.td_h1 + (size_t)(t + 1) * RH;
+        const float* mid = keep ? w.td_mid + (size_t)t * RH : w.td_h0 + (size_t)(t + 1) * RH;
+        float* dwt = dw + (size_t)t * E;                 // total gradient wrt this step's output (loss + feedback of step t+1)
+        float *dgi1 = w.td_dgi1 + (size_t)t * RG, *dgh1 = w.td_dgh1 + (size_t)t * RG;
+        float *dgi0 = w.td_dgi0 + (size_t)t * RG, *dgh0 = w.td_dgh0 + (size_t)t * RG;
+        // output projection
+        MMVAE_TRY(lin_dx(dwt, ldw, R, p + P.td_h2o_w, E, H, ino, 0, w.td_dh1, H, 1, s));
+        MMVAE_TRY(lin_dw(dwt, ldw, h1n, H, R, g + P.td_h2o_w, E, H, ino, 0, s));
+        // layer 1
+        GruBwd b{};
+        b.dh = w.td_dh1; b.sav = w.td_sav1 + (size_t)t * R * 4 * H; b.hprev = h1p; b.dgi = dgi1; b.lddgi = G; b.dgh = dgh1;
+        b.dh_out = w.td_dh1; b.rows = R;
+        MMVAE_TRY(gru_bwd(b, s));
+        MMVAE_TRY(lin_dx(dgi1, G, R, p + P.td1.wih, G, H, H, 0, w.td_dmid, H, 0, s));
+        MMVAE_TRY(lin_dx(dgh1, G, R, p + P.td1.whh, G, H, H, 0, w.td_dh1, H, 1, s));
+        // layer 0 (its output fed layer 1 through the dropout)
+        GruBwd a{};
+        a.dh = w.td_dh0; a.dh2 = w.td_dmid; a.keep = keep ? keep + (size_t)t * RH : nullptr; a.scale = scale;
+        a.sav = w.td_sav0 + (size_t)t * R * 4 * H; a.hprev = h0p; a.dgi = dgi0; a.lddgi = G; a.dgh = dgh0; a.dh_out = w.td_dh0; a.rows = R;
+        MMVAE_TRY(gru_bwd(a, s));
+        MMVAE_TRY(lin_dx(dgh0, G, R, p + P.td0.whh, G, H, H, 0, w.td_dh0, H, 1, s));
+        // input vector of this step: the previous output (gradient flows back into it) or '<s>' (a constant)
+        const float* win = t == 0 ? sos : sentence + (size_t)(t - 1) * E;
+        MMVAE_TRY(lin_dw(dgi0, G, win, t == 0 ? 0 : ldw, R, g + P.td0.wih, G, E, in0, 0, s));
+        if (t > 0) MMVAE_TRY(lin_dx(dgi0, G, R, p + P.td0.wih, G, E, in0, 0, dw + (size_t)(t - 1) * E, ldw, 1, s));
+        (void)mid;
+    }
+    const int TR = T * R;
+    // weight gradients whose operand pairs share the [t][row] layout: one GEMM over K = T*R each
+    MMVAE_TRY(lin_dw(w.td_dgh0, G, w.td_h0, H, TR, g + P.td0.whh, G, H, H, 0, s));
+    MMVAE_TRY(lin_dw(w.td_dgh1, G, w.td_h1, H, TR, g + P.td1.whh, G, H, H, 0, s));
+    MMVAE_TRY(lin_dw(w.td_dgi1, G, keep ? w.td_mid : w.td_h0 + RH, H, TR, g + P.td1.wih, G, H, H, 0, s));
+    MMVAE_TRY(launch_colsum_f32(w.td_dgh0, TR, G, g + P.td0.bhh, s));
+    MMVAE_TRY(launch_colsum_f32(w.td_dgi1, TR, G, g + P.td1.bih, s));
+    MMVAE_TRY(launch_colsum_f32(w.td_dgh1, TR, G, g + P.td1.bhh, s));
+    // initial hidden state h = z2h(z), shared by both layers
+    MMVAE_TRY(add2(w.td_dh0, w.td_dh1, (long long)RH, w.td_dhinit, s));
+    MMVAE_TRY(lin_dw(w.td_dhinit, H, z, D, R, g + P.td_z2h_w, H, D, D, 0, s));
+    MMVAE_TRY(launch_colsum_f32(w.td_dhinit, R, H, g + P.td_z2h_b, s));
+    MMVAE_TRY(lin_dx(w.td_dhinit, H, R, p + P.td_z2h_w, H, D, D, 0, dz, D, 0, s));
+    // time-invariant z terms: gradients of the time-summed pre-activations
+    MMVAE_TRY(sum_mid(w.td_dgi0, 1, T, (long long)RG, w.td_dzi0, s));
+    MMVAE_TRY(lin_dw(w.td_dzi0, G, z, D, R, g + P.td0.wih, G, D, in0, E, s));
+    MMVAE_TRY(launch_colsum_f32(w.td_dzi0, R, G, g + P.td0.bih, s));
+    MMVAE_TRY(lin_dx(w.td_dzi0, G, R, p + P.td0.wih, G, D, in0, E, dz, D, 1, s));
+    MMVAE_TRY(sum_mid(dw, R, T, E, w.td_dwsum, s));
+    MMVAE_TRY(lin_dw(w.td_dwsum, E, z, D, R, g + P.td_h2o_w, E, D, ino, H, s));
+    MMVAE_TRY(launch_colsum_f32(w.td_dwsum, R, E, g + P.td_h2o_b, s));
+    return lin_dx(w.td_dwsum, E, R, p + P.td_h2o_w, E, D, ino, H, dz, D, 1, s);
+}
+
+int coco_mse3(const float* recon, const float* target, int Gn, long long per_group, const float* coef, float* loss_sum, float* dw,
+              hipStream_t s) {
+    MMVAE_REQUIRE(Gn >= 1 && Gn <= 3, "mse3: groups=%d", Gn);
+    const unsigned nb = (unsigned)std::min<long long>((per_group + TPBT - 1) / TPBT, 4096);
+    hipLaunchKernelGGL(mse3_kernel, dim3(nb, Gn), dim3(TPBT), 0, s, recon, target, per_group, coef[0], coef[1], coef[2], loss_sum, dw);
+    return mmvae_check_launch("mse3");
+}

@@ -1,0 +1,138 @@
+// See gemm_f32.h.
+#include "gemm_f32.h"
+
+namespace {
+
+// ------------------------------------------------------------------ generic fp32 GEMM  C[m][n] = sum_k A(m,k) B(k,n) (+ bias[n])
+
+// one 32x32 output tile per workgroup: 2x2 tiles of v_mfma_f32_16x16x4_f32 (operand fragment: lane -> index lane%16,
+// one k per lane group lane/16; accumulator: lane -> column lane%16, rows 4*(lane/16)..+3).  The KS waves of the
+// workgroup split K (these GEMMs have 10..400 tiles: the K chain is the latency) and are summed through LDS.
+// Within a 16-deep step, MFMA s of lane group q consumes k = k0 + 4q + s: an operand that is contiguous along k is
+// then ONE 16-byte load per lane per step, a strided one four 4-byte loads of the same k's.
+template <int KS, bool AV, bool BV>
+__global__ __launch_bounds__(KS * 64) void gemm_f32_kernel(const F32Gemm g) {
+    __shared__ float red[KS > 1 ? (KS - 1) * 16 * 64 : 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
+    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* ap[2]; const float* bp[2];
+    bool aok[2], bok[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int m = m0 + t * 16 + fr, n = n0 + t * 16 + fr;
+        aok[t] = m < g.M; bok[t] = n < g.N;
+        ap[t] = g.A + (long long)(aok[t] ? m : 0) * g.a_rs;
+        bp[t] = g.B + (long long)(bok[t] ? n : 0) * g.b_cs;
+    }
+    const int nst_all = (g.K + 15) / 16;
+    const int nz = gridDim.z;                                      // grid-level K split (atomic epilogue)
+    const int zs0 = (int)((long long)nst_all * blockIdx.z / nz), zs1 = (int)((long long)nst_all * (blockIdx.z + 1) / nz);
+    const int nst = zs1 - zs0;
+    const int st0 = zs0 + nst * wave / KS, st1 = zs0 + nst * (wave + 1) / KS;
+    for (int st = st0; st < st1; ++st) {
+        const int kb = st * 16 + fq * 4;                   // this lane group's 4 consecutive k
+        float av[4][2], bv[4][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (AV && kb + 4 <= g.K) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(ap[t] + kb);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) av[q][t] = aok[t] ? v[q] : 0.f;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool kin = kb + q < g.K;
+                    const float v = ap[t][(long long)(kin ? kb + q : 0) * g.a_cs];
+                    av[q][t] = (kin && aok[t]) ? v : 0.f;
+                }
+            }
+            if (BV && kb + 4 <= g.K) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(bp[t] + kb);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bv[q][t] = bok[t] ? v[q] : 0.f;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool kin = kb + q < g.K;
+                    const float v = bp[t][(long long)(kin ? kb + q : 0) * g.b_rs];
+                    bv[q][t] = (kin && bok[t]) ? v : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][i], bv[q][j], acc[i][j], 0, 0, 0);
+    }
+    if (KS > 1) {
+        if (wave > 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[((wave - 1) * 16 + (i * 2 + j) * 4 + r) * 64 + lane] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 0; w < KS - 1; ++w)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] += red[(w * 16 + (i * 2 + j) * 4 + r) * 64 + lane];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + j * 16 + fr;
+            if (n >= g.N) continue;
+            const bool first = blockIdx.z == 0;
+            const float bias = (g.bias && first) ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + i * 16 + fq * 4 + r;
+                if (m >= g.M) continue;
+                float v = acc[i][j][r] + bias;
+                if (g.addm && first) v += g.addm[(size_t)m * g.ldadd + n];
+                float* c = g.C + (size_t)m * g.ldc + n;
+                if (nz > 1) atomicAdd(c, v);
+                else if (g.accumulate) *c += v;
+                else *c = v;
+            }
+        }
+}
+template <int KS>
+int gemm_f32_ks(const F32Gemm& g, bool av, bool bv, hipStream_t s) {
+    dim3 grid(ceil_div(g.M, 32), ceil_div(g.N, 32), g.ksplit > 1 ? g.ksplit : 1), block(KS * 64);
+    if (av && bv) hipLaunchKernelGGL((gemm_f32_kernel<KS, true, true>), grid, block, 0, s, g);
+    else if (av) hipLaunchKernelGGL((gemm_f32_kernel<KS, true, false>), grid, block, 0, s, g);
+    else if (bv) hipLaunchKernelGGL((gemm_f32_kernel<KS, false, true>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<KS, false, false>), grid, block, 0, s, g);
+    return mmvae_check_launch("gemm_f32");
+}
+}  // namespace
+
+int gemm_f32(const F32Gemm& g, hipStream_t s) {
+    MMVAE_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.A && g.B && g.C, "gemm_f32: bad arguments");
+    MMVAE_REQUIRE(g.ksplit <= 1 || g.ksplit <= (g.K + 15) / 16, "gemm_f32: ksplit=%d for K=%d", g.ksplit, g.K);
+    // 16-byte loads along k need a unit k stride, rows that start 16-byte aligned
+    const bool av = g.a_cs == 1 && g.a_rs % 4 == 0 && (reinterpret_cast<uintptr_t>(g.A) & 15) == 0;
+    const bool bv = g.b_rs == 1 && g.b_cs % 4 == 0 && (reinterpret_cast<uintptr_t>(g.B) & 15) == 0;
+    const int tiles = ceil_div(g.M, 32) * ceil_div(g.N, 32), nst = ceil_div(g.K, 16);
+    const int nz = g.ksplit > 1 ? g.ksplit : 1;
+    if (tiles * nz <= 256 && nst / nz >= 8) return gemm_f32_ks<4>(g, av, bv, s);
+    if (tiles * nz <= 512 && nst / nz >= 4) return gemm_f32_ks<2>(g, av, bv, s);
+    return gemm_f32_ks<1>(g, av, bv, s);
+}

@@ -12,137 +12,12 @@
 // forward (+ReLU) and backward as one thread per channel walking its group's rows, embedding gather / scatter.
 // Losses, product of experts, reparametrisation, KL and Adam are the shared fp32 kernels of elementwise.hip.
 #include "mnist_plan.h"
+#include "gemm_f32.h"
 
 namespace {
 
 constexpr int TPBF = 256;
 
-// ------------------------------------------------------------------ generic fp32 GEMM  C[m][n] = sum_k A(m,k) B(k,n) (+ bias[n])
-struct F32Gemm {
-    const float* A; long long a_rs, a_cs;      // A(m,k) = A[m*a_rs + k*a_cs]
-    const float* B; long long b_rs, b_cs;      // B(k,n) = B[k*b_rs + n*b_cs]
-    int M, N, K;
-    float* C; int ldc;
-    const float* bias;                         // [N] or null
-};
-
-// one 32x32 output tile per workgroup: 2x2 tiles of v_mfma_f32_16x16x4_f32 (operand fragment: lane -> index lane%16,
-// one k per lane group lane/16; accumulator: lane -> column lane%16, rows 4*(lane/16)..+3).  The KS waves of the
-// workgroup split K (these GEMMs have 10..400 tiles: the K chain is the latency) and are summed through LDS.
-// Within a 16-deep step, MFMA s of lane group q consumes k = k0 + 4q + s: an operand that is contiguous along k is
-// then ONE 16-byte load per lane per step, a strided one four 4-byte loads of the same k's.
-template <int KS, bool AV, bool BV>
-__global__ __launch_bounds__(KS * 64) void gemm_f32_kernel(const F32Gemm g) {
-    __shared__ float red[KS > 1 ? (KS - 1) * 16 * 64 : 1];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
-    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
-    f32x4 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* ap[2]; const float* bp[2];
-    bool aok[2], bok[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int m = m0 + t * 16 + fr, n = n0 + t * 16 + fr;
-        aok[t] = m < g.M; bok[t] = n < g.N;
-        ap[t] = g.A + (long long)(aok[t] ? m : 0) * g.a_rs;
-        bp[t] = g.B + (long long)(bok[t] ? n : 0) * g.b_cs;
-    }
-    const int nst = (g.K + 15) / 16;
-    const int st0 = nst * wave / KS, st1 = nst * (wave + 1) / KS;
-    for (int st = st0; st < st1; ++st) {
-        const int kb = st * 16 + fq * 4;                   // this lane group's 4 consecutive k
-        float av[4][2], bv[4][2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            if (AV && kb + 4 <= g.K) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(ap[t] + kb);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) av[q][t] = aok[t] ? v[q] : 0.f;
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const bool kin = kb + q < g.K;
-                    const float v = ap[t][(long long)(kin ? kb + q : 0) * g.a_cs];
-                    av[q][t] = (kin && aok[t]) ? v : 0.f;
-                }
-            }
-            if (BV && kb + 4 <= g.K) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(bp[t] + kb);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) bv[q][t] = bok[t] ? v[q] : 0.f;
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const bool kin = kb + q < g.K;
-                    const float v = bp[t][(long long)(kin ? kb + q : 0) * g.b_rs];
-                    bv[q][t] = (kin && bok[t]) ? v : 0.f;
-                }
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][i], bv[q][j], acc[i][j], 0, 0, 0);
-    }
-    if (KS > 1) {
-        if (wave > 0) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) red[((wave - 1) * 16 + (i * 2 + j) * 4 + r) * 64 + lane] = acc[i][j][r];
-        }
-        __syncthreads();
-        if (wave > 0) return;
-#pragma unroll
-        for (int w = 0; w < KS - 1; ++w)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[i][j][r] += red[(w * 16 + (i * 2 + j) * 4 + r) * 64 + lane];
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + j * 16 + fr;
-            if (n >= g.N) continue;
-            const float bias = g.bias ? g.bias[n] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + i * 16 + fq * 4 + r;
-                if (m < g.M) g.C[(size_t)m * g.ldc + n] = acc[i][j][r] + bias;
-            }
-        }
-}
-template <int KS>
-int gemm_f32_ks(const F32Gemm& g, bool av, bool bv, hipStream_t s) {
-    dim3 grid(ceil_div(g.M, 32), ceil_div(g.N, 32)), block(KS * 64);
-    if (av && bv) hipLaunchKernelGGL((gemm_f32_kernel<KS, true, true>), grid, block, 0, s, g);
-    else if (av) hipLaunchKernelGGL((gemm_f32_kernel<KS, true, false>), grid, block, 0, s, g);
-    else if (bv) hipLaunchKernelGGL((gemm_f32_kernel<KS, false, true>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<KS, false, false>), grid, block, 0, s, g);
-    return mmvae_check_launch("gemm_f32");
-}
-int gemm_f32(const F32Gemm& g, hipStream_t s) {
-    MMVAE_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.A && g.B && g.C, "gemm_f32: bad arguments");
-    // 16-byte loads along k need a unit k stride, rows that start 16-byte aligned
-    const bool av = g.a_cs == 1 && g.a_rs % 4 == 0 && (reinterpret_cast<uintptr_t>(g.A) & 15) == 0;
-    const bool bv = g.b_rs == 1 && g.b_cs % 4 == 0 && (reinterpret_cast<uintptr_t>(g.B) & 15) == 0;
-    const int tiles = ceil_div(g.M, 32) * ceil_div(g.N, 32), nst = ceil_div(g.K, 16);
-    if (tiles <= 256 && nst >= 8) return gemm_f32_ks<4>(g, av, bv, s);
-    if (tiles <= 512 && nst >= 4) return gemm_f32_ks<2>(g, av, bv, s);
-    return gemm_f32_ks<1>(g, av, bv, s);
-}
 // y[rows][N] = x[rows][K] W[N][K]^T + b
 int lin_fwd32(MnistPlan& P, const MlpLin& L, const float* x, int ldx, int rows, float* y, hipStream_t s) {
     F32Gemm g{};

@@ -25,11 +25,11 @@ __device__ __forceinline__ float dot8(bf16x8 a, bf16x8 b, float acc) {
 // Weights sit in LDS as bf16 [kh][kw][co][32 ci]; each output pixel is 4 taps x 32 channels = 16 dot2 x 4 per
 // output channel.  Fused sigmoid + BCE (+ gradient).
 constexpr int FR = 5;                       // input rows per strip (25 = 5*5, 32 = 6*5+2: the tail strip is masked)
-template <int COUT>
+template <int COUT, int CIN>
 __global__ __launch_bounds__(TPB) void convt_last_fwd_kernel(const ConvTLastFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16* wl = reinterpret_cast<bf16*>(smem);                       // [16 taps][COUT][32]
-    bf16* tile = wl + 16 * COUT * 32;                               // [(FR+2)][IW+2][32]
+    bf16* wl = reinterpret_cast<bf16*>(smem);                       // [16 taps][COUT][CIN]
+    bf16* tile = wl + 16 * COUT * CIN;                              // [(FR+2)][IW+2][CIN]
     __shared__ float part[TPB / 64];
     const int strips = (a.IH + FR - 1) / FR;
     const int n_in_g = blockIdx.x / strips, strip = blockIdx.x - n_in_g * strips;
@@ -37,13 +37,14 @@ __global__ __launch_bounds__(TPB) void convt_last_fwd_kernel(const ConvTLastFwdA
     const long long n = (long long)g * a.B + n_in_g;
     const int iy_base = strip * FR - 1;                             // first staged row (halo)
     const int TW = a.IW + 2;
-    for (int i = threadIdx.x; i < 16 * COUT * 32; i += TPB) {
-        const int ci = i & 31, co = (i >> 5) % COUT, tap = i / (32 * COUT);
+    for (int i = threadIdx.x; i < 16 * COUT * CIN; i += TPB) {
+        const int ci = i % CIN, co = (i / CIN) % COUT, tap = i / (CIN * COUT);
         wl[i] = (bf16)a.w[(ci * COUT + co) * 16 + tap];            // weight (Cin, Cout, 4, 4)
     }
-    const int nvec = (FR + 2) * TW * 4;                             // 16-byte vectors (32 channels = 4 vectors)
+    constexpr int VPP = CIN / 8;                                    // 16-byte vectors per pixel
+    const int nvec = (FR + 2) * TW * VPP;
     for (int v = threadIdx.x; v < nvec; v += TPB) {
-        const int q = v & 3, pixl = v >> 2;
+        const int q = v % VPP, pixl = v / VPP;
         const int ty = pixl / TW, tx = pixl - ty * TW;
         const int iy = iy_base + ty, ix = tx - 1;
         const bool ok = (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(TPB) void convt_last_fwd_kernel(const ConvTLastFwdA
 #pragma unroll
             for (int j = 0; j < 8; ++j) val[j] = (bf16)0.f;
         }
-        *reinterpret_cast<bf16x8*>(tile + (size_t)pixl * 32 + q * 8) = val;
+        *reinterpret_cast<bf16x8*>(tile + (size_t)pixl * CIN + q * 8) = val;
     }
     __syncthreads();
     const int OH = 2 * a.IH, OW = 2 * a.IW;
@@ -74,14 +75,14 @@ __global__ __launch_bounds__(TPB) void convt_last_fwd_kernel(const ConvTLastFwdA
 #pragma unroll
             for (int tx = 0; tx < 2; ++tx) {
                 const int iy = iy0 - ty, ix = ix0 - tx;             // in [-1, IH] x [-1, IW]: inside the halo tile
-                const bf16* src = tile + ((size_t)(iy - iy_base) * TW + (ix + 1)) * 32;
-                const bf16* wp = wl + ((kh0 + 2 * ty) * 4 + kw0 + 2 * tx) * COUT * 32;
+                const bf16* src = tile + ((size_t)(iy - iy_base) * TW + (ix + 1)) * CIN;
+                const bf16* wp = wl + ((kh0 + 2 * ty) * 4 + kw0 + 2 * tx) * COUT * CIN;
 #pragma unroll
-                for (int c0 = 0; c0 < 32; c0 += 8) {
+                for (int c0 = 0; c0 < CIN; c0 += 8) {
                     const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + c0);
 #pragma unroll
                     for (int co = 0; co < COUT; ++co)
-                        acc[co] = dot8(v, *reinterpret_cast<const bf16x8*>(wp + co * 32 + c0), acc[co]);
+                        acc[co] = dot8(v, *reinterpret_cast<const bf16x8*>(wp + co * CIN + c0), acc[co]);
                 }
             }
         }
@@ -198,12 +199,14 @@ __global__ __launch_bounds__(TPB) void convt_last_dgrad_kernel(const ConvTLastDg
 }  // namespace
 
 int launch_convt_last_fwd(const ConvTLastFwdArgs& a, hipStream_t s) {
-    MMVAE_REQUIRE(a.Cin == 32 && (a.Cout == 1 || a.Cout == 3) && a.G >= 1 && a.G <= 4, "convT last fwd: Cin=%d Cout=%d G=%d", a.Cin, a.Cout, a.G);
+    MMVAE_REQUIRE((a.Cin == 32 || (a.Cin == 64 && a.Cout == 3)) && (a.Cout == 1 || a.Cout == 3) && a.G >= 1 && a.G <= 4,
+                  "convT last fwd: Cin=%d Cout=%d G=%d", a.Cin, a.Cout, a.G);
     const int strips = (a.IH + FR - 1) / FR;
     dim3 grid(a.B * strips, a.G);
-    size_t lds = (size_t)16 * 32 * a.Cout * sizeof(bf16) + (size_t)(FR + 2) * (a.IW + 2) * 32 * sizeof(bf16);
-    if (a.Cout == 1) hipLaunchKernelGGL(convt_last_fwd_kernel<1>, grid, dim3(TPB), lds, s, a);
-    else hipLaunchKernelGGL(convt_last_fwd_kernel<3>, grid, dim3(TPB), lds, s, a);
+    size_t lds = (size_t)16 * a.Cin * a.Cout * sizeof(bf16) + (size_t)(FR + 2) * (a.IW + 2) * a.Cin * sizeof(bf16);
+    if (a.Cin == 64) hipLaunchKernelGGL((convt_last_fwd_kernel<3, 64>), grid, dim3(TPB), lds, s, a);
+    else if (a.Cout == 1) hipLaunchKernelGGL((convt_last_fwd_kernel<1, 32>), grid, dim3(TPB), lds, s, a);
+    else hipLaunchKernelGGL((convt_last_fwd_kernel<3, 32>), grid, dim3(TPB), lds, s, a);
     return mmvae_check_launch("convt_last_fwd");
 }
 int launch_convt_last_dgrad(const ConvTLastDgradArgs& a, hipStream_t s) {

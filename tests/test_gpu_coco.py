@@ -1,0 +1,266 @@
+"""GPU parity tests of the COCO MMVAE (coco/model.py, coco/train.py:66-84,138-173) through the C-ABI, against the golden
+vectors captured from the reference and the CPU oracle on the same seeded inputs.
+
+Tolerances.  Caption modules alone (fp32 MFMA path, 102 dependent GRU steps): outputs abs 2e-5, every gradient tensor
+rel-L2 2e-4.  Fused step / image modules (bf16 MFMA inputs, fp32 accumulation; B=4 fixtures, BatchNorm over 4 samples):
+ELBO losses rel 1e-3 | mu/logvar abs 1e-2 | per-tensor gradient rel-L2 5e-2 (+ 2e-4 of the total norm) | total gradient
+norm rel 1e-2.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mmvae_ref as R
+
+pytestmark = pytest.mark.gpu
+
+D = 100
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _state(dev, steps=R.COCO_MAX_WORDS):
+    from multimodal_vae_amd.core import CocoState
+    P = R.formula_params("coco", D, requires_grad=True)
+    st = CocoState(D, dev, steps)
+    assert [t[0] for t in st.table] == [n for n, _ in R.param_table("coco", D)]
+    for n, shape, off in st.table:
+        assert tuple(P[n].shape) == tuple(shape)
+        st.params[off:off + P[n].numel()] = P[n].detach().reshape(-1).to(dev)
+    return st, P
+
+
+def _grad_checks(st, P, tensor_tol=5e-2, total_tol=1e-2, floor=2e-4):
+    names = [n for n, _ in R.param_table("coco", D)]
+    g = st.grads.cpu()
+    tot_ref = torch.sqrt(sum(P[n].grad.double().pow(2).sum() for n in names)).item()
+    assert abs(g.double().norm().item() - tot_ref) <= total_tol * tot_ref
+    for n, shape, off in st.table:
+        gr = P[n].grad.reshape(-1)
+        gh = g[off:off + gr.numel()]
+        err = (gh - gr).norm().item()
+        assert err <= tensor_tol * gr.norm().item() + floor * tot_ref, (n, err, gr.norm().item())
+
+
+def _vae(dev, steps, P=None):
+    from multimodal_vae_amd import coco as M
+    P = P if P is not None else R.formula_params("coco", D, requires_grad=True)
+    vae = M.MultimodalVAE(D, use_cuda=True, sos=R.formula_sos(), steps=steps)
+    vae.load_state_dict({k: v.detach().clone() for k, v in P.items()}, strict=True)
+    return M, vae.cuda().train(), P
+
+
+@pytest.mark.parametrize("steps,B", [(5, 3), (102, 6)])
+def test_text_encoder_module_fp32(steps, B):
+    dev = _dev()
+    M, vae, P = _vae(dev, steps)
+    _, text = R.formula_inputs("coco", B)
+    text = text[:, :steps].contiguous()
+    w = torch.sin(torch.arange(B * 2 * D, dtype=torch.float32) * 0.37).view(B, 2 * D)
+    mu, lv = vae.text_encoder(text.to(dev))
+    (torch.cat((mu, lv), 1) * w.to(dev)).sum().backward()
+    o = R.coco_text_encoder(P, text)
+    (o * w).sum().backward()
+    np.testing.assert_allclose(torch.cat((mu, lv), 1).detach().cpu().numpy(), o.detach().numpy(), atol=2e-5)
+    for n, p in vae.text_encoder.named_parameters():
+        gr, gh = P["text_encoder." + n].grad, p.grad.cpu()
+        assert (gh - gr).norm().item() <= 2e-4 * gr.norm().item() + 1e-7, n
+
+
+@pytest.mark.parametrize("steps,B,drop", [(4, 3, False), (9, 5, True), (102, 4, False)])
+def test_text_decoder_module_fp32(steps, B, drop):
+    dev = _dev()
+    M, vae, P = _vae(dev, steps)
+    vae.text_decoder.gru.dropout = 0.1 if drop else 0.0
+    z = (0.8 * R.formula_eps(B, D, 1)).requires_grad_(True)
+    zd = z.detach().to(dev).requires_grad_(True)
+    keep = None
+    if drop:
+        g = torch.Generator().manual_seed(3)
+        keep = (torch.rand(steps, B, 200, generator=g) >= 0.1)
+    target = 0.3 * torch.cos(torch.arange(B * steps * 300, dtype=torch.float32) * 0.011).view(B, steps, 300)
+    sent = vae.text_decoder(zd, None if keep is None else keep.to(dev))
+    ((sent - target.to(dev)) ** 2).mean().backward()
+    o = R.coco_text_decoder(P, z, True, R.formula_sos(), steps, None if keep is None else [k.float() for k in keep],
+                            drop_p=0.1 if drop else 0.0)
+    ((o - target) ** 2).mean().backward()
+    assert sent.shape == (B, steps, 300)
+    np.testing.assert_allclose(sent.detach().cpu().numpy(), o.detach().numpy(), atol=2e-5)
+    assert (zd.grad.cpu() - z.grad).norm().item() <= 2e-4 * z.grad.norm().item()
+    for n, p in vae.text_decoder.named_parameters():
+        gr, gh = P["text_decoder." + n].grad, p.grad.cpu()
+        assert (gh - gr).norm().item() <= 2e-4 * gr.norm().item() + 1e-9, (n, (gh - gr).norm().item(), gr.norm().item())
+
+
+def test_image_modules_match_oracle():
+    dev = _dev()
+    B = 6
+    M, vae, P = _vae(dev, 4)
+    vae.image_encoder.classifier[2].p = 0.0; vae.image_encoder.classifier[5].p = 0.0
+    image, _ = R.formula_inputs("coco", B)
+    w = torch.sin(torch.arange(B * 2 * D, dtype=torch.float32) * 0.37).view(B, 2 * D)
+    mu, lv = vae.image_encoder(image.to(dev))
+    (torch.cat((mu, lv), 1) * w.to(dev)).sum().backward()
+    o = R.coco_image_encoder(P, image, True, None, drop_p=0.0)
+    (o * w).sum().backward()
+    np.testing.assert_allclose(torch.cat((mu, lv), 1).detach().cpu().numpy(), o.detach().numpy(), atol=2e-2)
+    for n, p in vae.image_encoder.named_parameters():
+        gr, gh = P["image_encoder." + n].grad, p.grad.cpu()
+        assert (gh - gr).norm().item() <= 5e-2 * gr.norm().item() + 1e-4, n
+    z = (0.8 * R.formula_eps(B, D, 2)).requires_grad_(True)
+    zd = z.detach().to(dev).requires_grad_(True)
+    recon = vae.image_decoder(zd)
+    t = image
+    torch.nn.functional.binary_cross_entropy(recon, t.to(dev)).backward()
+    ro = R.coco_image_decoder(P, z, True)
+    torch.nn.functional.binary_cross_entropy(ro, t).backward()
+    assert recon.shape == (B, 3, 32, 32)
+    np.testing.assert_allclose(recon.detach().cpu().numpy(), ro.detach().numpy(), atol=2e-2)
+    assert (zd.grad.cpu() - z.grad).norm().item() <= 5e-2 * z.grad.norm().item()
+    for n, p in vae.image_decoder.named_parameters():
+        gr, gh = P["image_decoder." + n].grad, p.grad.cpu()
+        assert (gh - gr).norm().item() <= 5e-2 * gr.norm().item() + 1e-6, n
+
+
+@pytest.mark.parametrize("fixture", ["coco_b4", "coco_b4_masks"])
+def test_fused_step_matches_golden_and_oracle(fixture, golden_dir):
+    from multimodal_vae_amd.core import FusedCocoStep
+    dev = _dev()
+    fx = np.load(os.path.join(golden_dir, fixture + ".npz"))
+    B, T = int(fx["B"]), R.COCO_MAX_WORDS
+    wm = bool(fx["with_masks"])
+    st, P = _state(dev)
+    image, text = R.formula_inputs("coco", B)
+    eps = [torch.from_numpy(fx[f"eps_{k}"]) for k in range(3)]
+    eng = FusedCocoStep(st, B, R.formula_sos(), lr=1e-3)
+    eng.enc_dropout = wm
+    eng.gru_dropout = False
+    kw, em = {}, None
+    if wm:
+        m1 = np.stack([np.unpackbits(fx[f"mask_{i}_0"], axis=1)[:, :1024] for i in range(2)]).astype(np.uint8)
+        m2 = np.stack([np.unpackbits(fx[f"mask_{i}_1"], axis=1)[:, :256] for i in range(2)]).astype(np.uint8)
+        kw = dict(enc_mask1=torch.from_numpy(m1).to(dev).contiguous(), enc_mask2=torch.from_numpy(m2).to(dev).contiguous())
+        em = ([torch.from_numpy(m1[0]).float(), torch.from_numpy(m2[0]).float()],
+              [torch.from_numpy(m1[1]).float(), torch.from_numpy(m2[1]).float()], None)
+    mu = torch.zeros(3, B, D, device=dev); lv = torch.zeros(3, B, D, device=dev)
+    rt = torch.zeros(3, B, T, 300, device=dev); ri = torch.zeros(3, B, 3, 32, 32, device=dev)
+    out = eng.forward_backward(image.to(dev).contiguous(), text.to(dev).contiguous(), True, True,
+                               eps=torch.stack(eps).to(dev).contiguous(), mu=mu, logvar=lv, recon_text=rt, recon_image=ri, **kw)
+    np.testing.assert_allclose(out.losses().cpu().numpy(), fx["loss"], rtol=1e-3)
+    for k in range(3):
+        np.testing.assert_allclose(mu[k].cpu().numpy(), fx[f"mu_{k}"], atol=1e-2)
+        np.testing.assert_allclose(lv[k].cpu().numpy(), fx[f"logvar_{k}"], atol=1e-2)
+        np.testing.assert_allclose(rt[k, :, :3].cpu().numpy(), fx[f"text_recon_head_{k}"], atol=1e-2)
+        np.testing.assert_allclose(rt[k, :, -2:].cpu().numpy(), fx[f"text_recon_tail_{k}"], atol=1e-2)
+        np.testing.assert_allclose(rt[k].double().norm().item(), fx[f"text_recon_stats_{k}"][1], rtol=5e-3)
+        np.testing.assert_allclose(ri[k].double().sum().item(), fx[f"image_recon_stats_{k}"][0], rtol=2e-3)
+        np.testing.assert_allclose(out.parts()[2][k].item(), float(fx[f"kl_sum_{k}"]), rtol=2e-3)
+    o_losses, _ = R.coco_step_losses(P, image, text, R.formula_sos(), True, 1e-3, eps, em,
+                                     enc_drop_p=0.1 if wm else 0.0, gru_drop_p=0.0)
+    (o_losses[0] + o_losses[1] + o_losses[2]).backward()
+    _grad_checks(st, P)
+    np.testing.assert_allclose(st.grads.double().norm().item(), float(fx["total_grad_norm"]), rtol=1e-2)
+    for pre, c, off in st.bn_table:
+        np.testing.assert_allclose(st.bn_stats[off:off + c].cpu().numpy(), fx["buf:" + pre + ".running_mean"], atol=2e-3)
+        np.testing.assert_allclose(st.bn_stats[off + c:off + 2 * c].cpu().numpy(), fx["buf:" + pre + ".running_var"], rtol=2e-2, atol=1e-4)
+    eng.optimizer_step()
+    p = st.params.cpu()
+    for (n, shape, off), ref, gs in zip(st.table, fx["after_adam_stats"], fx["grad_stats"]):
+        if gs[1] < 1e-6:
+            continue
+        numel = int(np.prod(shape))
+        np.testing.assert_allclose(p[off:off + numel].double().norm().item(), ref[1], rtol=3e-3, atol=1e-5, err_msg=n)
+
+
+def test_gru_dropout_masks_and_short_captions_match_oracle():
+    """Injected inter-layer dropout masks (the reference cannot inject them: oracle only), T = 7, B = 8."""
+    from multimodal_vae_amd.core import FusedCocoStep
+    dev = _dev()
+    B, T = 8, 7
+    st, P = _state(dev, T)
+    image, text = R.formula_inputs("coco", B)
+    text = text[:, :T].contiguous()
+    eps = [R.formula_eps(B, D, k) for k in range(3)]
+    g = torch.Generator().manual_seed(5)
+    keep = (torch.rand(T, 3 * B, 200, generator=g) >= 0.1)
+    eng = FusedCocoStep(st, B, R.formula_sos())
+    eng.enc_dropout = False
+    out = eng.forward_backward(image.to(dev).contiguous(), text.to(dev).contiguous(), True, True,
+                               eps=torch.stack(eps).to(dev).contiguous(), gru_keep=keep.to(torch.uint8).to(dev).contiguous())
+    gm = [[keep[t, k * B:(k + 1) * B].float() for t in range(T)] for k in range(3)]
+    o_losses, _ = R.coco_step_losses(P, image, text, R.formula_sos(), True, 1e-3, eps, None, gm, enc_drop_p=0.0, gru_drop_p=0.1)
+    (o_losses[0] + o_losses[1] + o_losses[2]).backward()
+    np.testing.assert_allclose(out.losses().cpu().numpy(), np.array([l.item() for l in o_losses]), rtol=1e-3)
+    _grad_checks(st, P, tensor_tol=4e-2)
+
+
+def test_training_reduces_loss_and_eval_mode():
+    from multimodal_vae_amd import coco as M
+    dev = _dev()
+    B, T = 16, 12
+    rng = np.random.default_rng(2)
+    text = torch.from_numpy((0.4 * rng.standard_normal((B, T, 300))).astype(np.float32))
+    text[:, 8:] = 0
+    img = torch.from_numpy(np.clip(rng.random((1, 3, 32, 32), dtype=np.float32) + 0.3 * text[:, 0, :3].numpy()[:, :, None, None], 0, 1).astype(np.float32))
+    torch.manual_seed(0)
+    vae = M.MultimodalVAE(D, use_cuda=True, sos=R.formula_sos(), steps=T).cuda()
+    tr = M.FusedTrainer(vae, B, lr=1e-3)
+    first = tr(img.to(dev), text.to(dev)).losses().sum().item()
+    for _ in range(30):
+        last = tr(img.to(dev), text.to(dev)).losses().sum().item()
+    assert np.isfinite(last) and last < 0.95 * first, (first, last)
+    sd = vae.state_dict()
+    assert "text_decoder.sos" not in sd and not any("glove" in k for k in sd)
+    assert int(sd["image_encoder.features.3.num_batches_tracked"].item()) == 2 * 31
+    assert int(sd["image_decoder.hallucinate.1.num_batches_tracked"].item()) == 3 * 31
+    ev = tr.evaluate(img.to(dev), text.to(dev)).losses()
+    Pe = {k: v.detach().cpu() for k, v in sd.items()}
+    with torch.no_grad():
+        o_losses, _ = R.coco_step_losses(Pe, img, text, R.formula_sos(), False)
+    np.testing.assert_allclose(ev.cpu().numpy(), np.array([l.item() for l in o_losses]), rtol=2e-3)
+
+
+def test_dropin_modules_match_golden(golden_dir):
+    """Reference-style loop (coco/train.py:138-173) through the drop-in model.py surface."""
+    dev = _dev()
+    fx = np.load(os.path.join(golden_dir, "coco_b4.npz"))
+    B = int(fx["B"])
+    M, vae, P = _vae(dev, R.COCO_MAX_WORDS)
+    vae.image_encoder.classifier[2].p = 0.0; vae.image_encoder.classifier[5].p = 0.0
+    vae.text_decoder.gru.dropout = 0.0
+    image, text = R.formula_inputs("coco", B)
+    imd, txd = image.to(dev), text.to(dev)
+    eps = [torch.from_numpy(fx[f"eps_{k}"]) for k in range(3)]
+    opt = torch.optim.Adam(vae.parameters(), lr=1e-3)
+    opt.zero_grad()
+    args = ((imd, txd), (imd, None), (None, txd))
+    total = 0
+    for k in range(3):
+        ri, rt, mu, lv = vae(image=args[k][0], text=args[k][1], eps=eps[k].to(dev))
+        assert ri.shape == (B, 3, 32, 32) and rt.shape == (B, 102, 300) and mu.shape == (B, D)
+        l = M.loss_function(mu, lv, recon_image=ri, image=imd, recon_text=rt, text=txd, kl_lambda=1e-3,
+                            lambda_xy=R.COCO_LAMBDAS[k][0], lambda_yx=R.COCO_LAMBDAS[k][1])
+        np.testing.assert_allclose(l.item(), fx["loss"][k], rtol=1e-3)
+        total = total + l
+    total.backward()
+    names = [n for n, _ in R.param_table("coco", D)]
+    gn = torch.sqrt(sum(p.grad.double().pow(2).sum() for p in vae.parameters())).item()
+    np.testing.assert_allclose(gn, float(fx["total_grad_norm"]), rtol=1e-2)
+    for (n, p), gs in zip(vae.named_parameters(), fx["grad_stats"]):
+        np.testing.assert_allclose(p.grad.double().norm().item(), gs[1], rtol=5e-2, atol=2e-4 * gn, err_msg=n)
+    opt.step()
+    with pytest.raises(AssertionError):
+        vae()
+
+
+def test_no_cpu_fallback():
+    from multimodal_vae_amd import coco as M, MMVAEError
+    vae = M.MultimodalVAE(D, sos=R.formula_sos())
+    with pytest.raises(MMVAEError):
+        vae(image=torch.zeros(2, 3, 32, 32), text=torch.zeros(2, 102, 300))
