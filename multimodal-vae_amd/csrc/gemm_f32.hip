@@ -20,57 +20,73 @@ __global__ __launch_bounds__(KS * 64) void gemm_f32_kernel(const F32Gemm g) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* ap[2]; const float* bp[2];
+    // Both operands go through buffer descriptors: 32-bit byte offsets, and an invalid element (row or column past the
+    // end, k past K, step past this wave's range) is an offset of 0xFFFFFFFF that the hardware range check turns into 0.
+    // (With plain pointers the compiler predicates every guarded load behind a branch and waits for it before issuing
+    // the next one: a strided operand then costs 16 serialized memory round trips per k-step -- measured 5x slower.)
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B), 0, 0x7FFFFFFF, 0x00020000);
+    const unsigned acs = (unsigned)g.a_cs * 4u, brs = (unsigned)g.b_rs * 4u;
+    unsigned arow[2], brow[2];
     bool aok[2], bok[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int m = m0 + t * 16 + fr, n = n0 + t * 16 + fr;
         aok[t] = m < g.M; bok[t] = n < g.N;
-        ap[t] = g.A + (long long)(aok[t] ? m : 0) * g.a_rs;
-        bp[t] = g.B + (long long)(bok[t] ? n : 0) * g.b_cs;
+        arow[t] = (unsigned)m * (unsigned)g.a_rs * 4u;
+        brow[t] = (unsigned)n * (unsigned)g.b_cs * 4u;
     }
     const int nst_all = (g.K + 15) / 16;
     const int nz = gridDim.z;                                      // grid-level K split (atomic epilogue)
     const int zs0 = (int)((long long)nst_all * blockIdx.z / nz), zs1 = (int)((long long)nst_all * (blockIdx.z + 1) / nz);
     const int nst = zs1 - zs0;
     const int st0 = zs0 + nst * wave / KS, st1 = zs0 + nst * (wave + 1) / KS;
-    for (int st = st0; st < st1; ++st) {
-        const int kb = st * 16 + fq * 4;                   // this lane group's 4 consecutive k
-        float av[4][2], bv[4][2];
+    // U steps per iteration: every load of the iteration is issued before its first MFMA (these GEMMs are a few steps
+    // per wave, so the loop is a chain of memory latencies unless the loads overlap)
+    constexpr int U = 4;
+    for (int st = st0; st < st1; st += U) {
+        float av[U][4][2], bv[U][4][2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            if (AV && kb + 4 <= g.K) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(ap[t] + kb);
+        for (int u = 0; u < U; ++u) {
+            const bool sin = st + u < st1;
+            const int kb = (st + u) * 16 + fq * 4;             // this lane group's 4 consecutive k
 #pragma unroll
-                for (int q = 0; q < 4; ++q) av[q][t] = aok[t] ? v[q] : 0.f;
-            } else {
+            for (int t = 0; t < 2; ++t) {
+                if (AV) {                                      // K % 4 == 0 (host): the 4 k are all inside or all outside
+                    const bool ok = sin && aok[t] && kb < g.K;
+                    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, ok ? arow[t] + (unsigned)kb * 4u : 0xFFFFFFFFu, 0, 0));
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const bool kin = kb + q < g.K;
-                    const float v = ap[t][(long long)(kin ? kb + q : 0) * g.a_cs];
-                    av[q][t] = (kin && aok[t]) ? v : 0.f;
+                    for (int q = 0; q < 4; ++q) av[u][q][t] = v[q];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bool ok = sin && aok[t] && kb + q < g.K;
+                        av[u][q][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(arsrc, ok ? arow[t] + (unsigned)(kb + q) * acs : 0xFFFFFFFFu, 0, 0));
+                    }
                 }
-            }
-            if (BV && kb + 4 <= g.K) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(bp[t] + kb);
+                if (BV) {
+                    const bool ok = sin && bok[t] && kb < g.K;
+                    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brsrc, ok ? brow[t] + (unsigned)kb * 4u : 0xFFFFFFFFu, 0, 0));
 #pragma unroll
-                for (int q = 0; q < 4; ++q) bv[q][t] = bok[t] ? v[q] : 0.f;
-            } else {
+                    for (int q = 0; q < 4; ++q) bv[u][q][t] = v[q];
+                } else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const bool kin = kb + q < g.K;
-                    const float v = bp[t][(long long)(kin ? kb + q : 0) * g.b_rs];
-                    bv[q][t] = (kin && bok[t]) ? v : 0.f;
+                    for (int q = 0; q < 4; ++q) {
+                        const bool ok = sin && bok[t] && kb + q < g.K;
+                        bv[u][q][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brsrc, ok ? brow[t] + (unsigned)(kb + q) * brs : 0xFFFFFFFFu, 0, 0));
+                    }
                 }
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][i], bv[q][j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][q][i], bv[u][q][j], acc[i][j], 0, 0, 0);
     }
     if (KS > 1) {
         if (wave > 0) {
@@ -127,11 +143,17 @@ int gemm_f32_ks(const F32Gemm& g, bool av, bool bv, hipStream_t s) {
 int gemm_f32(const F32Gemm& g, hipStream_t s) {
     MMVAE_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.A && g.B && g.C, "gemm_f32: bad arguments");
     MMVAE_REQUIRE(g.ksplit <= 1 || g.ksplit <= (g.K + 15) / 16, "gemm_f32: ksplit=%d for K=%d", g.ksplit, g.K);
-    // 16-byte loads along k need a unit k stride, rows that start 16-byte aligned
-    const bool av = g.a_cs == 1 && g.a_rs % 4 == 0 && (reinterpret_cast<uintptr_t>(g.A) & 15) == 0;
-    const bool bv = g.b_rs == 1 && g.b_cs % 4 == 0 && (reinterpret_cast<uintptr_t>(g.B) & 15) == 0;
+    // operands are addressed with 32-bit byte offsets from their base pointers
+    const long long amax = ((long long)(g.M - 1) * g.a_rs + (long long)(g.K - 1) * g.a_cs + 4) * 4;
+    const long long bmax = ((long long)(g.N - 1) * g.b_cs + (long long)(g.K - 1) * g.b_rs + 4) * 4;
+    MMVAE_REQUIRE(g.a_rs >= 0 && g.a_cs >= 0 && g.b_rs >= 0 && g.b_cs >= 0 && amax < 0x7FFFFFFFll && bmax < 0x7FFFFFFFll,
+                  "gemm_f32: operand spans more than 2 GiB (or has a negative stride)");
+    // 16-byte loads along k need a unit k stride, K a multiple of 4, rows that start 16-byte aligned
+    const bool av = g.a_cs == 1 && g.K % 4 == 0 && g.a_rs % 4 == 0 && (reinterpret_cast<uintptr_t>(g.A) & 15) == 0;
+    const bool bv = g.b_rs == 1 && g.K % 4 == 0 && g.b_cs % 4 == 0 && (reinterpret_cast<uintptr_t>(g.B) & 15) == 0;
     const int tiles = ceil_div(g.M, 32) * ceil_div(g.N, 32), nst = ceil_div(g.K, 16);
     const int nz = g.ksplit > 1 ? g.ksplit : 1;
+    if (tiles * nz <= 128 && nst / nz >= 16) return gemm_f32_ks<8>(g, av, bv, s);
     if (tiles * nz <= 256 && nst / nz >= 8) return gemm_f32_ks<4>(g, av, bv, s);
     if (tiles * nz <= 512 && nst / nz >= 4) return gemm_f32_ks<2>(g, av, bv, s);
     return gemm_f32_ks<1>(g, av, bv, s);

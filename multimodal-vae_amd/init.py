@@ -20,7 +20,8 @@ def default_init_(state, seed: int = 0) -> None:
         elif name.endswith("embed.weight") or (name == "text_encoder.net.0.weight" and tuple(shape) == (10, 50)):
             v = torch.randn(n, generator=g)                                   # nn.Embedding: N(0,1)
         elif ".gru." in name:
-            v = (torch.rand(n, generator=g) * 2 - 1) / math.sqrt(100.0)       # nn.GRU: U(+-1/sqrt(hidden))
+            hidden = shape[0] // 3                                            # weight_* / bias_* rows = 3 * hidden
+            v = (torch.rand(n, generator=g) * 2 - 1) / math.sqrt(float(hidden))   # nn.GRU: U(+-1/sqrt(hidden))
         else:
             if len(shape) == 4 and "hallucinate" in name:                     # ConvTranspose2d: fan_in = Cout*kh*kw
                 fan_in = shape[1] * shape[2] * shape[3]
