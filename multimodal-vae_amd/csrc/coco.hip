@@ -443,7 +443,7 @@ int coco_step(CocoPlan* Pp, const CocoStepIO& io, int training, int do_backward,
         for (int k = 0; k < 3; ++k) coef[k] = sk[k] ? 0.f : io.lambda_yx[k] / ((float)B * (float)T * (float)COCO_E);
         MMVAE_TRY(coco_mse3(sentence, io.text, 3, (long long)B * T * COCO_E, coef, w.sums, do_backward ? w.td_dw : nullptr, Tx));
     }
-    if (do_backward) MMVAE_TRY(coco_text_dec_bwd(P, w.z_f32, 3, io.sos, gk, sentence, w.td_dw, w.dz_txt, Tx));
+    if (do_backward) MMVAE_TRY(coco_text_dec_bwd(P, w.z_f32, 3, io.sos, gk, sentence, w.td_dw, w.dz_txt, Tx, serial ? Tx : P.st_wgrad2));
     ConvTLastFwdArgs last{};
     last.target = io.image; last.recon = io.recon_image; last.dlogit = do_backward ? w.dlogit : nullptr; last.loss_sum = w.sums;
     for (int k = 0; k < 3; ++k) last.coef[k] = sk[k] ? 0.f : io.lambda_xy[k] / (float)(B * NPIX);
@@ -540,5 +540,5 @@ int coco_text_decoder_bwd(CocoPlan* P, void* ws, size_t wsb, const float* z, con
     MMVAE_TRY(launch_fill_zero(w.td_dh0, (size_t)P->B * COCO_H * sizeof(float), s));
     MMVAE_TRY(launch_fill_zero(w.td_dh1, (size_t)P->B * COCO_H * sizeof(float), s));
     hipMemcpyAsync(w.td_dw, d_sentence, n * sizeof(float), hipMemcpyDeviceToDevice, s);
-    return coco_text_dec_bwd(*P, z, 1, sos, keep, sentence, w.td_dw, dz, s);
+    return coco_text_dec_bwd(*P, z, 1, sos, keep, sentence, w.td_dw, dz, s, s);
 }

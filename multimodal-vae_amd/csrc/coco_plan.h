@@ -48,6 +48,7 @@ int coco_text_enc_bwd(CocoPlan& P, const float* text, const float* d_out, hipStr
 // z: [rows][D] fp32, rows = groups*B; sentence: [rows][T][300]; keep: [T][rows][200] or null
 int coco_text_dec_fwd(CocoPlan& P, const float* z, int groups, const float* sos, const uint8_t* keep, int save, float* sentence, hipStream_t s);
 // dw: [rows][T][300] gradient wrt the sentence (consumed: the feedback gradients are accumulated into it); dz: [rows][D]
-int coco_text_dec_bwd(CocoPlan& P, const float* z, int groups, const float* sos, const uint8_t* keep, const float* sentence, float* dw, float* dz, hipStream_t s);
+// sw: stream for the weight gradients (== s: in order; a side stream: the caller joins it before reading the gradients)
+int coco_text_dec_bwd(CocoPlan& P, const float* z, int groups, const float* sos, const uint8_t* keep, const float* sentence, float* dw, float* dz, hipStream_t s, hipStream_t sw);
 // recon [G*B][T][300] vs target [B][T][300]: loss_sum[slot][4+g] += sum sq err ; dw = coef[g] * 2 (recon - target) (or null)
 int coco_mse3(const float* recon, const float* target, int G, long long per_group, const float* coef, float* loss_sum, float* dw, hipStream_t s);

@@ -288,7 +288,7 @@ int coco_text_dec_fwd(CocoPlan& P, const float* z, int groups, const float* sos,
 }
 
 int coco_text_dec_bwd(CocoPlan& P, const float* z, int groups, const float* sos, const uint8_t* keep, const float* sentence, float* dw,
-                      float* dz, hipStream_t s) {
+                      float* dz, hipStream_t s, hipStream_t sw) {
     CocoPlan::W& w = P.w;
     const int R = groups * P.B, T = P.T, D = P.D, in0 = E + D, ino = H + D;
     const float* p = P.buf.params;
@@ -296,7 +296,12 @@ int coco_text_dec_bwd(CocoPlan& P, const float* z, int groups, const float* sos,
     const size_t RH = (size_t)R * H, RG = (size_t)R * G;
     const long long ldw = (long long)T * E;
     const float scale = 1.f / (1.f - DROP_P);
-    // td_dh0 / td_dh1 (carried gradients of the two hidden states) start at zero: the caller zeroes them
+    // td_dh0 / td_dh1 (carried gradients of the two hidden states) start at zero: the caller zeroes them.
+    // Weight gradients only feed the optimizer: they go to `sw` (a side stream, or `s` itself) behind an event edge, off
+    // the 102-step dependency chain.  Their operands are never rewritten after the edge (per-step buffers; dw[:, t] is
+    // final once step t starts).
+    const bool fork = sw != s;
+    auto to_side = [&]() -> int { return fork ? edge(P, s, sw) : MMVAE_OK; };
     for (int t = T - 1; t >= 0; --t) {
         const float* h0p = w.td_h0 + (size_t)t * RH; const float* h1p = w.td_h1 + (size_t)t * RH;
         const float* h1n = w.td_h1 + (size_t)(t + 1) * RH;
@@ -306,7 +311,8 @@ int coco_text_dec_bwd(CocoPlan& P, const float* z, int groups, const float* sos,
         float *dgi0 = w.td_dgi0 + (size_t)t * RG, *dgh0 = w.td_dgh0 + (size_t)t * RG;
         // output projection
         MMVAE_TRY(lin_dx(dwt, ldw, R, p + P.td_h2o_w, E, H, ino, 0, w.td_dh1, H, 1, s));
-        MMVAE_TRY(lin_dw(dwt, ldw, h1n, H, R, g + P.td_h2o_w, E, H, ino, 0, s));
+        MMVAE_TRY(to_side());
+        MMVAE_TRY(lin_dw(dwt, ldw, h1n, H, R, g + P.td_h2o_w, E, H, ino, 0, sw));
         // layer 1
         GruBwd b{};
         b.dh = w.td_dh1; b.sav = w.td_sav1 + (size_t)t * R * 4 * H; b.hprev = h1p; b.dgi = dgi1; b.lddgi = G; b.dgh = dgh1;
@@ -322,18 +328,20 @@ int coco_text_dec_bwd(CocoPlan& P, const float* z, int groups, const float* sos,
         MMVAE_TRY(lin_dx(dgh0, G, R, p + P.td0.whh, G, H, H, 0, w.td_dh0, H, 1, s));
         // input vector of this step: the previous output (gradient flows back into it) or '<s>' (a constant)
         const float* win = t == 0 ? sos : sentence + (size_t)(t - 1) * E;
-        MMVAE_TRY(lin_dw(dgi0, G, win, t == 0 ? 0 : ldw, R, g + P.td0.wih, G, E, in0, 0, s));
+        MMVAE_TRY(to_side());
+        MMVAE_TRY(lin_dw(dgi0, G, win, t == 0 ? 0 : ldw, R, g + P.td0.wih, G, E, in0, 0, sw));
         if (t > 0) MMVAE_TRY(lin_dx(dgi0, G, R, p + P.td0.wih, G, E, in0, 0, dw + (size_t)(t - 1) * E, ldw, 1, s));
         (void)mid;
     }
     const int TR = T * R;
     // weight gradients whose operand pairs share the [t][row] layout: one GEMM over K = T*R each
-    MMVAE_TRY(lin_dw(w.td_dgh0, G, w.td_h0, H, TR, g + P.td0.whh, G, H, H, 0, s));
-    MMVAE_TRY(lin_dw(w.td_dgh1, G, w.td_h1, H, TR, g + P.td1.whh, G, H, H, 0, s));
-    MMVAE_TRY(lin_dw(w.td_dgi1, G, keep ? w.td_mid : w.td_h0 + RH, H, TR, g + P.td1.wih, G, H, H, 0, s));
-    MMVAE_TRY(launch_colsum_f32(w.td_dgh0, TR, G, g + P.td0.bhh, s));
-    MMVAE_TRY(launch_colsum_f32(w.td_dgi1, TR, G, g + P.td1.bih, s));
-    MMVAE_TRY(launch_colsum_f32(w.td_dgh1, TR, G, g + P.td1.bhh, s));
+    MMVAE_TRY(to_side());
+    MMVAE_TRY(lin_dw(w.td_dgh0, G, w.td_h0, H, TR, g + P.td0.whh, G, H, H, 0, sw));
+    MMVAE_TRY(lin_dw(w.td_dgh1, G, w.td_h1, H, TR, g + P.td1.whh, G, H, H, 0, sw));
+    MMVAE_TRY(lin_dw(w.td_dgi1, G, keep ? w.td_mid : w.td_h0 + RH, H, TR, g + P.td1.wih, G, H, H, 0, sw));
+    MMVAE_TRY(launch_colsum_f32(w.td_dgh0, TR, G, g + P.td0.bhh, sw));
+    MMVAE_TRY(launch_colsum_f32(w.td_dgi1, TR, G, g + P.td1.bih, sw));
+    MMVAE_TRY(launch_colsum_f32(w.td_dgh1, TR, G, g + P.td1.bhh, sw));
     // initial hidden state h = z2h(z), shared by both layers
     MMVAE_TRY(add2(w.td_dh0, w.td_dh1, (long long)RH, w.td_dhinit, s));
     MMVAE_TRY(lin_dw(w.td_dhinit, H, z, D, R, g + P.td_z2h_w, H, D, D, 0, s));

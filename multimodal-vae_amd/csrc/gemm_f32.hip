@@ -10,7 +10,7 @@ namespace {
 // workgroup split K (these GEMMs have 10..400 tiles: the K chain is the latency) and are summed through LDS.
 // Within a 16-deep step, MFMA s of lane group q consumes k = k0 + 4q + s: an operand that is contiguous along k is
 // then ONE 16-byte load per lane per step, a strided one four 4-byte loads of the same k's.
-template <int KS, bool AV, bool BV>
+template <int KS, bool AV, bool BV, int U>
 __global__ __launch_bounds__(KS * 64) void gemm_f32_kernel(const F32Gemm g) {
     __shared__ float red[KS > 1 ? (KS - 1) * 16 * 64 : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
@@ -43,7 +43,6 @@ __global__ __launch_bounds__(KS * 64) void gemm_f32_kernel(const F32Gemm g) {
     const int st0 = zs0 + nst * wave / KS, st1 = zs0 + nst * (wave + 1) / KS;
     // U steps per iteration: every load of the iteration is issued before its first MFMA (these GEMMs are a few steps
     // per wave, so the loop is a chain of memory latencies unless the loads overlap)
-    constexpr int U = 4;
     for (int st = st0; st < st1; st += U) {
         float av[U][4][2], bv[U][4][2];
 #pragma unroll
@@ -129,13 +128,13 @@ __global__ __launch_bounds__(KS * 64) void gemm_f32_kernel(const F32Gemm g) {
             }
         }
 }
-template <int KS>
+template <int KS, int U>
 int gemm_f32_ks(const F32Gemm& g, bool av, bool bv, hipStream_t s) {
     dim3 grid(ceil_div(g.M, 32), ceil_div(g.N, 32), g.ksplit > 1 ? g.ksplit : 1), block(KS * 64);
-    if (av && bv) hipLaunchKernelGGL((gemm_f32_kernel<KS, true, true>), grid, block, 0, s, g);
-    else if (av) hipLaunchKernelGGL((gemm_f32_kernel<KS, true, false>), grid, block, 0, s, g);
-    else if (bv) hipLaunchKernelGGL((gemm_f32_kernel<KS, false, true>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((gemm_f32_kernel<KS, false, false>), grid, block, 0, s, g);
+    if (av && bv) hipLaunchKernelGGL((gemm_f32_kernel<KS, true, true, U>), grid, block, 0, s, g);
+    else if (av) hipLaunchKernelGGL((gemm_f32_kernel<KS, true, false, U>), grid, block, 0, s, g);
+    else if (bv) hipLaunchKernelGGL((gemm_f32_kernel<KS, false, true, U>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_f32_kernel<KS, false, false, U>), grid, block, 0, s, g);
     return mmvae_check_launch("gemm_f32");
 }
 }  // namespace
@@ -153,8 +152,11 @@ int gemm_f32(const F32Gemm& g, hipStream_t s) {
     const bool bv = g.b_rs == 1 && g.K % 4 == 0 && g.b_cs % 4 == 0 && (reinterpret_cast<uintptr_t>(g.B) & 15) == 0;
     const int tiles = ceil_div(g.M, 32) * ceil_div(g.N, 32), nst = ceil_div(g.K, 16);
     const int nz = g.ksplit > 1 ? g.ksplit : 1;
-    if (tiles * nz <= 128 && nst / nz >= 16) return gemm_f32_ks<8>(g, av, bv, s);
-    if (tiles * nz <= 256 && nst / nz >= 8) return gemm_f32_ks<4>(g, av, bv, s);
-    if (tiles * nz <= 512 && nst / nz >= 4) return gemm_f32_ks<2>(g, av, bv, s);
-    return gemm_f32_ks<1>(g, av, bv, s);
+    // few tiles: the K chain is the latency -- split it over the waves of the workgroup, and when a wave's share fits one
+    // batch of U = 6 steps, issue all of its loads at once
+    const int per = nst / nz;
+    if (tiles * nz <= 128 && per >= 16) return per <= 48 ? gemm_f32_ks<8, 6>(g, av, bv, s) : gemm_f32_ks<8, 4>(g, av, bv, s);
+    if (tiles * nz <= 256 && per >= 8) return per <= 24 ? gemm_f32_ks<4, 6>(g, av, bv, s) : gemm_f32_ks<4, 4>(g, av, bv, s);
+    if (tiles * nz <= 512 && per >= 4) return gemm_f32_ks<2, 4>(g, av, bv, s);
+    return gemm_f32_ks<1, 4>(g, av, bv, s);
 }
