@@ -130,20 +130,28 @@ __global__ __launch_bounds__(TPBT) void mse3_kernel(const float* recon, const fl
 
 // ---- GEMM shorthands over PyTorch-layout weights W[N][ldw] (a column window [c0, c0+K) of it) -------------------------
 // y[M][N] (ldy) = x[M][K] (ldx) W[:, c0:c0+K]^T (+ bias) (+ addm)
-int lin(const float* x, long long ldx, int M, const float* W, int N, int K, long long ldw, int c0, const float* bias,
-        const float* addm, long long ldadd, float* y, long long ldy, hipStream_t s) {
+F32Gemm mk_lin(const float* x, long long ldx, int M, const float* W, int N, int K, long long ldw, int c0, const float* bias,
+               const float* addm, long long ldadd, float* y, long long ldy) {
     F32Gemm g{};
     g.A = x; g.a_rs = ldx; g.a_cs = 1; g.B = W + c0; g.b_rs = 1; g.b_cs = ldw;
     g.M = M; g.N = N; g.K = K; g.C = y; g.ldc = ldy; g.bias = bias; g.addm = addm; g.ldadd = ldadd;
-    return gemm_f32(g, s);
+    return g;
+}
+int lin(const float* x, long long ldx, int M, const float* W, int N, int K, long long ldw, int c0, const float* bias,
+        const float* addm, long long ldadd, float* y, long long ldy, hipStream_t s) {
+    return gemm_f32(mk_lin(x, ldx, M, W, N, K, ldw, c0, bias, addm, ldadd, y, ldy), s);
 }
 // dx[M][K] (lddx) (+)= dy[M][N] (lddy) W[:, c0:c0+K]
-int lin_dx(const float* dy, long long lddy, int M, const float* W, int N, int K, long long ldw, int c0, float* dx, long long lddx,
-           int accumulate, hipStream_t s) {
+F32Gemm mk_dx(const float* dy, long long lddy, int M, const float* W, int N, int K, long long ldw, int c0, float* dx, long long lddx,
+              int accumulate) {
     F32Gemm g{};
     g.A = dy; g.a_rs = lddy; g.a_cs = 1; g.B = W + c0; g.b_rs = ldw; g.b_cs = 1;
     g.M = M; g.N = K; g.K = N; g.C = dx; g.ldc = lddx; g.accumulate = accumulate;
-    return gemm_f32(g, s);
+    return g;
+}
+int lin_dx(const float* dy, long long lddy, int M, const float* W, int N, int K, long long ldw, int c0, float* dx, long long lddx,
+           int accumulate, hipStream_t s) {
+    return gemm_f32(mk_dx(dy, lddy, M, W, N, K, ldw, c0, dx, lddx, accumulate), s);
 }
 // dW[:, c0:c0+K] += dy[M][N]^T x[M][K]   (dW is zero at the start of the step; float atomics when K is split)
 int lin_dw(const float* dy, long long lddy, const float* x, long long ldx, int M, float* dW, int N, int K, long long ldw, int c0,
@@ -268,16 +276,17 @@ int coco_text_dec_fwd(CocoPlan& P, const float* z, int groups, const float* sos,
         const float* h1p = w.td_h1 + (size_t)t * RH; float* h1n = w.td_h1 + (size_t)(t + 1) * RH;
         const float* win = t == 0 ? sos : sentence + (size_t)(t - 1) * E;
         const long long ldwin = t == 0 ? 0 : (long long)T * E;
-        MMVAE_TRY(lin(win, ldwin, R, p + P.td0.wih, G, E, in0, 0, nullptr, w.td_zi0, G, w.td_gi, G, s));
-        MMVAE_TRY(lin(h0p, H, R, p + P.td0.whh, G, H, H, 0, p + P.td0.bhh, nullptr, 0, w.td_gh, G, s));
+        // input and hidden projections are independent: one launch
+        MMVAE_TRY(gemm_f32_pair(mk_lin(win, ldwin, R, p + P.td0.wih, G, E, in0, 0, nullptr, w.td_zi0, G, w.td_gi, G),
+                                mk_lin(h0p, H, R, p + P.td0.whh, G, H, H, 0, p + P.td0.bhh, nullptr, 0, w.td_gh, G), s));
         GruFwd a{};
         a.gi = w.td_gi; a.ldgi = G; a.gh = w.td_gh; a.hprev = h0p; a.h = h0n; a.rows = R;
         a.sav = save ? w.td_sav0 + (size_t)t * R * 4 * H : nullptr;
         const float* mid = h0n;
         if (keep) { a.keep = keep + (size_t)t * RH; a.scale = scale; a.mid = w.td_mid + (size_t)t * RH; mid = a.mid; }
         MMVAE_TRY(gru_fwd(a, s));
-        MMVAE_TRY(lin(mid, H, R, p + P.td1.wih, G, H, H, 0, p + P.td1.bih, nullptr, 0, w.td_gi, G, s));
-        MMVAE_TRY(lin(h1p, H, R, p + P.td1.whh, G, H, H, 0, p + P.td1.bhh, nullptr, 0, w.td_gh, G, s));
+        MMVAE_TRY(gemm_f32_pair(mk_lin(mid, H, R, p + P.td1.wih, G, H, H, 0, p + P.td1.bih, nullptr, 0, w.td_gi, G),
+                                mk_lin(h1p, H, R, p + P.td1.whh, G, H, H, 0, p + P.td1.bhh, nullptr, 0, w.td_gh, G), s));
         GruFwd b{};
         b.gi = w.td_gi; b.ldgi = G; b.gh = w.td_gh; b.hprev = h1p; b.h = h1n; b.rows = R;
         b.sav = save ? w.td_sav1 + (size_t)t * R * 4 * H : nullptr;
@@ -318,19 +327,23 @@ int coco_text_dec_bwd(CocoPlan& P, const float* z, int groups, const float* sos,
         b.dh = w.td_dh1; b.sav = w.td_sav1 + (size_t)t * R * 4 * H; b.hprev = h1p; b.dgi = dgi1; b.lddgi = G; b.dgh = dgh1;
         b.dh_out = w.td_dh1; b.rows = R;
         MMVAE_TRY(gru_bwd(b, s));
-        MMVAE_TRY(lin_dx(dgi1, G, R, p + P.td1.wih, G, H, H, 0, w.td_dmid, H, 0, s));
-        MMVAE_TRY(lin_dx(dgh1, G, R, p + P.td1.whh, G, H, H, 0, w.td_dh1, H, 1, s));
+        MMVAE_TRY(gemm_f32_pair(mk_dx(dgi1, G, R, p + P.td1.wih, G, H, H, 0, w.td_dmid, H, 0),
+                                mk_dx(dgh1, G, R, p + P.td1.whh, G, H, H, 0, w.td_dh1, H, 1), s));
         // layer 0 (its output fed layer 1 through the dropout)
         GruBwd a{};
         a.dh = w.td_dh0; a.dh2 = w.td_dmid; a.keep = keep ? keep + (size_t)t * RH : nullptr; a.scale = scale;
         a.sav = w.td_sav0 + (size_t)t * R * 4 * H; a.hprev = h0p; a.dgi = dgi0; a.lddgi = G; a.dgh = dgh0; a.dh_out = w.td_dh0; a.rows = R;
         MMVAE_TRY(gru_bwd(a, s));
-        MMVAE_TRY(lin_dx(dgh0, G, R, p + P.td0.whh, G, H, H, 0, w.td_dh0, H, 1, s));
-        // input vector of this step: the previous output (gradient flows back into it) or '<s>' (a constant)
+        // hidden-state path, and the input vector of this step: the previous output (gradient flows back into it) or
+        // '<s>' (a constant)
+        if (t > 0)
+            MMVAE_TRY(gemm_f32_pair(mk_dx(dgh0, G, R, p + P.td0.whh, G, H, H, 0, w.td_dh0, H, 1),
+                                    mk_dx(dgi0, G, R, p + P.td0.wih, G, E, in0, 0, dw + (size_t)(t - 1) * E, ldw, 1), s));
+        else
+            MMVAE_TRY(lin_dx(dgh0, G, R, p + P.td0.whh, G, H, H, 0, w.td_dh0, H, 1, s));
         const float* win = t == 0 ? sos : sentence + (size_t)(t - 1) * E;
         MMVAE_TRY(to_side());
         MMVAE_TRY(lin_dw(dgi0, G, win, t == 0 ? 0 : ldw, R, g + P.td0.wih, G, E, in0, 0, sw));
-        if (t > 0) MMVAE_TRY(lin_dx(dgi0, G, R, p + P.td0.wih, G, E, in0, 0, dw + (size_t)(t - 1) * E, ldw, 1, s));
         (void)mid;
     }
     const int TR = T * R;

@@ -17,3 +17,5 @@ struct F32Gemm {
                                                // C with float atomics (C must hold the value to accumulate onto, e.g. 0)
 };
 int gemm_f32(const F32Gemm& g, hipStream_t s);
+// two independent GEMMs (no grid-level K split) in ONE launch
+int gemm_f32_pair(const F32Gemm& a, const F32Gemm& b, hipStream_t s);

@@ -10,11 +10,12 @@ namespace {
 // workgroup split K (these GEMMs have 10..400 tiles: the K chain is the latency) and are summed through LDS.
 // Within a 16-deep step, MFMA s of lane group q consumes k = k0 + 4q + s: an operand that is contiguous along k is
 // then ONE 16-byte load per lane per step, a strided one four 4-byte loads of the same k's.
+// bz / nz: this workgroup's chunk of a grid-level K split (0 / 1 when there is none)
 template <int KS, bool AV, bool BV, int U>
-__global__ __launch_bounds__(KS * 64) void gemm_f32_kernel(const F32Gemm g) {
-    __shared__ float red[KS > 1 ? (KS - 1) * 16 * 64 : 1];
+__device__ __forceinline__ void gemm_f32_body(const F32Gemm& g, float* red, const int bz, const int nz) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
     const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    if (m0 >= g.M || n0 >= g.N) return;            // pair launches: the grid covers the larger problem (uniform per workgroup)
     f32x4 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -37,8 +38,7 @@ __global__ __launch_bounds__(KS * 64) void gemm_f32_kernel(const F32Gemm g) {
         brow[t] = (unsigned)n * (unsigned)g.b_cs * 4u;
     }
     const int nst_all = (g.K + 15) / 16;
-    const int nz = gridDim.z;                                      // grid-level K split (atomic epilogue)
-    const int zs0 = (int)((long long)nst_all * blockIdx.z / nz), zs1 = (int)((long long)nst_all * (blockIdx.z + 1) / nz);
+    const int zs0 = (int)((long long)nst_all * bz / nz), zs1 = (int)((long long)nst_all * (bz + 1) / nz);
     const int nst = zs1 - zs0;
     const int st0 = zs0 + nst * wave / KS, st1 = zs0 + nst * (wave + 1) / KS;
     // U steps per iteration: every load of the iteration is issued before its first MFMA (these GEMMs are a few steps
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(KS * 64) void gemm_f32_kernel(const F32Gemm g) {
         for (int j = 0; j < 2; ++j) {
             const int n = n0 + j * 16 + fr;
             if (n >= g.N) continue;
-            const bool first = blockIdx.z == 0;
+            const bool first = bz == 0;
             const float bias = (g.bias && first) ? g.bias[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -128,6 +128,29 @@ __global__ __launch_bounds__(KS * 64) void gemm_f32_kernel(const F32Gemm g) {
             }
         }
 }
+template <int KS, bool AV, bool BV, int U>
+__global__ __launch_bounds__(KS * 64) void gemm_f32_kernel(const F32Gemm g) {
+    __shared__ float red[KS > 1 ? (KS - 1) * 16 * 64 : 1];
+    gemm_f32_body<KS, AV, BV, U>(g, red, blockIdx.z, gridDim.z);
+}
+// two independent GEMMs in one launch: blockIdx.z picks the problem (no grid-level K split)
+struct F32GemmPair { F32Gemm p[2]; };
+template <int KS, bool AV, bool BV, int U>
+__global__ __launch_bounds__(KS * 64) void gemm_f32_pair_kernel(const F32GemmPair pr) {
+    __shared__ float red[KS > 1 ? (KS - 1) * 16 * 64 : 1];
+    if (blockIdx.z == 0) gemm_f32_body<KS, AV, BV, U>(pr.p[0], red, 0, 1);
+    else gemm_f32_body<KS, AV, BV, U>(pr.p[1], red, 0, 1);
+}
+template <int KS, int U>
+int gemm_f32_pair_ks(const F32GemmPair& pr, bool av, bool bv, hipStream_t s) {
+    const F32Gemm &a = pr.p[0], &b = pr.p[1];
+    dim3 grid(ceil_div(a.M > b.M ? a.M : b.M, 32), ceil_div(a.N > b.N ? a.N : b.N, 32), 2), block(KS * 64);
+    if (av && bv) hipLaunchKernelGGL((gemm_f32_pair_kernel<KS, true, true, U>), grid, block, 0, s, pr);
+    else if (av) hipLaunchKernelGGL((gemm_f32_pair_kernel<KS, true, false, U>), grid, block, 0, s, pr);
+    else if (bv) hipLaunchKernelGGL((gemm_f32_pair_kernel<KS, false, true, U>), grid, block, 0, s, pr);
+    else hipLaunchKernelGGL((gemm_f32_pair_kernel<KS, false, false, U>), grid, block, 0, s, pr);
+    return mmvae_check_launch("gemm_f32_pair");
+}
 template <int KS, int U>
 int gemm_f32_ks(const F32Gemm& g, bool av, bool bv, hipStream_t s) {
     dim3 grid(ceil_div(g.M, 32), ceil_div(g.N, 32), g.ksplit > 1 ? g.ksplit : 1), block(KS * 64);
@@ -139,7 +162,7 @@ int gemm_f32_ks(const F32Gemm& g, bool av, bool bv, hipStream_t s) {
 }
 }  // namespace
 
-int gemm_f32(const F32Gemm& g, hipStream_t s) {
+static int check_f32(const F32Gemm& g, bool& av, bool& bv) {
     MMVAE_REQUIRE(g.M > 0 && g.N > 0 && g.K > 0 && g.A && g.B && g.C, "gemm_f32: bad arguments");
     MMVAE_REQUIRE(g.ksplit <= 1 || g.ksplit <= (g.K + 15) / 16, "gemm_f32: ksplit=%d for K=%d", g.ksplit, g.K);
     // operands are addressed with 32-bit byte offsets from their base pointers
@@ -148,8 +171,29 @@ int gemm_f32(const F32Gemm& g, hipStream_t s) {
     MMVAE_REQUIRE(g.a_rs >= 0 && g.a_cs >= 0 && g.b_rs >= 0 && g.b_cs >= 0 && amax < 0x7FFFFFFFll && bmax < 0x7FFFFFFFll,
                   "gemm_f32: operand spans more than 2 GiB (or has a negative stride)");
     // 16-byte loads along k need a unit k stride, K a multiple of 4, rows that start 16-byte aligned
-    const bool av = g.a_cs == 1 && g.K % 4 == 0 && g.a_rs % 4 == 0 && (reinterpret_cast<uintptr_t>(g.A) & 15) == 0;
-    const bool bv = g.b_rs == 1 && g.K % 4 == 0 && g.b_cs % 4 == 0 && (reinterpret_cast<uintptr_t>(g.B) & 15) == 0;
+    av = g.a_cs == 1 && g.K % 4 == 0 && g.a_rs % 4 == 0 && (reinterpret_cast<uintptr_t>(g.A) & 15) == 0;
+    bv = g.b_rs == 1 && g.K % 4 == 0 && g.b_cs % 4 == 0 && (reinterpret_cast<uintptr_t>(g.B) & 15) == 0;
+    return MMVAE_OK;
+}
+
+int gemm_f32_pair(const F32Gemm& a, const F32Gemm& b, hipStream_t s) {
+    bool av0, bv0, av1, bv1;
+    MMVAE_TRY(check_f32(a, av0, bv0));
+    MMVAE_TRY(check_f32(b, av1, bv1));
+    MMVAE_REQUIRE(a.ksplit <= 1 && b.ksplit <= 1, "gemm_f32_pair: no grid-level K split");
+    F32GemmPair pr; pr.p[0] = a; pr.p[1] = b;
+    const bool av = av0 && av1, bv = bv0 && bv1;
+    const int tiles = ceil_div(a.M, 32) * ceil_div(a.N, 32) + ceil_div(b.M, 32) * ceil_div(b.N, 32);
+    const int per = ceil_div(a.K > b.K ? a.K : b.K, 16);
+    if (tiles <= 128 && per >= 16) return per <= 48 ? gemm_f32_pair_ks<8, 6>(pr, av, bv, s) : gemm_f32_pair_ks<8, 4>(pr, av, bv, s);
+    if (tiles <= 256 && per >= 8) return per <= 24 ? gemm_f32_pair_ks<4, 6>(pr, av, bv, s) : gemm_f32_pair_ks<4, 4>(pr, av, bv, s);
+    if (tiles <= 512 && per >= 4) return gemm_f32_pair_ks<2, 4>(pr, av, bv, s);
+    return gemm_f32_pair_ks<1, 4>(pr, av, bv, s);
+}
+
+int gemm_f32(const F32Gemm& g, hipStream_t s) {
+    bool av, bv;
+    MMVAE_TRY(check_f32(g, av, bv));
     const int tiles = ceil_div(g.M, 32) * ceil_div(g.N, 32), nst = ceil_div(g.K, 16);
     const int nz = g.ksplit > 1 ? g.ksplit : 1;
     // few tiles: the K chain is the latency -- split it over the waves of the workgroup, and when a wave's share fits one
