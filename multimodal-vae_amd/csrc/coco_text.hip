@@ -90,6 +90,143 @@ int gru_bwd(const GruBwd& a, hipStream_t s) {
     return mmvae_check_launch("gru_bwd");
 }
 
+// ------------------------------------------------------------------ fused GRU layer step (forward)
+// h' = GRU(x, h) in ONE launch: both projections on the fp32 MFMA and the gate math in the epilogue.  A workgroup owns 32
+// rows x 16 hidden units; its accumulators are the four pre-activation pieces of those units (r and z: input + hidden
+// parts summed in the same accumulator; n: input part and hidden part kept apart, n = tanh(i_n + r * h_n)).  The KS waves
+// split the k-steps of both phases and are summed through LDS; operands go through buffer descriptors (hardware zero
+// fill), U steps of loads are in flight before the first MFMA.  Replaces two GEMM launches, one gate kernel and the
+// [rows][600] x 2 round trip of the projections through memory.
+struct GruLayer {
+    const float* x; long long ldx; int Kx;     // layer input [rows][Kx] (ldx = 0: one row for all), Kx = 0: none
+    const float* Wih; long long ldwih;         // [3H][ldwih] input weights (column window applied by the caller)
+    const float* gi_add; long long ldgi;       // [rows][3H] added to the input projection (precomputed part), or null
+    const float* bih;                          // [3H] or null (already inside gi_add)
+    const float* hprev;                        // [rows][H]
+    const float* Whh; const float* bhh;        // [3H][H], [3H]
+    float* h; float* sav;                      // [rows][H]; [rows][4H] (r | z | n | h_n) or null
+    const uint8_t* keep; float scale; float* mid;   // inter-layer dropout of the output, or null
+    int rows;
+};
+template <int KS, int U>
+__global__ __launch_bounds__(KS * 64) void gru_layer_fwd_kernel(const GruLayer a) {
+    __shared__ float red[KS > 1 ? (KS - 1) * 32 * 64 : 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
+    const int m0 = blockIdx.x * 32, j0 = blockIdx.y * 16;
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool jok = j0 + fr < H;
+    bool rok[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) rok[t] = m0 + t * 16 + fr < a.rows;
+    // one phase = one (A operand, weight matrix, K) triple; phase 0 feeds (r, z, i_n), phase 1 feeds (r, z, h_n)
+#pragma unroll
+    for (int phase = 0; phase < 2; ++phase) {
+        const float* A = phase == 0 ? a.x : a.hprev;
+        const float* W = phase == 0 ? a.Wih : a.Whh;
+        const int K = phase == 0 ? a.Kx : H;
+        if (K == 0) continue;
+        const unsigned lda = phase == 0 ? (unsigned)a.ldx * 4u : (unsigned)H * 4u;
+        const unsigned ldw = phase == 0 ? (unsigned)a.ldwih * 4u : (unsigned)H * 4u;
+        const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, 0x7FFFFFFF, 0x00020000);
+        const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, 0x7FFFFFFF, 0x00020000);
+        unsigned arow[2], wrow[3];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) arow[t] = (unsigned)(m0 + t * 16 + fr) * lda;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) wrow[g] = (unsigned)(g * H + j0 + fr) * ldw;
+        const int nst = (K + 15) / 16;
+        const int st0 = nst * wave / KS, st1 = nst * (wave + 1) / KS;
+        for (int st = st0; st < st1; st += U) {
+            f32x4 av[U][2], bv[U][3];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int kb = (st + u) * 16 + fq * 4;
+                const bool kin = st + u < st1 && kb < K;          // K % 4 == 0: the 4 k are all inside or all outside
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    av[u][t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(arsrc, (kin && rok[t]) ? arow[t] + (unsigned)kb * 4u : 0xFFFFFFFFu, 0, 0));
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+                    bv[u][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, (kin && jok) ? wrow[g] + (unsigned)kb * 4u : 0xFFFFFFFFu, 0, 0));
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][t][q], bv[u][0][q], acc[t][0], 0, 0, 0);
+                        acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][t][q], bv[u][1][q], acc[t][1], 0, 0, 0);
+                        acc[t][2 + phase] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][t][q], bv[u][2][q], acc[t][2 + phase], 0, 0, 0);
+                    }
+        }
+    }
+    if (KS > 1) {
+        if (wave > 0) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[((wave - 1) * 32 + (t * 4 + c) * 4 + r) * 64 + lane] = acc[t][c][r];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 0; w < KS - 1; ++w)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[t][c][r] += red[(w * 32 + (t * 4 + c) * 4 + r) * 64 + lane];
+    }
+    const int j = j0 + fr;
+    if (!jok) return;
+    float br = a.bhh[j], bz = a.bhh[H + j], bin = 0.f;
+    const float bhn = a.bhh[2 * H + j];
+    if (a.bih) { br += a.bih[j]; bz += a.bih[H + j]; bin = a.bih[2 * H + j]; }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + t * 16 + fq * 4 + r;
+            if (m >= a.rows) continue;
+            float pr = acc[t][0][r] + br, pz = acc[t][1][r] + bz, pin = acc[t][2][r] + bin;
+            if (a.gi_add) {
+                const float* gi = a.gi_add + (size_t)m * a.ldgi;
+                pr += gi[j]; pz += gi[H + j]; pin += gi[2 * H + j];
+            }
+            const float ghn = acc[t][3][r] + bhn;
+            const float rr = sigm(pr), zz = sigm(pz);
+            const float nn = tanhf(pin + rr * ghn);
+            const size_t i = (size_t)m * H + j;
+            const float hh = (1.0f - zz) * nn + zz * a.hprev[i];
+            a.h[i] = hh;
+            if (a.sav) {
+                float* s = a.sav + (size_t)m * 4 * H;
+                s[j] = rr; s[H + j] = zz; s[2 * H + j] = nn; s[3 * H + j] = ghn;
+            }
+            if (a.mid) a.mid[i] = a.keep ? hh * (float)a.keep[i] * a.scale : hh;
+        }
+}
+int gru_layer_fwd(const GruLayer& a, hipStream_t s) {
+    MMVAE_REQUIRE(a.Kx % 4 == 0 && (a.Kx == 0 || (a.ldx % 4 == 0 && a.ldwih % 4 == 0)), "gru_layer: Kx=%d ldx=%lld", a.Kx, a.ldx);
+    MMVAE_REQUIRE((long long)a.rows * (a.ldx > H ? a.ldx : H) * 4 < 0x7FFFFFFFll, "gru_layer: operand spans more than 2 GiB");
+    const bool aligned = ((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.Wih) | reinterpret_cast<uintptr_t>(a.hprev) |
+                           reinterpret_cast<uintptr_t>(a.Whh)) & 15) == 0;
+    MMVAE_REQUIRE(aligned, "gru_layer: operands must be 16-byte aligned");
+    dim3 grid(ceil_div(a.rows, 32), ceil_div(H, 16));
+    const int nst = ceil_div(a.Kx, 16) + ceil_div(H, 16);
+    if ((int)(grid.x * grid.y) <= 512 || nst <= 16) hipLaunchKernelGGL((gru_layer_fwd_kernel<4, 4>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gru_layer_fwd_kernel<2, 4>), grid, dim3(128), 0, s, a);
+    return mmvae_check_launch("gru_layer_fwd");
+}
+
 __global__ __launch_bounds__(TPBT) void add2_kernel(const float* a, const float* b, long long n, float* out) {
     const long long i = (long long)blockIdx.x * TPBT + threadIdx.x;
     if (i < n) out[i] = a[i] + b[i];
@@ -206,11 +343,10 @@ int coco_text_enc_fwd(CocoPlan& P, const float* text, int save, float* out, hipS
     MMVAE_TRY(lin(text, E, B * T, p + P.te_f.wih, G, E, E, 0, p + P.te_f.bih, nullptr, 0, w.te_gi, G, s));
     for (int t = 0; t < T; ++t) {
         const float* hp = t == 0 ? w.zeros_h : w.te_h + (size_t)(t - 1) * B * H;
-        MMVAE_TRY(lin(hp, H, B, p + P.te_f.whh, G, H, H, 0, p + P.te_f.bhh, nullptr, 0, w.te_gh, G, s));
-        GruFwd a{};
-        a.gi = w.te_gi + (size_t)t * G; a.ldgi = (long long)T * G; a.gh = w.te_gh; a.hprev = hp;
+        GruLayer a{};
+        a.gi_add = w.te_gi + (size_t)t * G; a.ldgi = (long long)T * G; a.hprev = hp; a.Whh = p + P.te_f.whh; a.bhh = p + P.te_f.bhh;
         a.h = w.te_h + (size_t)t * B * H; a.sav = save ? w.te_sav + (size_t)t * B * 4 * H : nullptr; a.rows = B;
-        MMVAE_TRY(gru_fwd(a, s));
+        MMVAE_TRY(gru_layer_fwd(a, s));
     }
     {   // reverse direction: its output at the last position is its FIRST step (input T-1, h = 0)
         MMVAE_TRY(lin(text + (size_t)(T - 1) * E, (long long)T * E, B, p + P.te_r.wih, G, E, E, 0, p + P.te_r.bih, nullptr, 0, w.te_gi_r, G, s));
@@ -276,21 +412,18 @@ int coco_text_dec_fwd(CocoPlan& P, const float* z, int groups, const float* sos,
         const float* h1p = w.td_h1 + (size_t)t * RH; float* h1n = w.td_h1 + (size_t)(t + 1) * RH;
         const float* win = t == 0 ? sos : sentence + (size_t)(t - 1) * E;
         const long long ldwin = t == 0 ? 0 : (long long)T * E;
-        // input and hidden projections are independent: one launch
-        MMVAE_TRY(gemm_f32_pair(mk_lin(win, ldwin, R, p + P.td0.wih, G, E, in0, 0, nullptr, w.td_zi0, G, w.td_gi, G),
-                                mk_lin(h0p, H, R, p + P.td0.whh, G, H, H, 0, p + P.td0.bhh, nullptr, 0, w.td_gh, G), s));
-        GruFwd a{};
-        a.gi = w.td_gi; a.ldgi = G; a.gh = w.td_gh; a.hprev = h0p; a.h = h0n; a.rows = R;
+        GruLayer a{};
+        a.x = win; a.ldx = ldwin; a.Kx = E; a.Wih = p + P.td0.wih; a.ldwih = in0; a.gi_add = w.td_zi0; a.ldgi = G;
+        a.hprev = h0p; a.Whh = p + P.td0.whh; a.bhh = p + P.td0.bhh; a.h = h0n; a.rows = R;
         a.sav = save ? w.td_sav0 + (size_t)t * R * 4 * H : nullptr;
         const float* mid = h0n;
         if (keep) { a.keep = keep + (size_t)t * RH; a.scale = scale; a.mid = w.td_mid + (size_t)t * RH; mid = a.mid; }
-        MMVAE_TRY(gru_fwd(a, s));
-        MMVAE_TRY(gemm_f32_pair(mk_lin(mid, H, R, p + P.td1.wih, G, H, H, 0, p + P.td1.bih, nullptr, 0, w.td_gi, G),
-                                mk_lin(h1p, H, R, p + P.td1.whh, G, H, H, 0, p + P.td1.bhh, nullptr, 0, w.td_gh, G), s));
-        GruFwd b{};
-        b.gi = w.td_gi; b.ldgi = G; b.gh = w.td_gh; b.hprev = h1p; b.h = h1n; b.rows = R;
+        MMVAE_TRY(gru_layer_fwd(a, s));
+        GruLayer b{};
+        b.x = mid; b.ldx = H; b.Kx = H; b.Wih = p + P.td1.wih; b.ldwih = H; b.bih = p + P.td1.bih;
+        b.hprev = h1p; b.Whh = p + P.td1.whh; b.bhh = p + P.td1.bhh; b.h = h1n; b.rows = R;
         b.sav = save ? w.td_sav1 + (size_t)t * R * 4 * H : nullptr;
-        MMVAE_TRY(gru_fwd(b, s));
+        MMVAE_TRY(gru_layer_fwd(b, s));
         MMVAE_TRY(lin(h1n, H, R, p + P.td_h2o_w, E, H, ino, 0, nullptr, w.td_zo, E, sentence + (size_t)t * E, (long long)T * E, s));
     }
     return MMVAE_OK;
