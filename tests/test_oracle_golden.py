@@ -37,6 +37,13 @@ def _run(ds, fx):
             em = (m[0], m[1], None)
         losses, outs = R.multimnist_step_losses(P, image, second, True, 1e-3, eps, em,
                                                 enc_drop_p=0.1 if wm else 0.0, gru_drop_p=0.0)
+    elif ds == "coco":
+        em = None
+        if wm:
+            m = _unpack(fx, B, (1024, 256))
+            em = (m[0], m[1], None)
+        losses, outs = R.coco_step_losses(P, image, second, R.formula_sos(), True, 1e-3, eps, em,
+                                          enc_drop_p=0.1 if wm else 0.0, gru_drop_p=0.0)
     elif ds == "mnist":
         losses, outs = R.mnist_step_losses(P, image.view(-1, 784), second, True, eps)
     else:
@@ -50,7 +57,8 @@ def _run(ds, fx):
 
 
 CASES = [("multimnist", "multimnist_b8"), ("multimnist", "multimnist_b8_masks"), ("mnist", "mnist_b8"),
-         ("mnist", "mnist_b128_scalars"), ("celeba", "celeba_b4"), ("celeba", "celeba_b4_masks")]
+         ("mnist", "mnist_b128_scalars"), ("celeba", "celeba_b4"), ("celeba", "celeba_b4_masks"),
+         ("coco", "coco_b4"), ("coco", "coco_b4_masks")]
 
 
 @pytest.mark.parametrize("ds,name", CASES)
@@ -66,7 +74,12 @@ def test_oracle_matches_golden(ds, name, golden_dir):
         for k in range(3):
             np.testing.assert_allclose(outs[k][2].detach().numpy(), fx[f"mu_{k}"], atol=2e-5)
             np.testing.assert_allclose(outs[k][3].detach().numpy(), fx[f"logvar_{k}"], atol=2e-5)
-            np.testing.assert_allclose(outs[k][1].detach().numpy(), fx[f"second_recon_{k}"], atol=5e-5)
+            if ds == "coco":
+                np.testing.assert_allclose(outs[k][1][:, :3].detach().numpy(), fx[f"text_recon_head_{k}"], atol=5e-5)
+                np.testing.assert_allclose(outs[k][1][:, -2:].detach().numpy(), fx[f"text_recon_tail_{k}"], atol=5e-5)
+                np.testing.assert_allclose(outs[k][1].detach().double().norm().item(), fx[f"text_recon_stats_{k}"][1], rtol=1e-5)
+            else:
+                np.testing.assert_allclose(outs[k][1].detach().numpy(), fx[f"second_recon_{k}"], atol=5e-5)
             s = outs[k][0].detach().double().reshape(-1)
             np.testing.assert_allclose(s.sum().item(), fx[f"image_recon_stats_{k}"][0], rtol=1e-5)
         gs = fx["grad_stats"]
@@ -95,6 +108,7 @@ def test_param_table_counts():
     assert len(R.param_table("multimnist", 100)) == 52
     assert count("mnist", 20) == 806604
     assert count("celeba", 100) == 8808802
+    assert count("coco", 100) == 9488180          # 9.49 M
 
 
 def test_poe_is_variance_weighted():
