@@ -11,9 +11,10 @@ from __future__ import annotations
 import os
 from typing import Iterator, List, Sequence, Tuple
 
+import numpy as np
 import torch
 
-from ._lib import call, ptr
+from ._lib import MMVAEError, call, ptr
 from .utils import FILL, charlist_tensor, max_length
 
 PROCESSED = "processed"
@@ -60,24 +61,42 @@ def synthetic_multimnist(n: int, seed: int = 0, size: int = 50) -> Tuple[torch.T
 
 
 class DeviceBatcher:
-    """Iterates ``(image fp32 (B,1,H,W), text int64 (B,4))`` device batches over a uint8 dataset.
+    """Iterates ``(image fp32, second modality)`` device batches over a uint8 image dataset.
 
-    Host: one index gather per batch into a pinned uint8 staging buffer (two of them, alternating).  Copy stream: async
-    H2D of B*H*W bytes + B*4 labels.  Compute stream: waits for the copy event, then the u8->f32 kernel.  Batch i+1 is
-    copied while batch i trains.  ``drop_last`` because the fused plans are built for a fixed batch size."""
+    ``images_u8``: (N,H,W) -> batches (B,1,H,W) (MultiMNIST), or (N,C,H,W) -> (B,C,H,W) (CelebA / COCO pixels).
+    ``text``: (N, ...) of any dtype, copied as is: int64 tokens (B,4), fp32 attributes (B,18), fp32 caption vectors
+    (B,102,300) -- the asynchronous H2D image + caption pipeline of the COCO configuration.
+
+    Host: one index gather per batch into a pinned staging buffer (two of them, alternating).  Copy stream: async H2D of
+    the uint8 pixels + the second modality.  Compute stream: waits for the copy event, then the u8->f32 kernel (ToTensor
+    on the device).  Batch i+1 is copied while batch i trains.  ``drop_last`` because the fused plans are built for a fixed
+    batch size."""
 
     def __init__(self, images_u8: torch.Tensor, text: torch.Tensor, batch_size: int, device: torch.device, shuffle: bool = True,
                  seed: int = 0):
-        assert images_u8.dtype == torch.uint8 and text.dtype == torch.int64 and len(images_u8) == len(text)
+        assert images_u8.dtype == torch.uint8 and images_u8.dim() in (3, 4) and len(images_u8) == len(text)
         self.images, self.text, self.B, self.device = images_u8, text, int(batch_size), device
         self.shuffle, self.seed, self.epoch = shuffle, seed, 0
-        n, h, w = images_u8.shape
-        self.hw = (h, w)
-        self.stage_u8 = [torch.empty(self.B, h, w, dtype=torch.uint8).pin_memory() for _ in range(2)]
-        self.stage_tx = [torch.empty(self.B, text.shape[1], dtype=torch.int64).pin_memory() for _ in range(2)]
-        self.dev_u8 = [torch.empty(self.B, h, w, dtype=torch.uint8, device=device) for _ in range(2)]
-        self.dev_tx = [torch.empty(self.B, text.shape[1], dtype=torch.int64, device=device) for _ in range(2)]
-        self.dev_f32 = [torch.empty(self.B, 1, h, w, dtype=torch.float32, device=device) for _ in range(2)]
+        ishape = tuple(images_u8.shape[1:])
+        oshape = (1,) + ishape if images_u8.dim() == 3 else ishape
+        tshape = tuple(text.shape[1:])
+        self.hw = ishape[-2:]
+        self.stage_u8 = [torch.empty((self.B,) + ishape, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self.stage_tx = [torch.empty((self.B,) + tshape, dtype=text.dtype).pin_memory() for _ in range(2)]
+        self.dev_u8 = [torch.empty((self.B,) + ishape, dtype=torch.uint8, device=device) for _ in range(2)]
+        self.dev_tx = [torch.empty((self.B,) + tshape, dtype=text.dtype, device=device) for _ in range(2)]
+        self.dev_f32 = [torch.empty((self.B,) + oshape, dtype=torch.float32, device=device) for _ in range(2)]
+        # the copy stream is one more default-priority stream next to the step's: the engine's side streams must then run at
+        # default priority too (DESIGN.md section 5: 1.93 vs 1.10 ms per step measured with this loader)
+        try:
+            call("mmvae_set_stream_policy", 1)
+        except MMVAEError:
+            import warnings
+            warnings.warn("DeviceBatcher created after the first fused step: the engine's side streams keep their low "
+                          "priority and every kernel runs slower while the copy stream is active; create the loader first")
+        self._images_np, self._text_np = images_u8.numpy(), text.numpy()
+        self._stage_u8_np = [t.numpy() for t in self.stage_u8]
+        self._stage_tx_np = [t.numpy() for t in self.stage_tx]
         self.copy_stream = torch.cuda.Stream(device=device)
         self.ready = [torch.cuda.Event() for _ in range(2)]
         self.consumed = [torch.cuda.Event() for _ in range(2)]
@@ -87,8 +106,11 @@ class DeviceBatcher:
 
     def _stage(self, slot: int, idx: torch.Tensor) -> None:
         self.consumed[slot].synchronize()                   # the previous user of this slot finished with the buffers
-        torch.index_select(self.images, 0, idx, out=self.stage_u8[slot])
-        torch.index_select(self.text, 0, idx, out=self.stage_tx[slot])
+        # numpy's single-threaded take, NOT torch.index_select: next to a running HIP process the OpenMP team of a torch
+        # CPU op took 8 ms per 640 kB gather on the GPU box (0.03 ms when nothing else runs) -- 8x the training step
+        ix = idx.numpy()
+        np.take(self._images_np, ix, axis=0, out=self._stage_u8_np[slot])
+        np.take(self._text_np, ix, axis=0, out=self._stage_tx_np[slot])
         with torch.cuda.stream(self.copy_stream):
             self.dev_u8[slot].copy_(self.stage_u8[slot], non_blocking=True)
             self.dev_tx[slot].copy_(self.stage_tx[slot], non_blocking=True)

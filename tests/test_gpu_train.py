@@ -36,6 +36,26 @@ def test_device_batcher_equals_totensor():
     assert abs(sum(sums) - float(x[:256].float().sum() / 255.0)) < 1e-1
 
 
+def test_device_batcher_coco_shapes_feed_the_fused_step():
+    """Colour images (N,3,32,32) uint8 + fp32 caption vectors: the async H2D pipeline of the COCO configuration."""
+    from multimodal_vae_amd import data as D
+    from multimodal_vae_amd import coco as M
+    dev = _dev()
+    T, B = 6, 8
+    g = torch.Generator().manual_seed(3)
+    x = torch.randint(0, 256, (40, 3, 32, 32), dtype=torch.uint8, generator=g)
+    t = 0.4 * torch.randn(40, T, 300, generator=g)
+    loader = D.DeviceBatcher(x, t, B, dev, shuffle=False)
+    vae = M.MultimodalVAE(100, use_cuda=True, sos=0.4 * torch.randn(300, generator=g), steps=T).cuda()
+    tr = M.FusedTrainer(vae, B, lr=1e-3)
+    for b, (img, txt) in enumerate(loader):
+        assert img.shape == (B, 3, 32, 32) and txt.shape == (B, T, 300) and txt.dtype == torch.float32
+        assert torch.equal(img.cpu(), x[b * B:(b + 1) * B].float().div(255.0))
+        assert torch.equal(txt.cpu(), t[b * B:(b + 1) * B])
+        losses = tr(img, txt).losses()
+    assert len(loader) == 5 and torch.isfinite(losses).all()
+
+
 def test_driver_trains_and_writes_reference_checkpoints(tmp_path):
     from multimodal_vae_amd import train as T
     from multimodal_vae_amd.multimnist import MultimodalVAE
