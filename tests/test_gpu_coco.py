@@ -200,6 +200,38 @@ def test_gru_dropout_masks_and_short_captions_match_oracle():
     _grad_checks(st, P, tensor_tol=4e-2)
 
 
+def test_other_latent_size_and_eval_pass_matches_oracle():
+    """n_latents = 20 (the reference's constructor default), T = 5, B = 6: train step and eval forward vs the oracle."""
+    from multimodal_vae_amd.core import CocoState, FusedCocoStep
+    dev = _dev()
+    Dn, B, T = 20, 6, 5
+    P = R.formula_params("coco", Dn, requires_grad=True)
+    st = CocoState(Dn, dev, T)
+    for n, shape, off in st.table:
+        st.params[off:off + P[n].numel()] = P[n].detach().reshape(-1).to(dev)
+    image, text = R.formula_inputs("coco", B)
+    text = text[:, :T].contiguous()
+    eps = [R.formula_eps(B, Dn, k) for k in range(3)]
+    eng = FusedCocoStep(st, B, R.formula_sos())
+    eng.enc_dropout = eng.gru_dropout = False
+    out = eng.forward_backward(image.to(dev).contiguous(), text.to(dev).contiguous(), True, True,
+                               eps=torch.stack(eps).to(dev).contiguous())
+    o_losses, _ = R.coco_step_losses(P, image, text, R.formula_sos(), True, 1e-3, eps, None, None, 0.0, 0.0)
+    (o_losses[0] + o_losses[1] + o_losses[2]).backward()
+    np.testing.assert_allclose(out.losses().cpu().numpy(), np.array([l.item() for l in o_losses]), rtol=1e-3)
+    names = [n for n, _ in R.param_table("coco", Dn)]
+    tot = torch.sqrt(sum(P[n].grad.double().pow(2).sum() for n in names)).item()
+    np.testing.assert_allclose(st.grads.double().norm().item(), tot, rtol=1e-2)
+    ev = eng.forward_backward(image.to(dev).contiguous(), text.to(dev).contiguous(), False, False).losses()
+    Pe = R.formula_params("coco", Dn)
+    for pre, c, off in st.bn_table:
+        Pe[pre + ".running_mean"] = st.bn_stats[off:off + c].cpu()
+        Pe[pre + ".running_var"] = st.bn_stats[off + c:off + 2 * c].cpu()
+    with torch.no_grad():
+        e_losses, _ = R.coco_step_losses(Pe, image, text, R.formula_sos(), False)
+    np.testing.assert_allclose(ev.cpu().numpy(), np.array([l.item() for l in e_losses]), rtol=2e-3)
+
+
 def test_training_reduces_loss_and_eval_mode():
     from multimodal_vae_amd import coco as M
     dev = _dev()
