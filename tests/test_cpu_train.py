@@ -59,3 +59,15 @@ def test_multimnist_file_format_round_trip(tmp_path):
         assert t == l + [11] * (4 - len(l))
     with pytest.raises(RuntimeError):
         D.load_multimnist(str(tmp_path), False)
+
+
+def test_coco_driver_flags_and_synthetic_inputs():
+    from multimodal_vae_amd import train_coco as T
+    a = T.build_parser().parse_args([])
+    # coco/train.py:88-104: names and defaults
+    assert (a.n_latents, a.batch_size, a.epochs, a.lr, a.log_interval, a.anneal_kl, a.cuda) == (100, 64, 20, 1e-4, 10, False, False)
+    x, t, sos = T.synthetic_coco(9, seed=1)
+    assert x.shape == (9, 3, 32, 32) and x.dtype == torch.uint8 and t.shape == (9, 102, 300) and sos.shape == (300,)
+    assert (t[:, -1] == 0).all() and (t[:, 0] != 0).any()                # zero rows after the caption (coco/utils.py:40-47)
+    with pytest.raises(SystemExit):
+        T.main(["--epochs", "1"])                                        # no --cuda: refuses (no CPU fallback)

@@ -76,6 +76,19 @@ def test_driver_trains_and_writes_reference_checkpoints(tmp_path):
     assert os.path.exists(tmp_path / "res" / "sample_text_epoch3.txt")
 
 
+def test_coco_driver_runs_and_writes_reference_checkpoints(tmp_path):
+    from multimodal_vae_amd import train_coco as T
+    _dev()
+    hist = T.main(["--cuda", "--epochs", "2", "--synthetic", "192", "--batch_size", "32", "--lr", "1e-3", "--log_interval", "2",
+                   "--out", str(tmp_path / "ck"), "--results", str(tmp_path / "res")])
+    assert len(hist["train"]) == 2 and all(np.isfinite(v) for e in hist["train"] + hist["test"] for v in e)
+    assert sum(hist["train"][1]) < sum(hist["train"][0])
+    ck = torch.load(tmp_path / "ck" / "checkpoint.pth.tar", weights_only=False)
+    assert set(ck) == {'state_dict', 'best_loss', 'joint_loss', 'image_loss', 'text_loss', 'n_latents', 'optimizer'}   # coco/train.py:240-248
+    assert "text_decoder.gru.weight_ih_l1" in ck['state_dict'] and ck['state_dict']["text_decoder.h2o.weight"].shape == (300, 300)
+    assert torch.load(tmp_path / "res" / "sample_text_vector.pt").shape == (64, 102, 300)                             # :262-263
+
+
 def test_eval_consumers_match_oracle():
     """compute_nll (multimnist/loglikelihood.py:20-69) and test_multimnist (multimnist/test.py:23-59) on the HIP modules."""
     from multimodal_vae_amd import multimnist as M
