@@ -90,12 +90,14 @@ __global__ __launch_bounds__(TPB) void convt_last_fwd_kernel(const ConvTLastFwdA
         for (int co = 0; co < COUT; ++co) {
             const long long oidx = ((n * COUT + co) * OH + oy) * OW + ox;         // NCHW
             const float l = acc[co];
-            const float p = 1.0f / (1.0f + expf(-l));                           // F.sigmoid
+            // F.sigmoid and the two BCE logs on the hardware transcendentals (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1e-7
+            // relative): the accurate library versions were half of this kernel's VALU instructions
+            const float p = __builtin_amdgcn_rcpf(1.0f + __expf(-l));
             if (a.logits) a.logits[oidx] = l;
             if (a.recon) a.recon[oidx] = p;
             if (a.target) {
                 const float t = a.target[(((long long)n_in_g * COUT + co) * OH + oy) * OW + ox];
-                const float lp = fmaxf(logf(p), -100.f), lq = fmaxf(logf(1.0f - p), -100.f);   // BCE log clamp
+                const float lp = fmaxf(__logf(p), -100.f), lq = fmaxf(__logf(1.0f - p), -100.f);   // BCE log clamp
                 loss += -(t * lp + (1.0f - t) * lq);
                 if (a.dlogit) {
                     const float pq = p * (1.0f - p);
