@@ -200,6 +200,36 @@ def test_gru_dropout_masks_and_short_captions_match_oracle():
     _grad_checks(st, P, tensor_tol=4e-2)
 
 
+def test_full_length_larger_batch_matches_oracle():
+    """T = 102, B = 48 (BatchNorm over more samples than the fixtures; device-drawn dropout off): losses and every
+    gradient tensor against the oracle, plus linearity of the loss sums in the lambdas (a size-independent property)."""
+    from multimodal_vae_amd.core import FusedCocoStep
+    dev = _dev()
+    B = 48
+    st, P = _state(dev)
+    image, text = R.formula_inputs("coco", B)
+    eps = [R.formula_eps(B, D, k) for k in range(3)]
+    eng = FusedCocoStep(st, B, R.formula_sos())
+    eng.enc_dropout = eng.gru_dropout = False
+    args = (image.to(dev).contiguous(), text.to(dev).contiguous(), True, True)
+    out = eng.forward_backward(*args, eps=torch.stack(eps).to(dev).contiguous())
+    got = out.losses().cpu().numpy()
+    parts = [p.cpu().numpy().copy() for p in out.parts()]
+    o_losses, _ = R.coco_step_losses(P, image, text, R.formula_sos(), True, 1e-3, eps, None, None, 0.0, 0.0)
+    (o_losses[0] + o_losses[1] + o_losses[2]).backward()
+    np.testing.assert_allclose(got, np.array([l.item() for l in o_losses]), rtol=1e-3)
+    _grad_checks(st, P, tensor_tol=3e-2)
+    g1 = st.grads.clone()
+    # doubling every lambda and kl_lambda doubles every gradient (the step is linear in them); the loss parts do not move
+    eng.kl_lambda = 2e-3
+    out2 = eng.forward_backward(*args, eps=torch.stack(eps).to(dev).contiguous(), lambda_xy=(2., 2., 0.), lambda_yx=(2., 2., 2.))
+    for a, b in zip(parts, out2.parts()):        # (BatchNorm statistics are atomic fp32 sums: run-to-run differences ~1e-5)
+        np.testing.assert_allclose(b.cpu().numpy(), a, rtol=1e-3)
+    rel = ((st.grads - 2 * g1).norm() / (2 * g1).norm()).item()
+    assert rel < 5e-3, rel
+    eng.kl_lambda = 1e-3
+
+
 def test_other_latent_size_and_eval_pass_matches_oracle():
     """n_latents = 20 (the reference's constructor default), T = 5, B = 6: train step and eval forward vs the oracle."""
     from multimodal_vae_amd.core import CocoState, FusedCocoStep
