@@ -579,10 +579,10 @@ int launch_wgrad_v(WgradParams p, hipStream_t stream) {
     const int tiles = ceil_div(c.N, TN) * ceil_div(max_k, TK) * c.nclasses;
     // enough row chunks for ~3 workgroups per CU, each at least 4 iterations long
     // row chunks: every workgroup adds its whole tile into the packed gradient with fp32 atomics, so fewer, longer
-    // workgroups win once there are enough of them (measured at B=256: >= 8 iterations of 64 rows and 128..384 workgroups (flat; 256 chosen):
+    // workgroups win once there are enough of them (measured at B=256: >= 8 iterations of 64 rows and 128..384 workgroups (flat; 384 chosen):
     // step 0.991 -> 0.965 ms against 4 iterations / 768 workgroups); small problems keep the shorter chain
     static const int env_it = getenv("MMVAE_WGRAD_MINIT") ? atoi(getenv("MMVAE_WGRAD_MINIT")) : 0;
-    static const int blk_target = getenv("MMVAE_WGRAD_BLOCKS") ? atoi(getenv("MMVAE_WGRAD_BLOCKS")) : 256;
+    static const int blk_target = getenv("MMVAE_WGRAD_BLOCKS") ? atoi(getenv("MMVAE_WGRAD_BLOCKS")) : 384;
     const int min_it = env_it > 0 ? env_it : (max_rows >= 2048 ? 8 : 4);
     int chunks = max(1, min(ceil_div(max_rows, min_it * WM), ceil_div(blk_target, tiles)));
     p.rows_per_block = round_up(ceil_div(max_rows, chunks), WM);

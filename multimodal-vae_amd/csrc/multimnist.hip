@@ -558,6 +558,7 @@ MMPlan* mm_create(int D, int B) {
     if (D < 1 || D > 127 || B < 1) { mmvae_set_error("mm_create: need 1 <= n_latents <= 127 and batch >= 1"); return nullptr; }
     MMPlan* P = new MMPlan();
     P->D = D; P->B = B;
+    P->single_wgrad_stream = true;
     build_plan(*P);
     Workspace ws(nullptr, 0);
     carve(*P, ws);
