@@ -28,10 +28,10 @@ int mmvae_init(int device);                 /* checks the device is gfx950, make
 const char* mmvae_last_error(void);
 const char* mmvae_version(void);
 /* Priority policy of the engine's three side streams (second-modality path, weight gradients); call before the first
- * step of the process.  0 (default): lowest priority, they fill CUs the main chain leaves idle.  1: default priority --
- * REQUIRED when another library enqueues on a stream of its own next to the step (RCCL under torch.distributed in the
- * data-parallel path of multimnist/train.py's loop): mixed priorities then slow every kernel down several-fold.
- * MMVAE_ESTATE if the side streams already exist with the other policy. */
+ * step of the process.  1 (the default): default priority.  0: lowest priority, the side streams only fill CUs the main
+ * chain leaves idle -- up to 0.8 % faster (CelebA), but ONLY while no other stream of the process carries GPU work: with
+ * an H2D copy stream or a collective library's stream (RCCL under torch.distributed) active, mixed priorities slow every
+ * kernel down 2-3x.  MMVAE_ESTATE if the side streams already exist with the other policy. */
 int mmvae_set_stream_policy(int flat);
 
 /* ---------------------------------------------------------------- MultiMNIST plan (multimnist/model.py:21-93) */

@@ -336,11 +336,13 @@ inline int ensure_streams(PlanBase& P) {
         if (!shared[0]) {
             int least = 0, greatest = 0;
             hipDeviceGetStreamPriorityRange(&least, &greatest);
-            // policy 1 (mmvae_set_stream_policy; the data-parallel host sets it): every stream at the default priority.
-            // Measured on MI355X / ROCm 7: as soon as ANOTHER default-priority stream carries work next to the main one
-            // (a collective library's internal stream), lowest-priority side streams make every kernel of the process
-            // run several times slower (0.98 -> 2.63 ms per step); with flat priorities the same mix costs 2 %.
-            const bool flat = getenv("MMVAE_FLAT_PRIORITY") != nullptr || mmvae_stream_policy() == 1;
+            // Default: every stream at the default priority.  Lowest-priority side streams (policy 0, opt-in through
+            // mmvae_set_stream_policy) are worth <= 0.8 % (CelebA; nothing on MultiMNIST / COCO) and carry a cliff:
+            // measured on MI355X / ROCm 7, as soon as ANOTHER default-priority stream carries work next to the main one
+            // (an H2D copy stream, a collective library's internal stream) they make every kernel of the process run
+            // several times slower (0.98 -> 2.63 ms per step).
+            const bool low = (getenv("MMVAE_LOW_PRIORITY") != nullptr || mmvae_stream_policy() == 0) && getenv("MMVAE_FLAT_PRIORITY") == nullptr;
+            const bool flat = !low;
             mmvae_stream_policy_freeze();
             const int prio = flat ? 0 : least;
             for (int i = 0; i < 3; ++i)

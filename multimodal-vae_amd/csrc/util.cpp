@@ -31,7 +31,7 @@ void mmvae_stream_policy_freeze() { g_policy_frozen.store(true); }
 extern "C" int mmvae_set_stream_policy(int flat) {
     const int want = flat ? 1 : 0;
     if (g_policy_frozen.load()) {
-        const int have = g_policy.load() == 1 ? 1 : 0;
+        const int have = g_policy.load() == 0 ? 0 : 1;          // unset = flat
         if (have != want) {
             mmvae_set_error("stream policy: the side streams already exist with policy %d", have);
             return MMVAE_ESTATE;
