@@ -324,9 +324,8 @@ inline int edge(PlanBase& P, hipStream_t from, hipStream_t to) {
 }
 inline int ensure_streams(PlanBase& P) {
     if (!P.st_text) {
-        // side work (second-modality path, weight gradients) only feeds the optimizer at the end of the step: it runs at
-        // the LOWEST stream priority so that its workgroups fill CUs the main chain leaves idle instead of sharing them.
-        // The three side streams are shared by every plan of the process: ROCm gives a process 4 hardware queues, and
+        // side work (second-modality path, weight gradients) only feeds the optimizer at the end of the step and runs on
+        // side streams.  The three side streams are shared by every plan of the process: ROCm gives a process 4 hardware queues, and
         // once more streams than that carry work they are time-sliced onto shared queues and every kernel slows down
         // several-fold (measured: 0.98 -> 2.78 ms per step with 7 streams).  Plans enqueue behind event edges, so sharing
         // streams between plans only serialises what would have been serialised anyway.
