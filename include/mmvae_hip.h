@@ -54,7 +54,10 @@ int mmvae_mm_desc_copy(const mmvae_mm_t*, int which, void* host_out);   /* calle
 size_t mmvae_mm_workspace_bytes(const mmvae_mm_t*);
 int mmvae_mm_bind(mmvae_mm_t*, float* params, float* grads, float* bn_stats, long long* bn_num_batches_tracked,
                   void* packed_bf16, float* packed_vec, float* gpk, float* gpk_vec, void* desc_dev, void* gdesc_dev);
-int mmvae_mm_pack_weights(mmvae_mm_t*, void* stream);       /* refresh bf16 GEMM-layout copies after params change */
+int mmvae_mm_pack_weights(mmvae_mm_t*, void* stream);
+/* map[i] (int32, param_count entries) = where flat parameter i's packed gradient lives: >= 0 index into gpk, <= -2:
+ * -(index + 2) into gpk_vec, -1 none.  Built once per parameter layout; input of mmvae_adam_step_packed. */
+int mmvae_mm_grad_map(mmvae_mm_t*, int* map, void* stream);       /* refresh bf16 GEMM-layout copies after params change */
 
 /* One 3-pass ELBO step (multimnist/train.py:150-168): forward of (image,text), (image), (text), the three
  * loss_function sums and -- if do_backward -- the gradient of loss_1+loss_2+loss_3 written to `grads`
@@ -80,6 +83,8 @@ typedef struct {
     long long* tokens;                      /* out [3][B][4] or NULL */
     int pass_skip[3];                       /* 1: pass k absent from this step (multimnist/paired_weak.py:84-117,
                                              * modal_weak.py:87-117): no loss, no gradient, no BatchNorm running update */
+    int defer_unpack;                       /* 1: GEMM-weight gradients stay in the packed buffers for mmvae_adam_step_packed
+                                             * (loss.backward() + optimizer.step() of multimnist/train.py:168,173 in one pass) */
 } mmvae_mm_step_io;
 int mmvae_mm_step(mmvae_mm_t*, const mmvae_mm_step_io*, int training, int do_backward, void* stream);
 
@@ -326,6 +331,11 @@ int mmvae_u8_to_f32(const uint8_t* src, long long n, float denom, float* dst, vo
  * zero-initialised by the caller; grad_scale multiplies g first (1/world_size after a sum all-reduce). */
 int mmvae_adam_step(float* p, const float* g, float* m, float* v, long long n, long long* state, float lr, float beta1,
                     float beta2, float eps, float grad_scale, void* stream);
+/* The same update with the unpack of the packed weight gradients fused in (mmvae_mm_step_io.defer_unpack = 1):
+ * g[i] += packed gradient of i (through gmap), the completed g is written back, then Adam.  One pass instead of two. */
+int mmvae_adam_step_packed(float* p, float* g, float* m, float* v, long long n, long long* state, float lr, float beta1,
+                           float beta2, float eps, float grad_scale, const int* gmap, const float* gpk, const float* gpk_vec,
+                           void* stream);
 
 #ifdef __cplusplus
 }

@@ -26,6 +26,7 @@ class StepIO(C.Structure):
         ("sums", C.c_void_p), ("recon_image", C.c_void_p), ("recon_text", C.c_void_p),
         ("mu", C.c_void_p), ("logvar", C.c_void_p), ("tokens", C.c_void_p),
         ("pass_skip", C.c_int * 3),
+        ("defer_unpack", C.c_int),
     ]
 
 
@@ -102,6 +103,7 @@ SIGNATURES = {
     "mmvae_mm_workspace_bytes": (_SZ, [_P]),
     "mmvae_mm_bind": (_I, [_P] * 11),
     "mmvae_mm_pack_weights": (_I, [_P, _P]),
+    "mmvae_mm_grad_map": (_I, [_P, _P, _P]),
     "mmvae_mm_step": (_I, [_P, C.POINTER(StepIO), _I, _I, _P]),
     "mmvae_mm_image_encoder_fwd": (_I, [_P, _P, _SZ, _P, _P, _P, _I, _P, _P]),
     "mmvae_mm_image_encoder_bwd": (_I, [_P, _P, _SZ, _P, _P, _P, _P]),
@@ -130,6 +132,7 @@ SIGNATURES = {
     "mmvae_mse_bwd": (_I, [_P, _P, _LL, _F, _P, _P]),
     "mmvae_u8_to_f32": (_I, [_P, _LL, _F, _P, _P]),
     "mmvae_adam_step": (_I, [_P, _P, _P, _P, _LL, _P, _F, _F, _F, _F, _F, _P]),
+    "mmvae_adam_step_packed": (_I, [_P, _P, _P, _P, _LL, _P, _F, _F, _F, _F, _F, _P, _P, _P, _P]),
 }
 
 

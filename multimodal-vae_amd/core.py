@@ -6,6 +6,7 @@ PyTorch is used for plumbing only: it owns the device allocations (``torch.empty
 from __future__ import annotations
 
 import ctypes as C
+import os as _os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -97,6 +98,14 @@ class PlanState:
 
     def workspace_bytes(self, batch: int) -> int:
         return self._c("workspace_bytes", self.plan(batch))
+
+    def grad_map(self) -> torch.Tensor:
+        """int32 [nparams]: where each flat parameter's packed gradient lives (mmvae_<family>_grad_map), built once."""
+        if getattr(self, "_gmap", None) is None:
+            m = torch.empty(self.nparams, dtype=torch.int32, device=self.device)
+            self._c("grad_map", self.plan(1), ptr(m), _stream())
+            self._gmap = m
+        return self._gmap
 
     def pack_weights(self) -> None:
         self._c("pack_weights", self.plan(1), _stream())
@@ -275,7 +284,7 @@ class FusedELBOStep(_FusedStepBase):
 
     def forward_backward(self, image, text, training=True, backward=True, eps=None, enc_mask1=None, enc_mask2=None,
                          gru_keep=None, force_tokens=None, recon_image=None, recon_text=None, mu=None, logvar=None,
-                         tokens=None, passes=None, lambda_xy=None, lambda_yx=None) -> StepOutputs:
+                         tokens=None, passes=None, lambda_xy=None, lambda_yx=None, _defer_unpack=False) -> StepOutputs:
         """``passes`` = which of (joint, image-only, text-only) exist in this step and ``lambda_xy/lambda_yx`` = their loss
         weights: the weak-supervision steps of multimnist/paired_weak.py:84-117 and modal_weak.py:87-117."""
         assert image.is_contiguous() and text.is_contiguous() and image.dtype == torch.float32 and text.dtype == torch.int64
@@ -293,9 +302,24 @@ class FusedELBOStep(_FusedStepBase):
         self._pass_config(io, passes, lambda_xy, lambda_yx, "lambda_xy", "lambda_yx")
         io.seed = self.seed
         io.sums = self.sums.data_ptr()
+        io.defer_unpack = int(bool(_defer_unpack))
         # optimizer.zero_grad() (train.py:150) happens inside the step's prologue kernel when backward is requested
         call("mmvae_mm_step", self.h, C.byref(io), int(training), int(backward), _stream())
         return self._outputs()
+
+    def __call__(self, image, text, **kw) -> StepOutputs:
+        """backward + optimizer.step() of multimnist/train.py:168,173 in one pass over the parameters: the GEMM-weight
+        gradients stay in their packed layout and the Adam kernel gathers them (and completes ``grads``) itself.  The
+        data-parallel path needs the complete flat gradient BEFORE Adam (all-reduce), so it keeps the separate unpack."""
+        if (self.all_reduce is not None and self.world_size > 1) or _os.environ.get("MMVAE_SEPARATE_UNPACK"):
+            return super().__call__(image, text, **kw)
+        st = self.state
+        out = self.forward_backward(image, text, True, True, _defer_unpack=True, **kw)
+        call("mmvae_adam_step_packed", ptr(st.params), ptr(st.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq), st.nparams,
+             ptr(self.adam_state), self.lr, self.betas[0], self.betas[1], self.eps, 1.0, ptr(st.grad_map()), ptr(st.gpk),
+             ptr(st.gpk_vec), _stream())
+        st.pack_weights()
+        return out
 
 
 class FusedMnistStep(_FusedStepBase):

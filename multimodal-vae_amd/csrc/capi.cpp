@@ -155,6 +155,12 @@ int mmvae_mm_bind(mmvae_mm_t* p, float* params, float* grads, float* bn_stats, l
     return mm_bind(p, b);
     API_GUARD_END
 }
+int mmvae_mm_grad_map(mmvae_mm_t* p, int* map, void* stream) {
+    API_GUARD_BEGIN
+    MMVAE_REQUIRE(p && map, "mmvae_mm_grad_map: null argument");
+    return mm_grad_map(p, map, S(stream));
+    API_GUARD_END
+}
 int mmvae_mm_pack_weights(mmvae_mm_t* p, void* stream) {
     API_GUARD_BEGIN
     return mm_pack_weights(p, S(stream));
@@ -172,6 +178,7 @@ int mmvae_mm_step(mmvae_mm_t* p, const mmvae_mm_step_io* io, int training, int d
     s.seed = io->seed; s.sums = io->sums; s.recon_image = io->recon_image; s.recon_text = io->recon_text;
     s.mu = io->mu; s.logvar = io->logvar; s.tokens = io->tokens;
     for (int k = 0; k < 3; ++k) s.pass_skip[k] = io->pass_skip[k];
+    s.defer_unpack = io->defer_unpack;
     return mm_step_fwd_bwd(p, s, training, do_backward, S(stream));
     API_GUARD_END
 }
@@ -429,6 +436,14 @@ int mmvae_adam_step(float* p, const float* g, float* m, float* v, long long n, l
                     float eps, float grad_scale, void* s) {
     AdamArgs a{};
     a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.step = state; a.lr = lr; a.b1 = b1; a.b2 = b2; a.eps = eps; a.grad_scale = grad_scale;
+    return launch_adam(a, S(s));
+}
+int mmvae_adam_step_packed(float* p, float* g, float* m, float* v, long long n, long long* state, float lr, float b1, float b2,
+                           float eps, float grad_scale, const int* gmap, const float* gpk, const float* gpk_vec, void* s) {
+    MMVAE_REQUIRE(gmap && gpk && gpk_vec, "adam_step_packed: null gradient map / packed buffers");
+    AdamArgs a{};
+    a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.step = state; a.lr = lr; a.b1 = b1; a.b2 = b2; a.eps = eps; a.grad_scale = grad_scale;
+    a.gmap = gmap; a.gpk = gpk; a.gpk_vec = gpk_vec; a.g_out = g;
     return launch_adam(a, S(s));
 }
 

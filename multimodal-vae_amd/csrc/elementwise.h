@@ -130,8 +130,13 @@ struct AdamArgs {
     long long* step;         // device counter, incremented by the kernel (first call sees 0 -> t=1)
     float lr, b1, b2, eps;
     float grad_scale;        // applied to g before the update (1/world for data-parallel averaging)
+    // optional: the part of the gradient that is still in the packed weight-gradient buffers (fused unpack):
+    // g_total[i] = g[i] + gpk[gmap[i]] (gmap >= 0) or + gpk_vec[-gmap[i]-2] (gmap < -1); written back to g_out[i]
+    const int* gmap; const float* gpk; const float* gpk_vec; float* g_out;
 };
 int launch_adam(const AdamArgs& a, hipStream_t s);
+// map[flat parameter index] = location of its packed gradient (see AdamArgs), -1 where there is none
+int launch_unpack_map(const PackDesc* table_dev, const PackDesc* table_host, int nd, long long nparams, long long gmat_elems, int* map, hipStream_t s);
 int launch_fill_zero(void* p, size_t bytes, hipStream_t s);
 int launch_bce_fwd(const float* p, const float* t, long long n, float* out, hipStream_t s);
 int launch_bce_bwd(const float* p, const float* t, long long n, float coef, float* dp, hipStream_t s);

@@ -84,8 +84,11 @@ __global__ __launch_bounds__(TPB) void pack_kernel(const PackDesc* __restrict__ 
     }
 }
 
+// MAP = false: grads[flat] += packed value.  MAP = true: map[flat] = where that value lives (index into gmat, or
+// -(index + 2) into gvec) -- built once per plan for the optimizer kernel that consumes the packed gradients directly.
+template <bool MAP>
 __global__ __launch_bounds__(TPB) void unpack_kernel(const PackDesc* __restrict__ table, int nd, const float* __restrict__ gmat,
-                                                     const float* __restrict__ gvec, float* __restrict__ grads) {
+                                                     const float* __restrict__ gvec, float* __restrict__ grads, int* __restrict__ map) {
     const int di = find_desc(table, nd, blockIdx.x);
     const PackDesc d = table[di];
     const int v = (int)(blockIdx.x - d.first_block) * TPB + threadIdx.x;
@@ -96,9 +99,18 @@ __global__ __launch_bounds__(TPB) void unpack_kernel(const PackDesc* __restrict_
     const int k0 = kv * 8;
     if (k0 > d.K) return;
     const int nhi = fast_divmod_ew(n, d.NL, 1.0f / (float)d.NL, nlo);
-    const float* src = (d.is_f32 ? gvec : gmat) + d.dst_off + (long long)n * d.Kpad + k0;
-    const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
-    const float val[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    const long long sidx = d.dst_off + (long long)n * d.Kpad + k0;
+    float val[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (!MAP) {
+        const float* src = (d.is_f32 ? gvec : gmat) + sidx;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { val[j] = lo[j]; val[4 + j] = hi[j]; }
+    }
+    auto put = [&](long long dst, int j) {
+        if (MAP) map[dst] = d.is_f32 ? -(int)(sidx + j) - 2 : (int)(sidx + j);
+        else grads[dst] += val[j];
+    };
     if (d.C % 8 == 0 && k0 + 8 <= d.K) {
         const long long rowbase = d.src_off + (long long)nhi * d.s_nhi + (long long)nlo * d.s_nlo;
         int c, tx;
@@ -106,13 +118,13 @@ __global__ __launch_bounds__(TPB) void unpack_kernel(const PackDesc* __restrict_
         const int ty = fast_divmod_ew(tap, d.TW, 1.0f / (float)d.TW, tx);
         const long long b = rowbase + (long long)(d.o_ty + ty * d.step_t) * d.s_ty + (long long)(d.o_tx + tx * d.step_t) * d.s_tx + (long long)c * d.s_c;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) grads[b + (long long)j * d.s_c] += val[j];
+        for (int j = 0; j < 8; ++j) put(b + (long long)j * d.s_c, j);
     } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = k0 + j;
-            if (k < d.K) grads[pack_src(d, n, k)] += val[j];
-            else if (k == d.K && d.bias_off >= 0) grads[d.bias_off + (long long)nhi * d.b_nhi + (long long)nlo * d.b_nlo] += val[j];
+            if (k < d.K) put(pack_src(d, n, k), j);
+            else if (k == d.K && d.bias_off >= 0) put(d.bias_off + (long long)nhi * d.b_nhi + (long long)nlo * d.b_nlo, j);
         }
     }
 }
@@ -651,6 +663,15 @@ __global__ __launch_bounds__(TPB) void adam_kernel(const AdamArgs a, unsigned* d
         const long long e = i * 4;
         if (e + 4 <= a.n) {
             f32x4 g = *reinterpret_cast<const f32x4*>(a.g + e);
+            if (a.gmap) {       // gradient of the GEMM weights still in its packed layout: gather, add, keep the flat copy
+                const int4 mi = *reinterpret_cast<const int4*>(a.gmap + e);
+                const int mm[4] = {mi.x, mi.y, mi.z, mi.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (mm[j] >= 0) g[j] += a.gpk[mm[j]];
+                    else if (mm[j] < -1) g[j] += a.gpk_vec[-mm[j] - 2];
+                *reinterpret_cast<f32x4*>(a.g_out + e) = g;
+            }
             f32x4 m = *reinterpret_cast<const f32x4*>(a.m + e);
             f32x4 v = *reinterpret_cast<const f32x4*>(a.v + e);
             f32x4 p = *reinterpret_cast<const f32x4*>(a.p + e);
@@ -666,7 +687,13 @@ __global__ __launch_bounds__(TPB) void adam_kernel(const AdamArgs a, unsigned* d
             *reinterpret_cast<f32x4*>(a.p + e) = p;
         } else {
             for (long long q = e; q < a.n; ++q) {
-                float gj = a.g[q] * a.grad_scale;
+                float gq = a.g[q];
+                if (a.gmap) {
+                    const int mq = a.gmap[q];
+                    if (mq >= 0) gq += a.gpk[mq]; else if (mq < -1) gq += a.gpk_vec[-mq - 2];
+                    a.g_out[q] = gq;
+                }
+                float gj = gq * a.grad_scale;
                 float m = a.b1 * a.m[q] + (1.f - a.b1) * gj;
                 float v = a.b2 * a.v[q] + (1.f - a.b2) * gj * gj;
                 a.m[q] = m; a.v[q] = v;
@@ -842,8 +869,16 @@ int launch_unpack_grads(const PackDesc* table_dev, const PackDesc* table_host, i
     MMVAE_REQUIRE(nd > 0, "unpack: empty table");
     for (int i = 0; i < nd; ++i)
         MMVAE_REQUIRE((long long)table_host[i].Npad * (table_host[i].Kpad / 8) < (1 << 23), "unpack: matrix %d too large for 32-bit index math", i);
-    hipLaunchKernelGGL(unpack_kernel, dim3(table_blocks(table_host, nd)), dim3(TPB), 0, s, table_dev, nd, gmat, gvec, grads);
+    hipLaunchKernelGGL(unpack_kernel<false>, dim3(table_blocks(table_host, nd)), dim3(TPB), 0, s, table_dev, nd, gmat, gvec, grads, (int*)nullptr);
     return mmvae_check_launch("unpack_grads");
+}
+int launch_unpack_map(const PackDesc* table_dev, const PackDesc* table_host, int nd, long long nparams, long long gmat_elems, int* map, hipStream_t s) {
+    MMVAE_REQUIRE(nd > 0 && map, "unpack_map: empty table");
+    MMVAE_REQUIRE(gmat_elems < (1ll << 31) - 2, "unpack_map: packed gradient buffer too large for 32-bit indices");
+    if (hipMemsetAsync(map, 0xFF, (size_t)nparams * sizeof(int), s) != hipSuccess) { mmvae_set_error("hipMemsetAsync failed"); return MMVAE_EHIP; }
+    hipLaunchKernelGGL(unpack_kernel<true>, dim3(table_blocks(table_host, nd)), dim3(TPB), 0, s, table_dev, nd, (const float*)nullptr,
+                       (const float*)nullptr, (float*)nullptr, map);
+    return mmvae_check_launch("unpack_map");
 }
 int launch_im2col_small(const float* src, int Nimg, int Cin, int H, int W, int KH, int KW, int stride, int pad, int OH, int OW,
                         bf16* dst, int ld, hipStream_t s) {

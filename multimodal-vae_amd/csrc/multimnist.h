@@ -29,6 +29,8 @@ struct MMStepIO {
     float* mu = nullptr; float* logvar = nullptr;   // [3][B][D] or null
     long long* tokens = nullptr;        // [3][B][4] or null
     int pass_skip[3] = {0, 0, 0};       // 1: pass k is absent from this step (paired_weak.py / modal_weak.py)
+    int defer_unpack = 0;               // 1: leave the GEMM-weight gradients in their packed buffers (the optimizer kernel
+                                        // gathers them through mm_grad_map and completes the flat gradient itself)
 };
 
 struct MMPlan;
@@ -47,6 +49,7 @@ int mm_ngdesc(const MMPlan*); const PackDesc* mm_gdesc_host(const MMPlan*);
 size_t mm_workspace_bytes(const MMPlan*);
 int mm_bind(MMPlan*, const MMBuffers&);
 int mm_pack_weights(MMPlan*, hipStream_t);
+int mm_grad_map(MMPlan*, int* map, hipStream_t);      // [param_count] see AdamArgs::gmap
 // forward (3 passes) + losses; training!=0 also runs backward into `grads` (which the caller zeroed)
 int mm_step_fwd_bwd(MMPlan*, const MMStepIO&, int training, int do_backward, hipStream_t);
 // granular module entry points (drop-in modules); every call brings its own workspace

@@ -604,6 +604,10 @@ int mm_unpack_grads(MMPlan* P, hipStream_t s) {
     MMVAE_TRY(check_bound(P));
     return launch_unpack_grads(P->buf.gdesc_dev, P->gk.d.data(), (int)P->gk.d.size(), P->buf.gpk, P->buf.gpk_vec, P->buf.grads, s);
 }
+int mm_grad_map(MMPlan* P, int* map, hipStream_t s) {
+    MMVAE_TRY(check_bound(P));
+    return launch_unpack_map(P->buf.gdesc_dev, P->gk.d.data(), (int)P->gk.d.size(), P->nparams, P->gk.mat_elems, map, s);
+}
 static int zero_gpk(MMPlan* P, hipStream_t s) {
     return launch_fill_zero(P->buf.gpk, (size_t)P->gk.mat_elems * sizeof(float), s);
 }
@@ -711,7 +715,7 @@ int mm_step_fwd_bwd(MMPlan* Pp, const MMStepIO& io, int training, int do_backwar
     MMVAE_TRY(edge(P, T, s));
     MMVAE_TRY(edge(P, P.st_wgrad, s));
     if (P.st_wgrad2 != P.st_wgrad) MMVAE_TRY(edge(P, P.st_wgrad2, s));
-    MMVAE_TRY(mm_unpack_grads(Pp, s));
+    if (!io.defer_unpack) MMVAE_TRY(mm_unpack_grads(Pp, s));
     return MMVAE_OK;
 }
 

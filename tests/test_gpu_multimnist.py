@@ -163,6 +163,45 @@ def test_adam_matches_torch_semantics():
     np.testing.assert_allclose(pd.cpu().numpy(), ref.detach().numpy(), atol=2e-6)
 
 
+def test_packed_adam_equals_unpack_then_adam():
+    """mmvae_adam_step_packed (gradient gathered from the packed weight-gradient buffers through mmvae_mm_grad_map) ==
+    unpack kernel + mmvae_adam_step, bit for bit, on the same buffers; and the flat gradient is complete afterwards."""
+    from multimodal_vae_amd._lib import call, ptr
+    from multimodal_vae_amd.core import MultimnistState, FusedELBOStep
+    from multimodal_vae_amd.init import default_init_
+    dev = _dev()
+    B = 16
+    st = MultimnistState(D, dev); default_init_(st, 5)
+    eng = FusedELBOStep(st, B, seed=3)
+    image, text = R.formula_inputs("multimnist", B)
+    eng.forward_backward(image.to(dev).contiguous(), text.to(dev).contiguous(), True, True, _defer_unpack=True)
+    gmap = st.grad_map()
+    assert int((gmap >= 0).sum()) > 0.9 * st.nparams and int((gmap < -1).sum()) == 0 and int((gmap == -1).sum()) > 0
+    used = gmap[gmap >= 0]
+    assert used.unique().numel() == used.numel()                         # every packed element feeds exactly one parameter
+    direct, gpk = st.grads.clone(), st.gpk.clone()
+    p0 = st.params.clone()
+    s = __import__("ctypes").c_void_p(torch.cuda.current_stream().cuda_stream)
+    # reference order: unpack, then Adam
+    full = direct.clone()
+    full[gmap >= 0] += gpk[gmap[gmap >= 0].long()]
+    pa, ma, va, sa = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0), torch.zeros(2, dtype=torch.int64, device=dev)
+    call("mmvae_adam_step", ptr(pa), ptr(full), ptr(ma), ptr(va), st.nparams, ptr(sa), 1e-3, 0.9, 0.999, 1e-8, 1.0, s)
+    pb, gb, mb, vb, sb = p0.clone(), direct.clone(), torch.zeros_like(p0), torch.zeros_like(p0), torch.zeros(2, dtype=torch.int64, device=dev)
+    call("mmvae_adam_step_packed", ptr(pb), ptr(gb), ptr(mb), ptr(vb), st.nparams, ptr(sb), 1e-3, 0.9, 0.999, 1e-8, 1.0,
+         ptr(gmap), ptr(gpk), ptr(st.gpk_vec), s)
+    torch.cuda.synchronize()
+    assert torch.equal(gb, full) and torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    # and the step-level switch: fused __call__ leaves the same complete gradient as forward_backward's own unpack
+    eng2 = FusedELBOStep(st, B, seed=3)
+    eps = torch.stack([R.formula_eps(B, D, k) for k in range(3)]).to(dev).contiguous()
+    eng2.enc_dropout = eng2.gru_dropout = False
+    eng2.forward_backward(image.to(dev).contiguous(), text.to(dev).contiguous(), True, True, eps=eps)
+    g_ref = st.grads.clone()
+    eng2(image.to(dev).contiguous(), text.to(dev).contiguous(), eps=eps)
+    assert ((st.grads - g_ref).norm() / g_ref.norm()).item() < 2e-3      # (two runs differ by the atomics' summation order)
+
+
 def test_training_reduces_loss_and_graph_matches_eager():
     """Size-independent properties at the full configuration: loss goes down; a captured HIP graph replays the same step."""
     from multimodal_vae_amd.core import FusedELBOStep, MultimnistState
