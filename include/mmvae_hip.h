@@ -141,6 +141,7 @@ size_t mmvae_mnist_workspace_bytes(const mmvae_mnist_t*);
 int mmvae_mnist_bind(mmvae_mnist_t*, float* params, float* grads, float* bn_stats, long long* num_batches_tracked,
                      void* packed_bf16, float* packed_vec, float* gpk, float* gpk_vec, void* desc_dev, void* gdesc_dev);
 int mmvae_mnist_pack_weights(mmvae_mnist_t*, void* stream);
+int mmvae_mnist_grad_map(mmvae_mnist_t*, int* map, void* stream);                /* as mmvae_mm_grad_map */
 /* The train() closure body of mnist/train.py:131-147 (3 passes, 3 losses, backward): same contract as mmvae_mm_step */
 typedef struct {
     void* ws; size_t ws_bytes;
@@ -199,6 +200,7 @@ size_t mmvae_celeba_workspace_bytes(const mmvae_celeba_t*);
 int mmvae_celeba_bind(mmvae_celeba_t*, float* params, float* grads, float* bn_stats, long long* num_batches_tracked,
                       void* packed_bf16, float* packed_vec, float* gpk, float* gpk_vec, void* desc_dev, void* gdesc_dev);
 int mmvae_celeba_pack_weights(mmvae_celeba_t*, void* stream);
+int mmvae_celeba_grad_map(mmvae_celeba_t*, int* map, void* stream);                /* as mmvae_mm_grad_map */
 /* The train() closure body of celeba/train.py:131-147 (3 passes, 3 losses, backward) */
 typedef struct {
     void* ws; size_t ws_bytes;
@@ -216,6 +218,7 @@ typedef struct {
     float* recon_attrs;                     /* out [3][B][18] or NULL */
     float* mu; float* logvar;               /* out [3][B][D] or NULL */
     int pass_skip[3];                       /* 1: pass k absent from this step */
+    int defer_unpack;                       /* 1: the optimizer consumes the packed gradients itself (see the MultiMNIST step) */
 } mmvae_celeba_step_io;
 int mmvae_celeba_step(mmvae_celeba_t*, const mmvae_celeba_step_io*, int training, int do_backward, void* stream);
 /* Granular modules (forward + autograd backward), workspace rules as for mmvae_mm_*_fwd/bwd */
@@ -261,6 +264,7 @@ size_t mmvae_coco_workspace_bytes(const mmvae_coco_t*);
 int mmvae_coco_bind(mmvae_coco_t*, float* params, float* grads, float* bn_stats, long long* num_batches_tracked,
                     void* packed, float* packed_vec, float* gpk, float* gpk_vec, void* desc_dev, void* gdesc_dev);
 int mmvae_coco_pack_weights(mmvae_coco_t*, void* stream);
+int mmvae_coco_grad_map(mmvae_coco_t*, int* map, void* stream);                /* as mmvae_mm_grad_map */
 /* The train() closure body of coco/train.py:138-173 (3 passes, 3 losses, backward) */
 typedef struct {
     void* ws; size_t ws_bytes;

@@ -75,6 +75,7 @@ class CelebaStepIO(C.Structure):
         ("sums", C.c_void_p), ("recon_image", C.c_void_p), ("recon_attrs", C.c_void_p),
         ("mu", C.c_void_p), ("logvar", C.c_void_p),
         ("pass_skip", C.c_int * 3),
+        ("defer_unpack", C.c_int),
     ]
 
 
@@ -156,6 +157,7 @@ def _plan_api(pfx):
         "mmvae_%s_workspace_bytes" % pfx: (_SZ, [_P]),
         "mmvae_%s_bind" % pfx: (_I, [_P] * 11),
         "mmvae_%s_pack_weights" % pfx: (_I, [_P, _P]),
+        "mmvae_%s_grad_map" % pfx: (_I, [_P, _P, _P]),
     }
 
 

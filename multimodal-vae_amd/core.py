@@ -243,6 +243,20 @@ class _FusedStepBase:
         self.optimizer_step()
         return out
 
+    def _call_packed(self, a, b, **kw) -> StepOutputs:
+        """backward + optimizer.step() (multimnist/train.py:168,173) in one pass over the parameters: the GEMM-weight
+        gradients stay in their packed layout and the Adam kernel gathers them (and completes ``grads``) itself.  The
+        data-parallel path needs the complete flat gradient BEFORE Adam (all-reduce), so it keeps the separate unpack."""
+        if (self.all_reduce is not None and self.world_size > 1) or _os.environ.get("MMVAE_SEPARATE_UNPACK"):
+            return _FusedStepBase.__call__(self, a, b, **kw)
+        st = self.state
+        out = self.forward_backward(a, b, True, True, _defer_unpack=True, **kw)
+        call("mmvae_adam_step_packed", ptr(st.params), ptr(st.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq), st.nparams,
+             ptr(self.adam_state), self.lr, self.betas[0], self.betas[1], self.eps, 1.0, ptr(st.grad_map()), ptr(st.gpk),
+             ptr(st.gpk_vec), _stream())
+        st.pack_weights()
+        return out
+
     # -- HIP graph ------------------------------------------------------------------------------------
     def capture(self, a: torch.Tensor, b: torch.Tensor) -> None:
         """Capture the whole step (static input buffers) into a HIP graph; ``replay()`` launches it."""
@@ -308,18 +322,7 @@ class FusedELBOStep(_FusedStepBase):
         return self._outputs()
 
     def __call__(self, image, text, **kw) -> StepOutputs:
-        """backward + optimizer.step() of multimnist/train.py:168,173 in one pass over the parameters: the GEMM-weight
-        gradients stay in their packed layout and the Adam kernel gathers them (and completes ``grads``) itself.  The
-        data-parallel path needs the complete flat gradient BEFORE Adam (all-reduce), so it keeps the separate unpack."""
-        if (self.all_reduce is not None and self.world_size > 1) or _os.environ.get("MMVAE_SEPARATE_UNPACK"):
-            return super().__call__(image, text, **kw)
-        st = self.state
-        out = self.forward_backward(image, text, True, True, _defer_unpack=True, **kw)
-        call("mmvae_adam_step_packed", ptr(st.params), ptr(st.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq), st.nparams,
-             ptr(self.adam_state), self.lr, self.betas[0], self.betas[1], self.eps, 1.0, ptr(st.grad_map()), ptr(st.gpk),
-             ptr(st.gpk_vec), _stream())
-        st.pack_weights()
-        return out
+        return self._call_packed(image, text, **kw)
 
 
 class FusedMnistStep(_FusedStepBase):
@@ -374,8 +377,12 @@ class FusedCelebaStep(_FusedStepBase):
         passes, lx, ly = self._last
         return StepOutputs(self.sums, self.B * 3 * 64 * 64, self.B * self.N_ATTRS, self.kl_lambda / self.B, lx, ly, passes)
 
+    def __call__(self, image, attrs, **kw) -> StepOutputs:
+        return self._call_packed(image, attrs, **kw)
+
     def forward_backward(self, image, attrs, training=True, backward=True, eps=None, enc_mask=None, recon_image=None,
-                         recon_attrs=None, mu=None, logvar=None, passes=None, lambda_x=None, lambda_y=None) -> StepOutputs:
+                         recon_attrs=None, mu=None, logvar=None, passes=None, lambda_x=None, lambda_y=None,
+                         _defer_unpack=False) -> StepOutputs:
         assert image.is_contiguous() and attrs.is_contiguous() and image.dtype == torch.float32 and attrs.dtype == torch.float32
         assert image.shape == (self.B, 3, 64, 64) and attrs.shape == (self.B, self.N_ATTRS)
         io = _lib.CelebaStepIO()
@@ -390,6 +397,7 @@ class FusedCelebaStep(_FusedStepBase):
         self._pass_config(io, passes, lambda_x, lambda_y, "lambda_x", "lambda_y")
         io.seed = self.seed
         io.sums = self.sums.data_ptr()
+        io.defer_unpack = int(bool(_defer_unpack))
         call("mmvae_celeba_step", self.h, C.byref(io), int(training), int(backward), _stream())
         return self._outputs()
 

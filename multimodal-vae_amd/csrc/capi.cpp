@@ -55,6 +55,11 @@ static int pb_pack(PlanBase* P, hipStream_t s) {
     if (P->no_pack) return MMVAE_OK;
     return launch_pack(P->buf.desc_dev, P->pk.d.data(), (int)P->pk.d.size(), P->buf.params, P->buf.packed, P->buf.packed_vec, s);
 }
+static int pb_grad_map(PlanBase* P, int* map, hipStream_t s) {
+    MMVAE_TRY(check_bound(P));
+    MMVAE_REQUIRE(map != nullptr, "grad_map: null argument");
+    return launch_unpack_map(P->buf.gdesc_dev, P->gk.d.data(), (int)P->gk.d.size(), P->nparams, P->gk.mat_elems, map, s);
+}
 #define MMVAE_PLAN_API(pfx, T, BASE)                                                                                      \
     long long mmvae_##pfx##_param_count(const T* p) { return BASE(p)->nparams; }                                          \
     int mmvae_##pfx##_num_params(const T* p) { return (int)BASE(p)->params.size(); }                                      \
@@ -87,6 +92,11 @@ static int pb_pack(PlanBase* P, hipStream_t s) {
     int mmvae_##pfx##_pack_weights(T* p, void* stream) {                                                                  \
         API_GUARD_BEGIN                                                                                                   \
         return pb_pack(BASE(p), S(stream));                                                                               \
+        API_GUARD_END                                                                                                     \
+    }                                                                                                                     \
+    int mmvae_##pfx##_grad_map(T* p, int* map, void* stream) {                                                            \
+        API_GUARD_BEGIN                                                                                                   \
+        return pb_grad_map(BASE(p), map, S(stream));                                                                      \
         API_GUARD_END                                                                                                     \
     }
 static inline PlanBase* mnist_b(const mmvae_mnist_t* p) { return mnist_base(const_cast<mmvae_mnist_t*>(p)); }
@@ -303,6 +313,7 @@ int mmvae_celeba_step(mmvae_celeba_t* p, const mmvae_celeba_step_io* io, int tra
     s.seed = io->seed; s.sums = io->sums; s.recon_image = io->recon_image; s.recon_attrs = io->recon_attrs;
     s.mu = io->mu; s.logvar = io->logvar;
     for (int k = 0; k < 3; ++k) s.pass_skip[k] = io->pass_skip[k];
+    s.defer_unpack = io->defer_unpack;
     return celeba_step(p, s, training, do_backward, S(stream));
     API_GUARD_END
 }

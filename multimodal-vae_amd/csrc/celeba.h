@@ -22,6 +22,7 @@ struct CelebaStepIO {
     float* recon_attrs = nullptr;       // [3][B][18] or null
     float* mu = nullptr; float* logvar = nullptr;   // [3][B][D] or null
     int pass_skip[3] = {0, 0, 0};       // 1: pass k is absent from this step
+    int defer_unpack = 0;               // 1: leave the GEMM-weight gradients packed (the optimizer gathers them: grad_map)
 };
 
 struct CelebaPlan;

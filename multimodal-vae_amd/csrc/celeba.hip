@@ -516,7 +516,7 @@ int celeba_step(CelebaPlan* Pp, const CelebaStepIO& io, int training, int do_bac
     if (P.st_wgrad2 != P.st_wgrad) MMVAE_TRY(edge(P, P.st_wgrad2, s));
     hipLaunchKernelGGL(sum_slots_kernel, dim3(1), dim3(64), 0, s, w.sums, io.sums);
     MMVAE_TRY(mmvae_check_launch("sum_slots"));
-    return unpack(P, s);
+    return io.defer_unpack ? MMVAE_OK : unpack(P, s);
 }
 
 // ---------------------------------------------------------------- granular module entry points (drop-in modules)
