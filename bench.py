@@ -99,8 +99,8 @@ def cpu_baseline(B, D, image, text, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--batch", type=int, default=256, help="samples per GPU")
     ap.add_argument("--n_latents", type=int, default=100)
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (1 GPU only)")
