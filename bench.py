@@ -149,12 +149,16 @@ def main():
 
     for _ in range(args.warmup):
         run()
+    import gc
+    gc.collect()
+    gc.disable()            # a generational collection in the enqueue thread stalls the GPU for milliseconds
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = run()
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
