@@ -15,6 +15,8 @@ import time
 import numpy as np
 import torch
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # read by ROCr at hsa_init: before ANY GPU call (dp.ensure_ipc_env)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

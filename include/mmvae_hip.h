@@ -52,12 +52,15 @@ long long mmvae_mm_gpk_vec_elems(const mmvae_mm_t*);
 size_t mmvae_mm_desc_bytes(const mmvae_mm_t*, int which);   /* which: 0 = weight table, 1 = gradient table */
 int mmvae_mm_desc_copy(const mmvae_mm_t*, int which, void* host_out);   /* caller uploads it to the device */
 size_t mmvae_mm_workspace_bytes(const mmvae_mm_t*);
+/* workspace of ONE granular module call (the *_encoder_* / *_decoder_* entry points below run a single pass over B rows;
+   the fused step batches 3 passes and needs mmvae_mm_workspace_bytes) */
+size_t mmvae_mm_module_workspace_bytes(const mmvae_mm_t*);
 int mmvae_mm_bind(mmvae_mm_t*, float* params, float* grads, float* bn_stats, long long* bn_num_batches_tracked,
                   void* packed_bf16, float* packed_vec, float* gpk, float* gpk_vec, void* desc_dev, void* gdesc_dev);
-int mmvae_mm_pack_weights(mmvae_mm_t*, void* stream);
+int mmvae_mm_pack_weights(mmvae_mm_t*, void* stream);    /* refresh bf16 GEMM-layout copies after params change */
 /* map[i] (int32, param_count entries) = where flat parameter i's packed gradient lives: >= 0 index into gpk, <= -2:
  * -(index + 2) into gpk_vec, -1 none.  Built once per parameter layout; input of mmvae_adam_step_packed. */
-int mmvae_mm_grad_map(mmvae_mm_t*, int* map, void* stream);       /* refresh bf16 GEMM-layout copies after params change */
+int mmvae_mm_grad_map(mmvae_mm_t*, int* map, void* stream);
 
 /* One 3-pass ELBO step (multimnist/train.py:150-168): forward of (image,text), (image), (text), the three
  * loss_function sums and -- if do_backward -- the gradient of loss_1+loss_2+loss_3 written to `grads`
@@ -138,6 +141,9 @@ long long mmvae_mnist_gpk_vec_elems(const mmvae_mnist_t*);
 size_t mmvae_mnist_desc_bytes(const mmvae_mnist_t*, int which);
 int mmvae_mnist_desc_copy(const mmvae_mnist_t*, int which, void* host_out);
 size_t mmvae_mnist_workspace_bytes(const mmvae_mnist_t*);
+/* workspace of ONE granular module call (the *_encoder_* / *_decoder_* entry points below run a single pass over B rows;
+   the fused step batches 3 passes and needs mmvae_mnist_workspace_bytes) */
+size_t mmvae_mnist_module_workspace_bytes(const mmvae_mnist_t*);
 int mmvae_mnist_bind(mmvae_mnist_t*, float* params, float* grads, float* bn_stats, long long* num_batches_tracked,
                      void* packed_bf16, float* packed_vec, float* gpk, float* gpk_vec, void* desc_dev, void* gdesc_dev);
 int mmvae_mnist_pack_weights(mmvae_mnist_t*, void* stream);
@@ -197,6 +203,9 @@ long long mmvae_celeba_gpk_vec_elems(const mmvae_celeba_t*);
 size_t mmvae_celeba_desc_bytes(const mmvae_celeba_t*, int which);
 int mmvae_celeba_desc_copy(const mmvae_celeba_t*, int which, void* host_out);
 size_t mmvae_celeba_workspace_bytes(const mmvae_celeba_t*);
+/* workspace of ONE granular module call (the *_encoder_* / *_decoder_* entry points below run a single pass over B rows;
+   the fused step batches 3 passes and needs mmvae_celeba_workspace_bytes) */
+size_t mmvae_celeba_module_workspace_bytes(const mmvae_celeba_t*);
 int mmvae_celeba_bind(mmvae_celeba_t*, float* params, float* grads, float* bn_stats, long long* num_batches_tracked,
                       void* packed_bf16, float* packed_vec, float* gpk, float* gpk_vec, void* desc_dev, void* gdesc_dev);
 int mmvae_celeba_pack_weights(mmvae_celeba_t*, void* stream);
@@ -261,6 +270,9 @@ long long mmvae_coco_gpk_vec_elems(const mmvae_coco_t*);
 size_t mmvae_coco_desc_bytes(const mmvae_coco_t*, int which);
 int mmvae_coco_desc_copy(const mmvae_coco_t*, int which, void* host_out);
 size_t mmvae_coco_workspace_bytes(const mmvae_coco_t*);
+/* workspace of ONE granular module call (the *_encoder_* / *_decoder_* entry points below run a single pass over B rows;
+   the fused step batches 3 passes and needs mmvae_coco_workspace_bytes) */
+size_t mmvae_coco_module_workspace_bytes(const mmvae_coco_t*);
 int mmvae_coco_bind(mmvae_coco_t*, float* params, float* grads, float* bn_stats, long long* num_batches_tracked,
                     void* packed, float* packed_vec, float* gpk, float* gpk_vec, void* desc_dev, void* gdesc_dev);
 int mmvae_coco_pack_weights(mmvae_coco_t*, void* stream);
@@ -314,20 +326,22 @@ int mmvae_reparam_fwd(const float* mu, const float* logvar, const float* eps, in
 int mmvae_reparam_bwd(const float* logvar, const float* eps, const float* dz, int n, float* d_mu, float* d_logvar, void* stream);
 /* KL term of loss_function (multimnist/train.py:85): out[0] += -0.5*sum(1+lv-mu^2-exp(lv)) */
 int mmvae_kl_fwd(const float* mu, const float* logvar, int n, float* out_sum, void* stream);
-int mmvae_kl_bwd(const float* mu, const float* logvar, int n, float coef, float* d_mu, float* d_logvar, void* stream);
+/* every *_bwd below: the gradient is coef * (*gscale) * d(sum)/d(input); gscale (nullable) is a DEVICE scalar -- the upstream
+   gradient of the 0-d loss tensor, read by the kernel so that the host never synchronises on it */
+int mmvae_kl_bwd(const float* mu, const float* logvar, int n, float coef, const float* gscale, float* d_mu, float* d_logvar, void* stream);
 /* F.binary_cross_entropy on probabilities (multimnist/train.py:75): out[0] += sum of terms; bwd = coef * d/dp */
 int mmvae_bce_fwd(const float* p, const float* target, long long n, float* out_sum, void* stream);
-int mmvae_bce_bwd(const float* p, const float* target, long long n, float coef, float* d_p, void* stream);
+int mmvae_bce_bwd(const float* p, const float* target, long long n, float coef, const float* gscale, float* d_p, void* stream);
 /* F.nll_loss on log-probs [rows][classes] (multimnist/train.py:79) */
 int mmvae_nll_fwd(const float* logp, const long long* target, int rows, int classes, float* out_sum, void* stream);
-int mmvae_nll_bwd(const long long* target, int rows, int classes, float coef, float* d_logp, void* stream);
+int mmvae_nll_bwd(const long long* target, int rows, int classes, float coef, const float* gscale, float* d_logp, void* stream);
 /* counter-based RNG (Philox4x32-10) */
 int mmvae_normal(float* out, long long n, unsigned long long seed, const long long* step_counter, unsigned stream_id, void* stream);
 int mmvae_keep_mask(uint8_t* out, long long n, float p, unsigned long long seed, const long long* step_counter,
                     unsigned stream_id, void* stream);
 /* F.mse_loss of the COCO loss variant (coco/train.py:75): out[0] += sum (a-b)^2 ; bwd: d_a = coef * 2 (a-b) */
 int mmvae_mse_fwd(const float* a, const float* b, long long n, float* out_sum, void* stream);
-int mmvae_mse_bwd(const float* a, const float* b, long long n, float coef, float* d_a, void* stream);
+int mmvae_mse_bwd(const float* a, const float* b, long long n, float coef, const float* gscale, float* d_a, void* stream);
 /* Input pipeline: the ToTensor() transform of the reference's loaders (multimnist/train.py:113-121; dataset tensors are
  * uint8 (N,50,50), multimnist/datasets.py:180-181) done on the device: dst[i] = src[i] / denom (denom = 255, IEEE division: bit-equal to ToTensor) */
 int mmvae_u8_to_f32(const uint8_t* src, long long n, float denom, float* dst, void* stream);

@@ -102,6 +102,7 @@ SIGNATURES = {
     "mmvae_mm_desc_bytes": (_SZ, [_P, _I]),
     "mmvae_mm_desc_copy": (_I, [_P, _I, _P]),
     "mmvae_mm_workspace_bytes": (_SZ, [_P]),
+    "mmvae_mm_module_workspace_bytes": (_SZ, [_P]),
     "mmvae_mm_bind": (_I, [_P] * 11),
     "mmvae_mm_pack_weights": (_I, [_P, _P]),
     "mmvae_mm_grad_map": (_I, [_P, _P, _P]),
@@ -122,15 +123,15 @@ SIGNATURES = {
     "mmvae_reparam_fwd": (_I, [_P, _P, _P, _I, _P, _P]),
     "mmvae_reparam_bwd": (_I, [_P, _P, _P, _I, _P, _P, _P]),
     "mmvae_kl_fwd": (_I, [_P, _P, _I, _P, _P]),
-    "mmvae_kl_bwd": (_I, [_P, _P, _I, _F, _P, _P, _P]),
+    "mmvae_kl_bwd": (_I, [_P, _P, _I, _F, _P, _P, _P, _P]),
     "mmvae_bce_fwd": (_I, [_P, _P, _LL, _P, _P]),
-    "mmvae_bce_bwd": (_I, [_P, _P, _LL, _F, _P, _P]),
+    "mmvae_bce_bwd": (_I, [_P, _P, _LL, _F, _P, _P, _P]),
     "mmvae_nll_fwd": (_I, [_P, _P, _I, _I, _P, _P]),
-    "mmvae_nll_bwd": (_I, [_P, _I, _I, _F, _P, _P]),
+    "mmvae_nll_bwd": (_I, [_P, _I, _I, _F, _P, _P, _P]),
     "mmvae_normal": (_I, [_P, _LL, _ULL, _P, _U, _P]),
     "mmvae_keep_mask": (_I, [_P, _LL, _F, _ULL, _P, _U, _P]),
     "mmvae_mse_fwd": (_I, [_P, _P, _LL, _P, _P]),
-    "mmvae_mse_bwd": (_I, [_P, _P, _LL, _F, _P, _P]),
+    "mmvae_mse_bwd": (_I, [_P, _P, _LL, _F, _P, _P, _P]),
     "mmvae_u8_to_f32": (_I, [_P, _LL, _F, _P, _P]),
     "mmvae_adam_step": (_I, [_P, _P, _P, _P, _LL, _P, _F, _F, _F, _F, _F, _P]),
     "mmvae_adam_step_packed": (_I, [_P, _P, _P, _P, _LL, _P, _F, _F, _F, _F, _F, _P, _P, _P, _P]),
@@ -155,6 +156,7 @@ def _plan_api(pfx):
         "mmvae_%s_desc_bytes" % pfx: (_SZ, [_P, _I]),
         "mmvae_%s_desc_copy" % pfx: (_I, [_P, _I, _P]),
         "mmvae_%s_workspace_bytes" % pfx: (_SZ, [_P]),
+        "mmvae_%s_module_workspace_bytes" % pfx: (_SZ, [_P]),
         "mmvae_%s_bind" % pfx: (_I, [_P] * 11),
         "mmvae_%s_pack_weights" % pfx: (_I, [_P, _P]),
         "mmvae_%s_grad_map" % pfx: (_I, [_P, _P, _P]),

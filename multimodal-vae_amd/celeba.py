@@ -27,7 +27,7 @@ def _prep(mod: nn.Module, prefix: str, x: torch.Tensor):
     B = x.shape[0]
     names = [prefix + k for k, _ in mod.named_parameters()]
     plist = [p for _, p in mod.named_parameters()]
-    return core, st, B, st.plan(B), st.workspace_bytes(B), names, plist
+    return core, st, B, st.plan(B), st.module_workspace_bytes(B), names, plist
 
 
 class ImageEncoder(nn.Module):

@@ -20,7 +20,7 @@ import torch.nn as nn
 from ._lib import MMVAEError, call, ptr
 from .core import CocoState, FusedCocoStep, StepOutputs
 from .multimnist import (ProductOfExperts, Swish, _BCEMeanFn, _Core, _KLSumFn, _ModuleFn, _ReparamFn, _core_of,
-                         _seed_from_torch, _stream, swish)
+                         _gscale, _seed_from_torch, _stream, swish)
 
 MAX_WORDS = 102       # coco/utils.py:12-15
 N_EMBEDDING = 300
@@ -35,7 +35,7 @@ def _prep(mod: nn.Module, prefix: str, x: torch.Tensor):
     B = x.shape[0]
     names = [prefix + k for k, _ in mod.named_parameters()]
     plist = [p for _, p in mod.named_parameters()]
-    return core, st, B, st.plan(B), st.workspace_bytes(B), names, plist
+    return core, st, B, st.plan(B), st.module_workspace_bytes(B), names, plist
 
 
 def _keep(shape, device, salt):
@@ -304,7 +304,7 @@ class _MSEMeanFn(torch.autograd.Function):
     def backward(ctx, g):
         a, b = ctx.saved_tensors
         da = torch.empty_like(a)
-        call("mmvae_mse_bwd", ptr(a), ptr(b), a.numel(), float(g.item()) / a.numel(), ptr(da), _stream())
+        call("mmvae_mse_bwd", ptr(a), ptr(b), a.numel(), 1.0 / a.numel(), ptr(_gscale(g)), ptr(da), _stream())
         return da, None
 
 

@@ -99,6 +99,10 @@ class PlanState:
     def workspace_bytes(self, batch: int) -> int:
         return self._c("workspace_bytes", self.plan(batch))
 
+    def module_workspace_bytes(self, batch: int) -> int:
+        """Workspace of one granular module call (one pass over ``batch`` rows), not of the whole 3-pass step."""
+        return self._c("module_workspace_bytes", self.plan(batch))
+
     def grad_map(self) -> torch.Tensor:
         """int32 [nparams]: where each flat parameter's packed gradient lives (mmvae_<family>_grad_map), built once."""
         if getattr(self, "_gmap", None) is None:
@@ -173,18 +177,29 @@ class StepOutputs:
     def __init__(self, sums: torch.Tensor, bce_div: float, nll_div: float, kl_scale: float, lambda_xy, lambda_yx,
                  passes=(True, True, True)):
         self.sums, self.bce_div, self.nll_div, self.kl_scale = sums, bce_div, nll_div, kl_scale
-        self.lxy, self.lyx = lambda_xy, lambda_yx
+        self.lxy, self.lyx = tuple(float(x) for x in lambda_xy), tuple(float(x) for x in lambda_yx)
         self.passes = tuple(bool(x) for x in passes)
 
+    _W: Dict[tuple, torch.Tensor] = {}      # (device, weights...) -> [3][16] device matrix, uploaded once per configuration
+
     def losses(self) -> torch.Tensor:
-        """loss_1, loss_2, loss_3 of the reference's train() closure as a device tensor [3]."""
+        """loss_1, loss_2, loss_3 of the reference's train() closure as a device tensor [3].  Pure device arithmetic: the
+        loss weights live in a cached device matrix (a fresh ``torch.tensor(..., device=cuda)`` per call would be a blocking
+        pageable H2D copy, i.e. one host synchronisation per training step)."""
         s = self.sums
-        lxy = torch.tensor(self.lxy, device=s.device)
-        lyx = torch.tensor(self.lyx, device=s.device)
-        out = lxy * s[0:3] / self.bce_div + lyx * s[4:7] / self.nll_div + s[8:11] * self.kl_scale
-        if not all(self.passes):                                   # absent passes (weak supervision) report 0
-            out = out * torch.tensor([float(x) for x in self.passes], device=s.device)
-        return out
+        key = (s.device, self.lxy, self.lyx, self.passes, self.bce_div, self.nll_div, self.kl_scale)
+        m = StepOutputs._W.get(key)
+        if m is None:
+            h = torch.zeros(3, 16, dtype=torch.float32)
+            for k in range(3):
+                on = 1.0 if self.passes[k] else 0.0               # absent passes (weak supervision) report 0
+                h[k, k] = on * self.lxy[k] / self.bce_div
+                h[k, 4 + k] = on * self.lyx[k] / self.nll_div
+                h[k, 8 + k] = on * self.kl_scale
+            if len(StepOutputs._W) > 256:
+                StepOutputs._W.clear()
+            m = StepOutputs._W[key] = h.to(s.device)
+        return m @ s
 
     def parts(self):
         """(mean BCE, mean NLL, KL sum) per pass"""

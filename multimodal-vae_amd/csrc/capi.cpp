@@ -83,6 +83,9 @@ static int pb_grad_map(PlanBase* P, int* map, hipStream_t s) {
         return MMVAE_OK;                                                                                                  \
     }                                                                                                                     \
     size_t mmvae_##pfx##_workspace_bytes(const T* p) { return BASE(p)->ws_bytes; }                                        \
+    size_t mmvae_##pfx##_module_workspace_bytes(const T* p) {                                                             \
+        return BASE(p)->ws_bytes_module ? BASE(p)->ws_bytes_module : BASE(p)->ws_bytes;                                   \
+    }                                                                                                                     \
     int mmvae_##pfx##_bind(T* p, float* params, float* grads, float* bn_stats, long long* nbt, void* packed,              \
                            float* packed_vec, float* gpk, float* gpk_vec, void* desc_dev, void* gdesc_dev) {              \
         API_GUARD_BEGIN                                                                                                   \
@@ -156,6 +159,7 @@ int mmvae_mm_desc_copy(const mmvae_mm_t* p, int which, void* host_out) {
     return MMVAE_OK;
 }
 size_t mmvae_mm_workspace_bytes(const mmvae_mm_t* p) { return mm_workspace_bytes(p); }
+size_t mmvae_mm_module_workspace_bytes(const mmvae_mm_t* p) { return mm_module_workspace_bytes(p); }
 int mmvae_mm_bind(mmvae_mm_t* p, float* params, float* grads, float* bn_stats, long long* nbt, void* packed, float* packed_vec,
                   float* gpk, float* gpk_vec, void* desc_dev, void* gdesc_dev) {
     API_GUARD_BEGIN
@@ -431,17 +435,17 @@ int mmvae_reparam_bwd(const float* lv, const float* eps, const float* dz, int n,
     return launch_reparam_bwd(lv, eps, dz, n, dmu, dlv, S(s));
 }
 int mmvae_kl_fwd(const float* mu, const float* lv, int n, float* out, void* s) { return launch_kl_fwd(mu, lv, n, out, S(s)); }
-int mmvae_kl_bwd(const float* mu, const float* lv, int n, float coef, float* dmu, float* dlv, void* s) { return launch_kl_bwd(mu, lv, n, coef, dmu, dlv, S(s)); }
+int mmvae_kl_bwd(const float* mu, const float* lv, int n, float coef, const float* gs, float* dmu, float* dlv, void* s) { return launch_kl_bwd(mu, lv, n, coef, gs, dmu, dlv, S(s)); }
 int mmvae_bce_fwd(const float* p, const float* t, long long n, float* out, void* s) { return launch_bce_fwd(p, t, n, out, S(s)); }
-int mmvae_bce_bwd(const float* p, const float* t, long long n, float coef, float* dp, void* s) { return launch_bce_bwd(p, t, n, coef, dp, S(s)); }
+int mmvae_bce_bwd(const float* p, const float* t, long long n, float coef, const float* gs, float* dp, void* s) { return launch_bce_bwd(p, t, n, coef, gs, dp, S(s)); }
 int mmvae_nll_fwd(const float* lp, const long long* tg, int rows, int classes, float* out, void* s) { return launch_nll_fwd(lp, tg, rows, classes, out, S(s)); }
-int mmvae_nll_bwd(const long long* tg, int rows, int classes, float coef, float* dlp, void* s) { return launch_nll_bwd(tg, rows, classes, coef, dlp, S(s)); }
+int mmvae_nll_bwd(const long long* tg, int rows, int classes, float coef, const float* gs, float* dlp, void* s) { return launch_nll_bwd(tg, rows, classes, coef, gs, dlp, S(s)); }
 int mmvae_normal(float* out, long long n, unsigned long long seed, const long long* ctr, unsigned sid, void* s) { return launch_normal(out, n, seed, ctr, sid, S(s)); }
 int mmvae_keep_mask(uint8_t* out, long long n, float p, unsigned long long seed, const long long* ctr, unsigned sid, void* s) {
     return launch_keep_mask(out, n, p, seed, ctr, sid, S(s));
 }
 int mmvae_mse_fwd(const float* a, const float* b, long long n, float* out, void* s) { return launch_mse_fwd(a, b, n, out, S(s)); }
-int mmvae_mse_bwd(const float* a, const float* b, long long n, float coef, float* da, void* s) { return launch_mse_bwd(a, b, n, coef, da, S(s)); }
+int mmvae_mse_bwd(const float* a, const float* b, long long n, float coef, const float* gs, float* da, void* s) { return launch_mse_bwd(a, b, n, coef, gs, da, S(s)); }
 int mmvae_u8_to_f32(const uint8_t* src, long long n, float denom, float* dst, void* s) { return launch_u8_to_f32(src, n, denom, dst, S(s)); }
 int mmvae_adam_step(float* p, const float* g, float* m, float* v, long long n, long long* state, float lr, float b1, float b2,
                     float eps, float grad_scale, void* s) {

@@ -119,7 +119,7 @@ void build(CelebaPlan& P) {
 
 void carve(CelebaPlan& P, Workspace& ws) {
     CelebaPlan::W& w = P.w;
-    const size_t B = P.B, D = P.D, B3 = 3 * B, B2 = 2 * B;
+    const size_t B = P.B, D = P.D, B3 = (size_t)P.carve_passes * B, B2 = (size_t)(P.carve_passes < 2 ? P.carve_passes : 2) * B;
     const int SS = MMVAE_STAT_SLOTS;
     const int ec[3] = {64, 128, 256}, dc[3] = {128, 64, 32};
     char* z0 = ws.take<char>(0);
@@ -398,9 +398,11 @@ int att_dec_bwd(CelebaPlan& P, const float* dalogit, int groups, float* dz, hipS
     return mlp_dgrad(P, P.ad[0], w.d_ad, rows, 1, nullptr, dz, P.D, nullptr, nullptr, 0, s);
 }
 
-int use_ws(CelebaPlan* P, void* ws, size_t bytes) {
+int use_ws(CelebaPlan* P, void* ws, size_t bytes, bool module = true) {
     MMVAE_TRY(check_bound(P));
-    MMVAE_REQUIRE(ws != nullptr && bytes >= P->ws_bytes, "workspace too small (%zu < %zu)", bytes, P->ws_bytes);
+    const size_t need = module ? P->ws_bytes_module : P->ws_bytes;
+    MMVAE_REQUIRE(ws != nullptr && bytes >= need, "workspace too small (%zu < %zu)", bytes, need);
+    P->carve_passes = module ? 1 : 3;
     Workspace w(ws, bytes);
     carve(*P, w);
     P->wgrad_forked = false;
@@ -422,13 +424,24 @@ CelebaPlan* celeba_create(int D, int B) {
     Workspace ws(nullptr, 0);
     carve(*P, ws);
     P->ws_bytes = ws.used();
+    P->carve_passes = 1;
+    Workspace wm(nullptr, 0);
+    carve(*P, wm);
+    P->ws_bytes_module = wm.used();
+    P->carve_passes = 3;
     return P;
 }
 void celeba_destroy(CelebaPlan* P) { delete P; }
 PlanBase* celeba_base(CelebaPlan* P) { return P; }
 
+static int celeba_step_body(CelebaPlan* Pp, const CelebaStepIO& io, int training, int do_backward, hipStream_t s);
 int celeba_step(CelebaPlan* Pp, const CelebaStepIO& io, int training, int do_backward, hipStream_t s) {
-    MMVAE_TRY(use_ws(Pp, io.ws, io.ws_bytes));
+    const int rc = celeba_step_body(Pp, io, training, do_backward, s);
+    if (rc != MMVAE_OK && Pp) join_after_error(*Pp, s);
+    return rc;
+}
+static int celeba_step_body(CelebaPlan* Pp, const CelebaStepIO& io, int training, int do_backward, hipStream_t s) {
+    MMVAE_TRY(use_ws(Pp, io.ws, io.ws_bytes, false));
     CelebaPlan& P = *Pp;
     CelebaPlan::W& w = P.w;
     const int B = P.B, D = P.D, B3 = 3 * B;

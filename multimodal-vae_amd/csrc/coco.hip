@@ -105,7 +105,7 @@ void build(CocoPlan& P) {
 
 void carve(CocoPlan& P, Workspace& ws) {
     CocoPlan::W& w = P.w;
-    const size_t B = P.B, D = P.D, B3 = 3 * B, B2 = 2 * B, T = P.T;
+    const size_t B = P.B, D = P.D, B3 = (size_t)P.carve_passes * B, B2 = (size_t)(P.carve_passes < 2 ? P.carve_passes : 2) * B, T = P.T;
     const int SS = MMVAE_STAT_SLOTS;
     const int ec[3] = {128, 256, 512}, dc[3] = {256, 128, 64};
     char* z0 = ws.take<char>(0);
@@ -361,9 +361,11 @@ int dec_bwd(CocoPlan& P, const float* dlogit, int groups, float* dz, hipStream_t
     return MMVAE_OK;
 }
 
-int use_ws(CocoPlan* P, void* ws, size_t bytes) {
+int use_ws(CocoPlan* P, void* ws, size_t bytes, bool module = true) {
     MMVAE_TRY(check_bound(P));
-    MMVAE_REQUIRE(ws != nullptr && bytes >= P->ws_bytes, "workspace too small (%zu < %zu)", bytes, P->ws_bytes);
+    const size_t need = module ? P->ws_bytes_module : P->ws_bytes;
+    MMVAE_REQUIRE(ws != nullptr && bytes >= need, "workspace too small (%zu < %zu)", bytes, need);
+    P->carve_passes = module ? 1 : 3;
     Workspace w(ws, bytes);
     carve(*P, w);
     P->wgrad_forked = false;
@@ -389,14 +391,25 @@ CocoPlan* coco_create(int D, int B, int T) {
     Workspace ws(nullptr, 0);
     carve(*P, ws);
     P->ws_bytes = ws.used();
+    P->carve_passes = 1;
+    Workspace wm(nullptr, 0);
+    carve(*P, wm);
+    P->ws_bytes_module = wm.used();
+    P->carve_passes = 3;
     return P;
 }
 void coco_destroy(CocoPlan* P) { delete P; }
 PlanBase* coco_base(CocoPlan* P) { return P; }
 int coco_steps(const CocoPlan* P) { return P->T; }
 
+static int coco_step_body(CocoPlan* Pp, const CocoStepIO& io, int training, int do_backward, hipStream_t s);
 int coco_step(CocoPlan* Pp, const CocoStepIO& io, int training, int do_backward, hipStream_t s) {
-    MMVAE_TRY(use_ws(Pp, io.ws, io.ws_bytes));
+    const int rc = coco_step_body(Pp, io, training, do_backward, s);
+    if (rc != MMVAE_OK && Pp) join_after_error(*Pp, s);
+    return rc;
+}
+static int coco_step_body(CocoPlan* Pp, const CocoStepIO& io, int training, int do_backward, hipStream_t s) {
+    MMVAE_TRY(use_ws(Pp, io.ws, io.ws_bytes, false));
     CocoPlan& P = *Pp;
     CocoPlan::W& w = P.w;
     const int B = P.B, D = P.D, B3 = 3 * B, T = P.T;

@@ -319,7 +319,7 @@ void coco_text_build(CocoPlan& P) {
 
 void coco_text_carve(CocoPlan& P, Workspace& ws) {
     CocoPlan::W& w = P.w;
-    const size_t B = P.B, R = 3 * B, T = P.T, D = P.D;
+    const size_t B = P.B, R = (size_t)P.carve_passes * B, T = P.T, D = P.D;
     w.te_gi = ws.take<float>(B * T * G); w.te_gh = ws.take<float>(B * G); w.te_h = ws.take<float>(T * B * H);
     w.te_sav = ws.take<float>(T * B * 4 * H); w.te_gi_r = ws.take<float>(B * G); w.te_sav_r = ws.take<float>(B * 4 * H);
     w.te_hb = ws.take<float>(B * H); w.te_sum = ws.take<float>(B * H); w.txtout = ws.take<float>(B * 2 * D);

@@ -93,5 +93,15 @@ struct Philox {
 };
 __device__ __forceinline__ float u01(uint32_t x) { return ((x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 
+// One-time-per-DEVICE set-up (kernel attributes such as dynamic LDS above 64 KB): the bit mask is keyed by the current
+// device, so a process that drives several devices repeats the set-up on each (no "first device wins" global state).
+#include <atomic>
+static inline bool mmvae_first_use_on_device(std::atomic<unsigned>& mask) {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    const unsigned bit = 1u << (d & 31);
+    return (mask.fetch_or(bit) & bit) == 0;
+}
+
 __host__ __device__ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 __host__ __device__ static inline int round_up(int a, int b) { return ceil_div(a, b) * b; }

@@ -89,7 +89,7 @@ int launch_poe_bwd(const float* mu, const float* logvar, int M, int n, const flo
 int launch_reparam_fwd(const float* mu, const float* logvar, const float* eps, int n, float* z, hipStream_t s);
 int launch_reparam_bwd(const float* logvar, const float* eps, const float* dz, int n, float* d_mu, float* d_logvar, hipStream_t s);
 int launch_kl_fwd(const float* mu, const float* logvar, int n, float* kl_sum, hipStream_t s);
-int launch_kl_bwd(const float* mu, const float* logvar, int n, float coef, float* d_mu, float* d_logvar, hipStream_t s);
+int launch_kl_bwd(const float* mu, const float* logvar, int n, float coef, const float* gscale, float* d_mu, float* d_logvar, hipStream_t s);
 int launch_normal(float* out, long long n, unsigned long long seed, const long long* step_counter, unsigned stream_id, hipStream_t s);
 int launch_keep_mask(uint8_t* out, long long n, float p, unsigned long long seed, const long long* step_counter,
                      unsigned stream_id, hipStream_t s);
@@ -139,9 +139,9 @@ int launch_adam(const AdamArgs& a, hipStream_t s);
 int launch_unpack_map(const PackDesc* table_dev, const PackDesc* table_host, int nd, long long nparams, long long gmat_elems, int* map, hipStream_t s);
 int launch_fill_zero(void* p, size_t bytes, hipStream_t s);
 int launch_bce_fwd(const float* p, const float* t, long long n, float* out, hipStream_t s);
-int launch_bce_bwd(const float* p, const float* t, long long n, float coef, float* dp, hipStream_t s);
+int launch_bce_bwd(const float* p, const float* t, long long n, float coef, const float* gscale, float* dp, hipStream_t s);
 int launch_nll_fwd(const float* lp, const long long* tg, int rows, int classes, float* out, hipStream_t s);
-int launch_nll_bwd(const long long* tg, int rows, int classes, float coef, float* dlp, hipStream_t s);
+int launch_nll_bwd(const long long* tg, int rows, int classes, float coef, const float* gscale, float* dlp, hipStream_t s);
 
 // One launch at the top of the fused step: zero the accumulation buffers (16-byte stores) and draw the step's
 // stochastic inputs (eps ~ N(0,1), dropout keep flags) from Philox streams keyed by (seed, step counter).
@@ -180,4 +180,4 @@ int launch_colsum_bf16(const bf16* x, int ld, int rows, int cols, float* out, hi
 int launch_u8_to_f32(const uint8_t* src, long long n, float denom, float* dst, hipStream_t s);
 // F.mse_loss pieces of the COCO loss variant (coco/train.py:75)
 int launch_mse_fwd(const float* a, const float* b, long long n, float* out_sum, hipStream_t s);
-int launch_mse_bwd(const float* a, const float* b, long long n, float coef, float* d_a, hipStream_t s);
+int launch_mse_bwd(const float* a, const float* b, long long n, float coef, const float* gscale, float* d_a, hipStream_t s);

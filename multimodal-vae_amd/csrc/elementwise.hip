@@ -458,7 +458,8 @@ __global__ __launch_bounds__(TPB) void kl_fwd_kernel(const float* mu, const floa
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
 }
-__global__ __launch_bounds__(TPB) void kl_bwd_kernel(const float* mu, const float* lv, int n, float coef, float* dmu, float* dlv) {
+__global__ __launch_bounds__(TPB) void kl_bwd_kernel(const float* mu, const float* lv, int n, float coef, const float* gs, float* dmu, float* dlv) {
+    if (gs) coef *= *gs;                                   // upstream gradient (0-d device tensor): no host read
     int i = blockIdx.x * TPB + threadIdx.x;
     if (i < n) { dmu[i] = coef * mu[i]; dlv[i] = -0.5f * coef * (1.0f - expf(lv[i])); }
 }
@@ -532,7 +533,8 @@ __global__ __launch_bounds__(TPB) void bce_fwd_kernel(const float* p, const floa
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
 }
-__global__ __launch_bounds__(TPB) void bce_bwd_kernel(const float* p, const float* t, long long n, float coef, float* dp) {
+__global__ __launch_bounds__(TPB) void bce_bwd_kernel(const float* p, const float* t, long long n, float coef, const float* gs, float* dp) {
+    if (gs) coef *= *gs;
     long long i = (long long)blockIdx.x * TPB + threadIdx.x;
     if (i < n) dp[i] = coef * (p[i] - t[i]) / fmaxf((1.0f - p[i]) * p[i], 1e-12f);
 }
@@ -542,7 +544,8 @@ __global__ __launch_bounds__(TPB) void nll_fwd_kernel(const float* lp, const lon
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
 }
-__global__ __launch_bounds__(TPB) void nll_bwd_kernel(const long long* tg, int rows, int classes, float coef, float* dlp) {
+__global__ __launch_bounds__(TPB) void nll_bwd_kernel(const long long* tg, int rows, int classes, float coef, const float* gs, float* dlp) {
+    if (gs) coef *= *gs;
     int i = blockIdx.x * TPB + threadIdx.x;
     if (i < rows * classes) dlp[i] = (i % classes == (int)tg[i / classes]) ? -coef : 0.f;
 }
@@ -803,7 +806,8 @@ __global__ __launch_bounds__(TPB) void mse_fwd_kernel(const float* a, const floa
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
 }
-__global__ __launch_bounds__(TPB) void mse_bwd_kernel(const float* a, const float* b, long long n, float coef, float* da) {
+__global__ __launch_bounds__(TPB) void mse_bwd_kernel(const float* a, const float* b, long long n, float coef, const float* gs, float* da) {
+    if (gs) coef *= *gs;
     const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
     if (i < n) da[i] = coef * 2.f * (a[i] - b[i]);
 }
@@ -846,8 +850,8 @@ int launch_mse_fwd(const float* a, const float* b, long long n, float* out, hipS
     hipLaunchKernelGGL(mse_fwd_kernel, dim3(nblocks(n, TPB * 4, 256)), dim3(TPB), 0, s, a, b, n, out);
     return mmvae_check_launch("mse_fwd");
 }
-int launch_mse_bwd(const float* a, const float* b, long long n, float coef, float* da, hipStream_t s) {
-    hipLaunchKernelGGL(mse_bwd_kernel, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, s, a, b, n, coef, da);
+int launch_mse_bwd(const float* a, const float* b, long long n, float coef, const float* gs, float* da, hipStream_t s) {
+    hipLaunchKernelGGL(mse_bwd_kernel, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, s, a, b, n, coef, gs, da);
     return mmvae_check_launch("mse_bwd");
 }
 int launch_u8_to_f32(const uint8_t* src, long long n, float denom, float* dst, hipStream_t s) {
@@ -934,8 +938,8 @@ int launch_kl_fwd(const float* mu, const float* lv, int n, float* out, hipStream
     hipLaunchKernelGGL(kl_fwd_kernel, dim3(nblocks(n, TPB, 64)), dim3(TPB), 0, s, mu, lv, n, out);
     return mmvae_check_launch("kl_fwd");
 }
-int launch_kl_bwd(const float* mu, const float* lv, int n, float coef, float* dmu, float* dlv, hipStream_t s) {
-    hipLaunchKernelGGL(kl_bwd_kernel, dim3(ceil_div(n, TPB)), dim3(TPB), 0, s, mu, lv, n, coef, dmu, dlv);
+int launch_kl_bwd(const float* mu, const float* lv, int n, float coef, const float* gs, float* dmu, float* dlv, hipStream_t s) {
+    hipLaunchKernelGGL(kl_bwd_kernel, dim3(ceil_div(n, TPB)), dim3(TPB), 0, s, mu, lv, n, coef, gs, dmu, dlv);
     return mmvae_check_launch("kl_bwd");
 }
 int launch_normal(float* out, long long n, unsigned long long seed, const long long* step, unsigned stream_id, hipStream_t s) {
@@ -974,16 +978,16 @@ int launch_bce_fwd(const float* p, const float* t, long long n, float* out, hipS
     hipLaunchKernelGGL(bce_fwd_kernel, dim3(nblocks(n, TPB * 4, 1024)), dim3(TPB), 0, s, p, t, n, out);
     return mmvae_check_launch("bce_fwd");
 }
-int launch_bce_bwd(const float* p, const float* t, long long n, float coef, float* dp, hipStream_t s) {
-    hipLaunchKernelGGL(bce_bwd_kernel, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, s, p, t, n, coef, dp);
+int launch_bce_bwd(const float* p, const float* t, long long n, float coef, const float* gs, float* dp, hipStream_t s) {
+    hipLaunchKernelGGL(bce_bwd_kernel, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, s, p, t, n, coef, gs, dp);
     return mmvae_check_launch("bce_bwd");
 }
 int launch_nll_fwd(const float* lp, const long long* tg, int rows, int classes, float* out, hipStream_t s) {
     hipLaunchKernelGGL(nll_fwd_kernel, dim3(nblocks(rows, TPB, 64)), dim3(TPB), 0, s, lp, tg, rows, classes, out);
     return mmvae_check_launch("nll_fwd");
 }
-int launch_nll_bwd(const long long* tg, int rows, int classes, float coef, float* dlp, hipStream_t s) {
-    hipLaunchKernelGGL(nll_bwd_kernel, dim3(ceil_div(rows * classes, TPB)), dim3(TPB), 0, s, tg, rows, classes, coef, dlp);
+int launch_nll_bwd(const long long* tg, int rows, int classes, float coef, const float* gs, float* dlp, hipStream_t s) {
+    hipLaunchKernelGGL(nll_bwd_kernel, dim3(ceil_div(rows * classes, TPB)), dim3(TPB), 0, s, tg, rows, classes, coef, gs, dlp);
     return mmvae_check_launch("nll_bwd");
 }
 

@@ -588,11 +588,10 @@ int launch_wgrad_v(WgradParams p, hipStream_t stream) {
     p.rows_per_block = round_up(ceil_div(max_rows, chunks), WM);
     dim3 grid(ceil_div(c.N, TN), ceil_div(max_k, TK), ceil_div(max_rows, p.rows_per_block) * c.nclasses);
     const size_t lds = (size_t)WM * (TN + 16 + TK + 16) * sizeof(bf16);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned> attr_set{0};
+    if (mmvae_first_use_on_device(attr_set)) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<NWT, KWT, WN, WK>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        attr_set = true;
     }
     hipLaunchKernelGGL((wgrad_kernel<NWT, KWT, WN, WK>), grid, dim3(256), lds, stream, p);
     return mmvae_check_launch("wgrad");
@@ -816,10 +815,9 @@ int launch_rowtile(const GemmParams& p, hipStream_t stream) {
     const int kc = min(round_up(max_k, 32), RT_KC);
     const size_t lds = (size_t)RT_R * (kc + 8) * sizeof(bf16) + (size_t)RT_R * (round_up(p.c.N, 16) + 4) * sizeof(float) +
                        (size_t)round_up(p.c.N, 16) * sizeof(float2);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned> attr_set{0};
+    if (mmvae_first_use_on_device(attr_set)) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rowtile_kernel<NTW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-        attr_set = true;
     }
     dim3 grid(max_tiles * p.c.groups, 1, p.c.nclasses);
     hipLaunchKernelGGL(gemm_rowtile_kernel<NTW>, grid, dim3(256), lds, stream, p);
@@ -834,13 +832,12 @@ int launch_gemm_nt(const GemmParams& p, hipStream_t stream) {
     const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
     dim3 grid(max_tiles * p.c.groups, ceil_div(p.c.N, BN) * ksplit, p.c.nclasses);
     size_t lds = (size_t)2 * (BM + BN) * LDA * sizeof(bf16);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned> attr_set{0};
+    if (mmvae_first_use_on_device(attr_set)) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_gather_kernel<NT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&splitk_finish_kernel<NT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        attr_set = true;
     }
     hipLaunchKernelGGL(gemm_gather_kernel<NT>, grid, dim3(256), lds, stream, p);
     MMVAE_TRY(mmvae_check_launch("gemm_gather"));

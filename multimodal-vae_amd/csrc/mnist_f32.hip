@@ -2,7 +2,7 @@
 //
 // Why this model gets its own precision.  It is Linear -> BatchNorm1d -> ReLU: ReLU makes the gradient discontinuous in
 // the operand rounding of a bf16 MFMA path (an fp32 run of the reference with ONLY its GEMM operands rounded to bf16
-// moves image_encoder.net.0.weight.grad by 12-32 %, scratch/sim_bf16_mnist.py), and the whole step is 1.4 GFLOP, i.e.
+// moves image_encoder.net.0.weight.grad by 12-32 %, tools/sim_bf16_mnist.py), and the whole step is 1.4 GFLOP, i.e.
 // launch-latency sized on this chip at any precision.  So the default MNIST plan computes exactly what the reference
 // computes: fp32 operands, fp32 MFMA (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulate), fp32 activations,
 // two-pass BatchNorm statistics.  Parity against the reference is then at fp32 level (tests/test_gpu_mnist.py).

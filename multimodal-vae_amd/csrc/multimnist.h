@@ -47,6 +47,7 @@ long long mm_gpk_vec_elems(const MMPlan*);
 int mm_ndesc(const MMPlan*); const PackDesc* mm_desc_host(const MMPlan*);
 int mm_ngdesc(const MMPlan*); const PackDesc* mm_gdesc_host(const MMPlan*);
 size_t mm_workspace_bytes(const MMPlan*);
+size_t mm_module_workspace_bytes(const MMPlan*);
 int mm_bind(MMPlan*, const MMBuffers&);
 int mm_pack_weights(MMPlan*, hipStream_t);
 int mm_grad_map(MMPlan*, int* map, hipStream_t);      // [param_count] see AdamArgs::gmap

@@ -170,7 +170,7 @@ void build_plan(MMPlan& P) {
 // ------------------------------------------------------------------ workspace
 void carve(MMPlan& P, Workspace& ws) {
     MMPlan::W& w = P.w;
-    const size_t B = P.B, D = P.D, B3 = 3 * B, B2 = 2 * B;
+    const size_t B = P.B, D = P.D, B3 = (size_t)P.carve_passes * B, B2 = (size_t)(P.carve_passes < 2 ? P.carve_passes : 2) * B;
     char* z0 = ws.take<char>(0);
     const int ec[3] = {64, 128, 256}, dc[3] = {128, 64, 32};
     const int SS = MMVAE_STAT_SLOTS;
@@ -563,6 +563,11 @@ MMPlan* mm_create(int D, int B) {
     Workspace ws(nullptr, 0);
     carve(*P, ws);
     P->ws_bytes = ws.used();
+    P->carve_passes = 1;
+    Workspace wm(nullptr, 0);
+    carve(*P, wm);
+    P->ws_bytes_module = wm.used();
+    P->carve_passes = 3;
     return P;
 }
 void mm_destroy(MMPlan* P) { delete P; }
@@ -579,6 +584,7 @@ const PackDesc* mm_desc_host(const MMPlan* P) { return P->pk.d.data(); }
 int mm_ngdesc(const MMPlan* P) { return (int)P->gk.d.size(); }
 const PackDesc* mm_gdesc_host(const MMPlan* P) { return P->gk.d.data(); }
 size_t mm_workspace_bytes(const MMPlan* P) { return P->ws_bytes; }
+size_t mm_module_workspace_bytes(const MMPlan* P) { return P->ws_bytes_module; }
 
 int mm_bind(MMPlan* P, const MMBuffers& b) {
     MMVAE_REQUIRE(b.params && b.grads && b.bn_stats && b.bn_nbt && b.packed && b.packed_vec && b.gpk && b.gpk_vec &&
@@ -587,9 +593,11 @@ int mm_bind(MMPlan* P, const MMBuffers& b) {
     P->bound = true;
     return MMVAE_OK;
 }
-static int use_ws(MMPlan* P, void* ws, size_t bytes) {
+static int use_ws(MMPlan* P, void* ws, size_t bytes, bool module = true) {
     MMVAE_TRY(check_bound(P));
-    MMVAE_REQUIRE(ws != nullptr && bytes >= P->ws_bytes, "workspace too small (%zu < %zu)", bytes, P->ws_bytes);
+    const size_t need = module ? P->ws_bytes_module : P->ws_bytes;
+    MMVAE_REQUIRE(ws != nullptr && bytes >= need, "workspace too small (%zu < %zu)", bytes, need);
+    P->carve_passes = module ? 1 : 3;
     Workspace w(ws, bytes);
     carve(*P, w);
     P->dec_skip_mask = 0;
@@ -612,8 +620,14 @@ static int zero_gpk(MMPlan* P, hipStream_t s) {
     return launch_fill_zero(P->buf.gpk, (size_t)P->gk.mat_elems * sizeof(float), s);
 }
 
+static int mm_step_body(MMPlan* Pp, const MMStepIO& io, int training, int do_backward, hipStream_t s);
 int mm_step_fwd_bwd(MMPlan* Pp, const MMStepIO& io, int training, int do_backward, hipStream_t s) {
-    MMVAE_TRY(use_ws(Pp, io.ws, io.ws_bytes));
+    const int rc = mm_step_body(Pp, io, training, do_backward, s);
+    if (rc != MMVAE_OK && Pp) join_after_error(*Pp, s);      // the message of the first error stays in mmvae_last_error
+    return rc;
+}
+static int mm_step_body(MMPlan* Pp, const MMStepIO& io, int training, int do_backward, hipStream_t s) {
+    MMVAE_TRY(use_ws(Pp, io.ws, io.ws_bytes, false));
     MMPlan& P = *Pp;
     MMPlan::W& w = P.w;
     const int B = P.B, D = P.D, B3 = 3 * B;
@@ -908,7 +922,7 @@ static double gemm_flops(const GemmParams& g) {
     return f;
 }
 int mm_bench_layer(MMPlan* P, void* ws, size_t wsb, const char* layer, int iters, hipStream_t s) {
-    MMVAE_TRY(use_ws(P, ws, wsb));
+    MMVAE_TRY(use_ws(P, ws, wsb, false));
     GemmParams g{};
     MMVAE_REQUIRE(layer_gemm(*P, layer, g), "bench_layer: unknown layer '%s'", layer);
     for (int i = 0; i < iters; ++i) MMVAE_TRY(launch_gemm_gather(g, s));
@@ -933,6 +947,7 @@ long long mm_bn_floats(const MMPlan* P) { return P->bn[5].stat_off + 2 * P->bn[5
 // ---------------------------------------------------------------- test aid: byte offset of a named workspace buffer
 long long mm_debug_offset(MMPlan* P, const char* name) {
     Workspace ws((void*)0x1000, (size_t)1 << 40);
+    P->carve_passes = 3;
     carve(*P, ws);
     MMPlan::W& w = P->w;
     std::map<std::string, const void*> m = {

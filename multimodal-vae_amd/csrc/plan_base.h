@@ -68,6 +68,10 @@ struct PlanBase {
     std::vector<std::string> bn_names;
     std::vector<BnL> bn_list;
     size_t ws_bytes = 0;
+    // the granular module entry points run ONE pass (groups = variants = 1): their workspace is carved for B rows where the
+    // fused step needs 3B / 2B (carve_passes = 1 instead of 3), mmvae_<family>_module_workspace_bytes
+    size_t ws_bytes_module = 0;
+    int carve_passes = 3;
     virtual ~PlanBase() {}
 };
 
@@ -330,7 +334,10 @@ inline int ensure_streams(PlanBase& P) {
         // several-fold (measured: 0.98 -> 2.78 ms per step with 7 streams).  Plans enqueue behind event edges, so sharing
         // streams between plans only serialises what would have been serialised anyway.
         static std::mutex mu;
-        static hipStream_t shared[3] = {nullptr, nullptr, nullptr};
+        static hipStream_t shared_dev[32][3] = {};                  // per device: a second device gets streams of its own
+        int cur_dev = 0;
+        (void)hipGetDevice(&cur_dev);
+        hipStream_t* shared = shared_dev[cur_dev & 31];
         std::lock_guard<std::mutex> g(mu);
         if (!shared[0]) {
             int least = 0, greatest = 0;
@@ -360,6 +367,23 @@ inline int ensure_streams(PlanBase& P) {
     if (one_wgrad || (P.single_wgrad_stream && !two_wgrad)) P.st_wgrad2 = P.st_wgrad;
     P.next_event = 0; P.wgrad_rr = 0;
     return MMVAE_OK;
+}
+
+// Error exit of a multi-stream step: whatever was already forked onto the side streams is joined back into the caller's
+// stream (so a caller that catches the error and frees or reuses the workspace does not race with work in flight) and
+// the per-step scheduling state is reset.  Best effort: failures of the join itself are not reported over the first error.
+inline void join_after_error(PlanBase& P, hipStream_t s) {
+    if (P.st_text) {
+        hipStream_t side[3] = {P.st_text, P.st_wgrad, P.st_wgrad2};
+        for (int i = 0; i < 3; ++i) {
+            if (!side[i] || side[i] == s || (i > 0 && side[i] == side[i - 1])) continue;
+            hipEvent_t e = next_ev(P);
+            if (hipEventRecord(e, side[i]) == hipSuccess) (void)hipStreamWaitEvent(s, e, 0);
+        }
+        (void)hipGetLastError();
+    }
+    P.deferred.clear();
+    P.defer_wgrad = false; P.wgrad_forked = false; P.no_splitk = false;
 }
 
 inline int check_bound(const PlanBase* P) {

@@ -69,8 +69,12 @@ class DeviceBatcher:
 
     Host: one index gather per batch into a pinned staging buffer (two of them, alternating).  Copy stream: async H2D of
     the uint8 pixels + the second modality.  Compute stream: waits for the copy event, then the u8->f32 kernel (ToTensor
-    on the device).  Batch i+1 is copied while batch i trains.  ``drop_last`` because the fused plans are built for a fixed
-    batch size."""
+    on the device).  Two hazards, kept apart so the host never waits for the GPU's compute stream: (1) the pinned staging
+    buffer of a slot is free once that slot's previous H2D copy has finished (host waits on ``ready[slot]``, a copy-stream
+    event two batches old); (2) the device buffers of a slot are free once the step that read them is done -- a
+    device-side edge (``copy_stream.wait_event(consumed[slot])``), no host synchronisation.  So the host runs a full
+    step ahead: batch i+1 is gathered and copied while batch i trains.  ``drop_last`` because the fused plans are built
+    for a fixed batch size."""
 
     def __init__(self, images_u8: torch.Tensor, text: torch.Tensor, batch_size: int, device: torch.device, shuffle: bool = True,
                  seed: int = 0):
@@ -92,26 +96,32 @@ class DeviceBatcher:
             call("mmvae_set_stream_policy", 1)
         except MMVAEError:
             import warnings
-            warnings.warn("DeviceBatcher created after the first fused step: the engine's side streams keep their low "
-                          "priority and every kernel runs slower while the copy stream is active; create the loader first")
+            warnings.warn("DeviceBatcher created after the engine's side streams: if they were created with the opt-in "
+                          "lowest priority (mmvae_set_stream_policy(0)) every kernel runs slower while the copy stream "
+                          "is active; create the loader first or keep the default (flat) priorities")
         self._images_np, self._text_np = images_u8.numpy(), text.numpy()
         self._stage_u8_np = [t.numpy() for t in self.stage_u8]
         self._stage_tx_np = [t.numpy() for t in self.stage_tx]
         self.copy_stream = torch.cuda.Stream(device=device)
         self.ready = [torch.cuda.Event() for _ in range(2)]
         self.consumed = [torch.cuda.Event() for _ in range(2)]
+        self._used = [False, False]
 
     def __len__(self) -> int:
         return len(self.images) // self.B
 
     def _stage(self, slot: int, idx: torch.Tensor) -> None:
-        self.consumed[slot].synchronize()                   # the previous user of this slot finished with the buffers
+        if self._used[slot]:
+            self.ready[slot].synchronize()                  # hazard 1: this slot's previous H2D copy left the pinned buffer
         # numpy's single-threaded take, NOT torch.index_select: next to a running HIP process the OpenMP team of a torch
         # CPU op took 8 ms per 640 kB gather on the GPU box (0.03 ms when nothing else runs) -- 8x the training step
         ix = idx.numpy()
         np.take(self._images_np, ix, axis=0, out=self._stage_u8_np[slot])
         np.take(self._text_np, ix, axis=0, out=self._stage_tx_np[slot])
         with torch.cuda.stream(self.copy_stream):
+            if self._used[slot]:
+                self.copy_stream.wait_event(self.consumed[slot])   # hazard 2: device-side edge, the host does not wait
+            self._used[slot] = True
             self.dev_u8[slot].copy_(self.stage_u8[slot], non_blocking=True)
             self.dev_tx[slot].copy_(self.stage_tx[slot], non_blocking=True)
             self.ready[slot].record(self.copy_stream)
@@ -137,8 +147,10 @@ class DeviceBatcher:
             import ctypes as C
             call("mmvae_u8_to_f32", ptr(self.dev_u8[slot]), self.dev_u8[slot].numel(), 255.0, ptr(self.dev_f32[slot]),
                  C.c_void_p(cur.cuda_stream))
-            yield self.dev_f32[slot], self.dev_tx[slot]
-            self.consumed[slot].record(cur)
+            try:
+                yield self.dev_f32[slot], self.dev_tx[slot]
+            finally:                                        # also when the consumer abandons the iterator at this batch
+                self.consumed[slot].record(cur)
 
 
 __all__ = ["save_multimnist", "load_multimnist", "synthetic_multimnist", "DeviceBatcher", "FILL"]

@@ -1,7 +1,17 @@
 """Data parallelism for the fused ELBO step: one process per GPU, replicated parameters / Adam state, per-rank
-BatchNorm statistics (standard DDP semantics: each rank is exactly the reference at batch B on its shard), and ONE
-sum all-reduce of the flat fp32 gradient buffer per step over RCCL/xGMI.  The 1/world_size factor is folded into the
-Adam kernel (``grad_scale``), so no extra elementwise pass touches the gradients.
+BatchNorm BATCH statistics (each rank normalises with its own shard, i.e. is exactly the reference at batch B on its
+shard), and a sum all-reduce of the flat fp32 gradient buffer per step over RCCL/xGMI.  The 1/world_size factor is folded
+into the Adam kernel (``grad_scale``), so no extra elementwise pass touches the gradients.
+
+BatchNorm RUNNING statistics (eval / checkpoints) are rank-local between synchronisation points: unlike
+torch DDP's ``broadcast_buffers=True`` nothing re-broadcasts them every forward.  ``sync_bn_buffers`` averages
+``running_mean`` / ``running_var`` over the ranks (and takes the max of ``num_batches_tracked``); the training drivers call
+it before every eval pass and checkpoint, and once at start-up after the parameter broadcast.
+
+``HSA_ENABLE_IPC_MODE_LEGACY=0`` (dmabuf IPC, the only mode this host driver supports) is read by the ROCr runtime at
+``hsa_init``: it must be in the environment BEFORE the first GPU call of the process.  ``ensure_ipc_env()`` sets it and
+must therefore run at the very top of a launcher script (bench.py, train.py do); ``init_distributed`` refuses to create
+an RCCL group when the variable is missing or wrong instead of failing later at the first all-reduce.
 
 The path has exactly one exchange step; everything else is rank-local.  Backend "nccl" is RCCL on ROCm;
 the CPU tests drive the same code with "gloo".
@@ -15,6 +25,11 @@ import torch
 import torch.distributed as dist
 
 
+def ensure_ipc_env() -> None:
+    """Call before anything touches the GPU (``torch.cuda.set_device`` included)."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
 def init_distributed(backend: Optional[str] = None, device: Optional[torch.device] = None) -> tuple:
     """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torch.distributed.run) and creates the default group."""
     rank = int(os.environ.get("RANK", "0"))
@@ -22,8 +37,11 @@ def init_distributed(backend: Optional[str] = None, device: Optional[torch.devic
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this host driver
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        if backend == "nccl" and os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0":
+            # setting it here would be a no-op: the HSA runtime read it when the process first touched the GPU
+            raise RuntimeError("HSA_ENABLE_IPC_MODE_LEGACY=0 must be exported before the first GPU call "
+                               "(dp.ensure_ipc_env() at the top of the launcher, or the torchrun environment)")
         kw = {}
         if backend == "nccl" and device is not None:
             kw["device_id"] = device
@@ -53,6 +71,14 @@ def broadcast_flat(flat: torch.Tensor, src: int = 0, group=None) -> None:
     """Make every replica start from rank ``src``'s parameters / buffers."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.broadcast(flat, src=src, group=group)
+
+
+def sync_bn_buffers(bn_stats: torch.Tensor, bn_nbt: torch.Tensor, group=None) -> None:
+    """Average the BatchNorm running statistics over the ranks (num_batches_tracked: max), in place."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(bn_stats, group=group)
+        bn_stats.div_(dist.get_world_size(group))
+        dist.all_reduce(bn_nbt, op=dist.ReduceOp.MAX, group=group)
 
 
 def rank_seed(base: int, rank: int) -> int:

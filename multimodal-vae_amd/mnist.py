@@ -28,7 +28,7 @@ def _run_module(mod: nn.Module, prefix: str, x: torch.Tensor, out_shape, name: s
     if mod.training and B <= 1:
         raise ValueError("Expected more than 1 value per channel when training")
     h = st.plan(B)
-    wsb = st.workspace_bytes(B)
+    wsb = st.module_workspace_bytes(B)
     training = int(mod.training)
     names = [prefix + k for k, _ in mod.named_parameters()]
     plist = [p for _, p in mod.named_parameters()]

@@ -219,7 +219,7 @@ class ImageEncoder(nn.Module):
         if self.training and B * 625 <= 1:
             raise ValueError("Expected more than 1 value per channel when training")
         h = st.plan(B)
-        wsb = st.workspace_bytes(B)
+        wsb = st.module_workspace_bytes(B)
         p1, p2 = self.classifier[2].p, self.classifier[5].p
         m1 = m2 = None
         if self.training and (p1 > 0 or p2 > 0):
@@ -276,7 +276,7 @@ class ImageDecoder(nn.Module):
         if self.training and B * 36 <= 1:
             raise ValueError("Expected more than 1 value per channel when training")
         h = st.plan(B)
-        wsb = st.workspace_bytes(B)
+        wsb = st.module_workspace_bytes(B)
         training = int(self.training)
         names = ["image_decoder." + k for k, _ in self.named_parameters()]
         plist = [p for _, p in self.named_parameters()]
@@ -321,7 +321,7 @@ class TextEncoder(nn.Module):
         B = x.shape[0]
         assert x.shape == (B, max_length)
         h = st.plan(B)
-        wsb = st.workspace_bytes(B)
+        wsb = st.module_workspace_bytes(B)
         names = ["text_encoder." + k for k, _ in self.named_parameters()]
         plist = [p for _, p in self.named_parameters()]
 
@@ -365,7 +365,7 @@ class TextDecoder(nn.Module):
         z = z.contiguous().float()
         B = z.shape[0]
         h = st.plan(B)
-        wsb = st.workspace_bytes(B)
+        wsb = st.module_workspace_bytes(B)
         training = int(self.training)
         pdrop = self.gru.dropout
         if self.training and pdrop > 0:
@@ -525,6 +525,12 @@ class MultimodalVAE(nn.Module):
 # ----------------------------------------------------------------------------------------------------------------
 # loss_function (multimnist/train.py:69-87)
 # ----------------------------------------------------------------------------------------------------------------
+def _gscale(g: torch.Tensor) -> torch.Tensor:
+    """The upstream gradient of a 0-d loss as a contiguous fp32 device scalar: the backward kernels read it themselves
+    (a host ``.item()`` here would synchronise the stream three times per loss_function call)."""
+    return g.detach().reshape(1).to(torch.float32).contiguous()
+
+
 class _BCEMeanFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, p, t):
@@ -538,7 +544,7 @@ class _BCEMeanFn(torch.autograd.Function):
     def backward(ctx, g):
         p, t = ctx.saved_tensors
         dp = torch.empty_like(p)
-        call("mmvae_bce_bwd", ptr(p), ptr(t), p.numel(), float(g.item()) / p.numel(), ptr(dp), _stream())
+        call("mmvae_bce_bwd", ptr(p), ptr(t), p.numel(), 1.0 / p.numel(), ptr(_gscale(g)), ptr(dp), _stream())
         return dp, None
 
 
@@ -556,7 +562,7 @@ class _NLLMeanFn(torch.autograd.Function):
     def backward(ctx, g):
         rows, classes = ctx.shape
         d = torch.empty(rows, classes, dtype=torch.float32, device=ctx.target.device)
-        call("mmvae_nll_bwd", ptr(ctx.target), rows, classes, float(g.item()) / rows, ptr(d), _stream())
+        call("mmvae_nll_bwd", ptr(ctx.target), rows, classes, 1.0 / rows, ptr(_gscale(g)), ptr(d), _stream())
         return d, None
 
 
@@ -573,7 +579,7 @@ class _KLSumFn(torch.autograd.Function):
     def backward(ctx, g):
         mu, logvar = ctx.saved_tensors
         dmu = torch.empty_like(mu); dlv = torch.empty_like(mu)
-        call("mmvae_kl_bwd", ptr(mu), ptr(logvar), mu.numel(), float(g.item()), ptr(dmu), ptr(dlv), _stream())
+        call("mmvae_kl_bwd", ptr(mu), ptr(logvar), mu.numel(), 1.0, ptr(_gscale(g)), ptr(dmu), ptr(dlv), _stream())
         return dmu, dlv
 
 

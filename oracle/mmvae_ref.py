@@ -797,6 +797,12 @@ def formula_inputs(model: str, B: int, seed: int = 0):
     raise ValueError(model)
 
 
+def sample_idx(n: int, k: int = 32):
+    """Evenly spread sample positions of a flat tensor (fixtures store gradient samples at these positions)."""
+    import numpy as np
+    return np.unique(np.linspace(0, n - 1, num=min(k, n)).astype(np.int64))
+
+
 def formula_eps(B: int, D: int, k: int) -> Tensor:
     """Deterministic stand-in for N(0,1) draws: a smooth, roughly unit-variance field."""
     i = torch.arange(B * D, dtype=torch.float64)

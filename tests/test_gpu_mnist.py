@@ -10,7 +10,7 @@ model is Linear -> BatchNorm1d -> ReLU and ReLU makes the gradient DISCONTINUOUS
 operands, bf16 stored activations; fp32 accumulation):
   (1) against the reference's fp32 numbers (golden fixtures): ELBO losses rel 1e-3 (north-star bound), mu/logvar abs
       6e-2, total gradient norm rel 0.25 -- the bound is what an fp32 run of the reference itself moves by when only its
-      GEMM operands are rounded to bf16 (scratch/sim_bf16_mnist.py: net.0.weight of the image encoder moves by 12-32 %);
+      GEMM operands are rounded to bf16 (tools/sim_bf16_mnist.py: net.0.weight of the image encoder moves by 12-32 %);
   (2) against the oracle run under ``bf16_contract`` (same algorithm, same roundings at the same places): per-tensor
       gradient rel-L2 3e-2 (+ 2e-4 of the total norm), total norm rel 1e-2, mu/logvar abs 1e-2 -- this is the check
       that catches implementation errors.
