@@ -215,7 +215,7 @@ class _FusedStepBase:
         self.state, self.B, self.D = state, int(batch), state.n_latents
         self.lr, self.betas, self.eps, self.seed = lr, betas, eps, seed
         self.world_size, self.all_reduce = world_size, all_reduce
-        if all_reduce is not None and world_size > 1:
+        if all_reduce is not None and (world_size > 1 or getattr(all_reduce, "force", False)):
             # the collective library may enqueue on a stream of its own: mixed stream priorities then slow the whole
             # process down (include/mmvae_hip.h: mmvae_set_stream_policy)
             call("mmvae_set_stream_policy", 1)
@@ -247,11 +247,16 @@ class _FusedStepBase:
     def optimizer_step(self) -> None:
         """torch.optim.Adam(lr) semantics on the flat buffers, then refresh the packed bf16 weights."""
         st = self.state
-        if self.all_reduce is not None and self.world_size > 1:
+        if self._dp_active():
             self.all_reduce(st.grads)                                  # sum over ranks (RCCL), scaled inside Adam
         call("mmvae_adam_step", ptr(st.params), ptr(st.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq), st.nparams,
              ptr(self.adam_state), self.lr, self.betas[0], self.betas[1], self.eps, 1.0 / self.world_size, _stream())
         st.pack_weights()
+
+    def _dp_active(self) -> bool:
+        """The data-parallel exchange is on: more than one rank, or a collective that asks to run even on one rank
+        (``all_reduce.force``: the single-rank RCCL test that puts this branch on hardware)."""
+        return self.all_reduce is not None and (self.world_size > 1 or bool(getattr(self.all_reduce, "force", False)))
 
     def __call__(self, a, b, **kw) -> StepOutputs:
         out = self.forward_backward(a, b, True, True, **kw)
@@ -262,7 +267,7 @@ class _FusedStepBase:
         """backward + optimizer.step() (multimnist/train.py:168,173) in one pass over the parameters: the GEMM-weight
         gradients stay in their packed layout and the Adam kernel gathers them (and completes ``grads``) itself.  The
         data-parallel path needs the complete flat gradient BEFORE Adam (all-reduce), so it keeps the separate unpack."""
-        if (self.all_reduce is not None and self.world_size > 1) or _os.environ.get("MMVAE_SEPARATE_UNPACK"):
+        if self._dp_active() or _os.environ.get("MMVAE_SEPARATE_UNPACK"):
             return _FusedStepBase.__call__(self, a, b, **kw)
         st = self.state
         out = self.forward_backward(a, b, True, True, _defer_unpack=True, **kw)

@@ -958,6 +958,7 @@ long long mm_debug_offset(MMPlan* P, const char* name) {
         {"dy1", w.dy1}, {"db4", w.db4}, {"dr4", w.dr4}, {"d3e", w.d3e}, {"d2e", w.d2e}, {"d1e", w.d1e},
         {"aff_d0", w.aff_d[0]}, {"aff_d1", w.aff_d[1]}, {"aff_d2", w.aff_d[2]}, {"st_d0", w.st_d[0]}, {"patches4", w.patches4},
         {"tmp_f32", w.tmp_f32}, {"aff_e0", w.aff_e[0]}, {"aff_e1", w.aff_e[1]}, {"aff_e2", w.aff_e[2]},
+        {"eps", w.eps}, {"m1", w.m1}, {"m2", w.m2}, {"gkeep", w.gkeep},
     };
     auto it = m.find(name);
     if (it == m.end()) return -1;

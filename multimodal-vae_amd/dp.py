@@ -53,12 +53,13 @@ class GradAllReduce:
     """Callable handed to ``FusedELBOStep(all_reduce=...)``: in-place SUM over ranks of the flat gradient buffer,
     enqueued on the current stream (RCCL) -- the engine scales by 1/world inside Adam."""
 
-    def __init__(self, group=None, bucket_bytes: int = 0):
+    def __init__(self, group=None, bucket_bytes: int = 0, force: bool = False):
         self.group = group
         self.bucket_elems = bucket_bytes // 4
+        self.force = force          # issue the collective even in a group of one rank (single-GPU RCCL test)
 
     def __call__(self, flat: torch.Tensor) -> None:
-        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+        if not dist.is_initialized() or (dist.get_world_size(self.group) == 1 and not self.force):
             return
         if self.bucket_elems and flat.numel() > self.bucket_elems:
             for i in range(0, flat.numel(), self.bucket_elems):            # xGMI ring is per-link bound: a few large

@@ -401,12 +401,14 @@ class TextDecoder(nn.Module):
         return _ModuleFn.apply(fwd, bwd, 1, z, *plist)
 
     def generate(self, z):
-        """multimnist/model.py:290-296.  NB the reference samples ``torch.multinomial`` from LOG-probabilities
-        (negative weights): like the reference under a modern torch, this raises -- kept as is."""
+        """multimnist/model.py:290-296.  NB the reference samples ``torch.multinomial`` from LOG-probabilities (weights
+        <= 0): under a modern torch that raises ("probability tensor contains ... element < 0"), and so does this method.
+        The sampler runs on a host copy of the (B*4, 12) log-probabilities: on the GPU the same check is a device-side
+        assertion that aborts the whole process instead of raising."""
         words = self.forward(z)
         batch_size, char_size = words.size(0), words.size(2)
-        sample = torch.multinomial(words.view(-1, char_size), 1)
-        return sample.view(batch_size, max_length)
+        sample = torch.multinomial(words.detach().cpu().view(-1, char_size), 1)
+        return sample.view(batch_size, max_length).to(words.device)
 
 
 class _PoEFn(torch.autograd.Function):
