@@ -88,6 +88,9 @@ typedef struct {
                                              * modal_weak.py:87-117): no loss, no gradient, no BatchNorm running update */
     int defer_unpack;                       /* 1: GEMM-weight gradients stay in the packed buffers for mmvae_adam_step_packed
                                              * (loss.backward() + optimizer.step() of multimnist/train.py:168,173 in one pass) */
+    int pack_first;                         /* 1: the step's prologue launch also refreshes the packed bf16 weights from the
+                                             * parameters (what mmvae_mm_pack_weights does): set it after an optimizer step
+                                             * instead of calling mmvae_mm_pack_weights -- one launch less on the step's chain */
 } mmvae_mm_step_io;
 int mmvae_mm_step(mmvae_mm_t*, const mmvae_mm_step_io*, int training, int do_backward, void* stream);
 
@@ -112,7 +115,10 @@ int mmvae_mm_text_decoder_bwd(mmvae_mm_t*, void* ws, size_t ws_bytes, const floa
                               const float* d_words, float* dz, void* stream);
 /* Runs one named GEMM of the step `iters` times on the workspace contents of the last step (profiling aid). */
 int mmvae_mm_bench_layer(mmvae_mm_t*, void* ws, size_t ws_bytes, const char* layer, int iters, void* stream);
-double mmvae_mm_layer_flops(const mmvae_mm_t*, const char* layer);
+double mmvae_mm_layer_flops(const mmvae_mm_t*, const char* layer);        /* executed: 2*rows*N*K, zero-padded taps included */
+double mmvae_mm_layer_algo_flops(const mmvae_mm_t*, const char* layer);   /* algorithmic: the FlopCounterMode count of the reference layer */
+/* measurement aid: GEMM FLOPs enqueued by this process since the last reset (counted on the host by the launchers) */
+double mmvae_debug_flops(int reset);
 /* test aid: byte offset of a named intermediate inside the workspace (-1 if unknown) */
 long long mmvae_mm_debug_offset(mmvae_mm_t*, const char* name);
 

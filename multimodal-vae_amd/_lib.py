@@ -27,6 +27,7 @@ class StepIO(C.Structure):
         ("mu", C.c_void_p), ("logvar", C.c_void_p), ("tokens", C.c_void_p),
         ("pass_skip", C.c_int * 3),
         ("defer_unpack", C.c_int),
+        ("pack_first", C.c_int),
     ]
 
 
@@ -117,6 +118,8 @@ SIGNATURES = {
     "mmvae_mm_text_decoder_bwd": (_I, [_P, _P, _SZ, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mmvae_mm_bench_layer": (_I, [_P, _P, _SZ, C.c_char_p, _I, _P]),
     "mmvae_mm_layer_flops": (C.c_double, [_P, C.c_char_p]),
+    "mmvae_mm_layer_algo_flops": (C.c_double, [_P, C.c_char_p]),
+    "mmvae_debug_flops": (C.c_double, [_I]),
     "mmvae_mm_debug_offset": (_LL, [_P, C.c_char_p]),
     "mmvae_poe_fwd": (_I, [_P, _P, _I, _I, _P, _P, _P]),
     "mmvae_poe_bwd": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P]),

@@ -113,6 +113,15 @@ class PlanState:
 
     def pack_weights(self) -> None:
         self._c("pack_weights", self.plan(1), _stream())
+        self.pack_pending = False
+
+    pack_pending = False        # the parameters changed and the bf16 GEMM copies were not refreshed yet
+
+    def ensure_packed(self) -> None:
+        """Refresh the packed weights if an optimizer step deferred it (the MultiMNIST fused step folds the refresh into
+        its own prologue launch; everybody else who reads the packed weights calls this first)."""
+        if self.pack_pending:
+            self.pack_weights()
 
     def view(self, name: str) -> torch.Tensor:
         for n, shape, off in self.table:
@@ -251,7 +260,15 @@ class _FusedStepBase:
             self.all_reduce(st.grads)                                  # sum over ranks (RCCL), scaled inside Adam
         call("mmvae_adam_step", ptr(st.params), ptr(st.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq), st.nparams,
              ptr(self.adam_state), self.lr, self.betas[0], self.betas[1], self.eps, 1.0 / self.world_size, _stream())
-        st.pack_weights()
+        self._after_update()
+
+    _DEFER_PACK = False         # the family's step prologue can refresh the packed weights itself (pack_first)
+
+    def _after_update(self) -> None:
+        if self._DEFER_PACK and not _os.environ.get("MMVAE_EAGER_PACK"):
+            self.state.pack_pending = True
+        else:
+            self.state.pack_weights()
 
     def _dp_active(self) -> bool:
         """The data-parallel exchange is on: more than one rank, or a collective that asks to run even on one rank
@@ -274,7 +291,7 @@ class _FusedStepBase:
         call("mmvae_adam_step_packed", ptr(st.params), ptr(st.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq), st.nparams,
              ptr(self.adam_state), self.lr, self.betas[0], self.betas[1], self.eps, 1.0, ptr(st.grad_map()), ptr(st.gpk),
              ptr(st.gpk_vec), _stream())
-        st.pack_weights()
+        self._after_update()
         return out
 
     # -- HIP graph ------------------------------------------------------------------------------------
@@ -303,6 +320,7 @@ class FusedELBOStep(_FusedStepBase):
 
     LAMBDA_XY = (1.0, 1.0, 0.0)
     LAMBDA_YX = (1.0, 0.5, 1.0)
+    _DEFER_PACK = True
 
     def __init__(self, state: PlanState, batch: int, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  kl_lambda: float = 1e-3, seed: int = 1234, world_size: int = 1, all_reduce=None):
@@ -337,8 +355,10 @@ class FusedELBOStep(_FusedStepBase):
         io.seed = self.seed
         io.sums = self.sums.data_ptr()
         io.defer_unpack = int(bool(_defer_unpack))
+        io.pack_first = int(self.state.pack_pending)
         # optimizer.zero_grad() (train.py:150) happens inside the step's prologue kernel when backward is requested
         call("mmvae_mm_step", self.h, C.byref(io), int(training), int(backward), _stream())
+        self.state.pack_pending = False
         return self._outputs()
 
     def __call__(self, image, text, **kw) -> StepOutputs:

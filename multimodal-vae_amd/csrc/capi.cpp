@@ -193,6 +193,7 @@ int mmvae_mm_step(mmvae_mm_t* p, const mmvae_mm_step_io* io, int training, int d
     s.mu = io->mu; s.logvar = io->logvar; s.tokens = io->tokens;
     for (int k = 0; k < 3; ++k) s.pass_skip[k] = io->pass_skip[k];
     s.defer_unpack = io->defer_unpack;
+    s.pack_first = io->pack_first;
     return mm_step_fwd_bwd(p, s, training, do_backward, S(stream));
     API_GUARD_END
 }
@@ -245,6 +246,7 @@ int mmvae_mm_bench_layer(mmvae_mm_t* p, void* ws, size_t wsb, const char* layer,
     API_GUARD_END
 }
 double mmvae_mm_layer_flops(const mmvae_mm_t* p, const char* layer) { return mm_layer_flops(p, layer); }
+double mmvae_mm_layer_algo_flops(const mmvae_mm_t* p, const char* layer) { return mm_layer_algo_flops(p, layer); }
 long long mmvae_mm_debug_offset(mmvae_mm_t* p, const char* name) { return mm_debug_offset(p, name); }
 
 // ---- MNIST (mnist/model.py, mnist/train.py)

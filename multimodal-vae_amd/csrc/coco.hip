@@ -336,8 +336,7 @@ int dec_bwd(CocoPlan& P, const float* dlogit, int groups, float* dz, hipStream_t
         x.dgamma = P.buf.grads + b.w_off; x.dbeta = P.buf.grads + b.b_off;
         MMVAE_TRY(launch_bn_bwd_apply(x, s));
         {
-            WgradParams g = wgrad_of(P, L.fwd, L.gk, groups, B);
-            g.c.A = aq[l]; g.P = dq[l + 1]; g.ldp = L.g.Cout;
+            WgradParams g = convT_wgrad(P, L, groups, B, aq[l], dq[l + 1]);
             MMVAE_TRY(wgrad_async(P, g, s));
         }
         {

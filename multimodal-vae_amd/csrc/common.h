@@ -20,6 +20,8 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 // thread-local last error (include/mmvae_hip.h: mmvae_last_error)
 void mmvae_set_error(const char* fmt, ...);
 int mmvae_check_launch(const char* what);
+// measurement aid (mmvae_debug_flops): executed GEMM work, counted by the launchers on the host
+void mmvae_count_flops(double flops);
 // side-stream priority policy (include/mmvae_hip.h: mmvae_set_stream_policy); -1 until somebody asked
 int mmvae_stream_policy();
 void mmvae_stream_policy_freeze();      // the side streams exist from here on

@@ -121,6 +121,8 @@ struct Latent3BwdArgs {
     bf16* d_txt_out_bf;      // optional bf16 copy [B][2D]
     float* d_txt_bias;       // optional [2D] += column sums of the text-encoder output gradient
     float* d_img_out_f32;    // optional fp32 [B][2D] = pass-1 + pass-2 gradient (then d_img_out_bf is not written)
+    const float* loss_slots; // optional: the step's [MMVAE_LOSS_SLOTS][16] loss accumulators, summed into loss_out[16] by block 0
+    float* loss_out;         // (every loss term must be final when this kernel starts: saves the separate sum_slots launch)
 };
 int launch_latent3_bwd(const Latent3BwdArgs& a, hipStream_t s);
 
@@ -151,8 +153,12 @@ struct StepBeginArgs {
     uint8_t* mask[3]; long long n_mask[3];        // null -> not drawn
     float p;
     unsigned long long seed; const long long* step;
+    // optional: the weight pack of the previous optimizer step rides in the same launch (step_begin_with_pack)
+    const PackDesc* pack_table; int pack_nd; const float* pack_params; bf16* packed_bf; float* packed_f32; int pack_blocks;
 };
 int launch_step_begin(const StepBeginArgs& a, hipStream_t s);
+int step_begin_with_pack(StepBeginArgs& a, const PackDesc* table_dev, const PackDesc* table_host, int nd, const float* params,
+                         bf16* packed_bf, float* packed_f32);
 
 // ---- small ops of the MLP models (mnist/model.py:136-170) ----
 // x[r][:] = table[idx[r % idx_rows]][:] as bf16 rows of stride ld (pad columns zero) + BatchNorm column statistics

@@ -1,5 +1,6 @@
 // Streaming kernels (HBM/L2 bound; 16-B vector accesses, wave reductions + one atomic per block).
 #include "elementwise.h"
+#include "bn_dev.h"
 #include <math.h>
 
 namespace {
@@ -38,12 +39,12 @@ __device__ __forceinline__ long long pack_src(const PackDesc& d, int n, int k) {
 }
 
 // one thread = 8 consecutive columns of one packed row (16-byte bf16 store); Kpad is a multiple of 8
-__global__ __launch_bounds__(TPB) void pack_kernel(const PackDesc* __restrict__ table, int nd, const float* __restrict__ params,
-                                                   bf16* __restrict__ packed_bf, float* __restrict__ packed_f32) {
-    const int di = find_desc(table, nd, blockIdx.x);
+__device__ __forceinline__ void pack_block(const PackDesc* __restrict__ table, int nd, const float* __restrict__ params,
+                                           bf16* __restrict__ packed_bf, float* __restrict__ packed_f32, int block) {
+    const int di = find_desc(table, nd, block);
     const PackDesc d = table[di];
     // 32-bit index math with reciprocal divisions (packed matrices have < 2^23 vectors; launch_pack checks)
-    const int v = (int)(blockIdx.x - d.first_block) * TPB + threadIdx.x;
+    const int v = (int)(block - d.first_block) * TPB + threadIdx.x;
     const int vpr = d.Kpad / 8;
     if (v >= d.Npad * vpr) return;
     int kv;
@@ -86,6 +87,11 @@ __global__ __launch_bounds__(TPB) void pack_kernel(const PackDesc* __restrict__ 
 
 // MAP = false: grads[flat] += packed value.  MAP = true: map[flat] = where that value lives (index into gmat, or
 // -(index + 2) into gvec) -- built once per plan for the optimizer kernel that consumes the packed gradients directly.
+__global__ __launch_bounds__(TPB) void pack_kernel(const PackDesc* __restrict__ table, int nd, const float* __restrict__ params,
+                                                   bf16* __restrict__ packed_bf, float* __restrict__ packed_f32) {
+    pack_block(table, nd, params, packed_bf, packed_f32, blockIdx.x);
+}
+
 template <bool MAP>
 __global__ __launch_bounds__(TPB) void unpack_kernel(const PackDesc* __restrict__ table, int nd, const float* __restrict__ gmat,
                                                      const float* __restrict__ gvec, float* __restrict__ grads, int* __restrict__ map) {
@@ -210,26 +216,6 @@ __global__ void bn_finalize_kernel(const BnFinalizeArgs a) {
 }
 
 // ------------------------------------------------------------------ BatchNorm finalize + normalise + activation
-__device__ __forceinline__ void bn_channel_tables(const BnFinalizeArgs& a, int g, int c, float2& aff, float2& mr) {
-    const float gamma = a.gamma[c], beta = a.beta[c];
-    float mean, rstd;
-    if (a.training) {
-        float2 s = make_float2(0.f, 0.f);
-        for (int q = 0; q < MMVAE_STAT_SLOTS; ++q) {
-            float2 t = a.stats[(g * MMVAE_STAT_SLOTS + q) * a.C + c];
-            s.x += t.x; s.y += t.y;
-        }
-        mean = s.x / a.count;
-        float var = fmaxf(s.y / a.count - mean * mean, 0.f);
-        rstd = rsqrtf(var + a.eps);
-    } else {
-        mean = a.running_mean[c];
-        rstd = rsqrtf(a.running_var[c] + a.eps);
-    }
-    aff = make_float2(gamma * rstd, beta - mean * gamma * rstd);
-    mr = make_float2(mean, rstd);
-}
-
 __global__ __launch_bounds__(TPB) void bn_act_kernel(const BnActArgs a) {
     extern __shared__ float2 aff_s[];        // [G][C]
     const BnFinalizeArgs& f = a.fin;
@@ -239,30 +225,7 @@ __global__ __launch_bounds__(TPB) void bn_act_kernel(const BnActArgs a) {
         aff_s[i] = aff;
         if (blockIdx.x == 0) { f.affine[i] = aff; f.meanrstd[i] = mr; }
     }
-    if (blockIdx.x == 0 && f.training && f.running_mean) {
-        // running statistics: momentum update once per forward call, groups in pass order
-        for (int c = threadIdx.x; c < a.C; c += TPB) {
-            float rm = f.running_mean[c], rv = f.running_var[c];
-            for (int g = 0; g < a.G; ++g) {
-                float2 s = make_float2(0.f, 0.f);
-                for (int q = 0; q < MMVAE_STAT_SLOTS; ++q) {
-                    float2 t = f.stats[(g * MMVAE_STAT_SLOTS + q) * a.C + c];
-                    s.x += t.x; s.y += t.y;
-                }
-                float mean = s.x / f.count;
-                float var = fmaxf(s.y / f.count - mean * mean, 0.f);
-                float unbiased = var * f.count / (f.count - 1.f);
-                const int nu = ((f.skip_update_mask >> g) & 1u) ? 0 : f.updates_per_group;
-                for (int u = 0; u < nu; ++u) {
-                    rm = (1.f - f.momentum) * rm + f.momentum * mean;
-                    rv = (1.f - f.momentum) * rv + f.momentum * unbiased;
-                }
-            }
-            f.running_mean[c] = rm; f.running_var[c] = rv;
-        }
-        if (threadIdx.x == 0 && f.num_batches_tracked)
-            *f.num_batches_tracked += (long long)(a.G - __popc(f.skip_update_mask & ((1u << a.G) - 1u))) * f.updates_per_group;
-    }
+    if (blockIdx.x == 0) bn_running_update(f, threadIdx.x, TPB);
     __syncthreads();
     const int vpr = (a.C + 7) / 8;           // C need not be a multiple of 8: pad columns (< ld) are written as zero
     const long long nvec = (long long)a.rows * vpr;
@@ -489,7 +452,13 @@ __global__ __launch_bounds__(TPB) void keep_mask_kernel(uint8_t* out, long long 
 
 // ------------------------------------------------------------------ step prologue: zeroing + RNG in one launch
 __global__ __launch_bounds__(TPB) void step_begin_kernel(const StepBeginArgs a) {
-    const long long gtid = (long long)blockIdx.x * TPB + threadIdx.x, gstride = (long long)gridDim.x * TPB;
+    // the first pack_blocks workgroups refresh the bf16 GEMM copies of the weights (what pack_kernel does: after an
+    // optimizer step); the others zero the accumulators and draw the step's random numbers -- independent work, one launch
+    if ((int)blockIdx.x < a.pack_blocks) {
+        pack_block(a.pack_table, a.pack_nd, a.pack_params, a.packed_bf, a.packed_f32, blockIdx.x);
+        return;
+    }
+    const long long gtid = (long long)(blockIdx.x - a.pack_blocks) * TPB + threadIdx.x, gstride = (long long)(gridDim.x - a.pack_blocks) * TPB;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         if (!a.zero_ptr[r]) continue;
@@ -587,71 +556,89 @@ __global__ __launch_bounds__(TPB) void latent3_fwd_kernel(const Latent3Args a) {
     }
 }
 
+// Thread (tx, ty) of a 64 x 4 block: latent column d = 64*blockIdx.x + tx, sample rows b = L3B_ROWS*blockIdx.y + ty + 4*i.
+// The bias gradients (column sums over the batch) are reduced in registers and through LDS: ONE atomic per column per block
+// (the first version issued 4 atomics per element onto 2D addresses: same-address float atomics serialise at the memory
+// side, 16 us for a 25k-element kernel on the main chain).  Block (0,0) also folds the step's loss slots into io.sums.
+constexpr int L3B_ROWS = 4;     // one row per thread: B/4 x ceil(D/64) workgroups (the kernel is a latency chain on the main stream)
 __global__ __launch_bounds__(TPB) void latent3_bwd_kernel(const Latent3BwdArgs a) {
     const Latent3Args& f = a.f;
     const int n = f.B * f.D, D2 = 2 * f.D;
-    const int i = blockIdx.x * TPB + threadIdx.x;
-    if (i >= n) return;
-    const int b = i / f.D, d = i - b * f.D;
-    const float im0 = f.img_out[(size_t)b * D2 + d], il0 = f.img_out[(size_t)b * D2 + f.D + d];
-    const float* img_b = f.img_out_b ? f.img_out_b : f.img_out + (size_t)f.B * D2;
-    const float im1 = img_b[(size_t)b * D2 + d], il1 = img_b[(size_t)b * D2 + f.D + d];
-    const float tm = f.txt_out[(size_t)b * D2 + d], tl = f.txt_out[(size_t)b * D2 + f.D + d];
-    float gmu[3], glv[3];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int d = blockIdx.x * 64 + tx;
+    __shared__ float red[4][4][64];
+    if (a.loss_slots && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 16) {
+        float t = 0.f;
+        for (int q = 0; q < MMVAE_LOSS_SLOTS; ++q) t += a.loss_slots[q * 16 + threadIdx.x];
+        a.loss_out[threadIdx.x] = t;
+    }
+    float s_im = 0.f, s_il = 0.f, s_tm = 0.f, s_tl = 0.f;
+    const int b_end = min(f.B, (int)(blockIdx.y + 1) * L3B_ROWS);
+    if (d < f.D)
+    for (int b = blockIdx.y * L3B_ROWS + ty; b < b_end; b += 4) {
+        const int i = b * f.D + d;
+        const float im0 = f.img_out[(size_t)b * D2 + d], il0 = f.img_out[(size_t)b * D2 + f.D + d];
+        const float* img_b = f.img_out_b ? f.img_out_b : f.img_out + (size_t)f.B * D2;
+        const float im1 = img_b[(size_t)b * D2 + d], il1 = img_b[(size_t)b * D2 + f.D + d];
+        const float tm = f.txt_out[(size_t)b * D2 + d], tl = f.txt_out[(size_t)b * D2 + f.D + d];
+        float gmu[3], glv[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const size_t e = (size_t)k * n + i;
-        float dz = 0.f;
-        if (a.dz_a) dz += a.dz_a[e];
-        if (a.dz_b) dz += a.dz_b[e];
-        const float mu = f.mu[e], lv = f.logvar[e];
-        gmu[k] = dz + a.kl_coef[k] * mu;
-        glv[k] = -0.5f * a.kl_coef[k] * (1.0f - expf(lv));
-        if (f.training) glv[k] += dz * f.eps[e] * 0.5f * expf(0.5f * lv);
+        for (int k = 0; k < 3; ++k) {
+            const size_t e = (size_t)k * n + i;
+            float dz = 0.f;
+            if (a.dz_a) dz += a.dz_a[e];
+            if (a.dz_b) dz += a.dz_b[e];
+            const float mu = f.mu[e], lv = f.logvar[e];
+            gmu[k] = dz + a.kl_coef[k] * mu;
+            glv[k] = -0.5f * a.kl_coef[k] * (1.0f - expf(lv));
+            if (f.training) glv[k] += dz * f.eps[e] * 0.5f * expf(0.5f * lv);
+        }
+        float d_im0, d_il0, d_im1, d_il1, d_tm = 0.f, d_tl = 0.f;
+        {
+            float m[2] = {im0, tm}, l[2] = {il0, tl}, dm[2], dl[2];
+            poe_bwd_m<2>(m, l, gmu[0], glv[0], dm, dl);
+            d_im0 = dm[0]; d_il0 = dl[0]; d_tm += dm[1]; d_tl += dl[1];
+        }
+        {
+            float m[1] = {im1}, l[1] = {il1}, dm[1], dl[1];
+            poe_bwd_m<1>(m, l, gmu[1], glv[1], dm, dl);
+            d_im1 = dm[0]; d_il1 = dl[0];
+        }
+        {
+            float m[1] = {tm}, l[1] = {tl}, dm[1], dl[1];
+            poe_bwd_m<1>(m, l, gmu[2], glv[2], dm, dl);
+            d_tm += dm[0]; d_tl += dl[0];
+        }
+        if (a.d_img_out_f32) {          // fp32 model path (MNIST): summed gradient of the two passes that share the encoder
+            a.d_img_out_f32[(size_t)b * D2 + d] = d_im0 + d_im1;
+            a.d_img_out_f32[(size_t)b * D2 + f.D + d] = d_il0 + d_il1;
+        } else if (a.sum_img_variants) {       // the two variants share one encoder forward: its backward needs the summed gradient
+            a.d_img_out_bf[(size_t)b * D2 + d] = (bf16)(d_im0 + d_im1);
+            a.d_img_out_bf[(size_t)b * D2 + f.D + d] = (bf16)(d_il0 + d_il1);
+        } else {
+            a.d_img_out_bf[(size_t)b * D2 + d] = (bf16)d_im0;
+            a.d_img_out_bf[(size_t)b * D2 + f.D + d] = (bf16)d_il0;
+            a.d_img_out_bf[(size_t)(f.B + b) * D2 + d] = (bf16)d_im1;
+            a.d_img_out_bf[(size_t)(f.B + b) * D2 + f.D + d] = (bf16)d_il1;
+        }
+        if (a.d_txt_out) {
+            a.d_txt_out[(size_t)b * D2 + d] = d_tm;
+            a.d_txt_out[(size_t)b * D2 + f.D + d] = d_tl;
+        }
+        if (a.d_txt_out_bf) {
+            a.d_txt_out_bf[(size_t)b * D2 + d] = (bf16)d_tm;
+            a.d_txt_out_bf[(size_t)b * D2 + f.D + d] = (bf16)d_tl;
+        }
+        s_im += d_im0 + d_im1; s_il += d_il0 + d_il1; s_tm += d_tm; s_tl += d_tl;
     }
-    float d_im0, d_il0, d_im1, d_il1, d_tm = 0.f, d_tl = 0.f;
-    {
-        float m[2] = {im0, tm}, l[2] = {il0, tl}, dm[2], dl[2];
-        poe_bwd_m<2>(m, l, gmu[0], glv[0], dm, dl);
-        d_im0 = dm[0]; d_il0 = dl[0]; d_tm += dm[1]; d_tl += dl[1];
-    }
-    {
-        float m[1] = {im1}, l[1] = {il1}, dm[1], dl[1];
-        poe_bwd_m<1>(m, l, gmu[1], glv[1], dm, dl);
-        d_im1 = dm[0]; d_il1 = dl[0];
-    }
-    {
-        float m[1] = {tm}, l[1] = {tl}, dm[1], dl[1];
-        poe_bwd_m<1>(m, l, gmu[2], glv[2], dm, dl);
-        d_tm += dm[0]; d_tl += dl[0];
-    }
-    if (a.d_img_out_f32) {          // fp32 model path (MNIST): summed gradient of the two passes that share the encoder
-        a.d_img_out_f32[(size_t)b * D2 + d] = d_im0 + d_im1;
-        a.d_img_out_f32[(size_t)b * D2 + f.D + d] = d_il0 + d_il1;
-    } else if (a.sum_img_variants) {       // the two variants share one encoder forward: its backward needs the summed gradient
-        a.d_img_out_bf[(size_t)b * D2 + d] = (bf16)(d_im0 + d_im1);
-        a.d_img_out_bf[(size_t)b * D2 + f.D + d] = (bf16)(d_il0 + d_il1);
-    } else {
-        a.d_img_out_bf[(size_t)b * D2 + d] = (bf16)d_im0;
-        a.d_img_out_bf[(size_t)b * D2 + f.D + d] = (bf16)d_il0;
-        a.d_img_out_bf[(size_t)(f.B + b) * D2 + d] = (bf16)d_im1;
-        a.d_img_out_bf[(size_t)(f.B + b) * D2 + f.D + d] = (bf16)d_il1;
-    }
-    if (a.d_txt_out) {
-        a.d_txt_out[(size_t)b * D2 + d] = d_tm;
-        a.d_txt_out[(size_t)b * D2 + f.D + d] = d_tl;
-    }
-    if (a.d_txt_out_bf) {
-        a.d_txt_out_bf[(size_t)b * D2 + d] = (bf16)d_tm;
-        a.d_txt_out_bf[(size_t)b * D2 + f.D + d] = (bf16)d_tl;
-    }
-    if (a.d_txt_bias) {
-        atomicAdd(a.d_txt_bias + d, d_tm);
-        atomicAdd(a.d_txt_bias + f.D + d, d_tl);
-    }
-    if (a.d_img_bias) {
-        atomicAdd(a.d_img_bias + d, d_im0 + d_im1);
-        atomicAdd(a.d_img_bias + f.D + d, d_il0 + d_il1);
+    red[0][ty][tx] = s_im; red[1][ty][tx] = s_il; red[2][ty][tx] = s_tm; red[3][ty][tx] = s_tl;
+    __syncthreads();
+    if (ty == 0 && d < f.D) {
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = red[q][0][tx] + red[q][1][tx] + red[q][2][tx] + red[q][3][tx];
+        if (a.d_img_bias) { atomicAdd(a.d_img_bias + d, v[0]); atomicAdd(a.d_img_bias + f.D + d, v[1]); }
+        if (a.d_txt_bias) { atomicAdd(a.d_txt_bias + d, v[2]); atomicAdd(a.d_txt_bias + f.D + d, v[3]); }
     }
 }
 
@@ -956,7 +943,8 @@ int launch_latent3_fwd(const Latent3Args& a, hipStream_t s) {
     return mmvae_check_launch("latent3_fwd");
 }
 int launch_latent3_bwd(const Latent3BwdArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(latent3_bwd_kernel, dim3(ceil_div(a.f.B * a.f.D, TPB)), dim3(TPB), 0, s, a);
+    MMVAE_REQUIRE((a.loss_slots == nullptr) == (a.loss_out == nullptr), "latent3_bwd: loss_slots / loss_out go together");
+    hipLaunchKernelGGL(latent3_bwd_kernel, dim3(ceil_div(a.f.D, 64), ceil_div(a.f.B, L3B_ROWS)), dim3(TPB), 0, s, a);
     return mmvae_check_launch("latent3_bwd");
 }
 int launch_adam(const AdamArgs& a, hipStream_t s) {
@@ -994,8 +982,18 @@ int launch_nll_bwd(const long long* tg, int rows, int classes, float coef, const
 int launch_step_begin(const StepBeginArgs& a, hipStream_t s) {
     for (int r = 0; r < 4; ++r)
         MMVAE_REQUIRE(a.zero_ptr[r] == nullptr || (a.zero_bytes[r] % 16 == 0 && ((uintptr_t)a.zero_ptr[r] & 15) == 0), "step_begin: zero range %d is not 16-byte aligned", r);
-    hipLaunchKernelGGL(step_begin_kernel, dim3(2048), dim3(TPB), 0, s, a);
+    hipLaunchKernelGGL(step_begin_kernel, dim3(2048 + (a.pack_blocks > 0 ? a.pack_blocks : 0)), dim3(TPB), 0, s, a);
     return mmvae_check_launch("step_begin");
+}
+// fills the pack part of a step prologue (StepBeginArgs::pack_*) from a descriptor table
+int step_begin_with_pack(StepBeginArgs& a, const PackDesc* table_dev, const PackDesc* table_host, int nd, const float* params,
+                         bf16* packed_bf, float* packed_f32) {
+    MMVAE_REQUIRE(nd > 0, "pack: empty table");
+    for (int i = 0; i < nd; ++i)
+        MMVAE_REQUIRE((long long)table_host[i].Npad * (table_host[i].Kpad / 8) < (1 << 23), "pack: matrix %d too large for 32-bit index math", i);
+    a.pack_table = table_dev; a.pack_nd = nd; a.pack_params = params; a.packed_bf = packed_bf; a.packed_f32 = packed_f32;
+    a.pack_blocks = table_blocks(table_host, nd);
+    return MMVAE_OK;
 }
 
 int launch_embed_gather_stats(const float* table, int C, const long long* idx, int rows, int idx_rows, int rows_per_group,

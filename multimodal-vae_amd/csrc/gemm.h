@@ -5,6 +5,7 @@
 // row (n,oy,ox) and tap (ty,tx) is (n, oy*sy+offy+ty*dy, ox*sx+offx+tx*dx); K = TH*TW*C with c fastest.
 #pragma once
 #include "common.h"
+#include <vector>
 
 #define MMVAE_MAX_CLASSES 4
 
@@ -67,9 +68,7 @@ struct GemmParams {
     const float2* d_meanrstd;  // [groups][N] for xhat=(r-mean)*rstd, with d_red
     float2* d_red;             // [groups][MMVAE_STAT_SLOTS][N] += (sum v, sum v*xhat) or null
     float* d_colsum;           // [N] += sum v over all rows (bias gradient of the producer Linear) or null
-    int dbg;                   // experiments (gemm_direct): 1 no A loads, 2 no MFMA, 4 no epilogue
     int npad;                  // rows of the packed weight matrices (gemm_small range-checks weight rows against it)
-    int dblk[MMVAE_MAX_CLASSES + 1];   // gemm_direct: prefix sums of workgroups per class (filled by its launcher)
     int d_cmod;                // >0: the BatchNorm tables (d_affine/d_meanrstd/d_red) have d_cmod channels and output
                                // column n belongs to channel n % d_cmod (Linear over a flattened NHWC feature map)
 };
@@ -82,12 +81,37 @@ struct WgradParams {
     const float2* p_affine; // optional transform of the plain operand [groups][N]
     int p_act;
     int rows_per_block;     // multiple of 64
+    // slab form (filled by the launcher): partial tiles go to slab + chunk*slab_chunk_stride + slab_cls_off[class] as
+    // [rows][Kpad] with plain stores and wgrad_reduce_kernel sums the chunk copies into dWp; null: fp32 atomics into dWp
+    float* slab;
+    long long slab_chunk_stride;
+    long long slab_cls_off[MMVAE_MAX_CLASSES];
+};
+
+// Slab pool of one step (carved from the caller's workspace) and the reductions its launches owe
+struct WgradSlabJob { float* dst; const float* slab; int N, K, Kpad, chunks; long long chunk_stride; hipStream_t stream;
+                      int src_ld; };        // row length of a slab copy (0: Kpad)
+struct WgradSlabCtx {
+    float* pool = nullptr;
+    size_t cap = 0, used = 0;           // in floats
+    std::vector<WgradSlabJob> jobs;
+    void reset(float* p, size_t c) { pool = p; cap = c; used = 0; jobs.clear(); }
+    float* take(size_t n) {             // n floats of the pool (16-byte granules) or null when it is exhausted
+        n = (n + 3) / 4 * 4;
+        if (!pool || used + n > cap) return nullptr;
+        float* p = pool + used;
+        used += n;
+        return p;
+    }
 };
 
 int launch_gemm_gather(const GemmParams& p, hipStream_t stream);
-// gemm_direct.hip: narrow-output problems (N <= 64, large pixel grids); 1 = launched, 0 = not applicable, < 0 = error
-int try_launch_gemm_direct(const GemmParams& p, hipStream_t stream);
-// gemm_direct.hip: problems too small to fill the chip with 128-row tiles (classifier / bottleneck layers): one output
+// gemm_small.hip: problems too small to fill the chip with 128-row tiles (classifier / bottleneck layers): one output
 // tile per wave, both operands loaded straight into MFMA fragments, K optionally split over the waves of a workgroup
 int try_launch_gemm_small(const GemmParams& p, hipStream_t stream);
-int launch_wgrad(const WgradParams& p, hipStream_t stream);
+int launch_wgrad(const WgradParams& p, hipStream_t stream, WgradSlabCtx* ctx = nullptr);
+// n independent problems; the ones of the 128x128 tile class share ONE launch
+int launch_wgrad_group(const WgradParams* list, int n, hipStream_t stream, WgradSlabCtx* ctx = nullptr);
+// sums the slab copies into the packed gradients, one launch.  only_own = true: just the slabs whose kernels were issued
+// on `stream` itself (safe right behind them); false: every slab still owed -- the caller has joined the streams
+int launch_wgrad_reduce(WgradSlabCtx* ctx, hipStream_t stream, bool only_own = false);

@@ -12,6 +12,7 @@
 //   ds_read_b64_tr_b16 (LDS row stride 160 B makes the 8-row transposed reads conflict-free),
 //   split over row chunks with fp32 atomics into a packed gradient matrix.
 #include "gemm.h"
+#include "gemm_epi.h"
 #include <cstdlib>
 
 namespace {
@@ -21,204 +22,6 @@ constexpr int BK = 64;
 constexpr int LDA = BK + 8;    // bf16 elements per LDS row (144 B)
 
 typedef __attribute__((ext_vector_type(4))) int i32x4g;
-
-// q = r / d, rem = r % d for 0 <= r < 2^23 with inv = 1.0f/d (one correction step each way): ~7 VALU instructions
-// instead of the ~35 of an integer division
-__device__ __forceinline__ int fast_divmod(int r, int d, float inv, int& rem) {
-    int q = (int)((float)r * inv);
-    rem = r - q * d;
-    if (rem < 0) { --q; rem += d; }
-    else if (rem >= d) { ++q; rem -= d; }
-    return q;
-}
-
-struct RowCoord {
-    int pix;    // n*AH*AW (gather base) -- or -1 when the row is out of range
-    int y, x;   // oy*sy+offy, ox*sx+offx
-};
-
-__device__ __forceinline__ bf16x8 zero8() {
-    bf16x8 z;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) z[j] = (bf16)0.0f;
-    return z;
-}
-
-// applies (affine, act, keep-mask) to 8 gathered channels
-__device__ __forceinline__ bf16x8 transform8(bf16x8 v, const float2* aff, int act, const uint8_t* mask, float mscale) {
-    bf16x8 o;
-    uint64_t mbits = 0;
-    if (mask) mbits = *reinterpret_cast<const uint64_t*>(mask);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float f = (float)v[j];
-        if (aff) f = f * aff[j].x + aff[j].y;
-        f = act_fwd(act, f);
-        if (mask) f = ((mbits >> (8 * j)) & 0xff) ? f * mscale : 0.f;
-        o[j] = (bf16)f;
-    }
-    return o;
-}
-
-// Shared epilogue: consumes the fp32 tile `ct` ([BM][BN+4] in LDS) of output rows row0.. / columns n0..
-template <int NT, int ROWS>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const GatherClass& k, int g, int row0, int n0,
-                                              float* ct, char* smem, int tid) {
-    constexpr int BN = NT * 16;
-    constexpr int LDC = BN + 4;
-    constexpr int VPR = BN / 8;              // vectors per tile row
-    constexpr int RPP = 256 / VPR;           // tile rows per pass
-    constexpr int PASSES = ROWS / RPP;
-    const GatherCommon& c = p.c;
-    const int pix_per_img = k.OY * k.OX;
-    const float inv_pix = 1.0f / (float)pix_per_img, inv_ox = 1.0f / (float)k.OX;
-    const bool want_stats = p.colstats != nullptr;
-    const bool want_red = p.d_red != nullptr || p.d_colsum != nullptr;
-    const int cv = tid % VPR;
-    const int col0 = n0 + cv * 8;
-    const bool vec_ok = (col0 + 8 <= c.N) && (p.ldo % 8 == 0);
-    float s1[8], s2[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-    float bias8[8], dsc[8], dsh[8], dmean[8], drstd[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int col = min(col0 + j, c.N - 1);
-        bias8[j] = p.bias ? p.bias[col] : 0.f;
-        dsc[j] = 1.f; dsh[j] = 0.f; dmean[j] = 0.f; drstd[j] = 0.f;
-        const int tn = p.d_cmod > 0 ? p.d_cmod : c.N, tcol = p.d_cmod > 0 ? col % p.d_cmod : col;
-        if (p.d_affine) { float2 a = p.d_affine[g * tn + tcol]; dsc[j] = a.x; dsh[j] = a.y; }
-        if (p.d_meanrstd) { float2 m = p.d_meanrstd[g * tn + tcol]; dmean[j] = m.x; drstd[j] = m.y; }
-    }
-#pragma unroll
-    for (int ps = 0; ps < PASSES; ++ps) {
-        const int rl = ps * RPP + tid / VPR;
-        const int r = row0 + rl;
-        if (r >= k.rows_per_group || col0 >= c.N) continue;
-        int rem, ox;
-        const int img = fast_divmod(r, pix_per_img, inv_pix, rem);
-        const int oy = fast_divmod(rem, k.OX, inv_ox, ox);
-        const int nimg = g * c.group_n + img;
-        const size_t opix = (size_t)(nimg * c.OH + oy * c.osy + k.ooy) * c.OW + ox * c.osx + k.oox;
-        const size_t growi = (size_t)g * k.rows_per_group + r;
-        float v[8];
-        {
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(ct + rl * LDC + cv * 8);
-            const f32x4 hi = *reinterpret_cast<const f32x4*>(ct + rl * LDC + cv * 8 + 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { v[j] = lo[j] + bias8[j]; v[4 + j] = hi[j] + bias8[4 + j]; }
-        }
-        if (p.d_r) {
-            size_t rpix = opix;
-            if (p.d_bcast_n > 0) rpix = (size_t)((nimg % p.d_bcast_n) * c.OH + oy * c.osy + k.ooy) * c.OW + ox * c.osx + k.oox;
-            float rr[8];
-            if (vec_ok && p.d_ld % 8 == 0) {
-                const bf16x8 rv = *reinterpret_cast<const bf16x8*>(p.d_r + rpix * p.d_ld + col0);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) rr[j] = (float)rv[j];
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) rr[j] = (col0 + j < c.N) ? (float)p.d_r[rpix * p.d_ld + col0 + j] : 0.f;
-            }
-            uint64_t mb = ~0ull;
-            if (p.d_mask) {
-                if (vec_ok) mb = *reinterpret_cast<const uint64_t*>(p.d_mask + growi * c.N + col0);
-                else {
-                    mb = 0;
-                    for (int j = 0; j < 8; ++j)
-                        if (col0 + j < c.N && p.d_mask[growi * c.N + col0 + j]) mb |= 0xffull << (8 * j);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float x = v[j] * act_bwd(p.d_act, rr[j] * dsc[j] + dsh[j]);
-                if (p.d_mask) x = ((mb >> (8 * j)) & 0xff) ? x * p.d_mask_scale : 0.f;
-                v[j] = x;
-                if (want_red && col0 + j < c.N) { s1[j] += x; s2[j] += x * (rr[j] - dmean[j]) * drstd[j]; }
-            }
-        }
-        if (want_stats) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (col0 + j < c.N) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
-        }
-        float av[8];
-        if (p.out_act_bf) {
-            uint64_t mb = ~0ull;
-            if (p.e_mask) {
-                if (vec_ok) mb = *reinterpret_cast<const uint64_t*>(p.e_mask + growi * c.N + col0);
-                else {
-                    mb = 0;
-                    for (int j = 0; j < 8; ++j)
-                        if (col0 + j < c.N && p.e_mask[growi * c.N + col0 + j]) mb |= 0xffull << (8 * j);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float x = act_fwd(p.e_act, v[j]);
-                if (p.e_mask) x = ((mb >> (8 * j)) & 0xff) ? x * p.e_mask_scale : 0.f;
-                av[j] = x;
-            }
-        }
-        if (vec_ok) {
-            if (p.out_bf) {
-                bf16x8 o;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (bf16)v[j];
-                *reinterpret_cast<bf16x8*>(p.out_bf + opix * p.ldo + col0) = o;
-            }
-            if (p.out_act_bf) {
-                bf16x8 o;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (bf16)av[j];
-                *reinterpret_cast<bf16x8*>(p.out_act_bf + opix * p.ldo + col0) = o;
-            }
-            if (p.out_f) {
-                *reinterpret_cast<f32x4*>(p.out_f + opix * p.ldo + col0) = f32x4{v[0], v[1], v[2], v[3]};
-                *reinterpret_cast<f32x4*>(p.out_f + opix * p.ldo + col0 + 4) = f32x4{v[4], v[5], v[6], v[7]};
-            }
-        } else {
-            for (int j = 0; j < 8; ++j) {
-                if (col0 + j >= c.N) break;
-                if (p.out_bf) p.out_bf[opix * p.ldo + col0 + j] = (bf16)v[j];
-                if (p.out_act_bf) p.out_act_bf[opix * p.ldo + col0 + j] = (bf16)av[j];
-                if (p.out_f) p.out_f[opix * p.ldo + col0 + j] = v[j];
-            }
-        }
-    }
-    if (want_stats || want_red) {
-        __syncthreads();                                       // everyone is done reading ct
-        float2* red = reinterpret_cast<float2*>(smem);         // [RPP][BN]
-#pragma unroll
-        for (int j = 0; j < 8; ++j) red[(tid / VPR) * BN + cv * 8 + j] = make_float2(s1[j], s2[j]);
-        __syncthreads();
-        // two-level column sum: all 256 threads fold RPP rows down to PARTS partial rows, then BN threads finish
-        // (a single pass left BN threads walking RPP = 64 rows for the narrow tiles while 7/8 of the workgroup idled)
-        constexpr int PARTS = 256 / BN;
-        {
-            const int col = tid % BN, part = tid / BN;
-            float a = 0.f, b = 0.f;
-            for (int q = part; q < RPP; q += PARTS) { a += red[q * BN + col].x; b += red[q * BN + col].y; }
-            __syncthreads();
-            red[part * BN + col] = make_float2(a, b);
-        }
-        __syncthreads();
-        if (tid < BN && n0 + tid < c.N) {
-            float a = 0.f, b = 0.f;
-#pragma unroll
-            for (int q = 0; q < PARTS; ++q) { a += red[q * BN + tid].x; b += red[q * BN + tid].y; }
-            float2* dst = want_stats ? p.colstats : p.d_red;      // [groups][SLOTS][N]
-            if (dst) {
-                const bool cm = !want_stats && p.d_cmod > 0;
-                const int tn = cm ? p.d_cmod : c.N, tcol = cm ? (n0 + tid) % p.d_cmod : n0 + tid;
-                const int slot = (blockIdx.x + 5 * blockIdx.z + (cm ? (n0 + tid) / p.d_cmod : 0)) % MMVAE_STAT_SLOTS;
-                atomicAdd(&dst[(g * MMVAE_STAT_SLOTS + slot) * tn + tcol].x, a);
-                atomicAdd(&dst[(g * MMVAE_STAT_SLOTS + slot) * tn + tcol].y, b);
-            }
-            if (p.d_colsum) atomicAdd(p.d_colsum + n0 + tid, a);
-        }
-    }
-}
 
 template <int NT>
 __global__ __launch_bounds__(256) void gemm_gather_kernel(const GemmParams p) {
@@ -448,25 +251,30 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int mb, int c0, int 
 // operand (vector index (t&3) + 4*i), so one row decomposition serves all of a thread's loads; the (tap, channel)
 // of each gathered vector is fixed for the whole kernel.  Loads of iteration i+1 are issued before the MFMAs of
 // iteration i (register prefetch), LDS is single-buffered.
+//
+// Row chunks: the pixel rows are split over `chunks` workgroups per output tile.  With a slab (p.slab != nullptr) every
+// workgroup stores its partial tile with plain stores into its own slab copy and wgrad_reduce_kernel sums the copies
+// (deterministic, and plain stores run at ~5x the chip-wide float-atomic rate: MI355X_MICROARCH "Global float atomics"),
+// so the row chunks can be short (many workgroups, several per CU: the loop is a latency chain of gathered loads).
+// Without a slab the partial tiles are added into the zeroed packed gradient with fp32 atomics (first version).
 template <int NWT, int KWT, int WN, int WK>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
+__device__ __forceinline__ void wgrad_body(const WgradParams& p, const int bx, const int by, const int bz, char* smem) {
     constexpr int TN = 16 * NWT * WN, TK = 16 * KWT * WK;
     constexpr int LDP = TN + 16, LDG = TK + 16;          // +16 elements: conflict-free 8-row transposed reads
     constexpr int NPV = TN / 32, NGV = TK / 32;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* Ps = reinterpret_cast<bf16*>(smem);            // [64][LDP]
     bf16* Gs = Ps + WM * LDP;                            // [64][LDG]
     const GatherCommon& c = p.c;
     const int ncls = c.nclasses;
-    const int cls_i = blockIdx.z % ncls;
-    const int chunk = blockIdx.z / ncls;
+    const int cls_i = bz % ncls;
+    const int chunk = bz / ncls;
     const GatherClass& k = p.cls[cls_i];
-    const int n0 = blockIdx.x * TN, k0 = blockIdx.y * TK;
+    const int n0 = bx * TN, k0 = by * TK;
     if (k0 >= k.K) return;
     const int rows_total = c.groups * k.rows_per_group;
     const int r_begin = chunk * p.rows_per_block;
-    if (r_begin >= rows_total) return;
     const int r_end = min(rows_total, r_begin + p.rows_per_block);
+    if (r_begin >= rows_total && p.slab == nullptr) return;      // (a slab copy must be written even when it is all zeros)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave / WK, wk = wave % WK;
     const int pix_per_img = k.OY * k.OX;
@@ -534,7 +342,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
             *reinterpret_cast<bf16x8*>(Gs + row_l * LDG + (sub + 4 * i) * 8) = ((gok >> i) & 1) ? gv[i] : zero8();
     };
 
-    load_rows(r_begin);
+    if (r_begin < r_end) load_rows(r_begin);
     for (int rb = r_begin; rb < r_end; rb += WM) {
         __syncthreads();                                  // previous iteration's fragment reads are done
         store_rows();
@@ -555,6 +363,21 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
         }
     }
     const int fr = lane & 15, fq = lane >> 4;
+    if (p.slab) {
+        // partial tile -> this chunk's slab copy of class cls_i ([slab_rows][Kpad], rows n < slab_rows = tiles*TN)
+        float* dst = p.slab + (size_t)chunk * p.slab_chunk_stride + p.slab_cls_off[cls_i];
+#pragma unroll
+        for (int a = 0; a < NWT; ++a)
+#pragma unroll
+            for (int b = 0; b < KWT; ++b)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n0 + (wn * NWT + a) * 16 + fq * 4 + j;
+                    const int kc = k0 + (wk * KWT + b) * 16 + fr;
+                    if (kc < k.Kpad) dst[(size_t)n * k.Kpad + kc] = acc[a][b][j];
+                }
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < NWT; ++a)
 #pragma unroll
@@ -568,8 +391,90 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 }
 
 template <int NWT, int KWT, int WN, int WK>
-int launch_wgrad_v(WgradParams p, hipStream_t stream) {
-    constexpr int TN = 16 * NWT * WN, TK = 16 * KWT * WK;
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    wgrad_body<NWT, KWT, WN, WK>(p, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
+
+// Several independent weight-gradient problems in ONE launch (the GRU / Linear layers of the text path: ~0.1 GFLOP each,
+// every one of them a launch at the kernel-latency floor before): blockIdx.z runs over (problem, class x chunk), the x/y
+// extent is the largest tile grid of the group (the others return early).
+constexpr int WGRAD_MULTI_MAX = 6;
+struct WgradMulti {
+    WgradParams p[WGRAD_MULTI_MAX];
+    int zoff[WGRAD_MULTI_MAX + 1];       // prefix sums of the z extents
+    int gx[WGRAD_MULTI_MAX], gy[WGRAD_MULTI_MAX];
+    int n;
+};
+static_assert(sizeof(WgradMulti) <= 3800, "kernel arguments are limited to 4 KB");
+template <int NWT, int KWT, int WN, int WK>
+__global__ __launch_bounds__(256) void wgrad_multi_kernel(const WgradMulti m) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int i = 0;
+    while (i + 1 < m.n && (int)blockIdx.z >= m.zoff[i + 1]) ++i;
+    if ((int)blockIdx.x >= m.gx[i] || (int)blockIdx.y >= m.gy[i]) return;
+    wgrad_body<NWT, KWT, WN, WK>(m.p[i], blockIdx.x, blockIdx.y, blockIdx.z - m.zoff[i], smem);
+}
+
+// dst[n][k] += sum over chunks of slab[chunk][n][k]  for n < N, k < K.  One thread per (4 consecutive k, group of up to
+// REDUCE_CG chunks): a job with many chunks and few outputs (the thin first / last conv layers: 512 outputs, ~1000 chunks)
+// is spread over chunk groups whose partial sums meet in dst through float atomics (a few thousand atomics in all);
+// jobs with <= REDUCE_CG chunks -- every MFMA-sized layer -- are summed in a fixed order with a plain read-modify-write.
+constexpr int REDUCE_MAX_JOBS = 40;
+constexpr int REDUCE_CG = 32;
+struct WgradReduceArgs {
+    struct Job { float* dst; const float* slab; int N, K, Kpad, chunks; long long chunk_stride; int first_block, groups, src_ld; } job[REDUCE_MAX_JOBS];
+    int n;
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradReduceArgs a) {
+    int j = 0;
+    while (j + 1 < a.n && (int)blockIdx.x >= a.job[j + 1].first_block) ++j;
+    const WgradReduceArgs::Job& q = a.job[j];
+    const int kv = q.Kpad / 4;
+    const long long t = (long long)(blockIdx.x - q.first_block) * 256 + threadIdx.x;
+    const long long nvec = (long long)q.N * kv;
+    if (t >= nvec * q.groups) return;
+    const int grp = (int)(t / nvec);
+    const long long e = t - (long long)grp * nvec;
+    const int n = (int)(e / kv), k4 = (int)(e - (long long)n * kv) * 4;
+    if (k4 >= q.K) return;
+    const int c0 = grp * REDUCE_CG, c1 = min(q.chunks, c0 + REDUCE_CG);
+    const float* src = q.slab + (size_t)n * q.src_ld + k4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int cidx = c0;
+    for (; cidx + 8 <= c1; cidx += 8) {                        // 8 independent 16-byte loads in flight
+        f32x4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const f32x4*>(src + (size_t)(cidx + i) * q.chunk_stride);
+        s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    for (; cidx < c1; ++cidx) s += *reinterpret_cast<const f32x4*>(src + (size_t)cidx * q.chunk_stride);
+    float* d = q.dst + (size_t)n * q.Kpad + k4;
+    if (q.groups == 1) {
+        f32x4 o = *reinterpret_cast<f32x4*>(d);
+        o += s;
+        *reinterpret_cast<f32x4*>(d) = o;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) atomicAdd(d + i, s[i]);
+    }
+}
+
+struct WgradCfg { int TN, TK; };
+inline WgradCfg wgrad_cfg(const WgradParams& p) {
+    int max_k = 0;
+    for (int i = 0; i < p.c.nclasses; ++i) max_k = max(max_k, p.cls[i].K);
+    // tile shape by problem shape: thin outputs get a wide K tile so each staged pixel row feeds more MFMAs
+    if (max_k <= 64) return {32, 64};
+    if (p.c.N <= 32) return {32, 256};
+    if (p.c.N <= 64) return {64, 256};
+    return {128, 128};
+}
+
+// grid / row-chunk / slab set-up shared by the single and the grouped launch
+int wgrad_setup(WgradParams& p, WgradSlabCtx* ctx, dim3& grid, size_t& lds, hipStream_t stream, int group_size = 1) {
+    const WgradCfg cfg = wgrad_cfg(p);
+    const int TN = cfg.TN, TK = cfg.TK;
     const GatherCommon& c = p.c;
     int max_rows = 0, max_k = 0;
     for (int i = 0; i < c.nclasses; ++i) {
@@ -577,17 +482,61 @@ int launch_wgrad_v(WgradParams p, hipStream_t stream) {
         max_k = max(max_k, p.cls[i].K);
     }
     const int tiles = ceil_div(c.N, TN) * ceil_div(max_k, TK) * c.nclasses;
-    // enough row chunks for ~3 workgroups per CU, each at least 4 iterations long
-    // row chunks: every workgroup adds its whole tile into the packed gradient with fp32 atomics, so fewer, longer
-    // workgroups win once there are enough of them (measured at B=256: >= 8 iterations of 64 rows and 128..384 workgroups (flat; 384 chosen):
-    // step 0.991 -> 0.965 ms against 4 iterations / 768 workgroups); small problems keep the shorter chain
     static const int env_it = getenv("MMVAE_WGRAD_MINIT") ? atoi(getenv("MMVAE_WGRAD_MINIT")) : 0;
     static const int blk_target = getenv("MMVAE_WGRAD_BLOCKS") ? atoi(getenv("MMVAE_WGRAD_BLOCKS")) : 384;
-    const int min_it = env_it > 0 ? env_it : (max_rows >= 2048 ? 8 : 4);
-    int chunks = max(1, min(ceil_div(max_rows, min_it * WM), ceil_div(blk_target, tiles)));
-    p.rows_per_block = round_up(ceil_div(max_rows, chunks), WM);
-    dim3 grid(ceil_div(c.N, TN), ceil_div(max_k, TK), ceil_div(max_rows, p.rows_per_block) * c.nclasses);
-    const size_t lds = (size_t)WM * (TN + 16 + TK + 16) * sizeof(bf16);
+    static const int slab_target = getenv("MMVAE_WGRAD_SLAB_BLOCKS") ? atoi(getenv("MMVAE_WGRAD_SLAB_BLOCKS")) : 1024;
+    static const int slab_it = getenv("MMVAE_WGRAD_SLAB_MINIT") ? atoi(getenv("MMVAE_WGRAD_SLAB_MINIT")) : 2;
+    p.slab = nullptr;
+    int chunks;
+    // slab form: ~4 workgroups per CU, each at least 2 iterations long (a slab copy costs one plain-store pass and one
+    // read in the reduce kernel, not a float-atomic pass)
+    long long slab_elems = 0;
+    for (int i = 0; i < c.nclasses; ++i) slab_elems += (long long)ceil_div(c.N, TN) * TN * p.cls[i].Kpad;
+    if (ctx && ctx->pool) {
+        // (a grouped launch fills the chip with its problems together; every slab copy is written once and read once,
+        //  so a launch's copies are capped at SLAB_CAP floats: the big-weight layers have few rows per output anyway)
+        static const long long slab_cap = getenv("MMVAE_WGRAD_SLAB_CAP") ? atoll(getenv("MMVAE_WGRAD_SLAB_CAP")) : (3ll << 20);
+        chunks = max(1, min(ceil_div(max_rows, slab_it * WM), ceil_div(max(64, slab_target / group_size), tiles)));
+        chunks = (int)min((long long)chunks, max(1ll, slab_cap / slab_elems));
+        while (chunks > 1 && ctx->used + (size_t)chunks * slab_elems > ctx->cap) chunks = (chunks + 1) / 2;
+        if (chunks > 1 && ctx->used + (size_t)chunks * slab_elems <= ctx->cap && (int)ctx->jobs.size() + c.nclasses <= REDUCE_MAX_JOBS) {
+            p.slab = ctx->pool + ctx->used;
+            p.slab_chunk_stride = slab_elems;
+            long long off = 0;
+            p.rows_per_block = round_up(ceil_div(max_rows, chunks), WM);
+            const int real_chunks = ceil_div(max_rows, p.rows_per_block);
+            for (int i = 0; i < c.nclasses; ++i) {
+                p.slab_cls_off[i] = off;
+                WgradSlabJob j{};
+                j.dst = p.cls[i].dWp; j.slab = p.slab + off; j.N = c.N; j.K = p.cls[i].K; j.Kpad = p.cls[i].Kpad;
+                j.chunks = real_chunks; j.chunk_stride = slab_elems; j.stream = stream;
+                ctx->jobs.push_back(j);
+                off += (long long)ceil_div(c.N, TN) * TN * p.cls[i].Kpad;
+            }
+            ctx->used += (size_t)real_chunks * slab_elems;
+            chunks = real_chunks;
+        } else {
+            chunks = 0;      // decided below
+        }
+    } else {
+        chunks = 0;
+    }
+    if (!p.slab) {
+        // atomic form: every workgroup adds its whole tile into the packed gradient with fp32 atomics, so fewer, longer
+        // workgroups win once there are enough of them (measured at B=256: >= 8 iterations of 64 rows and 128..384
+        // workgroups: step 0.991 -> 0.965 ms against 4 iterations / 768 workgroups); small problems keep the shorter chain
+        const int min_it = env_it > 0 ? env_it : (max_rows >= 2048 ? 8 : 4);
+        chunks = max(1, min(ceil_div(max_rows, min_it * WM), ceil_div(blk_target, tiles)));
+        p.rows_per_block = round_up(ceil_div(max_rows, chunks), WM);
+        chunks = ceil_div(max_rows, p.rows_per_block);
+    }
+    grid = dim3(ceil_div(c.N, TN), ceil_div(max_k, TK), chunks * c.nclasses);
+    lds = (size_t)WM * (TN + 16 + TK + 16) * sizeof(bf16);
+    return MMVAE_OK;
+}
+
+template <int NWT, int KWT, int WN, int WK>
+int launch_wgrad_v(const WgradParams& p, dim3 grid, size_t lds, hipStream_t stream) {
     static std::atomic<unsigned> attr_set{0};
     if (mmvae_first_use_on_device(attr_set)) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<NWT, KWT, WN, WK>),
@@ -854,6 +803,11 @@ int launch_gemm_nt(const GemmParams& p, hipStream_t stream) {
 
 int launch_gemm_gather(const GemmParams& p, hipStream_t stream) {
     const GatherCommon& c = p.c;
+    {
+        double f = 0;
+        for (int i = 0; i < c.nclasses; ++i) f += 2.0 * c.groups * p.cls[i].rows_per_group * (double)c.N * p.cls[i].K;
+        mmvae_count_flops(f);
+    }
     MMVAE_REQUIRE(c.nclasses >= 1 && c.nclasses <= MMVAE_MAX_CLASSES, "gemm: bad class count %d", c.nclasses);
     MMVAE_REQUIRE(c.C % 8 == 0 && c.Ald % 8 == 0, "gemm: C=%d / Ald=%d must be multiples of 8", c.C, c.Ald);
     MMVAE_REQUIRE(c.groups >= 1 && c.group_n >= 1 && c.N >= 1, "gemm: empty problem");
@@ -875,13 +829,8 @@ int launch_gemm_gather(const GemmParams& p, hipStream_t stream) {
     }
     {
         static const bool no_small = getenv("MMVAE_NO_SMALL") != nullptr;        // A/B aids
-        static const bool direct = getenv("MMVAE_DIRECT") != nullptr;
         if (!no_small) {
             const int rc = try_launch_gemm_small(p, stream);
-            if (rc != 0) return rc < 0 ? rc : MMVAE_OK;
-        }
-        if (direct) {
-            const int rc = try_launch_gemm_direct(p, stream);
             if (rc != 0) return rc < 0 ? rc : MMVAE_OK;
         }
     }
@@ -908,24 +857,95 @@ int launch_gemm_gather(const GemmParams& p, hipStream_t stream) {
     return launch_gemm_nt<8>(p, stream);
 }
 
-int launch_wgrad(const WgradParams& p, hipStream_t stream) {
+static int wgrad_validate(const WgradParams& p) {
     const GatherCommon& c = p.c;
+    {
+        double f = 0;
+        for (int i = 0; i < c.nclasses; ++i) f += 2.0 * c.groups * p.cls[i].rows_per_group * (double)c.N * p.cls[i].K;
+        mmvae_count_flops(f);
+    }
     MMVAE_REQUIRE(c.nclasses >= 1 && c.nclasses <= MMVAE_MAX_CLASSES, "wgrad: bad class count %d", c.nclasses);
     MMVAE_REQUIRE(c.C % 8 == 0 && c.Ald % 8 == 0 && p.ldp % 8 == 0 && p.ldp >= round_up(c.N, 8),
                   "wgrad: C/Ald/ldp must be multiples of 8 and ldp >= round_up(N,8)");
     MMVAE_REQUIRE(c.a_mask == nullptr && c.a_affine == nullptr && c.a_act == ACT_NONE && p.p_affine == nullptr && p.p_act == ACT_NONE,
                   "wgrad: operand transforms are not supported");
-    int max_k = 0;
     for (int i = 0; i < c.nclasses; ++i) {
         const GatherClass& k = p.cls[i];
-        MMVAE_REQUIRE(k.Kpad >= k.K && k.K == k.TH * k.TW * c.C, "wgrad: class %d K=%d Kpad=%d", i, k.K, k.Kpad);
+        MMVAE_REQUIRE(k.Kpad >= k.K && k.Kpad % 4 == 0 && k.K == k.TH * k.TW * c.C, "wgrad: class %d K=%d Kpad=%d", i, k.K, k.Kpad);
         MMVAE_REQUIRE(k.rows_per_group == c.group_n * k.OY * k.OX && k.dWp != nullptr, "wgrad: class %d", i);
         MMVAE_REQUIRE((long long)c.groups * k.rows_per_group < (1 << 23), "wgrad: more than 2^23 rows");
-        max_k = max(max_k, k.K);
     }
-    // tile shape by problem shape: thin outputs get a wide K tile so each staged pixel row feeds more MFMAs
-    if (max_k <= 64) return launch_wgrad_v<2, 1, 1, 4>(p, stream);          //  32 x  64
-    if (c.N <= 32) return launch_wgrad_v<2, 4, 1, 4>(p, stream);            //  32 x 256
-    if (c.N <= 64) return launch_wgrad_v<4, 4, 1, 4>(p, stream);            //  64 x 256
-    return launch_wgrad_v<4, 4, 2, 2>(p, stream);                           // 128 x 128
+    return MMVAE_OK;
+}
+
+int launch_wgrad(const WgradParams& pin, hipStream_t stream, WgradSlabCtx* ctx) {
+    MMVAE_TRY(wgrad_validate(pin));
+    WgradParams p = pin;
+    dim3 grid; size_t lds;
+    MMVAE_TRY(wgrad_setup(p, ctx, grid, lds, stream));
+    const WgradCfg cfg = wgrad_cfg(p);
+    if (cfg.TK == 64) return launch_wgrad_v<2, 1, 1, 4>(p, grid, lds, stream);          //  32 x  64
+    if (cfg.TN == 32) return launch_wgrad_v<2, 4, 1, 4>(p, grid, lds, stream);          //  32 x 256
+    if (cfg.TN == 64) return launch_wgrad_v<4, 4, 1, 4>(p, grid, lds, stream);          //  64 x 256
+    return launch_wgrad_v<4, 4, 2, 2>(p, grid, lds, stream);                            // 128 x 128
+}
+
+// Several problems of the 128 x 128 tile class in one launch; anything that does not fit the grouped kernel (another tile
+// shape, more than WGRAD_MULTI_MAX problems) is launched on its own.
+int launch_wgrad_group(const WgradParams* list, int n, hipStream_t stream, WgradSlabCtx* ctx) {
+    static const bool no_group = getenv("MMVAE_NO_WGRAD_GROUP") != nullptr;
+    int i = 0;
+    while (i < n) {
+        WgradMulti m{};
+        int gxm = 0, gym = 0;
+        while (i < n && m.n < WGRAD_MULTI_MAX) {
+            MMVAE_TRY(wgrad_validate(list[i]));
+            const WgradCfg cfg = wgrad_cfg(list[i]);
+            if (cfg.TN != 128 || no_group) {
+                if (m.n > 0) break;                       // flush the group first (keeps the issue order)
+                MMVAE_TRY(launch_wgrad(list[i], stream, ctx));
+                ++i;
+                continue;
+            }
+            WgradParams p = list[i];
+            dim3 grid; size_t lds;
+            MMVAE_TRY(wgrad_setup(p, ctx, grid, lds, stream, min(n, WGRAD_MULTI_MAX)));
+            m.p[m.n] = p; m.gx[m.n] = (int)grid.x; m.gy[m.n] = (int)grid.y;
+            m.zoff[m.n + 1] = m.zoff[m.n] + (int)grid.z;
+            gxm = max(gxm, (int)grid.x); gym = max(gym, (int)grid.y);
+            ++m.n; ++i;
+        }
+        if (m.n == 0) continue;
+        static std::atomic<unsigned> attr_set{0};
+        if (mmvae_first_use_on_device(attr_set))
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_multi_kernel<4, 4, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        const size_t lds = (size_t)WM * (128 + 16 + 128 + 16) * sizeof(bf16);
+        hipLaunchKernelGGL((wgrad_multi_kernel<4, 4, 2, 2>), dim3(gxm, gym, m.zoff[m.n]), dim3(256), lds, stream, m);
+        MMVAE_TRY(mmvae_check_launch("wgrad_multi"));
+    }
+    return MMVAE_OK;
+}
+
+int launch_wgrad_reduce(WgradSlabCtx* ctx, hipStream_t stream, bool only_own) {
+    if (!ctx || ctx->jobs.empty()) return MMVAE_OK;
+    std::vector<WgradSlabJob> todo, keep;
+    for (const WgradSlabJob& j : ctx->jobs) (only_own && j.stream != stream ? keep : todo).push_back(j);
+    ctx->jobs.swap(keep);
+    size_t done = 0;
+    while (done < todo.size()) {
+        WgradReduceArgs a{};
+        int blocks = 0;
+        while (done < todo.size() && a.n < REDUCE_MAX_JOBS) {
+            const WgradSlabJob& j = todo[done++];
+            WgradReduceArgs::Job& q = a.job[a.n++];
+            q.dst = j.dst; q.slab = j.slab; q.N = j.N; q.K = j.K; q.Kpad = j.Kpad; q.chunks = j.chunks; q.chunk_stride = j.chunk_stride;
+            q.first_block = blocks;
+            q.src_ld = j.src_ld > 0 ? j.src_ld : j.Kpad;
+            q.groups = ceil_div(j.chunks, REDUCE_CG);
+            blocks += (int)(((long long)j.N * (j.Kpad / 4) * q.groups + 255) / 256);
+        }
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a);
+        MMVAE_TRY(mmvae_check_launch("wgrad_reduce"));
+    }
+    return MMVAE_OK;
 }

@@ -29,6 +29,7 @@ struct MMStepIO {
     float* mu = nullptr; float* logvar = nullptr;   // [3][B][D] or null
     long long* tokens = nullptr;        // [3][B][4] or null
     int pass_skip[3] = {0, 0, 0};       // 1: pass k is absent from this step (paired_weak.py / modal_weak.py)
+    int pack_first = 0;                 // 1: the prologue launch also refreshes the packed bf16 weights (after an optimizer step)
     int defer_unpack = 0;               // 1: leave the GEMM-weight gradients in their packed buffers (the optimizer kernel
                                         // gathers them through mm_grad_map and completes the flat gradient itself)
 };
@@ -68,6 +69,7 @@ int mm_text_decoder_bwd(MMPlan*, void* ws, size_t wsb, const float* z, const uin
 int mm_unpack_grads(MMPlan*, hipStream_t);
 int mm_bench_layer(MMPlan*, void* ws, size_t wsb, const char* layer, int iters, hipStream_t);
 double mm_layer_flops(const MMPlan*, const char* layer);
+double mm_layer_algo_flops(const MMPlan*, const char* layer);
 int mm_num_bn(const MMPlan*);
 int mm_bn_info(const MMPlan*, int i, std::string& prefix, int& C, long long& offset);
 long long mm_bn_floats(const MMPlan*);

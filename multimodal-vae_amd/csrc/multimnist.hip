@@ -37,6 +37,7 @@ struct MMPlan : PlanBase {
         bf16 *d_encout; float* d_txtout; bf16* te_dout_bf; bf16 *te_dgi_f, *te_dgh_f, *te_dgi_r;
         bf16 *dy2, *dy1, *db4, *dr4, *d3e, *d2e, *d1e;
         float* tmp_f32;
+        float* slab; size_t slab_floats;
     } w;
 };
 
@@ -222,6 +223,9 @@ void carve(MMPlan& P, Workspace& ws) {
     w.tmp_f32 = ws.take<float>(B3 * NPIX);
     P.sk_floats = (size_t)256 * 128 * 128;                 // split-K partial slabs (fully overwritten, never zeroed)
     P.sk_buf = ws.take<float>(P.sk_floats);
+    // weight-gradient partial-tile slabs (written and read once per step, never zeroed): gemm.h WgradSlabCtx
+    w.slab_floats = (size_t)(P.carve_passes >= 3 ? 48 : 16) << 20;
+    w.slab = ws.take<float>(w.slab_floats);
 }
 
 // ================================================================== image encoder
@@ -363,7 +367,7 @@ int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const
         GatherPlan pl = dense_plan(B * 625, 16, 16, 32);
         WgradParams g = wgrad_of(P, pl, P.conv[0].gk, 1, B * 625);
         g.c.A = w.patches1; g.P = w.d1e; g.ldp = 32;
-        MMVAE_TRY(launch_wgrad(g, s));
+        MMVAE_TRY(launch_wgrad(g, s, &P.slab));
     }
     return MMVAE_OK;
 }
@@ -371,7 +375,44 @@ int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const
 // ================================================================== image decoder (multimnist/model.py:211-216)
 // z_bf: [groups*B][ldz] with column D == 1.0 (folded bias).  The last layer is the fused direct kernel
 // ConvTranspose2d(32,1) + sigmoid (+ BCE and its gradient when `bce` is given).
-int dec_fwd(MMPlan& P, int groups, int training, ConvTLastFwdArgs* last, hipStream_t s, int last_groups = -1) {
+// BatchNorm finalize of hallucinate.7 + the thin last layer + (for the first bwd_groups groups) its gradients: thin.h
+int fused_tail(MMPlan& P, int groups, int training, const ConvTLastFwdArgs* last, int last_groups, int fused_bwd_groups, hipStream_t s) {
+    MMPlan::W& w = P.w;
+    const int B = P.B;
+    const ConvL& L = P.convT[2];
+    const BnL& b = P.bn[L.bn];
+    DecLastFusedArgs x{};
+    x.r = w.q3; x.act = ACT_SWISH; x.w = P.buf.params + P.convT[3].w_off;
+    x.G = last_groups > 0 ? last_groups : groups; x.B = B; x.IH = 25; x.IW = 25; x.Cin = 32;
+    x.bwd_groups = std::min(fused_bwd_groups, x.G);
+    BnFinalizeArgs& f = x.fin;
+    f.stats = w.st_d[2]; f.G = groups; f.C = b.C; f.count = (float)(B * L.g.OH * L.g.OW);
+    f.gamma = P.buf.params + b.w_off; f.beta = P.buf.params + b.b_off;
+    f.running_mean = P.buf.bn_stats + b.stat_off; f.running_var = P.buf.bn_stats + b.stat_off + b.C;
+    f.num_batches_tracked = P.buf.bn_nbt + b.idx;
+    f.updates_per_group = 1; f.affine = w.aff_d[2]; f.meanrstd = w.mr_d[2]; f.eps = BN_EPS; f.momentum = BN_MOM; f.training = training;
+    f.skip_update_mask = groups > 1 ? P.dec_skip_mask : 0u;
+    x.target = last->target; x.logits = last->logits; x.recon = last->recon; x.dlogit = nullptr;
+    for (int k = 0; k < 4; ++k) x.coef[k] = last->coef[k];
+    x.loss_sum = last->loss_sum;
+    if (x.bwd_groups > 0) {
+        const int chunks = x.bwd_groups * B * dec_last_fused_strips(25);
+        x.wslab = P.slab.take((size_t)chunks * 32 * 16);
+        MMVAE_REQUIRE(x.wslab != nullptr, "fused decoder tail: the weight-gradient slab pool is exhausted");
+        x.db = w.d3; x.red = w.red_d[2];
+        WgradSlabJob j{};
+        const PackDesc& gd = P.gk.d[P.convT[3].gk[0]];
+        j.dst = P.buf.gpk + gd.dst_off; j.slab = x.wslab; j.N = 32; j.K = 16; j.Kpad = gd.Kpad; j.chunks = chunks;
+        j.chunk_stride = 32 * 16; j.src_ld = 16; j.stream = s;
+        P.slab.jobs.push_back(j);
+    }
+    return launch_dec_last_fused(x, s);
+}
+
+// `fused_bwd_groups` >= 0: the fused tail (thin.h DecLastFusedArgs) replaces bn_act of the last BatchNorm + the thin last
+// layer, and for the first fused_bwd_groups groups also the last layer's data / weight gradients (step path only: the
+// granular modules get their upstream gradient from autograd and keep the separate kernels).
+int dec_fwd(MMPlan& P, int groups, int training, ConvTLastFwdArgs* last, hipStream_t s, int last_groups = -1, int fused_bwd_groups = -1) {
     MMPlan::W& w = P.w;
     const int B = P.B, rows = groups * B;
     {
@@ -384,27 +425,40 @@ int dec_fwd(MMPlan& P, int groups, int training, ConvTLastFwdArgs* last, hipStre
     bf16* aq[4] = {w.au, w.aq1, w.aq2, w.aq3};
     for (int l = 0; l < 3; ++l) {
         const ConvL& L = P.convT[l];
-        GemmParams g = gemm_of(P, L.fwd, L.pk_fwd, groups, B);
-        g.c.A = aq[l];
-        g.out_bf = q[l + 1]; g.ldo = L.g.Cout;
-        g.colstats = training ? w.st_d[l] : nullptr;
-        MMVAE_TRY(launch_gemm_gather(g, s));
+        {
+            GemmParams g = gemm_of(P, L.fwd, L.pk_fwd, groups, B);
+            g.c.A = aq[l];
+            g.out_bf = q[l + 1]; g.ldo = L.g.Cout;
+            g.colstats = training ? w.st_d[l] : nullptr;
+            MMVAE_TRY(launch_gemm_gather(g, s));
+        }
         const int rpg = B * L.g.OH * L.g.OW;
+        if (l == 2 && fused_bwd_groups >= 0) continue;
         MMVAE_TRY(bn_act(P, P.bn[L.bn], q[l + 1], aq[l + 1], groups * rpg, rpg, groups, w.st_d[l], 1, w.aff_d[l], w.mr_d[l], training, s));
     }
+    if (fused_bwd_groups >= 0) return fused_tail(P, groups, training, last, last_groups, fused_bwd_groups, s);
     ConvTLastFwdArgs x = *last;
     x.act = w.aq3; x.w = P.buf.params + P.convT[3].w_off; x.G = last_groups > 0 ? last_groups : groups; x.B = B; x.IH = 25; x.IW = 25; x.Cin = 32; x.Cout = 1;
     return launch_convt_last_fwd(x, s);
 }
 
 // dlogit: fp32 NCHW [groups*B][1][50][50] (grad wrt the pre-sigmoid logits). Writes dz (fp32 [groups*B][D]).
-int dec_bwd(MMPlan& P, const float* dlogit, int groups, float* dz, hipStream_t s) {
+int dec_bwd(MMPlan& P, const float* dlogit, int groups, float* dz, hipStream_t s, bool last_fused = false) {
     MMPlan::W& w = P.w;
     const int B = P.B, rows = groups * B;
     bf16* q[4] = {w.u, w.q1, w.q2, w.q3};
     bf16* aq[4] = {w.au, w.aq1, w.aq2, w.aq3};
     bf16* dq[4] = {w.du, w.d1, w.d2, w.d3};
-    {   // last transposed conv (32 -> 1): both gradients go through the im2col patches of dlogit (K = 16 taps):
+    if (last_fused) {
+        // d3, the BatchNorm-backward sums and the weight-gradient partials of the last layer came out of the fused tail
+        // (dec_fwd); only the sum of the partials is left, off the main chain
+        if (P.wgrad_forked) {
+            hipStream_t wst = P.st_wgrad;
+            MMVAE_TRY(edge(P, s, wst));
+            for (WgradSlabJob& j : P.slab.jobs) if (j.stream == s && j.src_ld == 16) j.stream = wst;
+            MMVAE_TRY(launch_wgrad_reduce(&P.slab, wst, true));
+        }
+    } else {   // last transposed conv (32 -> 1): both gradients go through the im2col patches of dlogit (K = 16 taps):
         // input gradient = dense GEMM patches x W (d-Swish + BatchNorm-backward sums in the epilogue), weight
         // gradient = patches^T x activated input.  (The direct dot-product kernel convt_last_dgrad is VALU-bound:
         // 52 us against 39 us for this GEMM at B=256.)
@@ -434,8 +488,7 @@ int dec_bwd(MMPlan& P, const float* dlogit, int groups, float* dz, hipStream_t s
         x.dgamma = P.buf.grads + b.w_off; x.dbeta = P.buf.grads + b.b_off;
         MMVAE_TRY(launch_bn_bwd_apply(x, s));
         {
-            WgradParams g = wgrad_of(P, L.fwd, L.gk, groups, B);
-            g.c.A = aq[l]; g.P = dq[l + 1]; g.ldp = L.g.Cout;
+            WgradParams g = convT_wgrad(P, L, groups, B, aq[l], dq[l + 1]);
             MMVAE_TRY(wgrad_async(P, g, s));
         }
         {
@@ -493,17 +546,21 @@ int txt_enc_bwd(MMPlan& P, const long long* text, const float* d_out, hipStream_
     a.g_bih_f = G + P.te_f.bih; a.g_bhh_f = G + P.te_f.bhh; a.g_bih_r = G + P.te_r.bih; a.g_bhh_r = G + P.te_r.bhh;
     a.g_h2p_bias = G + off(P, "text_encoder.h2p.bias");
     MMVAE_TRY(launch_text_encoder_bwd(a, s));
-    auto wg = [&](int gidx, const bf16* Pm, int N, int ldp, const bf16* Gm, int C, int rows) -> int {
+    // the four weight gradients of the text encoder share ONE grouped launch
+    WgradParams list[4];
+    int nl = 0;
+    auto wg = [&](int gidx, const bf16* Pm, int N, int ldp, const bf16* Gm, int C, int rows) {
         GatherPlan pl = dense_plan(rows, C, C, N);
         WgradParams g = wgrad_of(P, pl, &gidx, 1, rows);
         g.c.A = Gm; g.P = Pm; g.ldp = ldp;
-        return launch_wgrad(g, s);
+        list[nl++] = g;
     };
-    MMVAE_TRY(wg(P.te_f.g_wih, w.te_dgi_f, 300, 304, w.te_x, TXT_HP, 4 * B));
-    MMVAE_TRY(wg(P.te_f.g_whh, w.te_dgh_f, 300, 304, w.te_hprev, TXT_HP, 4 * B));
-    MMVAE_TRY(wg(P.te_r.g_wih, w.te_dgi_r, 300, 304, w.te_x + (size_t)3 * B * TXT_HP, TXT_HP, B));
-    MMVAE_TRY(wg(P.g_te_h2p, w.te_dout_bf, D2, round_up(D2, 8), w.te_hsum, TXT_HP, B));
-    return MMVAE_OK;
+    wg(P.te_f.g_wih, w.te_dgi_f, 300, 304, w.te_x, TXT_HP, 4 * B);
+    wg(P.te_f.g_whh, w.te_dgh_f, 300, 304, w.te_hprev, TXT_HP, 4 * B);
+    wg(P.te_r.g_wih, w.te_dgi_r, 300, 304, w.te_x + (size_t)3 * B * TXT_HP, TXT_HP, B);
+    wg(P.g_te_h2p, w.te_dout_bf, D2, round_up(D2, 8), w.te_hsum, TXT_HP, B);
+    MMVAE_TRY(launch_wgrad_group(list, nl, s, &P.slab));
+    return launch_wgrad_reduce(&P.slab, s, true);
 }
 TextDecArgs td_args(MMPlan& P, const float* z, int groups, bool save) {
     MMPlan::W& w = P.w;
@@ -535,20 +592,24 @@ int txt_dec_bwd(MMPlan& P, const TextDecArgs& f, const float* dwords, float* dz,
     a.g_b[0] = G + P.td0.bih; a.g_b[1] = G + P.td0.bhh; a.g_b[2] = G + P.td1.bih; a.g_b[3] = G + P.td1.bhh;
     a.g_h2o_bias = G + off(P, "text_decoder.h2o.bias"); a.g_z2h_bias = G + off(P, "text_decoder.z2h.bias");
     MMVAE_TRY(launch_text_decoder_bwd(a, s));
-    auto wg = [&](int gidx, const bf16* Pm, int N, int ldp, const bf16* Gm, int C, int rows) -> int {
+    // the six weight gradients of the text decoder: one grouped launch (128x128 tile class) + the thin h2o one
+    WgradParams list[6];
+    int nl = 0;
+    auto wg = [&](int gidx, const bf16* Pm, int N, int ldp, const bf16* Gm, int C, int rows) {
         GatherPlan pl = dense_plan(rows, C, C, N);
         WgradParams g = wgrad_of(P, pl, &gidx, 1, rows);
         g.c.A = Gm; g.P = Pm; g.ldp = ldp;
-        return launch_wgrad(g, s);
+        list[nl++] = g;
     };
     (void)XI;
-    MMVAE_TRY(wg(P.td0.g_wih, w.dgi0, 300, 304, w.td_x0, P.kx, 4 * R));
-    MMVAE_TRY(wg(P.td0.g_whh, w.dgh0, 300, 304, w.td_h0p, TXT_HP, 4 * R));
-    MMVAE_TRY(wg(P.td1.g_wih, w.dgi1, 300, 304, w.td_mid, TXT_HP, 4 * R));
-    MMVAE_TRY(wg(P.td1.g_whh, w.dgh1, 300, 304, w.td_h1p, TXT_HP, 4 * R));
-    MMVAE_TRY(wg(P.g_td_h2o, w.dlogit_bf, 12, 16, w.td_hz, P.kx, 4 * R));
-    MMVAE_TRY(wg(P.g_td_z2h, w.dhinit, 100, 112, w.td_zbf, P.kz, R));
-    return MMVAE_OK;
+    wg(P.td0.g_wih, w.dgi0, 300, 304, w.td_x0, P.kx, 4 * R);
+    wg(P.td0.g_whh, w.dgh0, 300, 304, w.td_h0p, TXT_HP, 4 * R);
+    wg(P.td1.g_wih, w.dgi1, 300, 304, w.td_mid, TXT_HP, 4 * R);
+    wg(P.td1.g_whh, w.dgh1, 300, 304, w.td_h1p, TXT_HP, 4 * R);
+    wg(P.g_td_z2h, w.dhinit, 100, 112, w.td_zbf, P.kz, R);
+    wg(P.g_td_h2o, w.dlogit_bf, 12, 16, w.td_hz, P.kx, 4 * R);
+    MMVAE_TRY(launch_wgrad_group(list, nl, s, &P.slab));
+    return launch_wgrad_reduce(&P.slab, s, true);
 }
 
 }  // namespace
@@ -601,6 +662,7 @@ static int use_ws(MMPlan* P, void* ws, size_t bytes, bool module = true) {
     Workspace w(ws, bytes);
     carve(*P, w);
     P->dec_skip_mask = 0;
+    P->slab.reset(P->w.slab, P->w.slab_floats);
     return MMVAE_OK;
 }
 
@@ -610,6 +672,7 @@ int mm_pack_weights(MMPlan* P, hipStream_t s) {
 }
 int mm_unpack_grads(MMPlan* P, hipStream_t s) {
     MMVAE_TRY(check_bound(P));
+    MMVAE_TRY(launch_wgrad_reduce(&P->slab, s));      // partial-tile slabs -> packed gradients (no-op when none are owed)
     return launch_unpack_grads(P->buf.gdesc_dev, P->gk.d.data(), (int)P->gk.d.size(), P->buf.gpk, P->buf.gpk_vec, P->buf.grads, s);
 }
 int mm_grad_map(MMPlan* P, int* map, hipStream_t s) {
@@ -647,6 +710,8 @@ static int mm_step_body(MMPlan* Pp, const MMStepIO& io, int training, int do_bac
     if (training && io.enc_dropout && !m1) { sb.mask[0] = w.m1; sb.n_mask[0] = (long long)2 * B * 400; m1 = w.m1; }
     if (training && io.enc_dropout && !m2) { sb.mask[1] = w.m2; sb.n_mask[1] = (long long)2 * B * 200; m2 = w.m2; }
     if (training && io.gru_dropout && !gk) { sb.mask[2] = w.gkeep; sb.n_mask[2] = (long long)4 * B3 * 100; gk = w.gkeep; }
+    if (io.pack_first)
+        MMVAE_TRY(step_begin_with_pack(sb, P.buf.desc_dev, P.pk.d.data(), (int)P.pk.d.size(), P.buf.params, P.buf.packed, P.buf.packed_vec));
     MMVAE_TRY(launch_step_begin(sb, s));
     if (do_backward && P.nparams % 4 != 0)
         MMVAE_TRY(launch_fill_zero(P.buf.grads + (P.nparams / 4) * 4, (size_t)(P.nparams % 4) * sizeof(float), s));
@@ -693,7 +758,13 @@ static int mm_step_body(MMPlan* Pp, const MMStepIO& io, int training, int do_bac
     int last_groups = 3;
     if (!io.recon_image)
         while (last_groups > 1 && last.coef[last_groups - 1] == 0.f) --last_groups;
-    MMVAE_TRY(dec_fwd(P, 3, training, &last, s, last_groups));
+    // image decoder backward runs for the leading groups with a non-zero image term (a pass with lambda_xy = 0 has exactly
+    // zero gradient); the fused tail needs to know it already in the forward
+    int img_groups = 3;
+    while (img_groups > 0 && (io.lambda_xy[img_groups - 1] == 0.f || sk[img_groups - 1])) --img_groups;
+    static const bool no_fuse_tail = getenv("MMVAE_NO_FUSED_TAIL") != nullptr;        // A/B aid
+    const bool fuse_tail = !no_fuse_tail && P.slab.pool != nullptr;
+    MMVAE_TRY(dec_fwd(P, 3, training, &last, s, last_groups, fuse_tail ? (do_backward ? std::min(img_groups, last_groups) : 0) : -1));
     if (!do_backward) {
         MMVAE_TRY(edge(P, T, s));
         hipLaunchKernelGGL(sum_slots_kernel, dim3(1), dim3(64), 0, s, w.sums, io.sums);
@@ -702,24 +773,18 @@ static int mm_step_body(MMPlan* Pp, const MMStepIO& io, int training, int do_bac
 
     // =============================== backward ===============================
     P.wgrad_forked = true;
-    // image decoder: a pass with lambda_xy = 0 (text-only) has exactly zero gradient: only the leading groups run
-    int img_groups = 3;
-    while (img_groups > 0 && (io.lambda_xy[img_groups - 1] == 0.f || sk[img_groups - 1])) --img_groups;
     int rc = MMVAE_OK;
     static const bool defer = getenv("MMVAE_DEFER_WGRAD") != nullptr;
     P.deferred.clear();
     P.defer_wgrad = defer && !serial;
-    if (img_groups > 0) rc = dec_bwd(P, w.dlogit, img_groups, w.dz_img, s);
+    if (img_groups > 0) rc = dec_bwd(P, w.dlogit, img_groups, w.dz_img, s, fuse_tail);
     if (rc == MMVAE_OK) rc = edge(P, T, s);          // dz of the text decoder
     Latent3BwdArgs lb{};
     lb.f = la; lb.dz_a = w.dz_img; lb.dz_b = w.dz_txt;
     for (int k = 0; k < 3; ++k) lb.kl_coef[k] = sk[k] ? 0.f : io.kl_lambda / (float)B;
     lb.d_img_out_bf = w.d_encout; lb.d_img_bias = P.buf.grads + P.fc[2].b_off; lb.d_txt_out = w.d_txtout;
+    lb.loss_slots = w.sums; lb.loss_out = io.sums;      // every loss term is final here (text-decoder NLL joined above)
     if (rc == MMVAE_OK) rc = launch_latent3_bwd(lb, s);
-    if (rc == MMVAE_OK) {       // every loss term is final here (text-decoder NLL joined above): keep this off the tail
-        hipLaunchKernelGGL(sum_slots_kernel, dim3(1), dim3(64), 0, s, w.sums, io.sums);
-        rc = mmvae_check_launch("sum_slots");
-    }
     if (rc == MMVAE_OK) rc = flush_wgrads(P, s);
     if (rc == MMVAE_OK) rc = edge(P, s, T);
     if (rc == MMVAE_OK) rc = txt_enc_bwd(P, io.text, w.d_txtout, T);
@@ -729,6 +794,7 @@ static int mm_step_body(MMPlan* Pp, const MMStepIO& io, int training, int do_bac
     MMVAE_TRY(edge(P, T, s));
     MMVAE_TRY(edge(P, P.st_wgrad, s));
     if (P.st_wgrad2 != P.st_wgrad) MMVAE_TRY(edge(P, P.st_wgrad2, s));
+    MMVAE_TRY(launch_wgrad_reduce(&P.slab, s));
     if (!io.defer_unpack) MMVAE_TRY(mm_unpack_grads(Pp, s));
     return MMVAE_OK;
 }
@@ -916,6 +982,47 @@ static bool layer_gemm(MMPlan& P, const std::string& name, GemmParams& g) {
     }
     return false;
 }
+// the weight gradients exactly as the step launches them (2 decoder passes carry a gradient)
+static bool layer_wgrad(MMPlan& P, const std::string& name, WgradParams& g) {
+    MMPlan::W& w = P.w;
+    const int B = P.B;
+    bf16* a[4] = {w.a1, w.a2, w.a3, w.a4};
+    bf16* dre[4] = {w.d1e, w.d2e, w.d3e, w.dr4};
+    bf16* aq[4] = {w.au, w.aq1, w.aq2, w.aq3};
+    bf16* dq[4] = {w.du, w.d1, w.d2, w.d3};
+    for (int l = 0; l < 3; ++l)
+        if (name == "dec_convT" + std::to_string(l + 1) + "_wgrad") {
+            const ConvL& L = P.convT[l];
+            g = convT_wgrad(P, L, 2, B, aq[l], dq[l + 1]);
+            return true;
+        }
+    for (int l = 1; l < 4; ++l)
+        if (name == "enc_conv" + std::to_string(l + 1) + "_wgrad") {
+            const ConvL& L = P.conv[l];
+            g = wgrad_of(P, L.fwd, L.gk, 1, B);
+            g.c.A = a[l - 1]; g.P = dre[l]; g.ldp = L.g.Cout;
+            return true;
+        }
+    if (name == "dec_last_wgrad") {
+        GatherPlan pl = plan_fwdform(1, 1, 25, 25, 16, 1, 1, 1, 0, 32, 2, B);
+        g = wgrad_of(P, pl, P.convT[3].gk, 2, B);
+        g.c.A = w.patches4; g.c.AH = 25; g.c.AW = 25; g.c.sy = g.c.sx = 1;
+        g.P = w.aq3; g.ldp = 32;
+        return true;
+    }
+    if (name == "enc_conv1_wgrad") {
+        GatherPlan pl = dense_plan(B * 625, 16, 16, 32);
+        g = wgrad_of(P, pl, P.conv[0].gk, 1, B * 625);
+        g.c.A = w.patches1; g.P = w.d1e; g.ldp = 32;
+        return true;
+    }
+    return false;
+}
+static double wgrad_flops(const WgradParams& g) {
+    double f = 0;
+    for (int i = 0; i < g.c.nclasses; ++i) f += 2.0 * g.c.groups * g.cls[i].rows_per_group * (double)g.c.N * g.cls[i].K;
+    return f;
+}
 static double gemm_flops(const GemmParams& g) {
     double f = 0;
     for (int i = 0; i < g.c.nclasses; ++i) f += 2.0 * g.c.groups * g.cls[i].rows_per_group * (double)g.c.N * g.cls[i].K;
@@ -923,6 +1030,26 @@ static double gemm_flops(const GemmParams& g) {
 }
 int mm_bench_layer(MMPlan* P, void* ws, size_t wsb, const char* layer, int iters, hipStream_t s) {
     MMVAE_TRY(use_ws(P, ws, wsb, false));
+    if (std::string(layer) == "dec_last_fused") {        // fused decoder tail as in the training step (2 of 3 passes carry a gradient)
+        ConvTLastFwdArgs last{};
+        last.target = (const float*)P->w.tmp_f32; last.loss_sum = P->w.sums;
+        last.coef[0] = last.coef[1] = 1.f / (float)(P->B * NPIX);
+        for (int i = 0; i < iters; ++i) {
+            P->slab.reset(P->w.slab, P->w.slab_floats);
+            MMVAE_TRY(fused_tail(*P, 3, 1, &last, 2, 2, s));
+            P->slab.jobs.clear();
+        }
+        return MMVAE_OK;
+    }
+    WgradParams wg{};
+    if (layer_wgrad(*P, layer, wg)) {            // kernel + its share of the slab reduction, as in the step
+        for (int i = 0; i < iters; ++i) {
+            P->slab.reset(P->w.slab, P->w.slab_floats);
+            MMVAE_TRY(launch_wgrad(wg, s, &P->slab));
+            MMVAE_TRY(launch_wgrad_reduce(&P->slab, s));
+        }
+        return MMVAE_OK;
+    }
     GemmParams g{};
     MMVAE_REQUIRE(layer_gemm(*P, layer, g), "bench_layer: unknown layer '%s'", layer);
     for (int i = 0; i < iters; ++i) MMVAE_TRY(launch_gemm_gather(g, s));
@@ -931,8 +1058,32 @@ int mm_bench_layer(MMPlan* P, void* ws, size_t wsb, const char* layer, int iters
 double mm_layer_flops(const MMPlan* Pc, const char* layer) {
     MMPlan& P = *const_cast<MMPlan*>(Pc);
     GemmParams g{};
+    WgradParams wg{};
+    if (std::string(layer) == "dec_last_fused") return 3.0 * 2.0 * 2 * P.B * 625 * 16 * 32;      // forward + both gradients, 2 passes
+    if (P.bound && layer_wgrad(P, layer, wg)) return wgrad_flops(wg);
     if (!P.bound || !layer_gemm(P, layer, g)) return -1.0;
     return gemm_flops(g);
+}
+// FLOPs of a layer the way torch's FlopCounterMode counts the reference: 2 * out_pixels * taps * Cin * Cout for a
+// Conv2d, 2 * in_pixels * taps * Cin * Cout for a ConvTranspose2d, the same number again for each of the two gradients --
+// padded / cropped taps are NOT subtracted by the counter, zero-padded GEMM columns of this engine are not added.
+double mm_layer_algo_flops(const MMPlan* Pc, const char* layer) {
+    const MMPlan& P = *Pc;
+    const std::string name = layer;
+    const int B = P.B;
+    auto conv = [&](const ConvL& L, int images) {
+        const ConvGeom& g = L.g;
+        const double pix = g.transposed ? (double)g.IH * g.IW : (double)g.OH * g.OW;
+        return 2.0 * pix * g.KH * g.KW * g.Cin * g.Cout * images;
+    };
+    for (int l = 0; l < 4; ++l) {
+        const std::string e = "enc_conv" + std::to_string(l + 1), d = "dec_convT" + std::to_string(l + 1);
+        if (name == e || name == e + "_dgrad" || name == e + "_wgrad") return conv(P.conv[l], B);
+        if (name == d) return conv(P.convT[l], 3 * B);
+        if (name == d + "_dgrad" || name == d + "_wgrad") return conv(P.convT[l], 2 * B);
+    }
+    if (name == "dec_last_wgrad" || name == "dec_last_dgrad_gemm") return conv(P.convT[3], 2 * B);
+    return mm_layer_flops(Pc, layer);          // dense layers: no padding in the count
 }
 int mm_num_bn(const MMPlan*) { return 6; }
 int mm_bn_info(const MMPlan* P, int i, std::string& prefix, int& C, long long& offset) {

@@ -29,6 +29,7 @@ struct ConvL {
     int bn;                       // index into bn tables or -1
     GatherPlan fwd, dgrad;        // geometry templates (groups/pointers filled per call)
     int pk_fwd[4], pk_dgrad[4], gk[4];
+    bool wgrad_fwdform = false;   // transposed conv: weight gradient in the data-gradient geometry (gk[0] only)
 };
 struct LinL {
     long long w_off, b_off;
@@ -62,6 +63,7 @@ struct PlanBase {
     bool single_wgrad_stream = false;   // the plan's weight gradients all go to ONE side stream (MultiMNIST: 0.967 -> 0.950 ms
                                         // per step; CelebA is 3 % slower that way and keeps two)
     bool no_splitk = false;         // set while enqueueing on a side stream: the split-K slabs belong to the main chain
+    WgradSlabCtx slab;              // weight-gradient partial-tile slabs of the running step (pool carved from the workspace)
     // split-K partial slabs (carved from the caller's workspace)
     float* sk_buf = nullptr; size_t sk_floats = 0; unsigned* sk_cnt = nullptr;
     // generic queries (capi.cpp): BatchNorm layers in state_dict order and the workspace size
@@ -81,11 +83,15 @@ inline int edge(PlanBase& P, hipStream_t from, hipStream_t to);
 // weight gradients only feed the optimizer: when the step runs multi-stream they go to the side stream
 inline int wgrad_async(PlanBase& P, const WgradParams& g, hipStream_t s) {
     static const bool serial = getenv("MMVAE_SERIAL") != nullptr;
-    if (!P.wgrad_forked || serial) return launch_wgrad(g, s);
+    if (!P.wgrad_forked || serial) return launch_wgrad(g, s, &P.slab);
     if (P.defer_wgrad) { P.deferred.push_back(g); return MMVAE_OK; }
     hipStream_t w = (P.wgrad_rr++ & 1) ? P.st_wgrad2 : P.st_wgrad;
     MMVAE_TRY(edge(P, s, w));
-    return launch_wgrad(g, w);
+    MMVAE_TRY(launch_wgrad(g, w, &P.slab));
+    // the slab copies are summed right behind the kernel on the SAME side stream: off the main chain (one reduce launch
+    // at the end of the step would read every slab of the step on the critical tail)
+    static const bool late = getenv("MMVAE_WGRAD_REDUCE_LATE") != nullptr;
+    return late ? MMVAE_OK : launch_wgrad_reduce(&P.slab, w, true);
 }
 
 // issue the weight gradients collected while defer_wgrad was set (their operands are complete on `s` by now)
@@ -94,7 +100,7 @@ inline int flush_wgrads(PlanBase& P, hipStream_t s) {
     for (const WgradParams& g : P.deferred) {
         hipStream_t w = (P.wgrad_rr++ & 1) ? P.st_wgrad2 : P.st_wgrad;
         MMVAE_TRY(edge(P, s, w));
-        MMVAE_TRY(launch_wgrad(g, w));
+        MMVAE_TRY(launch_wgrad(g, w, &P.slab));
     }
     P.deferred.clear();
     return MMVAE_OK;
@@ -153,13 +159,22 @@ inline void build_conv(PlanBase& P, ConvL& L, const std::string& wname, ConvGeom
                 PackDesc d = pack_conv(L.w_off, L.fwd.c, L.fwd.cls[ci], npad_for(g.Cout), kk, g.Cout * kk, g.KW,
                                        (ph + g.pad) % g.stride, (pw + g.pad) % g.stride, g.stride);
                 L.pk_fwd[ci] = P.pk.add(d);
-                PackDesc gd = d; gd.Npad = round_up(g.Cout, 64);
-                L.gk[ci] = P.gk.add(gd);
+                if (!need_dgrad) {
+                    PackDesc gd = d; gd.Npad = round_up(g.Cout, 64);
+                    L.gk[ci] = P.gk.add(gd);
+                }
             }
             if (need_dgrad) {
                 L.dgrad = plan_fwdform(g.OH, g.OW, g.IH, g.IW, g.Cout, g.KH, g.KW, g.stride, g.pad, g.Cin, 1, 1);
                 PackDesc d = pack_conv(L.w_off, L.dgrad.c, L.dgrad.cls[0], npad_for(g.Cin), g.Cout * kk, kk, g.KW, 0, 0, 1);
                 L.pk_dgrad[0] = P.pk.add(d);
+                // The weight gradient is taken in the SAME (forward-form) geometry: rows over the small input grid, the
+                // plain operand is the layer input [rows][Cin], the gathered one the output gradient (all taps, K =
+                // taps*Cout).  Against the class form (rows over the 4x larger output grid, one K = taps/4 * Cin per parity
+                // class) it has 4x fewer rows, half the gathered bytes and twice the MFMAs per staged row.
+                PackDesc gd = d; gd.Npad = round_up(g.Cin, 64);
+                L.gk[0] = P.gk.add(gd);
+                L.wgrad_fwdform = true;
             }
         } else {
             // thin output (Cout small): forward still class-form (N = Cout padded to 16); backward goes through
@@ -225,6 +240,19 @@ inline WgradParams wgrad_of(const PlanBase& P, const GatherPlan& pl, const int* 
     return g;
 }
 inline GatherPlan dense_plan(int rows, int C, int ld, int N) { return plan_dense(rows, C, ld, N); }
+
+// weight gradient of a (non-thin) ConvTranspose2d layer: `in_act` = the layer's activated input [groups*B][IH][IW][Cin],
+// `d_out` = gradient w.r.t. its raw output [groups*B][OH][OW][Cout]
+inline WgradParams convT_wgrad(const PlanBase& P, const ConvL& L, int groups, int B, const bf16* in_act, const bf16* d_out) {
+    if (L.wgrad_fwdform) {
+        WgradParams g = wgrad_of(P, L.dgrad, L.gk, groups, B);
+        g.c.A = d_out; g.P = in_act; g.ldp = L.g.Cin;
+        return g;
+    }
+    WgradParams g = wgrad_of(P, L.fwd, L.gk, groups, B);
+    g.c.A = in_act; g.P = d_out; g.ldp = L.g.Cout;
+    return g;
+}
 
 inline int bn_act(PlanBase& P, const BnL& b, const bf16* r, bf16* a, int rows, int rows_per_group, int G, const float2* stats,
            int updates, float2* aff, float2* mr, int training, hipStream_t s) {
@@ -383,6 +411,7 @@ inline void join_after_error(PlanBase& P, hipStream_t s) {
         (void)hipGetLastError();
     }
     P.deferred.clear();
+    P.slab.jobs.clear();
     P.defer_wgrad = false; P.wgrad_forked = false; P.no_splitk = false;
 }
 

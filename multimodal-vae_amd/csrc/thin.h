@@ -1,6 +1,7 @@
 // Direct kernels for the thin last ConvTranspose2d(32 -> 1 or 3, k4, s2, p1) of the image decoders. See thin.hip.
 #pragma once
 #include "common.h"
+#include "elementwise.h"
 
 struct ConvTLastFwdArgs {
     const bf16* act;         // activated input, NHWC [G*B][IH][IW][Cin]
@@ -27,3 +28,26 @@ struct ConvTLastDgradArgs {
     float2* red;             // [G][MMVAE_STAT_SLOTS][Cin] += (sum db, sum db*xhat)
 };
 int launch_convt_last_dgrad(const ConvTLastDgradArgs& a, hipStream_t s);
+
+// Fused tail of the image decoder for Cout = 1 (multimnist/model.py:206-216 + multimnist/train.py:75-76 and their backward):
+//   BatchNorm finalize of the producer layer (tables + running statistics) -> BN-apply + Swish while the input strip is
+//   staged (the activated tensor is never written) -> ConvTranspose2d(Cin,1,4,2,1) -> sigmoid -> BCE (+ its gradient)
+//   -> input gradient of the layer with the producer's d-Swish and BatchNorm-backward sums -> the layer's weight gradient.
+// One launch instead of bn_act + convt_last_fwd + im2col + dense-GEMM data gradient + weight-gradient GEMM.
+struct DecLastFusedArgs {
+    const bf16* r;           // raw (pre-BN) input, NHWC [>= G*B][IH][IW][Cin]
+    BnFinalizeArgs fin;      // BatchNorm of the producer layer over ALL its groups; block (0,0) writes tables + running stats
+    int act;
+    const float* w;          // fp32 (Cin, 1, 4, 4)
+    int G, B, IH, IW, Cin;   // G = groups (passes) whose last layer is computed
+    int bwd_groups;          // groups [0, bwd_groups) also produce db / red / weight-gradient partials (0: forward only)
+    const float* target;     // NCHW [B][1][2IH][2IW] or null
+    float* logits; float* recon; float* dlogit;      // optional dumps, NCHW [G*B][1][2IH][2IW]
+    float coef[4];
+    float* loss_sum;         // [MMVAE_LOSS_SLOTS][16] column g += BCE sums, or null
+    bf16* db;                // out NHWC [G*B][IH][IW][Cin]
+    float2* red;             // [fin.G][MMVAE_STAT_SLOTS][Cin] += (sum db, sum db*xhat)
+    float* wslab;            // [bwd_groups*B*strips][Cin][16]: per-workgroup weight-gradient partials (plain stores)
+};
+int dec_last_fused_strips(int IH);
+int launch_dec_last_fused(const DecLastFusedArgs& a, hipStream_t s);

@@ -1,4 +1,5 @@
 #include "common.h"
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 
@@ -20,6 +21,14 @@ int mmvae_check_launch(const char* what) {
         return MMVAE_EHIP;
     }
     return MMVAE_OK;
+}
+
+// ---- measurement aid: MFMA GEMM work (2*rows*N*K per launch, padded taps included) enqueued by this process
+static std::atomic<long long> g_mflops{0};
+void mmvae_count_flops(double f) { g_mflops.fetch_add((long long)(f * 1e-6)); }
+extern "C" double mmvae_debug_flops(int reset) {
+    const long long v = reset ? g_mflops.exchange(0) : g_mflops.load();
+    return (double)v * 1e6;
 }
 
 // ---- side-stream priority policy

@@ -77,6 +77,7 @@ class _Core:
             self.state = self.state_cls(self.n_latents, device)
             self._sig = None
         st = self.state
+        st.ensure_packed()                 # a fused step may have deferred the refresh of the bf16 weight copies
         owner, params, bufs = self._named()
         base = st.params.data_ptr()
         for name, shape, off in st.table:
