@@ -449,13 +449,13 @@ static int coco_step_body(CocoPlan* Pp, const CocoStepIO& io, int training, int 
     // ---- caption decoder (+ MSE, + its backward) on the side stream, image decoder on main
     MMVAE_TRY(edge(P, s, Tx));
     float* sentence = io.recon_text ? io.recon_text : w.td_recon;
-    MMVAE_TRY(coco_text_dec_fwd(P, w.z_f32, 3, io.sos, gk, do_backward, sentence, Tx));
+    MMVAE_TRY(coco_text_dec_fwd(P, w.z_f32, 3, io.sos, gk, do_backward, sentence, Tx, true));
     {
         float coef[3];
         for (int k = 0; k < 3; ++k) coef[k] = sk[k] ? 0.f : io.lambda_yx[k] / ((float)B * (float)T * (float)COCO_E);
         MMVAE_TRY(coco_mse3(sentence, io.text, 3, (long long)B * T * COCO_E, coef, w.sums, do_backward ? w.td_dw : nullptr, Tx));
     }
-    if (do_backward) MMVAE_TRY(coco_text_dec_bwd(P, w.z_f32, 3, io.sos, gk, sentence, w.td_dw, w.dz_txt, Tx, serial ? Tx : P.st_wgrad2));
+    if (do_backward) MMVAE_TRY(coco_text_dec_bwd(P, w.z_f32, 3, io.sos, gk, sentence, w.td_dw, w.dz_txt, Tx, serial ? Tx : P.st_wgrad2, true));
     ConvTLastFwdArgs last{};
     last.target = io.image; last.recon = io.recon_image; last.dlogit = do_backward ? w.dlogit : nullptr; last.loss_sum = w.sums;
     for (int k = 0; k < 3; ++k) last.coef[k] = sk[k] ? 0.f : io.lambda_xy[k] / (float)(B * NPIX);

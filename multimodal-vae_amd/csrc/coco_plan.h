@@ -7,6 +7,40 @@ constexpr int COCO_E = 300, COCO_H = 200, COCO_G = 3 * COCO_H;
 
 struct CocoGru { long long wih, whh, bih, bhh; };
 
+// bf16 persistent caption decoder (coco_text_bf16.hip): padded operand widths
+constexpr int CTB_HP = 224, CTB_XP = 320, CTB_GP = 608, CTB_EP = 304;
+
+struct CocoDecFwdArgs {
+    int R, T;
+    const float* hinit;      // [R][200] z2h(z)
+    const float* zi0;        // [R][600] z-part of the layer-0 input projection (+ b_ih)
+    const float* zo;         // [R][300] z-part of the output projection (+ bias)
+    const float* sos;        // [300]
+    const uint8_t* keep; float keep_scale;        // [T][R][200] inter-layer dropout keep flags or null
+    const bf16 *w_ih0, *w_hh0, *w_ih1, *w_hh1, *w_ho;       // packed [608][320], [608][224] x3, [304][224]
+    const float *bhh0, *bih1, *bhh1;
+    float* sentence;         // [R][T][300]
+    // saved for the backward pass (null: inference)
+    float *h0_all, *h1_all;  // [T+1][R][200] (index 0 = hinit, written by the caller)
+    float *sav0, *sav1;      // [T][R][4*200] (r, z, n, W_hn h + b_hn)
+    bf16 *xb_all, *h0b_all, *midb_all, *h1b_all;           // bf16 GEMM operands in [t][row] layout for the batched weight gradients
+};
+struct CocoDecBwdArgs {
+    int R, T;
+    const float* dw;         // [R][T][300] loss gradient wrt the sentence
+    const uint8_t* keep; float keep_scale;
+    const bf16 *w_hoT, *w_ih1T, *w_hh1T, *w_hh0T, *w_ih0T;  // packed [208][320], [208][608] x3, [304][608]
+    const float *h0_all, *h1_all, *sav0, *sav1;
+    bf16 *dout_b;            // [T][R][304] total gradient wrt each step's output
+    bf16 *dgi0_b, *dgh0_b, *dgi1_b, *dgh1_b;               // [T][R][608]
+    float *dhinit;           // [R][200]
+    float *dwsum;            // [R][300] time sum of the output gradient
+};
+int launch_coco_dec_fwd(const CocoDecFwdArgs& a, hipStream_t s);
+int launch_coco_dec_bwd(const CocoDecBwdArgs& a, hipStream_t s);
+// out[r][c] (fp32, [R][cols]) = sum over t of in[(t*R + r)*ld + c]
+int launch_coco_time_sum_bf16(const bf16* in, int T, int R, int ld, int cols, float* out, hipStream_t s);
+
 struct CocoPlan : PlanBase {
     int ldz, T;
     ConvL conv[4], convT[4];
@@ -16,6 +50,10 @@ struct CocoPlan : PlanBase {
     // caption half: offsets into the flat fp32 parameter buffer (the GEMMs read the weights where they are)
     CocoGru te_f, te_r, td0, td1;
     long long te_h2p_w, te_h2p_b, td_z2h_w, td_z2h_b, td_h2o_w, td_h2o_b;
+    // bf16 persistent caption decoder: packed weights (forward and transposed forms) and packed-gradient descriptors
+    bool text_bf16 = true;
+    int tb_ih0, tb_hh0, tb_ih1, tb_hh1, tb_ho, tb_hoT, tb_ih1T, tb_hh1T, tb_hh0T, tb_ih0T;
+    int tg_ih0, tg_hh0, tg_ih1, tg_hh1, tg_ho;
     struct W {
         char* zero_begin; size_t zero_bytes;
         float2 *st_e[3], *red_e[3], *st_d[3], *red_d[3];
@@ -35,6 +73,8 @@ struct CocoPlan : PlanBase {
         // caption decoder (3B rows)
         float *td_zi0, *td_zo, *td_gi, *td_gh, *td_h0, *td_h1, *td_mid, *td_sav0, *td_sav1, *td_recon;
         float *td_dw, *td_dgi0, *td_dgh0, *td_dgi1, *td_dgh1, *td_dmid, *td_dzi0, *td_dwsum, *td_dhinit;
+        // bf16 persistent decoder: operands of the batched weight gradients, [t][row] layout
+        bf16 *tb_x, *tb_h0, *tb_mid, *tb_h1, *tb_dout, *tb_dgi0, *tb_dgh0, *tb_dgi1, *tb_dgh1;
     } w;
 };
 
@@ -46,9 +86,11 @@ int coco_text_enc_fwd(CocoPlan& P, const float* text, int save, float* out, hipS
 // d_out: [B][2D] (the h2p bias gradient is added here); accumulates every caption-encoder gradient into P.buf.grads
 int coco_text_enc_bwd(CocoPlan& P, const float* text, const float* d_out, hipStream_t s);
 // z: [rows][D] fp32, rows = groups*B; sentence: [rows][T][300]; keep: [T][rows][200] or null
-int coco_text_dec_fwd(CocoPlan& P, const float* z, int groups, const float* sos, const uint8_t* keep, int save, float* sentence, hipStream_t s);
+int coco_text_dec_fwd(CocoPlan& P, const float* z, int groups, const float* sos, const uint8_t* keep, int save, float* sentence, hipStream_t s,
+                      bool bf16_path = false);
 // dw: [rows][T][300] gradient wrt the sentence (consumed: the feedback gradients are accumulated into it); dz: [rows][D]
 // sw: stream for the weight gradients (== s: in order; a side stream: the caller joins it before reading the gradients)
-int coco_text_dec_bwd(CocoPlan& P, const float* z, int groups, const float* sos, const uint8_t* keep, const float* sentence, float* dw, float* dz, hipStream_t s, hipStream_t sw);
+int coco_text_dec_bwd(CocoPlan& P, const float* z, int groups, const float* sos, const uint8_t* keep, const float* sentence, float* dw, float* dz, hipStream_t s, hipStream_t sw,
+                      bool bf16_path = false);
 // recon [G*B][T][300] vs target [B][T][300]: loss_sum[slot][4+g] += sum sq err ; dw = coef[g] * 2 (recon - target) (or null)
 int coco_mse3(const float* recon, const float* target, int G, long long per_group, const float* coef, float* loss_sum, float* dw, hipStream_t s);

@@ -315,6 +315,31 @@ void coco_text_build(CocoPlan& P) {
     P.te_h2p_w = off(P, "text_encoder.h2p.weight"); P.te_h2p_b = off(P, "text_encoder.h2p.bias");
     P.td_z2h_w = off(P, "text_decoder.z2h.weight"); P.td_z2h_b = off(P, "text_decoder.z2h.bias");
     P.td_h2o_w = off(P, "text_decoder.h2o.weight"); P.td_h2o_b = off(P, "text_decoder.h2o.bias");
+    // ---- bf16 persistent decoder (coco_text_bf16.hip): weights packed MFMA-fragment-major (PackDesc::frag), forward and
+    // transposed forms
+    const int D = P.D, in0 = E + D, ino = H + D;
+    static const bool fp32_text = getenv("MMVAE_COCO_TEXT_FP32") != nullptr;
+    P.text_bf16 = !fp32_text;
+    auto fragd = [&](PackDesc d) { d.frag = 1; return P.pk.add(d); };
+    auto fwdp = [&](long long w, int N, int K, int ld, int Npad, int Kpad) { return fragd(pack_dense(w, N, K, Npad, Kpad, ld, 1)); };
+    auto trp = [&](long long w, int Nout, int Kin, int ld, int Npad, int Kpad) { return fragd(pack_dense(w, Nout, Kin, Npad, Kpad, 1, ld)); };
+    P.tb_ih0 = fwdp(P.td0.wih, G, E, in0, CTB_GP, CTB_XP);      // columns 0..299 of weight_ih_l0 (the word vector part)
+    P.tb_hh0 = fwdp(P.td0.whh, G, H, H, CTB_GP, CTB_HP);
+    P.tb_ih1 = fwdp(P.td1.wih, G, H, H, CTB_GP, CTB_HP);
+    P.tb_hh1 = fwdp(P.td1.whh, G, H, H, CTB_GP, CTB_HP);
+    P.tb_ho = fwdp(P.td_h2o_w, E, H, ino, CTB_EP, CTB_HP);      // columns 0..199 of h2o (the hidden part)
+    P.tb_hoT = trp(P.td_h2o_w, H, E, ino, 208, CTB_XP);         // [j][e] = h2o[e][j]
+    P.tb_ih1T = trp(P.td1.wih, H, G, H, 208, CTB_GP);
+    P.tb_hh1T = trp(P.td1.whh, H, G, H, 208, CTB_GP);
+    P.tb_hh0T = trp(P.td0.whh, H, G, H, 208, CTB_GP);
+    P.tb_ih0T = trp(P.td0.wih, E, G, in0, CTB_EP, CTB_GP);      // [e][g] = weight_ih_l0[g][e]
+    // packed gradients [round64(N)][Kpad of the wgrad operand] -> scattered back by the unpack kernel
+    auto gkp = [&](long long w, int N, int K, int ld, int Kc) { return P.gk.add(pack_dense(w, N, K, round_up(N, 64), round_up(Kc, 64), ld, 1)); };
+    P.tg_ih0 = gkp(P.td0.wih, G, E, in0, CTB_XP);
+    P.tg_hh0 = gkp(P.td0.whh, G, H, H, CTB_HP);
+    P.tg_ih1 = gkp(P.td1.wih, G, H, H, CTB_HP);
+    P.tg_hh1 = gkp(P.td1.whh, G, H, H, CTB_HP);
+    P.tg_ho = gkp(P.td_h2o_w, E, H, ino, CTB_HP);
 }
 
 void coco_text_carve(CocoPlan& P, Workspace& ws) {
@@ -332,6 +357,12 @@ void coco_text_carve(CocoPlan& P, Workspace& ws) {
     w.td_dgi0 = ws.take<float>(T * R * G); w.td_dgh0 = ws.take<float>(T * R * G);
     w.td_dgi1 = ws.take<float>(T * R * G); w.td_dgh1 = ws.take<float>(T * R * G);
     w.td_dmid = ws.take<float>(R * H); w.td_dzi0 = ws.take<float>(R * G); w.td_dwsum = ws.take<float>(R * E); w.td_dhinit = ws.take<float>(R * H);
+    if (P.text_bf16) {
+        w.tb_x = ws.take<bf16>(T * R * CTB_XP); w.tb_h0 = ws.take<bf16>((T + 1) * R * CTB_HP); w.tb_mid = ws.take<bf16>(T * R * CTB_HP);
+        w.tb_h1 = ws.take<bf16>((T + 1) * R * CTB_HP); w.tb_dout = ws.take<bf16>(T * R * CTB_EP);
+        w.tb_dgi0 = ws.take<bf16>(T * R * CTB_GP); w.tb_dgh0 = ws.take<bf16>(T * R * CTB_GP);
+        w.tb_dgi1 = ws.take<bf16>(T * R * CTB_GP); w.tb_dgh1 = ws.take<bf16>(T * R * CTB_GP);
+    }
 }
 
 // ================================================================== caption encoder (coco/model.py:236-245)
@@ -395,7 +426,7 @@ int coco_text_enc_bwd(CocoPlan& P, const float* text, const float* d_out, hipStr
 
 // ================================================================== caption decoder (coco/model.py:266-312)
 int coco_text_dec_fwd(CocoPlan& P, const float* z, int groups, const float* sos, const uint8_t* keep, int save, float* sentence,
-                      hipStream_t s) {
+                      hipStream_t s, bool bf16_path) {
     CocoPlan::W& w = P.w;
     const int R = groups * P.B, T = P.T, D = P.D, in0 = E + D, ino = H + D;
     const float* p = P.buf.params;
@@ -407,6 +438,19 @@ int coco_text_dec_fwd(CocoPlan& P, const float* z, int groups, const float* sos,
     MMVAE_TRY(lin(z, D, R, p + P.td_z2h_w, H, D, D, 0, p + P.td_z2h_b, nullptr, 0, w.td_h0, H, s));
     hipMemcpyAsync(w.td_h1, w.td_h0, RH * sizeof(float), hipMemcpyDeviceToDevice, s);
     const float scale = 1.f / (1.f - DROP_P);
+    if (bf16_path && P.text_bf16) {      // the whole recurrence in ONE persistent launch (coco_text_bf16.hip)
+        CocoDecFwdArgs a{};
+        a.R = R; a.T = T; a.hinit = w.td_h0; a.zi0 = w.td_zi0; a.zo = w.td_zo; a.sos = sos; a.keep = keep; a.keep_scale = scale;
+        auto pw = [&](int i) { return P.buf.packed + P.pk.d[i].dst_off; };
+        a.w_ih0 = pw(P.tb_ih0); a.w_hh0 = pw(P.tb_hh0); a.w_ih1 = pw(P.tb_ih1); a.w_hh1 = pw(P.tb_hh1); a.w_ho = pw(P.tb_ho);
+        a.bhh0 = p + P.td0.bhh; a.bih1 = p + P.td1.bih; a.bhh1 = p + P.td1.bhh;
+        a.sentence = sentence;
+        if (save) {
+            a.h0_all = w.td_h0; a.h1_all = w.td_h1; a.sav0 = w.td_sav0; a.sav1 = w.td_sav1;
+            a.xb_all = w.tb_x; a.h0b_all = w.tb_h0; a.midb_all = w.tb_mid; a.h1b_all = w.tb_h1;
+        }
+        return launch_coco_dec_fwd(a, s);
+    }
     for (int t = 0; t < T; ++t) {
         const float* h0p = w.td_h0 + (size_t)t * RH; float* h0n = w.td_h0 + (size_t)(t + 1) * RH;
         const float* h1p = w.td_h1 + (size_t)t * RH; float* h1n = w.td_h1 + (size_t)(t + 1) * RH;
@@ -429,8 +473,59 @@ int coco_text_dec_fwd(CocoPlan& P, const float* z, int groups, const float* sos,
     return MMVAE_OK;
 }
 
+// bf16 persistent path: BPTT in one launch, then the weight gradients as batched bf16 GEMMs over all T*R rows
+static int coco_text_dec_bwd_bf16(CocoPlan& P, const float* z, int groups, const uint8_t* keep, float* dw, float* dz, hipStream_t s,
+                                  hipStream_t sw) {
+    CocoPlan::W& w = P.w;
+    const int R = groups * P.B, T = P.T, D = P.D, in0 = E + D, ino = H + D, TRn = T * R;
+    const float* p = P.buf.params;
+    float* g = P.buf.grads;
+    const float scale = 1.f / (1.f - DROP_P);
+    CocoDecBwdArgs a{};
+    a.R = R; a.T = T; a.dw = dw; a.keep = keep; a.keep_scale = scale;
+    auto pw = [&](int i) { return P.buf.packed + P.pk.d[i].dst_off; };
+    a.w_hoT = pw(P.tb_hoT); a.w_ih1T = pw(P.tb_ih1T); a.w_hh1T = pw(P.tb_hh1T); a.w_hh0T = pw(P.tb_hh0T); a.w_ih0T = pw(P.tb_ih0T);
+    a.h0_all = w.td_h0; a.h1_all = w.td_h1; a.sav0 = w.td_sav0; a.sav1 = w.td_sav1;
+    a.dout_b = w.tb_dout; a.dgi0_b = w.tb_dgi0; a.dgh0_b = w.tb_dgh0; a.dgi1_b = w.tb_dgi1; a.dgh1_b = w.tb_dgh1;
+    a.dhinit = w.td_dhinit; a.dwsum = w.td_dwsum;
+    MMVAE_TRY(launch_coco_dec_bwd(a, s));
+    MMVAE_TRY(launch_coco_time_sum_bf16(a.dgi0_b, T, R, CTB_GP, G, w.td_dzi0, s));
+    // ---- weight gradients: dW[N][K] = P[T*R][N]^T G[T*R][K], bf16 operands saved in [t][row] layout, off the main chain
+    const bool fork = sw != s;
+    if (fork) MMVAE_TRY(edge(P, s, sw));
+    WgradParams list[5];
+    auto wg = [&](int i, int gidx, const bf16* Pm, int N, int ldp, const bf16* Gm, int C) {
+        GatherPlan pl = dense_plan(TRn, C, C, N);
+        WgradParams q = wgrad_of(P, pl, &gidx, 1, TRn);
+        q.c.A = Gm; q.P = Pm; q.ldp = ldp;
+        list[i] = q;
+    };
+    const size_t RHP = (size_t)R * CTB_HP;
+    wg(0, P.tg_ih0, w.tb_dgi0, G, CTB_GP, w.tb_x, CTB_XP);
+    wg(1, P.tg_hh0, w.tb_dgh0, G, CTB_GP, w.tb_h0, CTB_HP);                    // h0 BEFORE each step: slices 0 .. T-1
+    wg(2, P.tg_ih1, w.tb_dgi1, G, CTB_GP, w.tb_mid, CTB_HP);
+    wg(3, P.tg_hh1, w.tb_dgh1, G, CTB_GP, w.tb_h1, CTB_HP);
+    wg(4, P.tg_ho, w.tb_dout, E, CTB_EP, w.tb_h1 + RHP, CTB_HP);               // h1 AFTER each step: slices 1 .. T
+    MMVAE_TRY(launch_wgrad_group(list, 5, sw, &P.slab));
+    MMVAE_TRY(launch_wgrad_reduce(&P.slab, sw, true));
+    MMVAE_TRY(launch_colsum_bf16(w.tb_dgh0, CTB_GP, TRn, G, g + P.td0.bhh, sw));
+    MMVAE_TRY(launch_colsum_bf16(w.tb_dgi1, CTB_GP, TRn, G, g + P.td1.bih, sw));
+    MMVAE_TRY(launch_colsum_bf16(w.tb_dgh1, CTB_GP, TRn, G, g + P.td1.bhh, sw));
+    // ---- initial hidden state h = z2h(z), shared by both layers; time-invariant z terms (as in the fp32 path)
+    MMVAE_TRY(lin_dw(w.td_dhinit, H, z, D, R, g + P.td_z2h_w, H, D, D, 0, s));
+    MMVAE_TRY(launch_colsum_f32(w.td_dhinit, R, H, g + P.td_z2h_b, s));
+    MMVAE_TRY(lin_dx(w.td_dhinit, H, R, p + P.td_z2h_w, H, D, D, 0, dz, D, 0, s));
+    MMVAE_TRY(lin_dw(w.td_dzi0, G, z, D, R, g + P.td0.wih, G, D, in0, E, s));
+    MMVAE_TRY(launch_colsum_f32(w.td_dzi0, R, G, g + P.td0.bih, s));
+    MMVAE_TRY(lin_dx(w.td_dzi0, G, R, p + P.td0.wih, G, D, in0, E, dz, D, 1, s));
+    MMVAE_TRY(lin_dw(w.td_dwsum, E, z, D, R, g + P.td_h2o_w, E, D, ino, H, s));
+    MMVAE_TRY(launch_colsum_f32(w.td_dwsum, R, E, g + P.td_h2o_b, s));
+    return lin_dx(w.td_dwsum, E, R, p + P.td_h2o_w, E, D, ino, H, dz, D, 1, s);
+}
+
 int coco_text_dec_bwd(CocoPlan& P, const float* z, int groups, const float* sos, const uint8_t* keep, const float* sentence, float* dw,
-                      float* dz, hipStream_t s, hipStream_t sw) {
+                      float* dz, hipStream_t s, hipStream_t sw, bool bf16_path) {
+    if (bf16_path && P.text_bf16) return coco_text_dec_bwd_bf16(P, z, groups, keep, dw, dz, s, sw);
     CocoPlan::W& w = P.w;
     const int R = groups * P.B, T = P.T, D = P.D, in0 = E + D, ino = H + D;
     const float* p = P.buf.params;

@@ -1,0 +1,470 @@
+// Caption decoder of the COCO MMVAE (coco/model.py:256-312) as TWO persistent launches: one for the 102-step forward
+// recurrence, one for backpropagation through time.
+//
+// The fp32 path (coco_text.hip) issues 3 dependent launches per forward step and 5 per backward step: 17 ms per training
+// step at the per-GPU batch of configuration 5, all of it dependent-launch latency.  Here one workgroup (8 waves) owns 16
+// rows of the 3B-row decoder batch for the WHOLE recurrence:
+//   * state (h0, h1, the fed-back output vector, the carried gradients) lives in LDS / registers, nothing synchronises
+//     across workgroups;
+//   * the weights (1.24 MB bf16 per step: 5 matrices forward, 6 backward) stream from L2 as MFMA-fragment-shaped 16-byte
+//     loads; the stream never stalls on the recurrence: while a wave runs the MFMAs of one 16-column tile it already holds
+//     the loads of its next tile in flight -- ACROSS the barriers between the GEMMs of a step (the weights do not depend on
+//     the data), so a step costs the L2 stream, not a latency chain;
+//   * bf16 MFMA operands, fp32 accumulation, gate math and state in fp32.  Measured against the reference (oracle with the
+//     GEMM operands of the caption GRUs rounded to bf16, 102 steps, B=16): losses move by <= 1e-4 relative, gradient
+//     tensors by <= 3e-3 -- inside the 1e-3 ELBO bound, so the 1/16-rate fp32 MFMA is not needed.
+// The weight gradients are batched GEMMs over all T*R rows afterwards (operands saved as bf16 in [t][row] layout).
+#include "coco_plan.h"
+
+namespace {
+
+constexpr int TR = 16, NW = 8, NTHR = NW * 64;
+constexpr int H = COCO_H, G = COCO_G, E = COCO_E;
+constexpr int HP = CTB_HP, XP = CTB_XP, GP = CTB_GP, EP = CTB_EP;   // 224, 320, 608, 304
+constexpr int LDH = HP + 8, LDX = XP + 8, LDGK = GP + 8;            // bf16 LDS row strides (+16 B: conflict-free ds_read_b128)
+constexpr int LDG = 612, LDO = 308, LDT = 212;                      // fp32 LDS row strides
+
+__device__ __forceinline__ float sigm(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
+
+// Weight streaming.  Every wave of the workgroup walks a FIXED list of weight chunks per recurrence step: for each GEMM of
+// the step, for each of its MAXT column tiles (wave, wave + 8, ...; a wave with fewer real tiles walks a clamped dummy one
+// so that all waves consume the same number of chunks), NCH chunks of up to KCH = 10 k-steps (one 16-byte load per lane
+// per k-step).  The chunk counts are compile-time constants and a step's total is a multiple of the ring depth D, so the
+// ring slot of every chunk is static: while a chunk feeds the MFMAs, the chunk D positions further down the list -- of
+// this tile, the next tile, or the NEXT GEMM, also across the barriers between the GEMMs -- is already in flight.  D
+// chunks of 10 KB per wave, 8 waves: 160-240 KB in flight per CU, which is what it takes to stream the 1.24 MB of weights
+// a step needs from L2 at bandwidth instead of at one round trip per tile.
+constexpr int KCH = 10;
+template <int KS, int NT> struct WMat {                     // [16*NT][32*KS] bf16, fragment-major (PackDesc::frag)
+    __amdgpu_buffer_rsrc_t r;
+    static constexpr int ks = KS, nt = NT, kpad = KS * 32, nch = (KS + KCH - 1) / KCH;
+    __device__ explicit WMat(const bf16* w) : r(__builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(w), 0, NT * 16 * KS * 32 * 2, 0x00020000)) {}
+};
+
+// chunk `pos` of this wave's list for matrix m: tile slot pos / nch, k-chunk pos % nch.  pos is a compile-time constant at
+// every call site (unrolled loops), so the k-step count and the load offsets are immediates; a wave whose tile slot is past
+// the matrix (dummy tile) requests nothing.
+template <class M>
+__device__ __forceinline__ void load_chunk(bf16x8 (&dst)[KCH], const M& m, int pos, int wave, int lane) {
+    const int i = pos / M::nch, c = pos - i * M::nch;
+    const int nt = wave + NW * i;
+    if (nt >= M::nt) return;
+    // fragment-major: one k-step = 1 KB, lane-ordered.  Buffer loads: descriptor + wave-uniform offset in SGPRs, the lane
+    // offset is the only VGPR address of the whole weight stream
+    const int ub = (nt * M::ks + c * KCH) * 1024;
+    const int kc = min(KCH, M::ks - c * KCH);
+#pragma unroll
+    for (int s = 0; s < KCH; ++s)
+        if (s < kc) dst[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(m.r, lane * 16, ub + s * 1024, 0));
+}
+
+// out[16][ldo] (fp32, LDS) = A[16][32*ks] (bf16, LDS) * W^T (+ cinit, a [rows][ldc] fp32 matrix in global memory whose row
+// r0.. block is the time-invariant part of the projection: it enters as the accumulators' initial value).  MAXT = tile
+// slots per wave of this GEMM (>= ceil(nt/8); more pads the step's chunk count to a multiple of D), mn = the next GEMM of
+// the list (its first chunks are requested from here), SLOT0 = the ring slot of this GEMM's first chunk.
+template <int MAXT, int D, int SLOT0, bool CINIT = false, class M, class MN>
+__device__ __forceinline__ void stream_gemm(const bf16* A, int lda, const M& m, float* out, int ldo, bf16x8 (&ring)[D][KCH],
+                                            const MN& mn, bool has_next, int wave, int lane, const float* cinit = nullptr,
+                                            int ldc = 0, int ncols = 0, int rows_ok = 0) {
+    const int fr = lane & 15, fq = lane >> 4;
+    constexpr int NCH = M::nch, NQ = NCH * MAXT;
+    static_assert(MAXT * NW >= M::nt, "tile slots");
+    f32x4 ci[MAXT];
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+        ci[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (CINIT) {            // rows / columns past the matrix read a clamped element: they land in rows / pad columns nobody reads
+            const int col = min((wave + NW * i) * 16 + fr, ncols - 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ci[i][j] = cinit[(size_t)min(fq * 4 + j, rows_ok - 1) * ldc + col];
+        }
+    }
+    bf16x8 af[NCH][KCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int s = 0; s < KCH; ++s)
+            if (c * KCH + s < M::ks) af[c][s] = *reinterpret_cast<const bf16x8*>(A + fr * lda + (c * KCH + s) * 32 + fq * 8);
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+        const int nt = wave + NW * i;
+        f32x4 acc = ci[i];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int q = i * NCH + c;
+            const int slot = (SLOT0 + q) % D;
+            if (nt < M::nt) {
+#pragma unroll
+                for (int s = 0; s < KCH; ++s)
+                    if (c * KCH + s < M::ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c][s], ring[slot][s], acc, 0, 0, 0);
+            }
+            // refill this slot with the chunk D positions further down the list
+            if (q + D < NQ) load_chunk(ring[slot], m, q + D, wave, lane);
+            else if (has_next) load_chunk(ring[slot], mn, q + D - NQ, wave, lane);
+        }
+        if (nt < M::nt) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[(fq * 4 + j) * ldo + nt * 16 + fr] = acc[j];
+        }
+    }
+}
+
+// The element-wise phases between the GEMMs map thread -> (row = tid / 32, columns c0 + 32 q): every global address of a
+// phase is one base plus immediates, and the phase's global loads are all issued before the first one is used.
+constexpr int NQH = (H + 31) / 32;      // 7
+constexpr int NQE = (E + 31) / 32;      // 10
+
+// ================================================================== forward
+template <bool KEEP, bool SAVE>
+__global__ __launch_bounds__(NTHR) void coco_dec_fwd_kernel(const CocoDecFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ga = reinterpret_cast<float*>(smem);                     // [16][LDG] input projection / output projection
+    float* gb = ga + TR * LDG;                                      // [16][LDG] hidden projection
+    float* h0f = gb + TR * LDG;                                     // [16][H]
+    float* h1f = h0f + TR * H;
+    float* bias = h1f + TR * H;                                     // b_hh0 | b_ih1 | b_hh1, [3][G]
+    bf16* xb = reinterpret_cast<bf16*>(bias + 3 * G);               // [16][LDX] current input vector
+    bf16* h0b = xb + TR * LDX;                                      // [16][LDH]
+    bf16* midb = h0b + TR * LDH;
+    bf16* h1b = midb + TR * LDH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index in an SGPR
+    const int r0 = blockIdx.x * TR, R = a.R, T = a.T;
+    const size_t RH = (size_t)R * H;
+    const int grow = tid >> 5, c0 = tid & 31;
+    const bool gok = r0 + grow < R;
+    const int rows_ok = min(TR, R - r0);
+    const size_t gr = gok ? r0 + grow : 0;
+
+    // ---- state: h0 = h1 = z2h(z) (given), x = '<s>'; pad columns of the bf16 operands are zero for the whole kernel
+    for (int i = tid; i < TR * LDX; i += NTHR) xb[i] = (bf16)0.f;
+    for (int i = tid; i < 3 * TR * LDH; i += NTHR) h0b[i] = (bf16)0.f;
+    for (int i = tid; i < G; i += NTHR) { bias[i] = a.bhh0[i]; bias[G + i] = a.bih1[i]; bias[2 * G + i] = a.bhh1[i]; }
+    __syncthreads();
+    for (int i = tid; i < TR * H; i += NTHR) {
+        const int row = i / H, j = i - row * H;
+        const float v = r0 + row < R ? a.hinit[(size_t)(r0 + row) * H + j] : 0.f;
+        h0f[i] = v; h1f[i] = v;
+        h0b[row * LDH + j] = (bf16)v; h1b[row * LDH + j] = (bf16)v;
+        if (SAVE && r0 + row < R) {
+            a.h0b_all[(size_t)(r0 + row) * HP + j] = (bf16)v; a.h1b_all[(size_t)(r0 + row) * HP + j] = (bf16)v;
+        }
+    }
+    for (int i = tid; i < TR * E; i += NTHR) {
+        const int row = i / E, e = i - row * E;
+        const bf16 v = (bf16)a.sos[e];
+        xb[row * LDX + e] = v;
+        if (SAVE && r0 + row < R) a.xb_all[(size_t)(r0 + row) * XP + e] = v;
+    }
+    // chunk schedule of a step (ring depth 3): ih0 5, hh0 5, ih1 5, hh1 5, ho 4 (3 real tile slots + 1 dummy) = 24 chunks
+    constexpr int D = 3;
+    const WMat<XP / 32, GP / 16> d_ih0(a.w_ih0);
+    const WMat<HP / 32, GP / 16> d_hh0(a.w_hh0), d_ih1(a.w_ih1), d_hh1(a.w_hh1);
+    const WMat<HP / 32, EP / 16> d_ho(a.w_ho);
+    bf16x8 ring[D][KCH];
+#pragma unroll
+    for (int q = 0; q < D; ++q) load_chunk(ring[q], d_ih0, q, wave, lane);
+    __syncthreads();
+    const float* zi0 = a.zi0 + (size_t)r0 * G;
+    const float* zo = a.zo + (size_t)r0 * E;
+    const float *pa = ga + grow * LDG, *pb = gb + grow * LDG;
+
+    for (int t = 0; t < T; ++t) {
+        // ---- layer 0: both projections (the z-part of the input projection enters as the accumulators' initial value)
+        stream_gemm<5, D, 0, true>(xb, LDX, d_ih0, ga, LDG, ring, d_hh0, true, wave, lane, zi0, G, G, rows_ok);
+        stream_gemm<5, D, 2>(h0b, LDH, d_hh0, gb, LDG, ring, d_ih1, true, wave, lane);
+        uint8_t kp[NQH];
+#pragma unroll
+        for (int q = 0; q < NQH; ++q) {
+            const int j = c0 + 32 * q;
+            kp[q] = 1;
+            if (KEEP) kp[q] = gok && j < H ? a.keep[(size_t)t * RH + gr * H + j] : 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NQH; ++q) {
+            const int j = c0 + 32 * q;
+            if (j < H) {
+                const int i = grow * H + j;
+                const float r = sigm(pa[j] + pb[j] + bias[j]);
+                const float z = sigm(pa[H + j] + pb[H + j] + bias[H + j]);
+                const float ghn = pb[2 * H + j] + bias[2 * H + j];
+                const float n = tanh_fast(pa[2 * H + j] + r * ghn);
+                const float hn = (1.0f - z) * n + z * h0f[i];
+                h0f[i] = hn;
+                h0b[grow * LDH + j] = (bf16)hn;
+                float mid = hn;
+                if (KEEP) mid = kp[q] ? hn * a.keep_scale : 0.f;
+                midb[grow * LDH + j] = (bf16)mid;
+                if (SAVE && gok) {
+                    a.h0_all[(size_t)(t + 1) * RH + gr * H + j] = hn;
+                    float* s = a.sav0 + ((size_t)t * R + gr) * 4 * H;
+                    s[j] = r; s[H + j] = z; s[2 * H + j] = n; s[3 * H + j] = ghn;
+                    a.h0b_all[((size_t)(t + 1) * R + gr) * HP + j] = (bf16)hn;
+                    a.midb_all[((size_t)t * R + gr) * HP + j] = (bf16)mid;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- layer 1
+        stream_gemm<5, D, 1>(midb, LDH, d_ih1, ga, LDG, ring, d_hh1, true, wave, lane);
+        stream_gemm<5, D, 0>(h1b, LDH, d_hh1, gb, LDG, ring, d_ho, true, wave, lane);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NQH; ++q) {
+            const int j = c0 + 32 * q;
+            if (j < H) {
+                const int i = grow * H + j;
+                const float r = sigm(pa[j] + bias[G + j] + pb[j] + bias[2 * G + j]);
+                const float z = sigm(pa[H + j] + bias[G + H + j] + pb[H + j] + bias[2 * G + H + j]);
+                const float ghn = pb[2 * H + j] + bias[2 * G + 2 * H + j];
+                const float n = tanh_fast(pa[2 * H + j] + bias[G + 2 * H + j] + r * ghn);
+                const float hn = (1.0f - z) * n + z * h1f[i];
+                h1f[i] = hn;
+                h1b[grow * LDH + j] = (bf16)hn;
+                if (SAVE && gok) {
+                    a.h1_all[(size_t)(t + 1) * RH + gr * H + j] = hn;
+                    float* s = a.sav1 + ((size_t)t * R + gr) * 4 * H;
+                    s[j] = r; s[H + j] = z; s[2 * H + j] = n; s[3 * H + j] = ghn;
+                    a.h1b_all[((size_t)(t + 1) * R + gr) * HP + j] = (bf16)hn;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- output projection: the word vector of this step, fed back as the next input (coco/model.py:284-286)
+        const bool last = t + 1 == T;
+        stream_gemm<4, D, 2, true>(h1b, LDH, d_ho, ga, LDG, ring, d_ih0, !last, wave, lane, zo, E, E, rows_ok);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NQE; ++q) {
+            const int e = c0 + 32 * q;
+            if (e < E) {
+                const float v = pa[e];
+                xb[grow * LDX + e] = (bf16)v;
+                if (gok) {
+                    a.sentence[(gr * T + t) * E + e] = v;
+                    if (SAVE && !last) a.xb_all[((size_t)(t + 1) * R + gr) * XP + e] = (bf16)v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ================================================================== backward (BPTT)
+// Thread (row, c0) keeps the time sum of the output gradient of its 10 columns in registers; the time sum of the layer-0
+// input-projection gradient (what the z-columns and the bias see) is taken from the saved operand afterwards.
+template <bool KEEP>
+__global__ __launch_bounds__(NTHR) void coco_dec_bwd_kernel(const CocoDecBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* dh0f = reinterpret_cast<float*>(smem);                   // [16][H] gradient carried into h0[t]
+    float* dh1f = dh0f + TR * H;
+    float* fb = dh1f + TR * H;                                      // [16][LDO] feedback gradient into the previous output
+    float* o1 = fb + TR * LDO;                                      // [16][LDT] GEMM results (200 hidden units)
+    float* o2 = o1 + TR * LDT;
+    bf16* dob = reinterpret_cast<bf16*>(o2 + TR * LDT);             // [16][LDX] total gradient wrt this step's output
+    bf16* dgi = dob + TR * LDX;                                     // [16][LDGK]
+    bf16* dgh = dgi + TR * LDGK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index in an SGPR
+    const int r0 = blockIdx.x * TR, R = a.R, T = a.T;
+    const size_t RH = (size_t)R * H;
+    const int grow = tid >> 5, c0 = tid & 31;
+    const bool gok = r0 + grow < R;
+    const size_t gr = gok ? r0 + grow : 0;
+    for (int i = tid; i < 2 * TR * H; i += NTHR) dh0f[i] = 0.f;
+    for (int i = tid; i < TR * LDO; i += NTHR) fb[i] = 0.f;
+    for (int i = tid; i < TR * LDX; i += NTHR) dob[i] = (bf16)0.f;
+    for (int i = tid; i < 2 * TR * LDGK; i += NTHR) dgi[i] = (bf16)0.f;
+    float ws_sum[NQE];
+#pragma unroll
+    for (int i = 0; i < NQE; ++i) ws_sum[i] = 0.f;
+    // chunk schedule of a step (ring depth 2): hoT 2, ih1T 4, hh1T 4, hh0T 4, ih0T 6 = 20 chunks (every GEMM starts in slot 0)
+    constexpr int D = 2;
+    const WMat<XP / 32, HP / 16 - 1> d_hoT(a.w_hoT);
+    const WMat<GP / 32, HP / 16 - 1> d_ih1T(a.w_ih1T), d_hh1T(a.w_hh1T), d_hh0T(a.w_hh0T);
+    const WMat<GP / 32, EP / 16> d_ih0T(a.w_ih0T);
+    bf16x8 ring[D][KCH];
+#pragma unroll
+    for (int q = 0; q < D; ++q) load_chunk(ring[q], d_hoT, q, wave, lane);
+    __syncthreads();
+
+    for (int t = T - 1; t >= 0; --t) {
+        // ---- total gradient wrt the output of step t: loss term + what step t+1 sent back through its input
+        {
+            float dwv[NQE];
+#pragma unroll
+            for (int q = 0; q < NQE; ++q) {
+                const int e = c0 + 32 * q;
+                dwv[q] = gok && e < E ? a.dw[(gr * T + t) * E + e] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < NQE; ++q) {
+                const int e = c0 + 32 * q;
+                if (e < E) {
+                    const float v = dwv[q] + fb[grow * LDO + e];
+                    ws_sum[q] += v;
+                    dob[grow * LDX + e] = (bf16)v;
+                    if (gok) a.dout_b[((size_t)t * R + gr) * EP + e] = (bf16)v;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- dh1 += dOut * Who[:, :200]
+        stream_gemm<2, D, 0>(dob, LDX, d_hoT, o1, LDT, ring, d_ih1T, true, wave, lane);
+        // ---- layer-1 gates backward
+        {
+            float sr[NQH], sz[NQH], sn[NQH], sg[NQH], hp[NQH];
+            const float* s = a.sav1 + ((size_t)t * R + gr) * 4 * H;
+            const float* hpp = a.h1_all + (size_t)t * RH + gr * H;
+#pragma unroll
+            for (int q = 0; q < NQH; ++q) {
+                const int j = min(c0 + 32 * q, H - 1);
+                sr[q] = s[j]; sz[q] = s[H + j]; sn[q] = s[2 * H + j]; sg[q] = s[3 * H + j]; hp[q] = hpp[j];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < NQH; ++q) {
+                const int j = c0 + 32 * q;
+                if (j < H) {
+                    const int i = grow * H + j;
+                    float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f, dd = 0.f;
+                    if (gok) {
+                        const float r = sr[q], z = sz[q], n = sn[q], ghn = sg[q];
+                        const float d = dh1f[i] + o1[grow * LDT + j];
+                        dn = d * (1.0f - z) * (1.0f - n * n);
+                        dz = d * (hp[q] - n) * z * (1.0f - z);
+                        dr = dn * ghn * r * (1.0f - r);
+                        dnr = dn * r;
+                        dd = d * z;
+                    }
+                    dh1f[i] = dd;
+                    dgi[grow * LDGK + j] = (bf16)dr; dgi[grow * LDGK + H + j] = (bf16)dz; dgi[grow * LDGK + 2 * H + j] = (bf16)dn;
+                    dgh[grow * LDGK + j] = (bf16)dr; dgh[grow * LDGK + H + j] = (bf16)dz; dgh[grow * LDGK + 2 * H + j] = (bf16)dnr;
+                    if (gok) {
+                        bf16* gi = a.dgi1_b + ((size_t)t * R + gr) * GP;
+                        bf16* gh = a.dgh1_b + ((size_t)t * R + gr) * GP;
+                        gi[j] = (bf16)dr; gi[H + j] = (bf16)dz; gi[2 * H + j] = (bf16)dn;
+                        gh[j] = (bf16)dr; gh[H + j] = (bf16)dz; gh[2 * H + j] = (bf16)dnr;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- dmid = dgi1 * Wih1 ; dh1[t-1] += dgh1 * Whh1
+        stream_gemm<2, D, 0>(dgi, LDGK, d_ih1T, o1, LDT, ring, d_hh1T, true, wave, lane);
+        stream_gemm<2, D, 0>(dgh, LDGK, d_hh1T, o2, LDT, ring, d_hh0T, true, wave, lane);
+        // ---- layer-0 gates backward (its output reached layer 1 through the dropout)
+        {
+            float sr[NQH], sz[NQH], sn[NQH], sg[NQH], hp[NQH];
+            uint8_t kp[NQH];
+            const float* s = a.sav0 + ((size_t)t * R + gr) * 4 * H;
+            const float* hpp = a.h0_all + (size_t)t * RH + gr * H;
+#pragma unroll
+            for (int q = 0; q < NQH; ++q) {
+                const int j = min(c0 + 32 * q, H - 1);
+                sr[q] = s[j]; sz[q] = s[H + j]; sn[q] = s[2 * H + j]; sg[q] = s[3 * H + j]; hp[q] = hpp[j];
+                kp[q] = 1;
+                if (KEEP) kp[q] = a.keep[(size_t)t * RH + gr * H + j];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < NQH; ++q) {
+                const int j = c0 + 32 * q;
+                if (j < H) {
+                    const int i = grow * H + j;
+                    dh1f[i] += o2[grow * LDT + j];
+                    float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f, dd = 0.f;
+                    if (gok) {
+                        const float r = sr[q], z = sz[q], n = sn[q], ghn = sg[q];
+                        float dm = o1[grow * LDT + j];
+                        if (KEEP) dm = kp[q] ? dm * a.keep_scale : 0.f;
+                        const float d = dh0f[i] + dm;
+                        dn = d * (1.0f - z) * (1.0f - n * n);
+                        dz = d * (hp[q] - n) * z * (1.0f - z);
+                        dr = dn * ghn * r * (1.0f - r);
+                        dnr = dn * r;
+                        dd = d * z;
+                    }
+                    dh0f[i] = dd;
+                    dgi[grow * LDGK + j] = (bf16)dr; dgi[grow * LDGK + H + j] = (bf16)dz; dgi[grow * LDGK + 2 * H + j] = (bf16)dn;
+                    dgh[grow * LDGK + j] = (bf16)dr; dgh[grow * LDGK + H + j] = (bf16)dz; dgh[grow * LDGK + 2 * H + j] = (bf16)dnr;
+                    if (gok) {
+                        bf16* gi = a.dgi0_b + ((size_t)t * R + gr) * GP;
+                        bf16* gh = a.dgh0_b + ((size_t)t * R + gr) * GP;
+                        gi[j] = (bf16)dr; gi[H + j] = (bf16)dz; gi[2 * H + j] = (bf16)dn;
+                        gh[j] = (bf16)dr; gh[H + j] = (bf16)dz; gh[2 * H + j] = (bf16)dnr;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- dh0[t-1] += dgh0 * Whh0 ; feedback into the previous output = dgi0 * Wih0[:, :300]
+        const bool first = t == 0;
+        stream_gemm<2, D, 0>(dgh, LDGK, d_hh0T, o2, LDT, ring, d_ih0T, true, wave, lane);
+        stream_gemm<3, D, 0>(dgi, LDGK, d_ih0T, fb, LDO, ring, d_hoT, !first, wave, lane);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NQH; ++q) {
+            const int j = c0 + 32 * q;
+            if (j < H) dh0f[grow * H + j] += o2[grow * LDT + j];
+        }
+        // (the next step's first phase touches fb / dob only; dh0f is next read after two more barriers)
+    }
+    __syncthreads();
+    // ---- what is left: gradient of the shared initial state, time sum for the z-term of the output projection
+    for (int i = tid; i < TR * H; i += NTHR) {
+        const int row = i / H;
+        if (r0 + row < R) a.dhinit[(size_t)(r0 + row) * H + (i - row * H)] = dh0f[i] + dh1f[i];
+    }
+#pragma unroll
+    for (int q = 0; q < NQE; ++q) {
+        const int e = c0 + 32 * q;
+        if (gok && e < E) a.dwsum[gr * E + e] = ws_sum[q];
+    }
+}
+
+// out[r][c] = sum_t in[(t*R + r)*ld + c]
+__global__ __launch_bounds__(256) void time_sum_bf16_kernel(const bf16* in, int T, int R, int ld, int cols, float* out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)R * cols) return;
+    const int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
+    const bf16* p = in + (size_t)r * ld + c;
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) acc += (float)p[(size_t)t * R * ld];
+    out[i] = acc;
+}
+
+}  // namespace
+
+int launch_coco_time_sum_bf16(const bf16* in, int T, int R, int ld, int cols, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(time_sum_bf16_kernel, dim3((unsigned)(((long long)R * cols + 255) / 256)), dim3(256), 0, s, in, T, R, ld, cols, out);
+    return mmvae_check_launch("coco_time_sum_bf16");
+}
+
+int launch_coco_dec_fwd(const CocoDecFwdArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)(2 * TR * LDG + 2 * TR * H + 3 * G) * sizeof(float) + (size_t)(TR * LDX + 3 * TR * LDH) * sizeof(bf16);
+    static std::atomic<unsigned> once{0};
+    if (mmvae_first_use_on_device(once)) {
+        auto big = [](auto kern) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); };
+        big(&coco_dec_fwd_kernel<true, true>); big(&coco_dec_fwd_kernel<true, false>);
+        big(&coco_dec_fwd_kernel<false, true>); big(&coco_dec_fwd_kernel<false, false>);
+    }
+    const bool save = a.sav0 != nullptr;
+    if (save) MMVAE_REQUIRE(a.sav1 && a.h0_all && a.h1_all && a.xb_all && a.h0b_all && a.midb_all && a.h1b_all, "coco_dec_fwd: save buffers");
+    auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(ceil_div(a.R, TR)), dim3(NTHR), lds, s, a); };
+    if (a.keep) { if (save) go(&coco_dec_fwd_kernel<true, true>); else go(&coco_dec_fwd_kernel<true, false>); }
+    else { if (save) go(&coco_dec_fwd_kernel<false, true>); else go(&coco_dec_fwd_kernel<false, false>); }
+    return mmvae_check_launch("coco_dec_fwd");
+}
+int launch_coco_dec_bwd(const CocoDecBwdArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)(2 * TR * H + TR * LDO + 2 * TR * LDT) * sizeof(float) + (size_t)(TR * LDX + 2 * TR * LDGK) * sizeof(bf16);
+    static std::atomic<unsigned> once{0};
+    if (mmvae_first_use_on_device(once))
+    {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&coco_dec_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&coco_dec_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    if (a.keep) hipLaunchKernelGGL(coco_dec_bwd_kernel<true>, dim3(ceil_div(a.R, TR)), dim3(NTHR), lds, s, a);
+    else hipLaunchKernelGGL(coco_dec_bwd_kernel<false>, dim3(ceil_div(a.R, TR)), dim3(NTHR), lds, s, a);
+    return mmvae_check_launch("coco_dec_bwd");
+}

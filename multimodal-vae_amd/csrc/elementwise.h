@@ -17,6 +17,8 @@ struct PackDesc {
     long long bias_off;     // >= 0: column K of every row holds a bias folded into the GEMM (operand column K == 1.0)
     int b_nhi, b_nlo;       // source strides of that bias vector
     int first_block;        // prefix sum of 256-thread blocks over the table
+    int frag;               // 1: MFMA-fragment-major destination -- 16-row tile nt, 32-column k-step ks: the 64 lanes' 8-element
+                            // vectors (lane = 16*(k/8 % 4) + n % 16) are one contiguous 1 KB block at ((nt*(Kpad/32) + ks)*64 + lane)*8
 };
 
 int launch_pack(const PackDesc* table_dev, const PackDesc* table_host, int ndesc, const float* params,

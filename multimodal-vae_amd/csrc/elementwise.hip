@@ -73,7 +73,7 @@ __device__ __forceinline__ void pack_block(const PackDesc* __restrict__ table, i
             }
         }
     }
-    const long long e = (long long)n * d.Kpad + k0;
+    const long long e = d.frag ? ((long long)((n >> 4) * (d.Kpad >> 5) + (kv >> 2)) * 64 + (kv & 3) * 16 + (n & 15)) * 8 : (long long)n * d.Kpad + k0;
     if (d.is_f32) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) packed_f32[d.dst_off + e + j] = val[j];
