@@ -37,6 +37,7 @@ struct CelebaPlan : PlanBase {
         bf16 *d_encout, *d_attout_bf, *d_ae;
         bf16 *dy1, *db4, *dr4, *d3e, *d2e, *d1e;
         float* tmp_f32;
+        float* slab; size_t slab_floats;
     } w;
 };
 
@@ -158,6 +159,9 @@ void carve(CelebaPlan& P, Workspace& ws) {
     w.tmp_f32 = ws.take<float>(B3 * NPIX);
     P.sk_floats = (size_t)256 * 128 * 128;
     P.sk_buf = ws.take<float>(P.sk_floats);
+    // weight-gradient partial-tile slabs (written and read once per step, never zeroed): gemm.h WgradSlabCtx
+    w.slab_floats = (size_t)(P.carve_passes >= 3 ? 48 : 16) << 20;
+    w.slab = ws.take<float>(w.slab_floats);
 }
 
 // zero-padded bf16 copy of fp32 rows: out[r][0..ld) = (x[r][0..cols), 0...)
@@ -406,9 +410,11 @@ int use_ws(CelebaPlan* P, void* ws, size_t bytes, bool module = true) {
     carve(*P, w);
     P->wgrad_forked = false;
     P->dec_skip_mask = 0;
+    P->slab.reset(P->w.slab, P->w.slab_floats);
     return MMVAE_OK;
 }
 int unpack(CelebaPlan& P, hipStream_t s) {
+    MMVAE_TRY(launch_wgrad_reduce(&P.slab, s));      // slab copies nobody summed yet (every side stream has joined s)
     return launch_unpack_grads(P.buf.gdesc_dev, P.gk.d.data(), (int)P.gk.d.size(), P.buf.gpk, P.buf.gpk_vec, P.buf.grads, s);
 }
 int zero_gpk(CelebaPlan& P, hipStream_t s) { return launch_fill_zero(P.buf.gpk, (size_t)P.gk.mat_elems * sizeof(float), s); }

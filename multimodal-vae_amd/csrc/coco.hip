@@ -141,6 +141,9 @@ void carve(CocoPlan& P, Workspace& ws) {
     w.tmp_f32 = ws.take<float>(B3 * NPIX);
     P.sk_floats = (size_t)256 * 128 * 128;
     P.sk_buf = ws.take<float>(P.sk_floats);
+    // weight-gradient partial-tile slabs (written and read once per step, never zeroed): gemm.h WgradSlabCtx
+    w.slab_floats = (size_t)(P.carve_passes >= 3 ? 48 : 16) << 20;
+    w.slab = ws.take<float>(w.slab_floats);
     coco_text_carve(P, ws);
 }
 
@@ -369,9 +372,11 @@ int use_ws(CocoPlan* P, void* ws, size_t bytes, bool module = true) {
     carve(*P, w);
     P->wgrad_forked = false;
     P->dec_skip_mask = 0;
+    P->slab.reset(P->w.slab, P->w.slab_floats);
     return MMVAE_OK;
 }
 int unpack(CocoPlan& P, hipStream_t s) {
+    MMVAE_TRY(launch_wgrad_reduce(&P.slab, s));      // slab copies nobody summed yet (every side stream has joined s)
     return launch_unpack_grads(P.buf.gdesc_dev, P.gk.d.data(), (int)P.gk.d.size(), P.buf.gpk, P.buf.gpk_vec, P.buf.grads, s);
 }
 int zero_gpk(CocoPlan& P, hipStream_t s) { return launch_fill_zero(P.buf.gpk, (size_t)P.gk.mat_elems * sizeof(float), s); }
@@ -438,7 +443,7 @@ static int coco_step_body(CocoPlan* Pp, const CocoStepIO& io, int training, int 
     hipStream_t Tx = serial ? s : P.st_text;
     // ---- encoders: caption GRU on the side stream, image encoder on main
     MMVAE_TRY(edge(P, s, Tx));
-    MMVAE_TRY(coco_text_enc_fwd(P, io.text, do_backward, w.txtout, Tx));
+    MMVAE_TRY(coco_text_enc_fwd(P, io.text, do_backward, w.txtout, Tx, true));
     MMVAE_TRY(enc_fwd(P, io.image, 2, m1, m2, enc_drop, training, 2 - sk[0] - sk[1], w.encout, s));
     MMVAE_TRY(edge(P, Tx, s));
     Latent3Args la{};
@@ -479,7 +484,7 @@ static int coco_step_body(CocoPlan* Pp, const CocoStepIO& io, int training, int 
     lb.d_txt_out = w.d_txtout;
     if (rc == MMVAE_OK) rc = launch_latent3_bwd(lb, s);
     if (rc == MMVAE_OK) rc = edge(P, s, Tx);
-    if (rc == MMVAE_OK) rc = coco_text_enc_bwd(P, io.text, w.d_txtout, Tx);
+    if (rc == MMVAE_OK) rc = coco_text_enc_bwd(P, io.text, w.d_txtout, Tx, serial ? Tx : P.st_wgrad2, true);
     if (rc == MMVAE_OK) rc = enc_bwd(P, w.d_encout, 2, m1, m2, enc_drop, s);
     P.wgrad_forked = false;
     MMVAE_TRY(rc);
@@ -532,11 +537,11 @@ int coco_image_decoder_bwd(CocoPlan* P, void* ws, size_t wsb, const float* d_rec
 int coco_text_encoder_fwd(CocoPlan* P, void* ws, size_t wsb, const float* text, float* out, hipStream_t s) {
     MMVAE_TRY(use_ws(P, ws, wsb));
     MMVAE_TRY(zero_ws(*P, s));
-    return coco_text_enc_fwd(*P, text, 1, out, s);
+    return coco_text_enc_fwd(*P, text, 1, out, s, false);
 }
 int coco_text_encoder_bwd(CocoPlan* P, void* ws, size_t wsb, const float* text, const float* d_out, hipStream_t s) {
     MMVAE_TRY(use_ws(P, ws, wsb));
-    return coco_text_enc_bwd(*P, text, d_out, s);
+    return coco_text_enc_bwd(*P, text, d_out, s, s, false);
 }
 int coco_text_decoder_fwd(CocoPlan* P, void* ws, size_t wsb, const float* z, const float* sos, const uint8_t* keep, int training,
                           float* sentence, hipStream_t s) {

@@ -36,6 +36,26 @@ struct CocoDecBwdArgs {
     float *dhinit;           // [R][200]
     float *dwsum;            // [R][300] time sum of the output gradient
 };
+struct CocoEncFwdArgs {
+    int B, T;
+    const float* gi;         // [B][T][600] input projection of every step (+ b_ih)
+    const bf16* w_hh;        // packed [608][224]
+    const float* bhh;
+    float* h_all;            // [T][B][200] h after each step
+    float* sav;              // [T][B][4*200] (r, z, n, W_hn h + b_hn) or null (inference)
+    bf16* hb_all;            // [T][B][224] bf16 copy of h_all: operand of the batched weight gradient
+};
+struct CocoEncBwdArgs {
+    int B, T;
+    const float* dh_init;    // [B][200] gradient wrt h[T-1]
+    const float *sav, *h_all;
+    const bf16* w_hhT;       // packed [208][608]
+    bf16 *dgi_b, *dgh_b;     // [T][B][608] gradients wrt the input / hidden projections
+};
+int launch_coco_enc_fwd(const CocoEncFwdArgs& a, hipStream_t s);
+int launch_coco_enc_bwd(const CocoEncBwdArgs& a, hipStream_t s);
+// dst[(t*B + b)*ld + e] = bf16(text[(b*T + t)*300 + e])
+int launch_coco_text_tb(const float* text, int B, int T, int ld, bf16* dst, hipStream_t s);
 int launch_coco_dec_fwd(const CocoDecFwdArgs& a, hipStream_t s);
 int launch_coco_dec_bwd(const CocoDecBwdArgs& a, hipStream_t s);
 // out[r][c] (fp32, [R][cols]) = sum over t of in[(t*R + r)*ld + c]
@@ -52,8 +72,8 @@ struct CocoPlan : PlanBase {
     long long te_h2p_w, te_h2p_b, td_z2h_w, td_z2h_b, td_h2o_w, td_h2o_b;
     // bf16 persistent caption decoder: packed weights (forward and transposed forms) and packed-gradient descriptors
     bool text_bf16 = true;
-    int tb_ih0, tb_hh0, tb_ih1, tb_hh1, tb_ho, tb_hoT, tb_ih1T, tb_hh1T, tb_hh0T, tb_ih0T;
-    int tg_ih0, tg_hh0, tg_ih1, tg_hh1, tg_ho;
+    int tb_ih0, tb_hh0, tb_ih1, tb_hh1, tb_ho, tb_hoT, tb_ih1T, tb_hh1T, tb_hh0T, tb_ih0T, tb_e_hh, tb_e_hhT;
+    int tg_ih0, tg_hh0, tg_ih1, tg_hh1, tg_ho, tg_e_ih, tg_e_hh;
     struct W {
         char* zero_begin; size_t zero_bytes;
         float2 *st_e[3], *red_e[3], *st_d[3], *red_d[3];
@@ -67,6 +87,7 @@ struct CocoPlan : PlanBase {
         bf16 *patches4, *d3, *d2, *d1, *du;
         bf16 *d_encout, *dy2, *dy1, *db4, *dr4, *d3e, *d2e, *d1e;
         float* tmp_f32;
+        float* slab; size_t slab_floats;
         // caption encoder (B rows)
         float *te_gi, *te_gh, *te_h, *te_sav, *te_gi_r, *te_sav_r, *te_hb, *te_sum, *txtout;
         float *d_txtout, *te_dsum, *te_dh, *te_dgi, *te_dgh, *te_dgi_r;
@@ -75,6 +96,7 @@ struct CocoPlan : PlanBase {
         float *td_dw, *td_dgi0, *td_dgh0, *td_dgi1, *td_dgh1, *td_dmid, *td_dzi0, *td_dwsum, *td_dhinit;
         // bf16 persistent decoder: operands of the batched weight gradients, [t][row] layout
         bf16 *tb_x, *tb_h0, *tb_mid, *tb_h1, *tb_dout, *tb_dgi0, *tb_dgh0, *tb_dgi1, *tb_dgh1;
+        bf16 *te_xb, *te_hb_all, *te_dgi_b, *te_dgh_b;
     } w;
 };
 
@@ -82,9 +104,9 @@ struct CocoPlan : PlanBase {
 void coco_text_build(CocoPlan& P);                      // parameter offsets (the parameters are added by coco.hip's build)
 void coco_text_carve(CocoPlan& P, Workspace& ws);       // the non-zeroed caption buffers
 // text: [B][T][300]; out: [B][2D]
-int coco_text_enc_fwd(CocoPlan& P, const float* text, int save, float* out, hipStream_t s);
+int coco_text_enc_fwd(CocoPlan& P, const float* text, int save, float* out, hipStream_t s, bool bf16_path);
 // d_out: [B][2D] (the h2p bias gradient is added here); accumulates every caption-encoder gradient into P.buf.grads
-int coco_text_enc_bwd(CocoPlan& P, const float* text, const float* d_out, hipStream_t s);
+int coco_text_enc_bwd(CocoPlan& P, const float* text, const float* d_out, hipStream_t s, hipStream_t sw, bool bf16_path);
 // z: [rows][D] fp32, rows = groups*B; sentence: [rows][T][300]; keep: [T][rows][200] or null
 int coco_text_dec_fwd(CocoPlan& P, const float* z, int groups, const float* sos, const uint8_t* keep, int save, float* sentence, hipStream_t s,
                       bool bf16_path = false);

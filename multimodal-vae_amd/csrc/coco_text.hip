@@ -333,6 +333,8 @@ void coco_text_build(CocoPlan& P) {
     P.tb_hh1T = trp(P.td1.whh, H, G, H, 208, CTB_GP);
     P.tb_hh0T = trp(P.td0.whh, H, G, H, 208, CTB_GP);
     P.tb_ih0T = trp(P.td0.wih, E, G, in0, CTB_EP, CTB_GP);      // [e][g] = weight_ih_l0[g][e]
+    P.tb_e_hh = fwdp(P.te_f.whh, G, H, H, CTB_GP, CTB_HP);      // caption encoder, forward direction
+    P.tb_e_hhT = trp(P.te_f.whh, H, G, H, 208, CTB_GP);
     // packed gradients [round64(N)][Kpad of the wgrad operand] -> scattered back by the unpack kernel
     auto gkp = [&](long long w, int N, int K, int ld, int Kc) { return P.gk.add(pack_dense(w, N, K, round_up(N, 64), round_up(Kc, 64), ld, 1)); };
     P.tg_ih0 = gkp(P.td0.wih, G, E, in0, CTB_XP);
@@ -340,6 +342,8 @@ void coco_text_build(CocoPlan& P) {
     P.tg_ih1 = gkp(P.td1.wih, G, H, H, CTB_HP);
     P.tg_hh1 = gkp(P.td1.whh, G, H, H, CTB_HP);
     P.tg_ho = gkp(P.td_h2o_w, E, H, ino, CTB_HP);
+    P.tg_e_ih = gkp(P.te_f.wih, G, E, E, CTB_XP);
+    P.tg_e_hh = gkp(P.te_f.whh, G, H, H, CTB_HP);
 }
 
 void coco_text_carve(CocoPlan& P, Workspace& ws) {
@@ -362,16 +366,25 @@ void coco_text_carve(CocoPlan& P, Workspace& ws) {
         w.tb_h1 = ws.take<bf16>((T + 1) * R * CTB_HP); w.tb_dout = ws.take<bf16>(T * R * CTB_EP);
         w.tb_dgi0 = ws.take<bf16>(T * R * CTB_GP); w.tb_dgh0 = ws.take<bf16>(T * R * CTB_GP);
         w.tb_dgi1 = ws.take<bf16>(T * R * CTB_GP); w.tb_dgh1 = ws.take<bf16>(T * R * CTB_GP);
+        w.te_xb = ws.take<bf16>(T * B * CTB_XP); w.te_hb_all = ws.take<bf16>(T * B * CTB_HP);
+        w.te_dgi_b = ws.take<bf16>(T * B * CTB_GP); w.te_dgh_b = ws.take<bf16>(T * B * CTB_GP);
     }
 }
 
 // ================================================================== caption encoder (coco/model.py:236-245)
-int coco_text_enc_fwd(CocoPlan& P, const float* text, int save, float* out, hipStream_t s) {
+int coco_text_enc_fwd(CocoPlan& P, const float* text, int save, float* out, hipStream_t s, bool bf16_path) {
     CocoPlan::W& w = P.w;
     const int B = P.B, T = P.T, D2 = 2 * P.D;
     const float* p = P.buf.params;
     // input projection of every time step at once: rows (b, t)
     MMVAE_TRY(lin(text, E, B * T, p + P.te_f.wih, G, E, E, 0, p + P.te_f.bih, nullptr, 0, w.te_gi, G, s));
+    if (bf16_path && P.text_bf16) {      // the recurrence in ONE persistent launch (coco_text_bf16.hip)
+        CocoEncFwdArgs a{};
+        a.B = B; a.T = T; a.gi = w.te_gi; a.w_hh = P.buf.packed + P.pk.d[P.tb_e_hh].dst_off; a.bhh = p + P.te_f.bhh;
+        a.h_all = w.te_h;
+        if (save) { a.sav = w.te_sav; a.hb_all = w.te_hb_all; }
+        MMVAE_TRY(launch_coco_enc_fwd(a, s));
+    } else
     for (int t = 0; t < T; ++t) {
         const float* hp = t == 0 ? w.zeros_h : w.te_h + (size_t)(t - 1) * B * H;
         GruLayer a{};
@@ -390,7 +403,7 @@ int coco_text_enc_fwd(CocoPlan& P, const float* text, int save, float* out, hipS
     return lin(w.te_sum, H, B, p + P.te_h2p_w, D2, H, H, 0, p + P.te_h2p_b, nullptr, 0, out, D2, s);
 }
 
-int coco_text_enc_bwd(CocoPlan& P, const float* text, const float* d_out, hipStream_t s) {
+int coco_text_enc_bwd(CocoPlan& P, const float* text, const float* d_out, hipStream_t s, hipStream_t sw, bool bf16_path) {
     CocoPlan::W& w = P.w;
     const int B = P.B, T = P.T, D2 = 2 * P.D;
     const float* p = P.buf.params;
@@ -405,6 +418,29 @@ int coco_text_enc_bwd(CocoPlan& P, const float* text, const float* d_out, hipStr
         MMVAE_TRY(launch_colsum_f32(w.te_dgi_r, B, G, g + P.te_r.bih, s));
         MMVAE_TRY(launch_colsum_f32(w.te_gh, B, G, g + P.te_r.bhh, s));
         MMVAE_TRY(lin_dw(w.te_dgi_r, G, text + (size_t)(T - 1) * E, (long long)T * E, B, g + P.te_r.wih, G, E, E, 0, s));
+    }
+    if (bf16_path && P.text_bf16) {      // BPTT in one launch, then the weight gradients as batched bf16 GEMMs over all T*B rows
+        CocoEncBwdArgs a{};
+        a.B = B; a.T = T; a.dh_init = w.te_dsum; a.sav = w.te_sav; a.h_all = w.te_h;
+        a.w_hhT = P.buf.packed + P.pk.d[P.tb_e_hhT].dst_off; a.dgi_b = w.te_dgi_b; a.dgh_b = w.te_dgh_b;
+        MMVAE_TRY(launch_coco_enc_bwd(a, s));
+        const bool fork = sw != s;
+        if (fork) MMVAE_TRY(edge(P, s, sw));
+        MMVAE_TRY(launch_coco_text_tb(text, B, T, CTB_XP, w.te_xb, sw));
+        WgradParams list[2];
+        int n = 0;
+        auto wg = [&](int gidx, const bf16* Pm, const bf16* Gm, int C, int rows) {
+            GatherPlan pl = dense_plan(rows, C, C, G);
+            WgradParams q = wgrad_of(P, pl, &gidx, 1, rows);
+            q.c.A = Gm; q.P = Pm; q.ldp = CTB_GP;
+            list[n++] = q;
+        };
+        wg(P.tg_e_ih, w.te_dgi_b, w.te_xb, CTB_XP, T * B);
+        if (T > 1) wg(P.tg_e_hh, w.te_dgh_b + (size_t)B * CTB_GP, w.te_hb_all, CTB_HP, (T - 1) * B);   // pairs (dgh[t], h[t-1])
+        MMVAE_TRY(launch_wgrad_group(list, n, sw, &P.slab));
+        MMVAE_TRY(launch_wgrad_reduce(&P.slab, sw, true));
+        MMVAE_TRY(launch_colsum_bf16(w.te_dgi_b, CTB_GP, T * B, G, g + P.te_f.bih, sw));
+        return launch_colsum_bf16(w.te_dgh_b, CTB_GP, T * B, G, g + P.te_f.bhh, sw);
     }
     // forward direction: backpropagation through time
     hipMemcpyAsync(w.te_dh, w.te_dsum, (size_t)B * H * sizeof(float), hipMemcpyDeviceToDevice, s);

@@ -423,6 +423,151 @@ __global__ __launch_bounds__(NTHR) void coco_dec_bwd_kernel(const CocoDecBwdArgs
     }
 }
 
+// ================================================================== caption encoder (forward direction of the bi-GRU)
+// coco/model.py:236-245.  The input projection of all T steps is one batched GEMM done by the caller; what is sequential is
+// h[t] = GRU(gi[t], h[t-1]): one hidden projection (W_hh, 272 KB bf16) and the gate math per step.  Same scheme as the
+// decoder: 16 rows per workgroup for the whole recurrence, the weights streamed through the register ring.
+template <bool SAVE>
+__global__ __launch_bounds__(NTHR) void coco_enc_fwd_kernel(const CocoEncFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* gb = reinterpret_cast<float*>(smem);                     // [16][LDG] hidden projection
+    float* hf = gb + TR * LDG;                                      // [16][H]
+    float* bias = hf + TR * H;                                      // b_hh [G]
+    bf16* hb = reinterpret_cast<bf16*>(bias + G);                   // [16][LDH]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r0 = blockIdx.x * TR, R = a.B, T = a.T;
+    const size_t RH = (size_t)R * H;
+    const int grow = tid >> 5, c0 = tid & 31;
+    const bool gok = r0 + grow < R;
+    const size_t gr = gok ? r0 + grow : 0;
+    for (int i = tid; i < TR * H; i += NTHR) hf[i] = 0.f;
+    for (int i = tid; i < TR * LDH; i += NTHR) hb[i] = (bf16)0.f;
+    for (int i = tid; i < G; i += NTHR) bias[i] = a.bhh[i];
+    // chunk schedule of a step (ring depth 3): hh 5 tile slots + 1 dummy = 6 chunks
+    constexpr int D = 3;
+    const WMat<HP / 32, GP / 16> d_hh(a.w_hh);
+    bf16x8 ring[D][KCH];
+#pragma unroll
+    for (int q = 0; q < D; ++q) load_chunk(ring[q], d_hh, q, wave, lane);
+    __syncthreads();
+    const float* pb = gb + grow * LDG;
+    for (int t = 0; t < T; ++t) {
+        float g_r[NQH], g_z[NQH], g_n[NQH];
+        const float* gi = a.gi + (gr * T + t) * G;
+#pragma unroll
+        for (int q = 0; q < NQH; ++q) {
+            const int j = min(c0 + 32 * q, H - 1);
+            g_r[q] = gi[j]; g_z[q] = gi[H + j]; g_n[q] = gi[2 * H + j];
+        }
+        stream_gemm<6, D, 0>(hb, LDH, d_hh, gb, LDG, ring, d_hh, t + 1 < T, wave, lane);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NQH; ++q) {
+            const int j = c0 + 32 * q;
+            if (j < H) {
+                const int i = grow * H + j;
+                const float r = sigm(g_r[q] + pb[j] + bias[j]);
+                const float z = sigm(g_z[q] + pb[H + j] + bias[H + j]);
+                const float ghn = pb[2 * H + j] + bias[2 * H + j];
+                const float n = tanh_fast(g_n[q] + r * ghn);
+                const float hn = (1.0f - z) * n + z * hf[i];
+                hf[i] = hn;
+                hb[grow * LDH + j] = (bf16)hn;
+                if (gok) {
+                    a.h_all[(size_t)t * RH + gr * H + j] = hn;
+                    if (SAVE) {
+                        float* s = a.sav + ((size_t)t * R + gr) * 4 * H;
+                        s[j] = r; s[H + j] = z; s[2 * H + j] = n; s[3 * H + j] = ghn;
+                        a.hb_all[((size_t)t * R + gr) * HP + j] = (bf16)hn;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// BPTT of the same recurrence: per step the gate backward and dh[t-1] += dgh[t] * W_hh (253 KB bf16 streamed).
+__global__ __launch_bounds__(NTHR) void coco_enc_bwd_kernel(const CocoEncBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* dhf = reinterpret_cast<float*>(smem);                    // [16][H] direct path d * z
+    float* o = dhf + TR * H;                                        // [16][LDT] dgh[t+1] * W_hh
+    bf16* dgh = reinterpret_cast<bf16*>(o + TR * LDT);              // [16][LDGK]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r0 = blockIdx.x * TR, R = a.B, T = a.T;
+    const size_t RH = (size_t)R * H;
+    const int grow = tid >> 5, c0 = tid & 31;
+    const bool gok = r0 + grow < R;
+    const size_t gr = gok ? r0 + grow : 0;
+    for (int i = tid; i < TR * H; i += NTHR) {
+        const int row = i / H;
+        dhf[i] = r0 + row < R ? a.dh_init[(size_t)(r0 + row) * H + (i - row * H)] : 0.f;
+    }
+    for (int i = tid; i < TR * LDT; i += NTHR) o[i] = 0.f;
+    for (int i = tid; i < TR * LDGK; i += NTHR) dgh[i] = (bf16)0.f;
+    constexpr int D = 2;                                            // hhT: 2 tile slots x 2 k-chunks = 4 chunks per step
+    const WMat<GP / 32, HP / 16 - 1> d_hhT(a.w_hhT);
+    bf16x8 ring[D][KCH];
+#pragma unroll
+    for (int q = 0; q < D; ++q) load_chunk(ring[q], d_hhT, q, wave, lane);
+    float sr[NQH], sz[NQH], sn[NQH], sg[NQH], hp[NQH];
+    auto fetch = [&](int t) {       // saved gates of step t and h[t-1]: requested one GEMM ahead of their use
+        const float* s = a.sav + ((size_t)t * R + gr) * 4 * H;
+        const float* hpp = a.h_all + (size_t)(t > 0 ? t - 1 : 0) * RH + gr * H;
+#pragma unroll
+        for (int q = 0; q < NQH; ++q) {
+            const int j = min(c0 + 32 * q, H - 1);
+            sr[q] = s[j]; sz[q] = s[H + j]; sn[q] = s[2 * H + j]; sg[q] = s[3 * H + j];
+            hp[q] = t > 0 ? hpp[j] : 0.f;
+        }
+    };
+    fetch(T - 1);
+    __syncthreads();
+    for (int t = T - 1; t >= 0; --t) {
+#pragma unroll
+        for (int q = 0; q < NQH; ++q) {
+            const int j = c0 + 32 * q;
+            if (j < H) {
+                const int i = grow * H + j;
+                float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f, dd = 0.f;
+                if (gok) {
+                    const float r = sr[q], z = sz[q], n = sn[q], ghn = sg[q];
+                    const float d = dhf[i] + o[grow * LDT + j];
+                    dn = d * (1.0f - z) * (1.0f - n * n);
+                    dz = d * (hp[q] - n) * z * (1.0f - z);
+                    dr = dn * ghn * r * (1.0f - r);
+                    dnr = dn * r;
+                    dd = d * z;
+                }
+                dhf[i] = dd;
+                dgh[grow * LDGK + j] = (bf16)dr; dgh[grow * LDGK + H + j] = (bf16)dz; dgh[grow * LDGK + 2 * H + j] = (bf16)dnr;
+                if (gok) {
+                    bf16* gi = a.dgi_b + ((size_t)t * R + gr) * GP;
+                    bf16* gh = a.dgh_b + ((size_t)t * R + gr) * GP;
+                    gi[j] = (bf16)dr; gi[H + j] = (bf16)dz; gi[2 * H + j] = (bf16)dn;
+                    gh[j] = (bf16)dr; gh[H + j] = (bf16)dz; gh[2 * H + j] = (bf16)dnr;
+                }
+            }
+        }
+        __syncthreads();
+        if (t > 0) {
+            fetch(t - 1);
+            stream_gemm<2, D, 0>(dgh, LDGK, d_hhT, o, LDT, ring, d_hhT, t > 1, wave, lane);
+        }
+        __syncthreads();
+    }
+}
+
+// dst[(t*B + b)*ld + e] = bf16(src[(b*T + t)*E + e]): the captions as the [t][row] bf16 operand of the batched weight gradient
+__global__ __launch_bounds__(256) void text_tb_kernel(const float* src, int B, int T, int ld, bf16* dst) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)B * T * E) return;
+    const int e = (int)(i % E);
+    const long long bt = i / E;
+    const int t = (int)(bt % T), b = (int)(bt / T);
+    dst[((size_t)t * B + b) * ld + e] = (bf16)src[i];
+}
+
 // out[r][c] = sum_t in[(t*R + r)*ld + c]
 __global__ __launch_bounds__(256) void time_sum_bf16_kernel(const bf16* in, int T, int R, int ld, int cols, float* out) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -467,4 +612,29 @@ int launch_coco_dec_bwd(const CocoDecBwdArgs& a, hipStream_t s) {
     if (a.keep) hipLaunchKernelGGL(coco_dec_bwd_kernel<true>, dim3(ceil_div(a.R, TR)), dim3(NTHR), lds, s, a);
     else hipLaunchKernelGGL(coco_dec_bwd_kernel<false>, dim3(ceil_div(a.R, TR)), dim3(NTHR), lds, s, a);
     return mmvae_check_launch("coco_dec_bwd");
+}
+
+int launch_coco_enc_fwd(const CocoEncFwdArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)(TR * LDG + TR * H + G) * sizeof(float) + (size_t)(TR * LDH) * sizeof(bf16);
+    static std::atomic<unsigned> once{0};
+    if (mmvae_first_use_on_device(once)) {
+        auto big = [](auto kern) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); };
+        big(&coco_enc_fwd_kernel<true>); big(&coco_enc_fwd_kernel<false>);
+    }
+    MMVAE_REQUIRE(a.h_all && (!a.sav || a.hb_all), "coco_enc_fwd: save buffers");
+    if (a.sav) hipLaunchKernelGGL(coco_enc_fwd_kernel<true>, dim3(ceil_div(a.B, TR)), dim3(NTHR), lds, s, a);
+    else hipLaunchKernelGGL(coco_enc_fwd_kernel<false>, dim3(ceil_div(a.B, TR)), dim3(NTHR), lds, s, a);
+    return mmvae_check_launch("coco_enc_fwd");
+}
+int launch_coco_enc_bwd(const CocoEncBwdArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)(TR * H + TR * LDT) * sizeof(float) + (size_t)(TR * LDGK) * sizeof(bf16);
+    static std::atomic<unsigned> once{0};
+    if (mmvae_first_use_on_device(once))
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&coco_enc_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(coco_enc_bwd_kernel, dim3(ceil_div(a.B, TR)), dim3(NTHR), lds, s, a);
+    return mmvae_check_launch("coco_enc_bwd");
+}
+int launch_coco_text_tb(const float* text, int B, int T, int ld, bf16* dst, hipStream_t s) {
+    hipLaunchKernelGGL(text_tb_kernel, dim3((unsigned)(((long long)B * T * E + 255) / 256)), dim3(256), 0, s, text, B, T, ld, dst);
+    return mmvae_check_launch("coco_text_tb");
 }
