@@ -373,6 +373,7 @@ int use_ws(CocoPlan* P, void* ws, size_t bytes, bool module = true) {
     P->wgrad_forked = false;
     P->dec_skip_mask = 0;
     P->slab.reset(P->w.slab, P->w.slab_floats);
+    P->dec_wg_pending = false;
     return MMVAE_OK;
 }
 int unpack(CocoPlan& P, hipStream_t s) {
@@ -485,6 +486,7 @@ static int coco_step_body(CocoPlan* Pp, const CocoStepIO& io, int training, int 
     if (rc == MMVAE_OK) rc = launch_latent3_bwd(lb, s);
     if (rc == MMVAE_OK) rc = edge(P, s, Tx);
     if (rc == MMVAE_OK) rc = coco_text_enc_bwd(P, io.text, w.d_txtout, Tx, serial ? Tx : P.st_wgrad2, true);
+    if (rc == MMVAE_OK) rc = coco_text_dec_wgrads(P, serial ? Tx : P.st_wgrad2);   // (no-op: issued behind the encoder's BPTT launch)
     if (rc == MMVAE_OK) rc = enc_bwd(P, w.d_encout, 2, m1, m2, enc_drop, s);
     P.wgrad_forked = false;
     MMVAE_TRY(rc);

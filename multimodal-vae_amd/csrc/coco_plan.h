@@ -43,7 +43,7 @@ struct CocoEncFwdArgs {
     const float* bhh;
     float* h_all;            // [T][B][200] h after each step
     float* sav;              // [T][B][4*200] (r, z, n, W_hn h + b_hn) or null (inference)
-    bf16* hb_all;            // [T][B][224] bf16 copy of h_all: operand of the batched weight gradient
+    bf16* hb_all;            // [T][B][224] bf16 h BEFORE each step (slice 0 = zeros), column 200 = 1.0: operand of the batched weight gradient
 };
 struct CocoEncBwdArgs {
     int B, T;
@@ -54,7 +54,7 @@ struct CocoEncBwdArgs {
 };
 int launch_coco_enc_fwd(const CocoEncFwdArgs& a, hipStream_t s);
 int launch_coco_enc_bwd(const CocoEncBwdArgs& a, hipStream_t s);
-// dst[(t*B + b)*ld + e] = bf16(text[(b*T + t)*300 + e])
+// dst[(t*B + b)*ld + e] = bf16(text[(b*T + t)*300 + e]); column 300 = 1.0
 int launch_coco_text_tb(const float* text, int B, int T, int ld, bf16* dst, hipStream_t s);
 int launch_coco_dec_fwd(const CocoDecFwdArgs& a, hipStream_t s);
 int launch_coco_dec_bwd(const CocoDecBwdArgs& a, hipStream_t s);
@@ -72,6 +72,7 @@ struct CocoPlan : PlanBase {
     long long te_h2p_w, te_h2p_b, td_z2h_w, td_z2h_b, td_h2o_w, td_h2o_b;
     // bf16 persistent caption decoder: packed weights (forward and transposed forms) and packed-gradient descriptors
     bool text_bf16 = true;
+    bool dec_wg_pending = false; const float* dec_wg_z = nullptr; int dec_wg_groups = 0;   // deferred weight gradients of the bf16 decoder
     int tb_ih0, tb_hh0, tb_ih1, tb_hh1, tb_ho, tb_hoT, tb_ih1T, tb_hh1T, tb_hh0T, tb_ih0T, tb_e_hh, tb_e_hhT;
     int tg_ih0, tg_hh0, tg_ih1, tg_hh1, tg_ho, tg_e_ih, tg_e_hh;
     struct W {
@@ -104,6 +105,8 @@ struct CocoPlan : PlanBase {
 void coco_text_build(CocoPlan& P);                      // parameter offsets (the parameters are added by coco.hip's build)
 void coco_text_carve(CocoPlan& P, Workspace& ws);       // the non-zeroed caption buffers
 // text: [B][T][300]; out: [B][2D]
+// issues the caption decoder's deferred weight gradients (bf16 path) on `sw`; no-op when none are pending
+int coco_text_dec_wgrads(CocoPlan& P, hipStream_t sw);
 int coco_text_enc_fwd(CocoPlan& P, const float* text, int save, float* out, hipStream_t s, bool bf16_path);
 // d_out: [B][2D] (the h2p bias gradient is added here); accumulates every caption-encoder gradient into P.buf.grads
 int coco_text_enc_bwd(CocoPlan& P, const float* text, const float* d_out, hipStream_t s, hipStream_t sw, bool bf16_path);

@@ -336,14 +336,19 @@ void coco_text_build(CocoPlan& P) {
     P.tb_e_hh = fwdp(P.te_f.whh, G, H, H, CTB_GP, CTB_HP);      // caption encoder, forward direction
     P.tb_e_hhT = trp(P.te_f.whh, H, G, H, 208, CTB_GP);
     // packed gradients [round64(N)][Kpad of the wgrad operand] -> scattered back by the unpack kernel
-    auto gkp = [&](long long w, int N, int K, int ld, int Kc) { return P.gk.add(pack_dense(w, N, K, round_up(N, 64), round_up(Kc, 64), ld, 1)); };
-    P.tg_ih0 = gkp(P.td0.wih, G, E, in0, CTB_XP);
-    P.tg_hh0 = gkp(P.td0.whh, G, H, H, CTB_HP);
-    P.tg_ih1 = gkp(P.td1.wih, G, H, H, CTB_HP);
-    P.tg_hh1 = gkp(P.td1.whh, G, H, H, CTB_HP);
-    P.tg_ho = gkp(P.td_h2o_w, E, H, ino, CTB_HP);
-    P.tg_e_ih = gkp(P.te_f.wih, G, E, E, CTB_XP);
-    P.tg_e_hh = gkp(P.te_f.whh, G, H, H, CTB_HP);
+    // bias >= 0: the saved operand carries 1.0 in column K, so column K of the packed gradient is the bias gradient
+    auto gkp = [&](long long w, int N, int K, int ld, int Kc, long long bias) {
+        PackDesc d = pack_dense(w, N, K, round_up(N, 64), round_up(Kc, 64), ld, 1);
+        if (bias >= 0) { d.bias_off = bias; d.b_nhi = 0; d.b_nlo = 1; }
+        return P.gk.add(d);
+    };
+    P.tg_ih0 = gkp(P.td0.wih, G, E, in0, CTB_XP, -1);           // (b_ih of layer 0 sees the time sum: with the z-terms)
+    P.tg_hh0 = gkp(P.td0.whh, G, H, H, CTB_HP, P.td0.bhh);
+    P.tg_ih1 = gkp(P.td1.wih, G, H, H, CTB_HP, P.td1.bih);
+    P.tg_hh1 = gkp(P.td1.whh, G, H, H, CTB_HP, P.td1.bhh);
+    P.tg_ho = gkp(P.td_h2o_w, E, H, ino, CTB_HP, -1);
+    P.tg_e_ih = gkp(P.te_f.wih, G, E, E, CTB_XP, P.te_f.bih);
+    P.tg_e_hh = gkp(P.te_f.whh, G, H, H, CTB_HP, P.te_f.bhh);
 }
 
 void coco_text_carve(CocoPlan& P, Workspace& ws) {
@@ -408,25 +413,30 @@ int coco_text_enc_bwd(CocoPlan& P, const float* text, const float* d_out, hipStr
     const int B = P.B, T = P.T, D2 = 2 * P.D;
     const float* p = P.buf.params;
     float* g = P.buf.grads;
-    MMVAE_TRY(launch_colsum_f32(d_out, B, D2, g + P.te_h2p_b, s));
-    MMVAE_TRY(lin_dw(d_out, D2, w.te_sum, H, B, g + P.te_h2p_w, D2, H, H, 0, s));
+    const bool bf = bf16_path && P.text_bf16;
+    hipStream_t so = bf ? sw : s;        // where everything that only feeds the optimizer goes
     MMVAE_TRY(lin_dx(d_out, D2, B, p + P.te_h2p_w, D2, H, H, 0, w.te_dsum, H, 0, s));
-    {   // reverse direction (one step from h = 0: no hidden-weight gradient, only its bias)
-        GruBwd a{};
-        a.dh = w.te_dsum; a.sav = w.te_sav_r; a.hprev = w.zeros_h; a.dgi = w.te_dgi_r; a.lddgi = G; a.dgh = w.te_gh; a.dh_out = w.te_dh; a.rows = B;
-        MMVAE_TRY(gru_bwd(a, s));
-        MMVAE_TRY(launch_colsum_f32(w.te_dgi_r, B, G, g + P.te_r.bih, s));
-        MMVAE_TRY(launch_colsum_f32(w.te_gh, B, G, g + P.te_r.bhh, s));
-        MMVAE_TRY(lin_dw(w.te_dgi_r, G, text + (size_t)(T - 1) * E, (long long)T * E, B, g + P.te_r.wih, G, E, E, 0, s));
-    }
-    if (bf16_path && P.text_bf16) {      // BPTT in one launch, then the weight gradients as batched bf16 GEMMs over all T*B rows
+    if (bf) {       // BPTT of the forward direction in one launch; it is the critical chain, everything else goes behind it
+        if (so != s) MMVAE_TRY(edge(P, s, so));
         CocoEncBwdArgs a{};
         a.B = B; a.T = T; a.dh_init = w.te_dsum; a.sav = w.te_sav; a.h_all = w.te_h;
         a.w_hhT = P.buf.packed + P.pk.d[P.tb_e_hhT].dst_off; a.dgi_b = w.te_dgi_b; a.dgh_b = w.te_dgh_b;
         MMVAE_TRY(launch_coco_enc_bwd(a, s));
-        const bool fork = sw != s;
-        if (fork) MMVAE_TRY(edge(P, s, sw));
-        MMVAE_TRY(launch_coco_text_tb(text, B, T, CTB_XP, w.te_xb, sw));
+        MMVAE_TRY(coco_text_dec_wgrads(P, so));      // the caption decoder's weight gradients, deferred to here by the step
+    }
+    MMVAE_TRY(launch_colsum_f32(d_out, B, D2, g + P.te_h2p_b, so));
+    MMVAE_TRY(lin_dw(d_out, D2, w.te_sum, H, B, g + P.te_h2p_w, D2, H, H, 0, so));
+    {   // reverse direction (one step from h = 0: no hidden-weight gradient, only its bias)
+        GruBwd a{};
+        a.dh = w.te_dsum; a.sav = w.te_sav_r; a.hprev = w.zeros_h; a.dgi = w.te_dgi_r; a.lddgi = G; a.dgh = w.te_gh; a.dh_out = w.te_dh; a.rows = B;
+        MMVAE_TRY(gru_bwd(a, so));
+        MMVAE_TRY(launch_colsum_f32(w.te_dgi_r, B, G, g + P.te_r.bih, so));
+        MMVAE_TRY(launch_colsum_f32(w.te_gh, B, G, g + P.te_r.bhh, so));
+        MMVAE_TRY(lin_dw(w.te_dgi_r, G, text + (size_t)(T - 1) * E, (long long)T * E, B, g + P.te_r.wih, G, E, E, 0, so));
+    }
+    if (bf) {       // weight gradients of the forward direction as batched bf16 GEMMs over all T*B rows
+        MMVAE_TRY(launch_coco_text_tb(text, B, T, CTB_XP, w.te_xb, so));
+        if (so != s) MMVAE_TRY(edge(P, s, so));
         WgradParams list[2];
         int n = 0;
         auto wg = [&](int gidx, const bf16* Pm, const bf16* Gm, int C, int rows) {
@@ -435,12 +445,11 @@ int coco_text_enc_bwd(CocoPlan& P, const float* text, const float* d_out, hipStr
             q.c.A = Gm; q.P = Pm; q.ldp = CTB_GP;
             list[n++] = q;
         };
+        // pairs (dgi[t], x[t]) and (dgh[t], h[t-1]); column 300 / 200 of the second operand is 1.0: b_ih, b_hh ride along
         wg(P.tg_e_ih, w.te_dgi_b, w.te_xb, CTB_XP, T * B);
-        if (T > 1) wg(P.tg_e_hh, w.te_dgh_b + (size_t)B * CTB_GP, w.te_hb_all, CTB_HP, (T - 1) * B);   // pairs (dgh[t], h[t-1])
-        MMVAE_TRY(launch_wgrad_group(list, n, sw, &P.slab));
-        MMVAE_TRY(launch_wgrad_reduce(&P.slab, sw, true));
-        MMVAE_TRY(launch_colsum_bf16(w.te_dgi_b, CTB_GP, T * B, G, g + P.te_f.bih, sw));
-        return launch_colsum_bf16(w.te_dgh_b, CTB_GP, T * B, G, g + P.te_f.bhh, sw);
+        wg(P.tg_e_hh, w.te_dgh_b, w.te_hb_all, CTB_HP, T * B);
+        MMVAE_TRY(launch_wgrad_group(list, n, so, &P.slab));
+        return launch_wgrad_reduce(&P.slab, so, true);
     }
     // forward direction: backpropagation through time
     hipMemcpyAsync(w.te_dh, w.te_dsum, (size_t)B * H * sizeof(float), hipMemcpyDeviceToDevice, s);
@@ -513,9 +522,8 @@ int coco_text_dec_fwd(CocoPlan& P, const float* z, int groups, const float* sos,
 static int coco_text_dec_bwd_bf16(CocoPlan& P, const float* z, int groups, const uint8_t* keep, float* dw, float* dz, hipStream_t s,
                                   hipStream_t sw) {
     CocoPlan::W& w = P.w;
-    const int R = groups * P.B, T = P.T, D = P.D, in0 = E + D, ino = H + D, TRn = T * R;
+    const int R = groups * P.B, T = P.T, D = P.D, in0 = E + D, ino = H + D;
     const float* p = P.buf.params;
-    float* g = P.buf.grads;
     const float scale = 1.f / (1.f - DROP_P);
     CocoDecBwdArgs a{};
     a.R = R; a.T = T; a.dw = dw; a.keep = keep; a.keep_scale = scale;
@@ -526,9 +534,26 @@ static int coco_text_dec_bwd_bf16(CocoPlan& P, const float* z, int groups, const
     a.dhinit = w.td_dhinit; a.dwsum = w.td_dwsum;
     MMVAE_TRY(launch_coco_dec_bwd(a, s));
     MMVAE_TRY(launch_coco_time_sum_bf16(a.dgi0_b, T, R, CTB_GP, G, w.td_dzi0, s));
-    // ---- weight gradients: dW[N][K] = P[T*R][N]^T G[T*R][K], bf16 operands saved in [t][row] layout, off the main chain
-    const bool fork = sw != s;
-    if (fork) MMVAE_TRY(edge(P, s, sw));
+    // ---- what the rest of the step waits for: dz through the three z-terms (initial state, layer-0 input, output projection)
+    MMVAE_TRY(lin_dx(w.td_dhinit, H, R, p + P.td_z2h_w, H, D, D, 0, dz, D, 0, s));
+    MMVAE_TRY(lin_dx(w.td_dzi0, G, R, p + P.td0.wih, G, D, in0, E, dz, D, 1, s));
+    MMVAE_TRY(lin_dx(w.td_dwsum, E, R, p + P.td_h2o_w, E, D, ino, H, dz, D, 1, s));
+    // ---- the weight gradients only feed the optimizer: the step issues them (coco_text_dec_wgrads) on the side stream
+    // once the caption encoder's BPTT launch -- 8 workgroups, the rest of the chip idle -- is under way
+    P.dec_wg_pending = true; P.dec_wg_z = z; P.dec_wg_groups = groups;
+    if (sw == s) return coco_text_dec_wgrads(P, s);
+    return MMVAE_OK;
+}
+
+// weight gradients of the bf16 caption decoder: dW[N][K] = P[T*R][N]^T G[T*R][K], bf16 operands saved in [t][row] layout.
+// The caller has ordered `sw` behind the decoder's BPTT launch and its time sums.
+int coco_text_dec_wgrads(CocoPlan& P, hipStream_t sw) {
+    if (!P.dec_wg_pending) return MMVAE_OK;
+    P.dec_wg_pending = false;
+    CocoPlan::W& w = P.w;
+    const float* z = P.dec_wg_z;
+    const int R = P.dec_wg_groups * P.B, T = P.T, D = P.D, in0 = E + D, ino = H + D, TRn = T * R;
+    float* g = P.buf.grads;
     WgradParams list[5];
     auto wg = [&](int i, int gidx, const bf16* Pm, int N, int ldp, const bf16* Gm, int C) {
         GatherPlan pl = dense_plan(TRn, C, C, N);
@@ -544,19 +569,14 @@ static int coco_text_dec_bwd_bf16(CocoPlan& P, const float* z, int groups, const
     wg(4, P.tg_ho, w.tb_dout, E, CTB_EP, w.tb_h1 + RHP, CTB_HP);               // h1 AFTER each step: slices 1 .. T
     MMVAE_TRY(launch_wgrad_group(list, 5, sw, &P.slab));
     MMVAE_TRY(launch_wgrad_reduce(&P.slab, sw, true));
-    MMVAE_TRY(launch_colsum_bf16(w.tb_dgh0, CTB_GP, TRn, G, g + P.td0.bhh, sw));
-    MMVAE_TRY(launch_colsum_bf16(w.tb_dgi1, CTB_GP, TRn, G, g + P.td1.bih, sw));
-    MMVAE_TRY(launch_colsum_bf16(w.tb_dgh1, CTB_GP, TRn, G, g + P.td1.bhh, sw));
-    // ---- initial hidden state h = z2h(z), shared by both layers; time-invariant z terms (as in the fp32 path)
-    MMVAE_TRY(lin_dw(w.td_dhinit, H, z, D, R, g + P.td_z2h_w, H, D, D, 0, s));
-    MMVAE_TRY(launch_colsum_f32(w.td_dhinit, R, H, g + P.td_z2h_b, s));
-    MMVAE_TRY(lin_dx(w.td_dhinit, H, R, p + P.td_z2h_w, H, D, D, 0, dz, D, 0, s));
-    MMVAE_TRY(lin_dw(w.td_dzi0, G, z, D, R, g + P.td0.wih, G, D, in0, E, s));
-    MMVAE_TRY(launch_colsum_f32(w.td_dzi0, R, G, g + P.td0.bih, s));
-    MMVAE_TRY(lin_dx(w.td_dzi0, G, R, p + P.td0.wih, G, D, in0, E, dz, D, 1, s));
-    MMVAE_TRY(lin_dw(w.td_dwsum, E, z, D, R, g + P.td_h2o_w, E, D, ino, H, s));
-    MMVAE_TRY(launch_colsum_f32(w.td_dwsum, R, E, g + P.td_h2o_b, s));
-    return lin_dx(w.td_dwsum, E, R, p + P.td_h2o_w, E, D, ino, H, dz, D, 1, s);
+    // (b_hh0, b_ih1, b_hh1: column 200 of the three hidden-state operands is 1.0, their gradients are column 200 above)
+    // initial hidden state h = z2h(z), shared by both layers; time-invariant z terms (as in the fp32 path)
+    MMVAE_TRY(lin_dw(w.td_dhinit, H, z, D, R, g + P.td_z2h_w, H, D, D, 0, sw));
+    MMVAE_TRY(launch_colsum_f32(w.td_dhinit, R, H, g + P.td_z2h_b, sw));
+    MMVAE_TRY(lin_dw(w.td_dzi0, G, z, D, R, g + P.td0.wih, G, D, in0, E, sw));
+    MMVAE_TRY(launch_colsum_f32(w.td_dzi0, R, G, g + P.td0.bih, sw));
+    MMVAE_TRY(lin_dw(w.td_dwsum, E, z, D, R, g + P.td_h2o_w, E, D, ino, H, sw));
+    return launch_colsum_f32(w.td_dwsum, R, E, g + P.td_h2o_b, sw);
 }
 
 int coco_text_dec_bwd(CocoPlan& P, const float* z, int groups, const float* sos, const uint8_t* keep, const float* sentence, float* dw,

@@ -150,6 +150,8 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_kernel(const CocoDecFwdArgs
             a.h0b_all[(size_t)(r0 + row) * HP + j] = (bf16)v; a.h1b_all[(size_t)(r0 + row) * HP + j] = (bf16)v;
         }
     }
+    // column H of the saved hidden-state operands is 1.0: the batched weight gradients then carry the bias gradients in it
+    if (SAVE && c0 == 0 && gok) { a.h0b_all[gr * HP + H] = (bf16)1.f; a.h1b_all[gr * HP + H] = (bf16)1.f; }
     for (int i = tid; i < TR * E; i += NTHR) {
         const int row = i / E, e = i - row * E;
         const bf16 v = (bf16)a.sos[e];
@@ -204,6 +206,11 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_kernel(const CocoDecFwdArgs
                     a.midb_all[((size_t)t * R + gr) * HP + j] = (bf16)mid;
                 }
             }
+        }
+        if (SAVE && c0 == 0 && gok) {
+            a.h0b_all[((size_t)(t + 1) * R + gr) * HP + H] = (bf16)1.f;
+            a.midb_all[((size_t)t * R + gr) * HP + H] = (bf16)1.f;
+            a.h1b_all[((size_t)(t + 1) * R + gr) * HP + H] = (bf16)1.f;
         }
         __syncthreads();
         // ---- layer 1
@@ -443,6 +450,12 @@ __global__ __launch_bounds__(NTHR) void coco_enc_fwd_kernel(const CocoEncFwdArgs
     for (int i = tid; i < TR * H; i += NTHR) hf[i] = 0.f;
     for (int i = tid; i < TR * LDH; i += NTHR) hb[i] = (bf16)0.f;
     for (int i = tid; i < G; i += NTHR) bias[i] = a.bhh[i];
+    if (SAVE && gok) {          // slice 0 of the saved operand: h before the first step (zeros) + the 1.0 column of the bias gradient
+#pragma unroll
+        for (int q = 0; q < NQH; ++q)
+            if (c0 + 32 * q < H) a.hb_all[gr * HP + c0 + 32 * q] = (bf16)0.f;
+        if (c0 == 0) a.hb_all[gr * HP + H] = (bf16)1.f;
+    }
     // chunk schedule of a step (ring depth 3): hh 5 tile slots + 1 dummy = 6 chunks
     constexpr int D = 3;
     const WMat<HP / 32, GP / 16> d_hh(a.w_hh);
@@ -473,12 +486,13 @@ __global__ __launch_bounds__(NTHR) void coco_enc_fwd_kernel(const CocoEncFwdArgs
                 const float hn = (1.0f - z) * n + z * hf[i];
                 hf[i] = hn;
                 hb[grow * LDH + j] = (bf16)hn;
+                if (SAVE && q == 0 && c0 == 0 && gok && t + 1 < T) a.hb_all[((size_t)(t + 1) * R + gr) * HP + H] = (bf16)1.f;
                 if (gok) {
                     a.h_all[(size_t)t * RH + gr * H + j] = hn;
                     if (SAVE) {
                         float* s = a.sav + ((size_t)t * R + gr) * 4 * H;
                         s[j] = r; s[H + j] = z; s[2 * H + j] = n; s[3 * H + j] = ghn;
-                        a.hb_all[((size_t)t * R + gr) * HP + j] = (bf16)hn;
+                        if (t + 1 < T) a.hb_all[((size_t)(t + 1) * R + gr) * HP + j] = (bf16)hn;
                     }
                 }
             }
@@ -566,6 +580,7 @@ __global__ __launch_bounds__(256) void text_tb_kernel(const float* src, int B, i
     const long long bt = i / E;
     const int t = (int)(bt % T), b = (int)(bt / T);
     dst[((size_t)t * B + b) * ld + e] = (bf16)src[i];
+    if (e == 0) dst[((size_t)t * B + b) * ld + E] = (bf16)1.f;          // 1.0 column: the bias gradient rides in the weight gradient
 }
 
 // out[r][c] = sum_t in[(t*R + r)*ld + c]

@@ -831,6 +831,43 @@ __global__ __launch_bounds__(TPB) void colsum_kernel_t(const T* x, int ld, int r
     }
 }
 
+// bf16 rows of ld (multiple of 8) elements: a thread owns one 8-column vector (16-byte loads) of every RL-th row
+__global__ __launch_bounds__(TPB) void colsum_bf16_kernel(const bf16* x, int ld, int rows, int cols, float* out) {
+    __shared__ float part[TPB][8];
+    const int vpr = ld >> 3, RL = TPB / vpr;
+    const int rl = threadIdx.x / vpr, v = threadIdx.x - rl * vpr;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (rl < RL) {
+        const long long step = (long long)gridDim.x * RL;
+        long long r = (long long)blockIdx.x * RL + rl;
+        for (; r + 3 * step < rows; r += 4 * step) {        // four rows in flight per thread
+            bf16x8 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[u] = *reinterpret_cast<const bf16x8*>(x + (size_t)(r + u * step) * ld + v * 8);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += (float)q[u][j];
+        }
+        for (; r < rows; r += step) {
+            const bf16x8 q = *reinterpret_cast<const bf16x8*>(x + (size_t)r * ld + v * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += (float)q[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) part[threadIdx.x][j] = acc[j];
+    __syncthreads();
+    if (threadIdx.x < vpr) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float t = 0.f;
+            for (int w = 0; w < RL; ++w) t += part[w * vpr + threadIdx.x][j];
+            if (threadIdx.x * 8 + j < cols) atomicAdd(out + threadIdx.x * 8 + j, t);
+        }
+    }
+}
+
 }  // namespace
 
 int launch_mse_fwd(const float* a, const float* b, long long n, float* out, hipStream_t s) {
@@ -1019,6 +1056,11 @@ int launch_colsum_f32(const float* x, int rows, int cols, float* out, hipStream_
     return mmvae_check_launch("colsum_f32");
 }
 int launch_colsum_bf16(const bf16* x, int ld, int rows, int cols, float* out, hipStream_t s) {
+    if (ld % 8 == 0 && ld / 8 <= TPB && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        const int RL = TPB / (ld / 8);
+        hipLaunchKernelGGL(colsum_bf16_kernel, dim3(max(1, min(256, ceil_div(rows, RL * 8)))), dim3(TPB), 0, s, x, ld, rows, cols, out);
+        return mmvae_check_launch("colsum_bf16");
+    }
     hipLaunchKernelGGL(colsum_kernel_t<bf16>, dim3(ceil_div(cols, 64), min(64, ceil_div(rows, 16))), dim3(TPB), 0, s, x, ld, rows, cols, out);
     return mmvae_check_launch("colsum_bf16");
 }
