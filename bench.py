@@ -164,11 +164,16 @@ def roofline_entry(eng, call, layer, kernel, B, D):
     us = time_layer(eng, call, lb)
     algo = call("mmvae_mm_layer_algo_flops", eng.h, lb)
     executed = call("mmvae_mm_layer_flops", eng.h, lb)
+    algo_bytes = call("mmvae_mm_layer_algo_bytes", eng.h, lb)
     traffic, src = measured_traffic("%s:%d:%d" % (layer, B, D))
     ach = algo / (us * 1e-6) / 1e12
-    return {"kernel": "%s (%s)" % (kernel, layer), "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / PEAK_BF16_TFLOPS, "us_per_launch": us, "flops_per_launch": algo, "executed_flops_per_launch": executed,
-            "traffic": traffic, "traffic_source": src}
+    e = {"kernel": "%s (%s)" % (kernel, layer), "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+         "frac": ach / PEAK_BF16_TFLOPS, "us_per_launch": us, "flops_per_launch": algo, "executed_flops_per_launch": executed,
+         "algorithmic_bytes_per_launch": algo_bytes, "hbm_frac_algorithmic": algo_bytes / (us * 1e-6) / (PEAK_HBM_GBS * 1e9),
+         "traffic": traffic, "traffic_source": src}
+    if traffic:
+        e["hbm_frac_measured"] = traffic / (us * 1e-6) / (PEAK_HBM_GBS * 1e9)
+    return e
 
 
 def main():
@@ -301,9 +306,12 @@ def main():
 
     if rank == 0:
         if wl == "multimnist":
-            # ---- roofline: dominant kernel family by GPU time (weight gradients) and the largest forward GEMM
-            result["roofline"] = roofline_entry(eng, call, "dec_convT3_wgrad", "wgrad_kernel + wgrad_reduce_kernel", B, D)
-            result["roofline_gemm"] = roofline_entry(eng, call, "dec_convT3", "gemm kernel", B, D)
+            # ---- roofline: the gather-GEMM family holds the most GPU time of the step (profiles/r02_*kernel_stats.csv), its
+            # longest launch is the forward of the last 64->32 ConvTranspose2d; next to it the weight gradient of that layer
+            # (round 1's dominant kernel) and its data gradient
+            result["roofline"] = roofline_entry(eng, call, "dec_convT3", "gemm_gather_kernel<2>", B, D)
+            result["roofline_wgrad"] = roofline_entry(eng, call, "dec_convT3_wgrad", "wgrad_kernel + wgrad_reduce_kernel", B, D)
+            result["roofline_dgrad"] = roofline_entry(eng, call, "dec_convT3_dgrad", "gemm_gather_kernel<4>", B, D)
         else:
             # no per-layer replay hook for this family: the whole step against the MFMA roof on the executed GEMM FLOPs
             ms = result["ms_per_step"]

@@ -117,6 +117,7 @@ int mmvae_mm_text_decoder_bwd(mmvae_mm_t*, void* ws, size_t ws_bytes, const floa
 int mmvae_mm_bench_layer(mmvae_mm_t*, void* ws, size_t ws_bytes, const char* layer, int iters, void* stream);
 double mmvae_mm_layer_flops(const mmvae_mm_t*, const char* layer);        /* executed: 2*rows*N*K, zero-padded taps included */
 double mmvae_mm_layer_algo_flops(const mmvae_mm_t*, const char* layer);   /* algorithmic: the FlopCounterMode count of the reference layer */
+double mmvae_mm_layer_algo_bytes(const mmvae_mm_t*, const char* layer);   /* algorithmic: each operand read once, the result written once (0: not a conv layer) */
 /* measurement aid: GEMM FLOPs enqueued by this process since the last reset (counted on the host by the launchers) */
 double mmvae_debug_flops(int reset);
 /* test aid: byte offset of a named intermediate inside the workspace (-1 if unknown) */

@@ -119,6 +119,7 @@ SIGNATURES = {
     "mmvae_mm_bench_layer": (_I, [_P, _P, _SZ, C.c_char_p, _I, _P]),
     "mmvae_mm_layer_flops": (C.c_double, [_P, C.c_char_p]),
     "mmvae_mm_layer_algo_flops": (C.c_double, [_P, C.c_char_p]),
+    "mmvae_mm_layer_algo_bytes": (C.c_double, [_P, C.c_char_p]),
     "mmvae_debug_flops": (C.c_double, [_I]),
     "mmvae_mm_debug_offset": (_LL, [_P, C.c_char_p]),
     "mmvae_poe_fwd": (_I, [_P, _P, _I, _I, _P, _P, _P]),

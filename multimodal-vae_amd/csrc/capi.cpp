@@ -247,6 +247,7 @@ int mmvae_mm_bench_layer(mmvae_mm_t* p, void* ws, size_t wsb, const char* layer,
 }
 double mmvae_mm_layer_flops(const mmvae_mm_t* p, const char* layer) { return mm_layer_flops(p, layer); }
 double mmvae_mm_layer_algo_flops(const mmvae_mm_t* p, const char* layer) { return mm_layer_algo_flops(p, layer); }
+double mmvae_mm_layer_algo_bytes(const mmvae_mm_t* p, const char* layer) { return mm_layer_algo_bytes(p, layer); }
 long long mmvae_mm_debug_offset(mmvae_mm_t* p, const char* name) { return mm_debug_offset(p, name); }
 
 // ---- MNIST (mnist/model.py, mnist/train.py)

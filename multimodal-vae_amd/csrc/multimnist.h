@@ -70,6 +70,7 @@ int mm_unpack_grads(MMPlan*, hipStream_t);
 int mm_bench_layer(MMPlan*, void* ws, size_t wsb, const char* layer, int iters, hipStream_t);
 double mm_layer_flops(const MMPlan*, const char* layer);
 double mm_layer_algo_flops(const MMPlan*, const char* layer);
+double mm_layer_algo_bytes(const MMPlan*, const char* layer);
 int mm_num_bn(const MMPlan*);
 int mm_bn_info(const MMPlan*, int i, std::string& prefix, int& C, long long& offset);
 long long mm_bn_floats(const MMPlan*);

@@ -1085,6 +1085,28 @@ double mm_layer_algo_flops(const MMPlan* Pc, const char* layer) {
     if (name == "dec_last_wgrad" || name == "dec_last_dgrad_gemm") return conv(P.convT[3], 2 * B);
     return mm_layer_flops(Pc, layer);          // dense layers: no padding in the count
 }
+// Algorithmic bytes of one conv-shaped layer launch: every operand tensor read once and the result written once (bf16
+// activations / gradients, bf16 packed weights; the weight gradient is fp32).  What the launch would move with perfect
+// reuse -- the PMC traffic of the same launch (profiles/r02_traffic.json) is compared against it.  0: not a conv layer.
+double mm_layer_algo_bytes(const MMPlan* Pc, const char* layer) {
+    const MMPlan& P = *Pc;
+    const std::string name = layer;
+    const int B = P.B;
+    auto conv = [&](const ConvL& L, int images, bool wgrad) {
+        const ConvGeom& g = L.g;
+        const double act = (double)images * ((double)g.IH * g.IW * g.Cin + (double)g.OH * g.OW * g.Cout) * 2.0;
+        return act + (double)g.Cin * g.Cout * g.KH * g.KW * (wgrad ? 4.0 : 2.0);
+    };
+    for (int l = 0; l < 4; ++l) {
+        const std::string e = "enc_conv" + std::to_string(l + 1), d = "dec_convT" + std::to_string(l + 1);
+        if (name == e || name == e + "_dgrad") return conv(P.conv[l], B, false);
+        if (name == e + "_wgrad") return conv(P.conv[l], B, true);
+        if (name == d) return conv(P.convT[l], 3 * B, false);
+        if (name == d + "_dgrad") return conv(P.convT[l], 2 * B, false);
+        if (name == d + "_wgrad") return conv(P.convT[l], 2 * B, true);
+    }
+    return 0.0;
+}
 int mm_num_bn(const MMPlan*) { return 6; }
 int mm_bn_info(const MMPlan* P, int i, std::string& prefix, int& C, long long& offset) {
     if (i < 0 || i >= 6) return MMVAE_EINVAL;
