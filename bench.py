@@ -232,7 +232,7 @@ def main():
         eng = core.FusedCocoStep(state, B, R.formula_sos(), seed=seed, world_size=world, all_reduce=all_reduce)
         metric = "ELBO-steps/sec (whole node), COCO 32x32 + 102-step captions b=%d per GPU" % B
         workload = "coco_32x32_conv_mmvae_glove_caption_gru_3pass_elbo_step"
-        dtype = "bf16 (image half) + f32 (caption GRUs)"
+        dtype = "bf16 (MFMA operands of the image half and of the caption GRUs; f32 accumulation, gate math, state; MMVAE_COCO_TEXT_FP32=1: f32 caption GRUs)"
     dp.broadcast_flat(state.params)
     dp.broadcast_flat(state.bn_stats)
     a_d, b_d = a.to(dev).contiguous(), b.to(dev).contiguous()
