@@ -14,9 +14,10 @@ The JSON line carries, next to the contract fields:
                    included; counted by the launchers), and step_mfma_frac_executed on that count
   step_hbm_frac    algorithmic bytes per step (0.59 GB at B=256) x steps/s / 8 TB/s
   roofline         the kernel family with the largest GPU-time share of the step (rocprofv3 --kernel-trace --stats of this
-                   command: profiles/r02_bench_kernel_stats.csv) -- the weight-gradient kernel -- on its largest launch
-                   (dec_convT3): ALGORITHMIC FLOPs / average launch time measured live with HIP events
-  roofline_gemm    the largest forward GEMM (dec_convT3), same definition
+                   command: profiles/r02_multimnist_kernel_stats.csv) -- the gather GEMM -- on its longest launch, the forward
+                   of dec_convT3: ALGORITHMIC FLOPs / average launch time measured live with HIP events; executed FLOPs,
+                   algorithmic bytes and the PMC-measured HBM-side traffic of the same launch (profiles/r02_traffic.json) beside it
+  roofline_wgrad / roofline_dgrad   the weight- and data-gradient launches of the same layer, same definition
 """
 import argparse
 import json
@@ -25,6 +26,10 @@ import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # read by ROCr at hsa_init: before ANY GPU call (dp.ensure_ipc_env)
+# The step uses up to 4 streams and an RCCL process group brings its own: past the runtime's default of 4 hardware queues
+# the streams are time-sliced onto shared queues and EVERY kernel slows down (measured with a world-1 RCCL group:
+# 0.90 -> 1.20 ms per step; with 8 queues 0.90 -> 0.91).  Read when the HIP runtime initialises: before any GPU call.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
 import torch
@@ -62,6 +67,11 @@ def synthetic_batch_for(workload, B, seed):
                 torch.from_numpy((rng.random((B, 18)) < 0.3).astype(np.float32)))
     return (torch.from_numpy(rng.random((B, 3, 32, 32), dtype=np.float32)),
             torch.from_numpy((0.4 * rng.standard_normal((B, 102, 300))).astype(np.float32)))
+
+
+def synthetic_sos():
+    """Stand-in for the GloVe vector of '<s>' (coco/train.py feeds it as the first decoder input): fixed synthetic data."""
+    return torch.from_numpy((0.4 * np.random.default_rng(4242).standard_normal(300)).astype(np.float32))
 
 
 def measured_traffic(kernel_key):
@@ -111,7 +121,7 @@ def cpu_baseline(workload, B, D, a, b, budget_s=20.0):
     plist = [P[n] for n in names]
     m = [torch.zeros_like(p) for p in plist]
     v = [torch.zeros_like(p) for p in plist]
-    sos = R.formula_sos() if workload == "coco" else None
+    sos = synthetic_sos() if workload == "coco" else None
 
     def step_losses():
         if workload == "multimnist":
@@ -206,7 +216,12 @@ def main():
     all_reduce = None
     if world > 1:
         dp.init_distributed("nccl", dev)                   # backend "nccl" IS RCCL on ROCm
-        all_reduce = dp.GradAllReduce()                     # SUM all-reduce of the flat gradient, 1/world folded into Adam
+        # SUM all-reduce of the flat gradient, 1/world folded into Adam.  MMVAE_DP_OVERLAP=1 (MultiMNIST): the decoders'
+        # gradient ranges go out while the encoders' backward still runs (core.FusedELBOStep._call_dp_overlap).  Not the
+        # default: measured on one GPU with a world-1 RCCL group the extra communication stream (parked on the early-gradient
+        # event) lands on a hardware queue shared with the step's streams and stalls them (0.91 -> 2.2 ms per step), and even
+        # without that the split costs 0.05 ms against the ~0.06 ms of a 9.4 MB exchange it can hide
+        all_reduce = dp.GradAllReduce(overlap=os.environ.get("MMVAE_DP_OVERLAP") == "1")
 
     B, D = args.batch or DEFAULT_BATCH[wl], args.n_latents
     seed = dp.rank_seed(1234, rank)
@@ -228,8 +243,7 @@ def main():
     else:
         state = core.CocoState(D, dev)
         default_init_(state, seed=1234)
-        from oracle import mmvae_ref as R                  # (formula_sos only: the stand-in GloVe('<s>') vector of the fixtures)
-        eng = core.FusedCocoStep(state, B, R.formula_sos(), seed=seed, world_size=world, all_reduce=all_reduce)
+        eng = core.FusedCocoStep(state, B, synthetic_sos(), seed=seed, world_size=world, all_reduce=all_reduce)
         metric = "ELBO-steps/sec (whole node), COCO 32x32 + 102-step captions b=%d per GPU" % B
         workload = "coco_32x32_conv_mmvae_glove_caption_gru_3pass_elbo_step"
         dtype = "bf16 (MFMA operands of the image half and of the caption GRUs; f32 accumulation, gate math, state; MMVAE_COCO_TEXT_FP32=1: f32 caption GRUs)"

@@ -91,8 +91,15 @@ typedef struct {
     int pack_first;                         /* 1: the step's prologue launch also refreshes the packed bf16 weights from the
                                              * parameters (what mmvae_mm_pack_weights does): set it after an optimizer step
                                              * instead of calling mmvae_mm_pack_weights -- one launch less on the step's chain */
+    int dp_split;                           /* 1 (data-parallel replica): the gradients of image_decoder.* and text_decoder.* are
+                                             * complete in `grads` before the encoders' backward has run -- order a communication
+                                             * stream behind them with mmvae_mm_wait_early_grads and all-reduce those two parameter
+                                             * ranges while the rest of the step runs; the other ranges are complete when the step is */
 } mmvae_mm_step_io;
 int mmvae_mm_step(mmvae_mm_t*, const mmvae_mm_step_io*, int training, int do_backward, void* stream);
+/* `stream` waits (hipStreamWaitEvent) for the early gradient part of the most recent dp_split step of this plan.
+ * The collective itself stays with the host framework (torch.distributed over RCCL): INTEGRATION.md, Data parallelism. */
+int mmvae_mm_wait_early_grads(mmvae_mm_t*, void* stream);
 
 /* Granular modules (drop-in for ImageEncoder/ImageDecoder/TextEncoder/TextDecoder.forward + autograd backward).
  * Every forward keeps its saved activations in the workspace passed to it; pass the same one to the backward. */

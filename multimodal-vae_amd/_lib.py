@@ -28,6 +28,7 @@ class StepIO(C.Structure):
         ("pass_skip", C.c_int * 3),
         ("defer_unpack", C.c_int),
         ("pack_first", C.c_int),
+        ("dp_split", C.c_int),
     ]
 
 
@@ -108,6 +109,7 @@ SIGNATURES = {
     "mmvae_mm_pack_weights": (_I, [_P, _P]),
     "mmvae_mm_grad_map": (_I, [_P, _P, _P]),
     "mmvae_mm_step": (_I, [_P, C.POINTER(StepIO), _I, _I, _P]),
+    "mmvae_mm_wait_early_grads": (_I, [_P, _P]),
     "mmvae_mm_image_encoder_fwd": (_I, [_P, _P, _SZ, _P, _P, _P, _I, _P, _P]),
     "mmvae_mm_image_encoder_bwd": (_I, [_P, _P, _SZ, _P, _P, _P, _P]),
     "mmvae_mm_image_decoder_fwd": (_I, [_P, _P, _SZ, _P, _I, _P, _P]),

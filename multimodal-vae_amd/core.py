@@ -336,7 +336,7 @@ class FusedELBOStep(_FusedStepBase):
 
     def forward_backward(self, image, text, training=True, backward=True, eps=None, enc_mask1=None, enc_mask2=None,
                          gru_keep=None, force_tokens=None, recon_image=None, recon_text=None, mu=None, logvar=None,
-                         tokens=None, passes=None, lambda_xy=None, lambda_yx=None, _defer_unpack=False) -> StepOutputs:
+                         tokens=None, passes=None, lambda_xy=None, lambda_yx=None, _defer_unpack=False, _dp_split=False) -> StepOutputs:
         """``passes`` = which of (joint, image-only, text-only) exist in this step and ``lambda_xy/lambda_yx`` = their loss
         weights: the weak-supervision steps of multimnist/paired_weak.py:84-117 and modal_weak.py:87-117."""
         assert image.is_contiguous() and text.is_contiguous() and image.dtype == torch.float32 and text.dtype == torch.int64
@@ -356,12 +356,72 @@ class FusedELBOStep(_FusedStepBase):
         io.sums = self.sums.data_ptr()
         io.defer_unpack = int(bool(_defer_unpack))
         io.pack_first = int(self.state.pack_pending)
+        io.dp_split = int(bool(_dp_split))
         # optimizer.zero_grad() (train.py:150) happens inside the step's prologue kernel when backward is requested
         call("mmvae_mm_step", self.h, C.byref(io), int(training), int(backward), _stream())
         self.state.pack_pending = False
         return self._outputs()
 
+    # -- data parallelism: the decoders' gradients are exchanged while the encoders' backward still runs -------------
+    EARLY_PREFIXES = ("image_decoder.", "text_decoder.")     # what mmvae_mm_step_io.dp_split completes early
+
+    def grad_ranges(self):
+        """(early, late): lists of (offset, length) runs of the flat gradient buffer, early = complete at the event of
+        ``mmvae_mm_wait_early_grads``.  Adjacent parameters of the same kind are merged: a few large messages."""
+        runs = ([], [])
+        end = 0
+        for i, (name, shape, off) in enumerate(self.state.table):
+            n = 1
+            for d in shape:
+                n *= int(d)
+            kind = 0 if name.startswith(self.EARLY_PREFIXES) else 1
+            r = runs[kind]
+            if r and r[-1][0] + r[-1][1] == off and getattr(self, "_last_kind", None) == kind:
+                r[-1] = (r[-1][0], r[-1][1] + n)
+            else:
+                r.append((off, n))
+            self._last_kind = kind
+            end = max(end, off + n)
+        assert end == self.state.nparams
+        return runs
+
+    def _call_dp_overlap(self, image, text, **kw) -> StepOutputs:
+        """One data-parallel step with the gradient exchange in two parts: the early ranges are all-reduced on a
+        communication stream ordered behind the step's early-gradient event (they overlap latent/encoder backward and the
+        encoders' weight gradients), the late ranges after the step; Adam (1/world folded in) waits for both.
+
+        Opt-in (``GradAllReduce(overlap=True)``), correct (tests/test_gpu_configs_r2.py) but NOT faster on this runtime: a
+        stream parked on an event occupies its hardware queue, and when the runtime maps the communication stream onto a
+        queue shared with one of the step's streams the step stalls behind it (0.91 -> 2.2 ms measured with a world-1 RCCL
+        group, GPU_MAX_HW_QUEUES=8).  The plain exchange after the step is the default."""
+        st = self.state
+        if getattr(self, "_ranges", None) is None:
+            self._ranges = self.grad_ranges()
+            self._comm = torch.cuda.Stream(device=st.device)
+        early, late = self._ranges
+        out = self.forward_backward(image, text, True, True, _dp_split=True, **kw)
+        # async collectives: the library's stream is ordered behind the stream that is current at the call (the
+        # communication stream, whose only content is the wait for the early-gradient event, for the early ranges; the main
+        # stream for the late ones) and Work.wait() orders the main stream behind the results.  NOT main.wait_stream(comm):
+        # an event recorded on a stream that holds nothing but a pending wait costs ~1.3 ms per step on this runtime.
+        works = []
+        call("mmvae_mm_wait_early_grads", self.h, C.c_void_p(self._comm.cuda_stream))
+        with torch.cuda.stream(self._comm):
+            for off, n in early:
+                works.append(self.all_reduce(st.grads[off:off + n], async_op=True))
+        for off, n in late:
+            works.append(self.all_reduce(st.grads[off:off + n], async_op=True))
+        for w in works:
+            if w is not None:
+                w.wait()
+        call("mmvae_adam_step", ptr(st.params), ptr(st.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq), st.nparams,
+             ptr(self.adam_state), self.lr, self.betas[0], self.betas[1], self.eps, 1.0 / self.world_size, _stream())
+        self._after_update()
+        return out
+
     def __call__(self, image, text, **kw) -> StepOutputs:
+        if self._dp_active() and getattr(self.all_reduce, "overlap", False) and not _os.environ.get("MMVAE_DP_NO_OVERLAP"):
+            return self._call_dp_overlap(image, text, **kw)
         return self._call_packed(image, text, **kw)
 
 

@@ -180,6 +180,11 @@ int mmvae_mm_pack_weights(mmvae_mm_t* p, void* stream) {
     return mm_pack_weights(p, S(stream));
     API_GUARD_END
 }
+int mmvae_mm_wait_early_grads(mmvae_mm_t* p, void* stream) {
+    API_GUARD_BEGIN
+    return mm_wait_early_grads(p, S(stream));
+    API_GUARD_END
+}
 int mmvae_mm_step(mmvae_mm_t* p, const mmvae_mm_step_io* io, int training, int do_backward, void* stream) {
     API_GUARD_BEGIN
     MMVAE_REQUIRE(p && io, "mmvae_mm_step: null argument");
@@ -194,6 +199,7 @@ int mmvae_mm_step(mmvae_mm_t* p, const mmvae_mm_step_io* io, int training, int d
     for (int k = 0; k < 3; ++k) s.pass_skip[k] = io->pass_skip[k];
     s.defer_unpack = io->defer_unpack;
     s.pack_first = io->pack_first;
+    s.dp_split = io->dp_split;
     return mm_step_fwd_bwd(p, s, training, do_backward, S(stream));
     API_GUARD_END
 }

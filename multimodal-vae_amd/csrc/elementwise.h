@@ -17,6 +17,7 @@ struct PackDesc {
     long long bias_off;     // >= 0: column K of every row holds a bias folded into the GEMM (operand column K == 1.0)
     int b_nhi, b_nlo;       // source strides of that bias vector
     int first_block;        // prefix sum of 256-thread blocks over the table
+    int part;               // gradient descriptors: 1 = complete early in the step (decoders), 0 = with the encoders' backward
     int frag;               // 1: MFMA-fragment-major destination -- 16-row tile nt, 32-column k-step ks: the 64 lanes' 8-element
                             // vectors (lane = 16*(k/8 % 4) + n % 16) are one contiguous 1 KB block at ((nt*(Kpad/32) + ks)*64 + lane)*8
 };
@@ -24,8 +25,10 @@ struct PackDesc {
 int launch_pack(const PackDesc* table_dev, const PackDesc* table_host, int ndesc, const float* params,
                 bf16* packed_bf, float* packed_f32, hipStream_t s);
 // grads_flat[src] += packed_grad[dst]  (inverse of the matrix packing, fp32 -> fp32)
+// part >= 0: only the descriptors with PackDesc::part == part (the data-parallel step hands the early part to the collective
+// while the rest of the backward pass runs)
 int launch_unpack_grads(const PackDesc* table_dev, const PackDesc* table_host, int ndesc, const float* gpk_mat,
-                        const float* gpk_vec, float* grads_flat, hipStream_t s);
+                        const float* gpk_vec, float* grads_flat, hipStream_t s, int part = -1);
 
 int launch_im2col_small(const float* src, int Nimg, int Cin, int H, int W, int KH, int KW, int stride, int pad,
                         int OH, int OW, bf16* dst, int ld, hipStream_t s);

@@ -94,9 +94,11 @@ __global__ __launch_bounds__(TPB) void pack_kernel(const PackDesc* __restrict__ 
 
 template <bool MAP>
 __global__ __launch_bounds__(TPB) void unpack_kernel(const PackDesc* __restrict__ table, int nd, const float* __restrict__ gmat,
-                                                     const float* __restrict__ gvec, float* __restrict__ grads, int* __restrict__ map) {
+                                                     const float* __restrict__ gvec, float* __restrict__ grads, int* __restrict__ map,
+                                                     int part) {
     const int di = find_desc(table, nd, blockIdx.x);
     const PackDesc d = table[di];
+    if (part >= 0 && d.part != part) return;
     const int v = (int)(blockIdx.x - d.first_block) * TPB + threadIdx.x;
     const int vpr = d.Kpad / 8;
     if (v >= d.N * vpr) return;
@@ -893,11 +895,11 @@ int launch_pack(const PackDesc* table_dev, const PackDesc* table_host, int nd, c
     return mmvae_check_launch("pack");
 }
 int launch_unpack_grads(const PackDesc* table_dev, const PackDesc* table_host, int nd, const float* gmat, const float* gvec,
-                        float* grads, hipStream_t s) {
+                        float* grads, hipStream_t s, int part) {
     MMVAE_REQUIRE(nd > 0, "unpack: empty table");
     for (int i = 0; i < nd; ++i)
         MMVAE_REQUIRE((long long)table_host[i].Npad * (table_host[i].Kpad / 8) < (1 << 23), "unpack: matrix %d too large for 32-bit index math", i);
-    hipLaunchKernelGGL(unpack_kernel<false>, dim3(table_blocks(table_host, nd)), dim3(TPB), 0, s, table_dev, nd, gmat, gvec, grads, (int*)nullptr);
+    hipLaunchKernelGGL(unpack_kernel<false>, dim3(table_blocks(table_host, nd)), dim3(TPB), 0, s, table_dev, nd, gmat, gvec, grads, (int*)nullptr, part);
     return mmvae_check_launch("unpack_grads");
 }
 int launch_unpack_map(const PackDesc* table_dev, const PackDesc* table_host, int nd, long long nparams, long long gmat_elems, int* map, hipStream_t s) {
@@ -905,7 +907,7 @@ int launch_unpack_map(const PackDesc* table_dev, const PackDesc* table_host, int
     MMVAE_REQUIRE(gmat_elems < (1ll << 31) - 2, "unpack_map: packed gradient buffer too large for 32-bit indices");
     if (hipMemsetAsync(map, 0xFF, (size_t)nparams * sizeof(int), s) != hipSuccess) { mmvae_set_error("hipMemsetAsync failed"); return MMVAE_EHIP; }
     hipLaunchKernelGGL(unpack_kernel<true>, dim3(table_blocks(table_host, nd)), dim3(TPB), 0, s, table_dev, nd, (const float*)nullptr,
-                       (const float*)nullptr, (float*)nullptr, map);
+                       (const float*)nullptr, (float*)nullptr, map, -1);
     return mmvae_check_launch("unpack_map");
 }
 int launch_im2col_small(const float* src, int Nimg, int Cin, int H, int W, int KH, int KW, int stride, int pad, int OH, int OW,

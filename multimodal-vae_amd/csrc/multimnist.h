@@ -32,6 +32,9 @@ struct MMStepIO {
     int pack_first = 0;                 // 1: the prologue launch also refreshes the packed bf16 weights (after an optimizer step)
     int defer_unpack = 0;               // 1: leave the GEMM-weight gradients in their packed buffers (the optimizer kernel
                                         // gathers them through mm_grad_map and completes the flat gradient itself)
+    int dp_split = 0;                   // 1 (data-parallel step): the decoders' gradients (image_decoder.*, text_decoder.*) are
+                                        // unpacked into the flat buffer as soon as they are complete -- mm_wait_early_grads --
+                                        // so that their all-reduce overlaps the encoders' backward; the rest at the end as usual
 };
 
 struct MMPlan;
@@ -67,6 +70,8 @@ int mm_text_decoder_fwd(MMPlan*, void* ws, size_t wsb, const float* z, int train
 int mm_text_decoder_bwd(MMPlan*, void* ws, size_t wsb, const float* z, const uint8_t* keep, const long long* force_tokens,
                         const float* words, const long long* tokens, const float* d_words, float* dz, hipStream_t);
 int mm_unpack_grads(MMPlan*, hipStream_t);
+// makes `s` wait until the early gradient part of the last dp_split step is complete in the flat gradient buffer
+int mm_wait_early_grads(MMPlan*, hipStream_t s);
 int mm_bench_layer(MMPlan*, void* ws, size_t wsb, const char* layer, int iters, hipStream_t);
 double mm_layer_flops(const MMPlan*, const char* layer);
 double mm_layer_algo_flops(const MMPlan*, const char* layer);

@@ -166,6 +166,12 @@ void build_plan(MMPlan& P) {
         const long long w = off(P, "text_decoder.h2o.weight");
         P.td_h2o = rt(w, 12, 100 + D, false); P.td_h2oT = rt(w, 12, 100 + D, true); P.g_td_h2o = gw(w, 12, 100 + D, P.kx);
     }
+    // gradient descriptors of the decoders (image_decoder.*, text_decoder.*): complete before the encoders' backward has run
+    // (MMStepIO::dp_split scatters them into the flat gradient buffer early)
+    for (PackDesc& d : P.gk.d)
+        for (const ParamInfo& pi : P.params)
+            if (d.src_off >= pi.offset && d.src_off < pi.offset + pi.numel)
+                d.part = pi.name.rfind("image_decoder.", 0) == 0 || pi.name.rfind("text_decoder.", 0) == 0;
 }
 
 // ------------------------------------------------------------------ workspace
@@ -779,6 +785,22 @@ static int mm_step_body(MMPlan* Pp, const MMStepIO& io, int training, int do_bac
     P.defer_wgrad = defer && !serial;
     if (img_groups > 0) rc = dec_bwd(P, w.dlogit, img_groups, w.dz_img, s, fuse_tail);
     if (rc == MMVAE_OK) rc = edge(P, T, s);          // dz of the text decoder
+    const bool dp_split = io.dp_split && !io.defer_unpack;
+    if (dp_split && rc == MMVAE_OK) {
+        // Data-parallel step: every gradient of image_decoder.* and text_decoder.* has been issued -- on s (which has just
+        // joined T) and on the weight-gradient streams.  T is idle until the text encoder's backward: it waits for those
+        // streams, scatters the early descriptors into the flat gradient buffer and marks the event the collective waits on.
+        rc = edge(P, s, T);
+        if (rc == MMVAE_OK && P.st_wgrad != T) rc = edge(P, P.st_wgrad, T);
+        if (rc == MMVAE_OK && P.st_wgrad2 != P.st_wgrad && P.st_wgrad2 != T) rc = edge(P, P.st_wgrad2, T);
+        if (rc == MMVAE_OK) rc = launch_wgrad_reduce(&P.slab, T);
+        if (rc == MMVAE_OK)
+            rc = launch_unpack_grads(P.buf.gdesc_dev, P.gk.d.data(), (int)P.gk.d.size(), P.buf.gpk, P.buf.gpk_vec, P.buf.grads, T, 1);
+        if (rc == MMVAE_OK) {
+            if (!P.ev_early) hipEventCreateWithFlags(&P.ev_early, hipEventDisableTiming);
+            if (hipEventRecord(P.ev_early, T) != hipSuccess) { mmvae_set_error("early-gradient event failed"); rc = MMVAE_EHIP; }
+        }
+    }
     Latent3BwdArgs lb{};
     lb.f = la; lb.dz_a = w.dz_img; lb.dz_b = w.dz_txt;
     for (int k = 0; k < 3; ++k) lb.kl_coef[k] = sk[k] ? 0.f : io.kl_lambda / (float)B;
@@ -795,7 +817,16 @@ static int mm_step_body(MMPlan* Pp, const MMStepIO& io, int training, int do_bac
     MMVAE_TRY(edge(P, P.st_wgrad, s));
     if (P.st_wgrad2 != P.st_wgrad) MMVAE_TRY(edge(P, P.st_wgrad2, s));
     MMVAE_TRY(launch_wgrad_reduce(&P.slab, s));
+    if (dp_split) return launch_unpack_grads(P.buf.gdesc_dev, P.gk.d.data(), (int)P.gk.d.size(), P.buf.gpk, P.buf.gpk_vec, P.buf.grads, s, 0);
     if (!io.defer_unpack) MMVAE_TRY(mm_unpack_grads(Pp, s));
+    return MMVAE_OK;
+}
+int mm_wait_early_grads(MMPlan* P, hipStream_t s) {
+    MMVAE_REQUIRE(P && P->ev_early, "mm_wait_early_grads: no dp_split step has run on this plan");
+    if (hipStreamWaitEvent(s, P->ev_early, 0) != hipSuccess) {
+        mmvae_set_error("mm_wait_early_grads: %s", hipGetErrorString(hipGetLastError()));
+        return MMVAE_EHIP;
+    }
     return MMVAE_OK;
 }
 

@@ -56,6 +56,7 @@ struct PlanBase {
     std::vector<WgradParams> deferred;
     std::vector<hipEvent_t> events;
     size_t next_event = 0;
+    hipEvent_t ev_early = nullptr;  // data-parallel step: the early gradient part is complete in the flat buffer
     bool wgrad_forked = false;
     unsigned dec_skip_mask = 0;     // bit k: pass k is absent from this step (weak-supervision variants): its decoder BatchNorm
                                     // group leaves the running statistics alone

@@ -26,8 +26,13 @@ import torch.distributed as dist
 
 
 def ensure_ipc_env() -> None:
-    """Call before anything touches the GPU (``torch.cuda.set_device`` included)."""
+    """Call before anything touches the GPU (``torch.cuda.set_device`` included).
+
+    ``GPU_MAX_HW_QUEUES``: the fused step runs on up to 4 streams and RCCL adds its own; beyond the HIP runtime's default
+    of 4 hardware queues the streams share queues and every kernel of the process slows down (measured with a world-1
+    RCCL group on MI355X: 0.90 -> 1.20 ms per MultiMNIST step; with 8 queues 0.91)."""
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 
 def init_distributed(backend: Optional[str] = None, device: Optional[torch.device] = None) -> tuple:
@@ -53,14 +58,19 @@ class GradAllReduce:
     """Callable handed to ``FusedELBOStep(all_reduce=...)``: in-place SUM over ranks of the flat gradient buffer,
     enqueued on the current stream (RCCL) -- the engine scales by 1/world inside Adam."""
 
-    def __init__(self, group=None, bucket_bytes: int = 0, force: bool = False):
+    def __init__(self, group=None, bucket_bytes: int = 0, force: bool = False, overlap: bool = False):
         self.group = group
         self.bucket_elems = bucket_bytes // 4
         self.force = force          # issue the collective even in a group of one rank (single-GPU RCCL test)
+        self.overlap = overlap      # engines that support it (MultiMNIST) exchange the decoders' gradient ranges on a
+                                    # communication stream while the encoders' backward runs (core.FusedELBOStep._call_dp_overlap);
+                                    # measured slower than the plain exchange on this runtime: opt-in only
 
-    def __call__(self, flat: torch.Tensor) -> None:
+    def __call__(self, flat: torch.Tensor, async_op: bool = False):
         if not dist.is_initialized() or (dist.get_world_size(self.group) == 1 and not self.force):
-            return
+            return None
+        if async_op:        # one message, the caller waits on the returned Work (overlapped exchange)
+            return dist.all_reduce(flat, group=self.group, async_op=True)
         if self.bucket_elems and flat.numel() > self.bucket_elems:
             for i in range(0, flat.numel(), self.bucket_elems):            # xGMI ring is per-link bound: a few large
                 dist.all_reduce(flat[i:i + self.bucket_elems], group=self.group)   # messages, never many small ones
