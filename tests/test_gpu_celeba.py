@@ -2,8 +2,8 @@
 golden vectors captured from the reference and the CPU oracle on the same seeded inputs.
 
 Tolerances (bf16 MFMA inputs / fp32 accumulation; the fixtures use B=4, where BatchNorm divides by the deviation of
-4 samples): ELBO losses rel 1e-3 | mu/logvar abs 1e-2 | per-tensor gradient rel-L2 5e-2 (+ 2e-4 of the total norm) |
-total gradient norm rel 1e-2.
+4 samples): ELBO losses rel 1e-3 | mu/logvar abs 1e-2 | per-tensor gradient rel-L2 6e-2, no absolute slack (tests/gradcheck.py; measured 4.0e-2) |
+total gradient norm rel 2e-3.
 """
 import os
 
@@ -12,6 +12,7 @@ import pytest
 import torch
 
 from oracle import mmvae_ref as R
+from gradcheck import check_gradients
 
 pytestmark = pytest.mark.gpu
 
@@ -36,19 +37,13 @@ def _state(dev):
     return st, P
 
 
-def _grad_checks(st, P, tensor_tol=5e-2):
-    names = [n for n, _ in R.param_table("celeba", D)]
+def _grad_checks(st, P, tensor_tol=6e-2, total_tol=2e-3, label="celeba"):     # measured 4.0e-2 / 7.3e-4
     g = st.grads.cpu()
-    tot_ref = torch.sqrt(sum(P[n].grad.double().pow(2).sum() for n in names)).item()
-    assert abs(g.double().norm().item() - tot_ref) <= 1e-2 * tot_ref
     for n, shape, off in st.table:
-        gr = P[n].grad.reshape(-1)
-        gh = g[off:off + gr.numel()]
         if n in PRE_BN_BIAS:
-            assert gh.abs().max().item() <= 1e-5, n
-            continue
-        err = (gh - gr).norm().item()
-        assert err <= tensor_tol * gr.norm().item() + 2e-4 * tot_ref, (n, err, gr.norm().item())
+            assert g[off:off + P[n].numel()].abs().max().item() <= 1e-5, n
+    check_gradients(((n, g[off:off + P[n].numel()], P[n].grad) for n, shape, off in st.table), tensor_tol, total_tol, label,
+                    zero_names=PRE_BN_BIAS)
 
 
 @pytest.mark.parametrize("fixture", ["celeba_b4", "celeba_b4_masks"])
@@ -113,7 +108,7 @@ def test_larger_batch_matches_oracle():
     o_losses, _ = R.celeba_step_losses(P, image, attrs, True, eps, None, 0.0)
     (o_losses[0] + o_losses[1] + o_losses[2]).backward()
     np.testing.assert_allclose(out.losses().cpu().numpy(), np.array([l.item() for l in o_losses]), rtol=1e-3)
-    _grad_checks(st, P, tensor_tol=3e-2)
+    _grad_checks(st, P, tensor_tol=4e-2, total_tol=1e-3)       # measured 2.5e-2 / 2.4e-4
 
 
 def test_training_reduces_loss_and_eval_mode():
@@ -168,13 +163,10 @@ def test_dropin_modules_match_oracle(golden_dir):
     total.backward()
     o_losses, _ = R.celeba_step_losses(P, image, attrs, True, eps, None, 0.0)
     (o_losses[0] + o_losses[1] + o_losses[2]).backward()
-    tot = torch.sqrt(sum(p.grad.double().pow(2).sum() for p in P.values() if p.grad is not None)).item()
     for n, p in vae.named_parameters():
-        gr, gh = P[n].grad, p.grad.cpu()
         if n in PRE_BN_BIAS:
-            assert gh.abs().max().item() <= 1e-5, n
-            continue
-        assert (gh - gr).norm().item() <= 5e-2 * gr.norm().item() + 2e-4 * tot, n
+            assert p.grad.abs().max().item() <= 1e-5, n
+    check_gradients(((n, p.grad, P[n].grad) for n, p in vae.named_parameters()), 6e-2, None, "celeba modules", zero_names=PRE_BN_BIAS)
     opt.step()
     vae.eval()
     ri, ra, mu, lv = vae(image=imd, attrs=atd)

@@ -3,7 +3,7 @@ vectors captured from the reference and the CPU oracle on the same seeded inputs
 
 Tolerances.  Caption modules alone (fp32 MFMA path, 102 dependent GRU steps): outputs abs 2e-5, every gradient tensor
 rel-L2 2e-4.  Fused step / image modules (bf16 MFMA inputs, fp32 accumulation; B=4 fixtures, BatchNorm over 4 samples):
-ELBO losses rel 1e-3 | mu/logvar abs 1e-2 | per-tensor gradient rel-L2 5e-2 (+ 2e-4 of the total norm) | total gradient
+ELBO losses rel 1e-3 | mu/logvar abs 1e-2 | per-tensor gradient rel-L2 4.5e-2, no absolute slack (tests/gradcheck.py; measured 2.3e-2) | total gradient
 norm rel 1e-2.
 """
 import os
@@ -13,6 +13,7 @@ import pytest
 import torch
 
 from oracle import mmvae_ref as R
+from gradcheck import check_gradients
 
 pytestmark = pytest.mark.gpu
 
@@ -36,16 +37,9 @@ def _state(dev, steps=R.COCO_MAX_WORDS):
     return st, P
 
 
-def _grad_checks(st, P, tensor_tol=5e-2, total_tol=1e-2, floor=2e-4):
-    names = [n for n, _ in R.param_table("coco", D)]
+def _grad_checks(st, P, tensor_tol=4.5e-2, total_tol=1e-3, label="coco"):     # measured 2.3e-2 / 1.6e-4
     g = st.grads.cpu()
-    tot_ref = torch.sqrt(sum(P[n].grad.double().pow(2).sum() for n in names)).item()
-    assert abs(g.double().norm().item() - tot_ref) <= total_tol * tot_ref
-    for n, shape, off in st.table:
-        gr = P[n].grad.reshape(-1)
-        gh = g[off:off + gr.numel()]
-        err = (gh - gr).norm().item()
-        assert err <= tensor_tol * gr.norm().item() + floor * tot_ref, (n, err, gr.norm().item())
+    check_gradients(((n, g[off:off + P[n].numel()], P[n].grad) for n, shape, off in st.table), tensor_tol, total_tol, label)
 
 
 def _vae(dev, steps, P=None):
@@ -197,7 +191,7 @@ def test_gru_dropout_masks_and_short_captions_match_oracle():
     o_losses, _ = R.coco_step_losses(P, image, text, R.formula_sos(), True, 1e-3, eps, None, gm, enc_drop_p=0.0, gru_drop_p=0.1)
     (o_losses[0] + o_losses[1] + o_losses[2]).backward()
     np.testing.assert_allclose(out.losses().cpu().numpy(), np.array([l.item() for l in o_losses]), rtol=1e-3)
-    _grad_checks(st, P, tensor_tol=4e-2)
+    _grad_checks(st, P, tensor_tol=3.2e-2)         # measured 1.6e-2
 
 
 def test_full_length_larger_batch_matches_oracle():
@@ -218,7 +212,7 @@ def test_full_length_larger_batch_matches_oracle():
     o_losses, _ = R.coco_step_losses(P, image, text, R.formula_sos(), True, 1e-3, eps, None, None, 0.0, 0.0)
     (o_losses[0] + o_losses[1] + o_losses[2]).backward()
     np.testing.assert_allclose(got, np.array([l.item() for l in o_losses]), rtol=1e-3)
-    _grad_checks(st, P, tensor_tol=3e-2)
+    _grad_checks(st, P, tensor_tol=2.6e-2)         # measured 1.3e-2
     g1 = st.grads.clone()
     # doubling every lambda and kl_lambda doubles every gradient (the step is linear in them); the loss parts do not move
     eng.kl_lambda = 2e-3
@@ -314,8 +308,16 @@ def test_dropin_modules_match_golden(golden_dir):
     names = [n for n, _ in R.param_table("coco", D)]
     gn = torch.sqrt(sum(p.grad.double().pow(2).sum() for p in vae.parameters())).item()
     np.testing.assert_allclose(gn, float(fx["total_grad_norm"]), rtol=1e-2)
+    worst = 0.0
     for (n, p), gs in zip(vae.named_parameters(), fx["grad_stats"]):
-        np.testing.assert_allclose(p.grad.double().norm().item(), gs[1], rtol=5e-2, atol=2e-4 * gn, err_msg=n)
+        if gs[1] < 1e-6 * gn:          # analytically zero (hidden weights of the one-step reverse direction)
+            assert p.grad.double().norm().item() <= 1e-4 * gn, n
+            continue
+        rel = abs(p.grad.double().norm().item() - gs[1]) / gs[1]
+        worst = max(worst, rel)
+        assert rel <= 1e-2, (n, rel)         # measured 3.2e-3
+    if os.environ.get("MMVAE_TOL_REPORT"):
+        print("TOL coco drop-in modules: worst tensor-norm rel %.3e" % worst)
     opt.step()
     with pytest.raises(AssertionError):
         vae()

@@ -13,6 +13,7 @@ import pytest
 import torch
 
 from oracle import mmvae_ref as R
+from gradcheck import check_gradients
 
 pytestmark = pytest.mark.gpu
 
@@ -36,22 +37,18 @@ def _state_with_formula_params(dev):
     return st, P
 
 
+NORM_TOL_B256 = 5e-3        # per-tensor gradient NORM of the free-running B=256 step, measured 1.6e-3 (direction: test_gpu_parity_r2.py)
+
+
 def _unpack_masks(fx, B):
     m1 = np.stack([np.unpackbits(fx[f"mask_{i}_0"], axis=1)[:, :400] for i in range(2)])
     m2 = np.stack([np.unpackbits(fx[f"mask_{i}_1"], axis=1)[:, :200] for i in range(2)])
     return torch.from_numpy(m1.astype(np.uint8)), torch.from_numpy(m2.astype(np.uint8))
 
 
-def _grad_checks(st, P, tot_tol=1e-2, tensor_tol=3e-2):
-    names = [n for n, _ in R.param_table("multimnist", D)]
+def _grad_checks(st, P, tot_tol=1e-3, tensor_tol=2.5e-2, label="multimnist"):
     g = st.grads.cpu()
-    tot_ref = torch.sqrt(sum(P[n].grad.double().pow(2).sum() for n in names)).item()
-    assert abs(g.double().norm().item() - tot_ref) <= tot_tol * tot_ref
-    for n, shape, off in st.table:
-        gr = P[n].grad.reshape(-1)
-        gh = g[off:off + gr.numel()]
-        err = (gh - gr).norm().item()
-        assert err <= tensor_tol * gr.norm().item() + 2e-4 * tot_ref, (n, err, gr.norm().item())
+    check_gradients(((n, g[off:off + P[n].numel()], P[n].grad) for n, shape, off in st.table), tensor_tol, tot_tol, label)
 
 
 @pytest.mark.parametrize("fixture", ["multimnist_b8", "multimnist_b8_masks"])
@@ -130,14 +127,24 @@ def test_full_size_b256_scalars(golden_dir):
     eng = FusedELBOStep(st, B)
     eng.enc_dropout = eng.gru_dropout = False
     out = eng.forward_backward(image.to(dev), text.to(dev), True, True, eps=torch.stack(eps).to(dev).contiguous())
-    # free-running greedy decode at full size: a handful of near-tie flips are expected -> slightly looser than 1e-3
-    np.testing.assert_allclose(out.losses().cpu().numpy(), fx["loss"], rtol=3e-3)
+    # free-running greedy decode at full size (measured 2e-5; a near-tie flip of a fed-back token would show up here)
+    if os.environ.get("MMVAE_TOL_REPORT"):
+        print("TOL multimnist b256 free-running losses rel", np.abs(out.losses().cpu().numpy() / fx["loss"] - 1).max())
+    np.testing.assert_allclose(out.losses().cpu().numpy(), fx["loss"], rtol=1e-3)
     g = st.grads.cpu()
     tot = float(fx["total_grad_norm"])
-    np.testing.assert_allclose(g.double().norm().item(), tot, rtol=2e-2)
+    np.testing.assert_allclose(g.double().norm().item(), tot, rtol=1e-3)           # measured 1.7e-4
+    worst = 0.0
     for (n, shape, off), ref in zip(st.table, fx["grad_norms"]):
         numel = int(np.prod(shape))
-        assert abs(g[off:off + numel].double().norm().item() - ref) <= 5e-2 * ref + 1e-3 * tot, n
+        if ref < 1e-6 * tot:
+            assert g[off:off + numel].double().norm().item() <= 1e-4 * tot, n
+            continue
+        rel = abs(g[off:off + numel].double().norm().item() - ref) / ref
+        worst = max(worst, rel)
+        assert rel <= NORM_TOL_B256, (n, rel)
+    if os.environ.get("MMVAE_TOL_REPORT"):
+        print("TOL multimnist b256 free-running: worst tensor-norm rel %.3e, total %.3e" % (worst, abs(g.double().norm().item() - tot) / tot))
 
 
 def test_adam_matches_torch_semantics():
