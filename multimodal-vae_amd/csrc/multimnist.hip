@@ -2,6 +2,7 @@
 // Reference: multimnist/model.py:21-93 (MultimodalVAE), :150-216 (image enc/dec), :219-307 (text enc/dec),
 //            multimnist/train.py:69-87 (loss_function), :146-173 (3-pass step).
 #include "multimnist.h"
+#include "mlp_tail.h"
 #include "plan_base.h"
 #include "thin.h"
 #include <cstring>
@@ -18,6 +19,9 @@ struct MMPlan : PlanBase {
     // text packs
     struct GruIdx { int wih, whh, wihT, whhT, g_wih, g_whh; long long bih, bhh; } te_f, te_r, td0, td1;
     int te_h2p, te_h2pT, g_te_h2p, td_z2h, td_z2hT, g_td_z2h, td_h2o, td_h2oT, g_td_h2o;
+    // fused classifier tail (mlp_tail.hip; n_latents = 100 only): fragment-major copies of classifier.3 / classifier.6
+    bool mlp_tail = false;
+    int mt_w2, mt_w3, mt_w3t, mt_w2t;
     // ---- workspace pointers
     struct W {
         char* zero_begin; size_t zero_bytes;
@@ -118,6 +122,15 @@ void build_plan(MMPlan& P) {
     };
     lin(P.fc[1], "image_encoder.classifier.3", 200, 400);
     lin(P.fc[2], "image_encoder.classifier.6", 2 * D, 200);
+    if (D == 100) {      // the widths mlp_tail.hip is compiled for
+        static const bool off_ = getenv("MMVAE_NO_MLP_TAIL") != nullptr;     // A/B aid
+        P.mlp_tail = !off_;
+        auto fragd = [&](PackDesc d) { d.frag = 1; return P.pk.add(d); };
+        P.mt_w2 = fragd(pack_dense(P.fc[1].w_off, 200, 400, 208, 416, 400, 1));
+        P.mt_w3 = fragd(pack_dense(P.fc[2].w_off, 200, 200, 208, 224, 200, 1));
+        P.mt_w3t = fragd(pack_dense(P.fc[2].w_off, 200, 200, 208, 224, 1, 200));    // [fc2 unit][fc3 output]
+        P.mt_w2t = fragd(pack_dense(P.fc[1].w_off, 400, 200, 400, 224, 1, 400));    // [fc1 unit][fc2 unit]
+    }
     {   // upsample Linear(D, 1024): output columns permuted to NHWC n' = s*256 + c  <->  row c*4 + s
         LinL& f = P.up;
         f.w_off = off(P, "image_decoder.upsample.0.weight"); f.b_off = off(P, "image_decoder.upsample.0.bias");
@@ -272,6 +285,15 @@ int enc_fwd(MMPlan& P, const float* image, int variants, const uint8_t* m1, cons
         g.out_act_bf = w.ay1; g.e_act = ACT_SWISH; if (drop) { g.e_mask = m1; g.e_mask_scale = ms; }
         MMVAE_TRY(launch_gemm_gather(g, s));
     }
+    if (P.mlp_tail) {      // classifier.3 + Swish + Dropout + classifier.6 in one row-block launch
+        Mlp2FwdArgs a{};
+        a.rows = rows; a.x = w.ay1;
+        a.w2 = P.buf.packed + P.pk.d[P.mt_w2].dst_off; a.b2 = P.buf.params + P.fc[1].b_off;
+        a.w3 = P.buf.packed + P.pk.d[P.mt_w3].dst_off; a.b3 = P.buf.params + P.fc[2].b_off;
+        if (drop) { a.mask = m2; a.mask_scale = ms; }
+        a.y2 = w.y2; a.ay2 = w.ay2; a.out = out;
+        return launch_mlp2_fwd(a, s);
+    }
     {
         GatherPlan pl = dense_plan(rows, 400, 400, 200);
         GemmParams g = gemm_of(P, pl, &P.fc[1].pk_fwd, 1, rows);
@@ -295,6 +317,26 @@ int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const
     MMPlan::W& w = P.w;
     const int B = P.B, rows = variants * B, D2 = 2 * P.D;
     const float ms = 1.f / (1.f - DROP_P);
+    if (P.mlp_tail) {      // both data gradients in one row-block launch; the weight gradients follow on the side stream
+        {
+            GatherPlan pl = dense_plan(rows, 200, 200, D2);
+            WgradParams g = wgrad_of(P, pl, &P.fc[2].gk, 1, rows);
+            g.c.A = w.ay2; g.P = d_out; g.ldp = D2;
+            MMVAE_TRY(wgrad_async(P, g, s));
+        }
+        Mlp2BwdArgs a{};
+        a.rows = rows; a.d_out = d_out;
+        a.w3t = P.buf.packed + P.pk.d[P.mt_w3t].dst_off; a.w2t = P.buf.packed + P.pk.d[P.mt_w2t].dst_off;
+        a.y2 = w.y2; a.y1 = w.y1;
+        if (dropout) { a.mask2 = m2; a.mask1 = m1; a.mask_scale = ms; }
+        a.dy2 = w.dy2; a.dy1 = w.dy1;
+        a.db2 = P.buf.grads + P.fc[1].b_off; a.db1 = P.buf.grads + P.fc[0].b_off;
+        MMVAE_TRY(launch_mlp2_bwd(a, s));
+        GatherPlan pl = dense_plan(rows, 400, 400, 200);
+        WgradParams g = wgrad_of(P, pl, &P.fc[1].gk, 1, rows);
+        g.c.A = w.ay1; g.P = w.dy2; g.ldp = 200;
+        MMVAE_TRY(wgrad_async(P, g, s));
+    } else {
     {   // fc3
         GatherPlan pl = dense_plan(rows, 200, 200, D2);
         WgradParams g = wgrad_of(P, pl, &P.fc[2].gk, 1, rows);
@@ -318,6 +360,7 @@ int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const
         d.d_r = w.y1; d.d_ld = 400; d.d_act = ACT_SWISH; if (dropout) { d.d_mask = m1; d.d_mask_scale = ms; }
         d.d_colsum = P.buf.grads + P.fc[0].b_off;
         MMVAE_TRY(launch_gemm_gather(d, s));
+    }
     }
     {   // fc1: wgrad gathers the shared 2x2x256 map; dgrad emits NHWC gradients for `rows` samples
         GatherPlan pl = plan_fwdform(2, 2, 1, 1, 256, 2, 2, 1, 0, 400, 1, rows);
