@@ -39,7 +39,8 @@ struct CocoDecBwdArgs {
 struct CocoEncFwdArgs {
     int B, T;
     const float* gi;         // [B][T][600] input projection of every step (+ b_ih)
-    const bf16* w_hh;        // packed [608][224]
+    const bf16* w_hh;        // packed [608][224]; resident form: three per-gate [208][224] matrices back to back
+    int resident;            // 1: the weights stay in registers / LDS for the whole recurrence (coco_enc_fwd_res_kernel)
     const float* bhh;
     float* h_all;            // [T][B][200] h after each step
     float* sav;              // [T][B][4*200] (r, z, n, W_hn h + b_hn) or null (inference)
@@ -73,7 +74,7 @@ struct CocoPlan : PlanBase {
     // bf16 persistent caption decoder: packed weights (forward and transposed forms) and packed-gradient descriptors
     bool text_bf16 = true;
     bool dec_wg_pending = false; const float* dec_wg_z = nullptr; int dec_wg_groups = 0;   // deferred weight gradients of the bf16 decoder
-    int tb_ih0, tb_hh0, tb_ih1, tb_hh1, tb_ho, tb_hoT, tb_ih1T, tb_hh1T, tb_hh0T, tb_ih0T, tb_e_hh, tb_e_hhT;
+    int tb_ih0, tb_hh0, tb_ih1, tb_hh1, tb_ho, tb_hoT, tb_ih1T, tb_hh1T, tb_hh0T, tb_ih0T, tb_e_hh, tb_e_hhT, tb_e_hhg[3];
     int tg_ih0, tg_hh0, tg_ih1, tg_hh1, tg_ho, tg_e_ih, tg_e_hh;
     struct W {
         char* zero_begin; size_t zero_bytes;

@@ -335,6 +335,8 @@ void coco_text_build(CocoPlan& P) {
     P.tb_ih0T = trp(P.td0.wih, E, G, in0, CTB_EP, CTB_GP);      // [e][g] = weight_ih_l0[g][e]
     P.tb_e_hh = fwdp(P.te_f.whh, G, H, H, CTB_GP, CTB_HP);      // caption encoder, forward direction
     P.tb_e_hhT = trp(P.te_f.whh, H, G, H, 208, CTB_GP);
+    for (int g3 = 0; g3 < 3; ++g3)                               // per-gate copies for the weight-resident forward kernel
+        P.tb_e_hhg[g3] = fwdp(P.te_f.whh + (long long)g3 * H * H, H, H, H, 208, CTB_HP);
     // packed gradients [round64(N)][Kpad of the wgrad operand] -> scattered back by the unpack kernel
     // bias >= 0: the saved operand carries 1.0 in column K, so column K of the packed gradient is the bias gradient
     auto gkp = [&](long long w, int N, int K, int ld, int Kc, long long bias) {
@@ -385,7 +387,12 @@ int coco_text_enc_fwd(CocoPlan& P, const float* text, int save, float* out, hipS
     MMVAE_TRY(lin(text, E, B * T, p + P.te_f.wih, G, E, E, 0, p + P.te_f.bih, nullptr, 0, w.te_gi, G, s));
     if (bf16_path && P.text_bf16) {      // the recurrence in ONE persistent launch (coco_text_bf16.hip)
         CocoEncFwdArgs a{};
-        a.B = B; a.T = T; a.gi = w.te_gi; a.w_hh = P.buf.packed + P.pk.d[P.tb_e_hh].dst_off; a.bhh = p + P.te_f.bhh;
+        static const bool streamed = getenv("MMVAE_COCO_ENC_STREAMED") != nullptr;      // A/B aid: the weight-streaming kernel
+        a.B = B; a.T = T; a.gi = w.te_gi; a.bhh = p + P.te_f.bhh;
+        a.resident = !streamed;
+        a.w_hh = P.buf.packed + P.pk.d[streamed ? P.tb_e_hh : P.tb_e_hhg[0]].dst_off;
+        MMVAE_REQUIRE(P.pk.d[P.tb_e_hhg[1]].dst_off == P.pk.d[P.tb_e_hhg[0]].dst_off + 208ll * CTB_HP &&
+                      P.pk.d[P.tb_e_hhg[2]].dst_off == P.pk.d[P.tb_e_hhg[0]].dst_off + 2 * 208ll * CTB_HP, "per-gate packs not contiguous");
         a.h_all = w.te_h;
         if (save) { a.sav = w.te_sav; a.hb_all = w.te_hb_all; }
         MMVAE_TRY(launch_coco_enc_fwd(a, s));

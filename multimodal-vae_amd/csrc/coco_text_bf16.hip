@@ -421,6 +421,112 @@ __global__ __launch_bounds__(NTHR) void coco_enc_fwd_kernel(const CocoEncFwdArgs
     }
 }
 
+// The same recurrence with W_hh RESIDENT on the CU: 272 KB of bf16 fit the registers of 8 waves (84 VGPRs per lane for a
+// wave's first 16-unit block of the three gates) plus 105 KB of LDS (the second block of waves 0-4), so a step streams
+// nothing.  The weights are packed per gate (three fragment-major [208][224] matrices), a wave owns unit blocks
+// wave and wave + 8 of ALL THREE gates, so r, z and n of a hidden unit meet in the accumulators of one lane (MFMA C layout:
+// rows 4*(lane/16) .. +3 of column lane%16) and the gate math runs in registers -- the state h lives there too, in fp32.
+// One barrier per step (the bf16 copy of h that feeds the next step's A operand is double-buffered in LDS).
+template <bool SAVE>
+__global__ __launch_bounds__(NTHR) void coco_enc_fwd_res_kernel(const CocoEncFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* hb = reinterpret_cast<bf16*>(smem);                       // [2][16][LDH]
+    bf16* wl = hb + 2 * TR * LDH;                                   // [5 waves][3 gates][7 k-steps][64 lanes][8]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int r0 = blockIdx.x * TR, R = a.B, T = a.T;
+    const size_t RH = (size_t)R * H;
+    constexpr int KS = HP / 32, NB = (H + 15) / 16;                 // 7 k-steps, 13 unit blocks
+    constexpr size_t GATE = (size_t)NB * 16 * HP;                   // elements of one packed gate matrix
+    const bool two = wave + NW < NB;                                // waves 0-4 own a second block
+    bf16x8 w0[3][KS];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            w0[g][s] = *reinterpret_cast<const bf16x8*>(a.w_hh + g * GATE + ((size_t)(wave * KS + s) * 64 + lane) * 8);
+            if (two) *reinterpret_cast<bf16x8*>(wl + ((size_t)((wave * 3 + g) * KS + s) * 64 + lane) * 8) =
+                *reinterpret_cast<const bf16x8*>(a.w_hh + g * GATE + ((size_t)((wave + NW) * KS + s) * 64 + lane) * 8);
+        }
+    for (int i = tid; i < 2 * TR * LDH; i += NTHR) hb[i] = (bf16)0.f;
+    int ju[2]; bool uok[2]; float br[2], bz[2], bn[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        ju[i] = (wave + NW * i) * 16 + fr;
+        uok[i] = (i == 0 || two) && ju[i] < H;
+        const int j = min(ju[i], H - 1);
+        br[i] = a.bhh[j]; bz[i] = a.bhh[H + j]; bn[i] = a.bhh[2 * H + j];
+    }
+    size_t grow[4]; bool rok[4];
+#pragma unroll
+    for (int jr = 0; jr < 4; ++jr) { rok[jr] = r0 + fq * 4 + jr < R; grow[jr] = rok[jr] ? r0 + fq * 4 + jr : 0; }
+    if (SAVE && tid < TR && r0 + tid < R) {      // slice 0 of the saved operand: h before the first step (zeros) + the 1.0 column
+        bf16* p = a.hb_all + (size_t)(r0 + tid) * HP;
+        for (int j = 0; j < H; ++j) p[j] = (bf16)0.f;
+        p[H] = (bf16)1.f;
+    }
+    float hst[2][4] = {};
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const bf16* hc = hb + (t & 1) * TR * LDH;
+        bf16* hn_b = hb + ((t + 1) & 1) * TR * LDH;
+        // this step's input projection (+ b_ih), requested before the MFMAs
+        float gi[2][3][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jr = 0; jr < 4; ++jr) {
+                const float* p = a.gi + (grow[jr] * T + t) * G + min(ju[i], H - 1);
+#pragma unroll
+                for (int g = 0; g < 3; ++g) gi[i][g][jr] = p[g * H];
+            }
+        bf16x8 af[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) af[s] = *reinterpret_cast<const bf16x8*>(hc + fr * LDH + s * 32 + fq * 8);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (i == 1 && !two) break;
+            f32x4 acc[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const bf16x8 wv = i == 0 ? w0[g][s] : *reinterpret_cast<const bf16x8*>(wl + ((size_t)((wave * 3 + g) * KS + s) * 64 + lane) * 8);
+                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s], wv, acc[g], 0, 0, 0);
+                }
+            }
+            if (uok[i]) {
+                const int j = ju[i];
+#pragma unroll
+                for (int jr = 0; jr < 4; ++jr) {
+                    const float r = sigm(gi[i][0][jr] + acc[0][jr] + br[i]);
+                    const float z = sigm(gi[i][1][jr] + acc[1][jr] + bz[i]);
+                    const float ghn = acc[2][jr] + bn[i];
+                    const float n = tanh_fast(gi[i][2][jr] + r * ghn);
+                    const float hn = (1.0f - z) * n + z * hst[i][jr];
+                    hst[i][jr] = hn;
+                    hn_b[(fq * 4 + jr) * LDH + j] = (bf16)hn;
+                    if (rok[jr]) {
+                        a.h_all[(size_t)t * RH + grow[jr] * H + j] = hn;
+                        if (SAVE) {
+                            float* sv = a.sav + ((size_t)t * R + grow[jr]) * 4 * H;
+                            sv[j] = r; sv[H + j] = z; sv[2 * H + j] = n; sv[3 * H + j] = ghn;
+                            if (t + 1 < T) a.hb_all[((size_t)(t + 1) * R + grow[jr]) * HP + j] = (bf16)hn;
+                        }
+                    }
+                }
+            }
+        }
+        if (SAVE && wave == 0 && fr == 0 && t + 1 < T) {
+#pragma unroll
+            for (int jr = 0; jr < 4; ++jr)
+                if (rok[jr]) a.hb_all[((size_t)(t + 1) * R + grow[jr]) * HP + H] = (bf16)1.f;
+        }
+        __syncthreads();
+    }
+}
+
 // BPTT of the same recurrence: per step the gate backward and dh[t-1] += dgh[t] * W_hh (253 KB bf16 streamed).
 __global__ __launch_bounds__(NTHR) void coco_enc_bwd_kernel(const CocoEncBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -550,13 +656,20 @@ int launch_coco_dec_bwd(const CocoDecBwdArgs& a, hipStream_t s) {
 }
 
 int launch_coco_enc_fwd(const CocoEncFwdArgs& a, hipStream_t s) {
-    const size_t lds = (size_t)(TR * LDG + TR * H + G) * sizeof(float) + (size_t)(TR * LDH) * sizeof(bf16);
+    MMVAE_REQUIRE(a.h_all && (!a.sav || a.hb_all), "coco_enc_fwd: save buffers");
     static std::atomic<unsigned> once{0};
     if (mmvae_first_use_on_device(once)) {
         auto big = [](auto kern) { hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); };
         big(&coco_enc_fwd_kernel<true>); big(&coco_enc_fwd_kernel<false>);
+        big(&coco_enc_fwd_res_kernel<true>); big(&coco_enc_fwd_res_kernel<false>);
     }
-    MMVAE_REQUIRE(a.h_all && (!a.sav || a.hb_all), "coco_enc_fwd: save buffers");
+    if (a.resident) {       // a.w_hh = three per-gate matrices, back to back
+        const size_t lds = (size_t)(2 * TR * LDH + 5 * 3 * (HP / 32) * 64 * 8) * sizeof(bf16);
+        if (a.sav) hipLaunchKernelGGL(coco_enc_fwd_res_kernel<true>, dim3(ceil_div(a.B, TR)), dim3(NTHR), lds, s, a);
+        else hipLaunchKernelGGL(coco_enc_fwd_res_kernel<false>, dim3(ceil_div(a.B, TR)), dim3(NTHR), lds, s, a);
+        return mmvae_check_launch("coco_enc_fwd_res");
+    }
+    const size_t lds = (size_t)(TR * LDG + TR * H + G) * sizeof(float) + (size_t)(TR * LDH) * sizeof(bf16);
     if (a.sav) hipLaunchKernelGGL(coco_enc_fwd_kernel<true>, dim3(ceil_div(a.B, TR)), dim3(NTHR), lds, s, a);
     else hipLaunchKernelGGL(coco_enc_fwd_kernel<false>, dim3(ceil_div(a.B, TR)), dim3(NTHR), lds, s, a);
     return mmvae_check_launch("coco_enc_fwd");
