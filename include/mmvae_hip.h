@@ -34,6 +34,19 @@ const char* mmvae_version(void);
  * kernel down 2-3x.  MMVAE_ESTATE if the side streams already exist with the other policy. */
 int mmvae_set_stream_policy(int flat);
 
+/* ---- collective face: the path's ONE exchange step, for hosts without a communicator of their own ----------
+ * In-place SUM all-reduce of the flat fp32 gradient buffer over RCCL / xGMI, enqueued on the caller's stream; fold the
+ * 1/world averaging into mmvae_adam_step's grad_scale.  librccl is bound with dlopen on first use (a copy already loaded
+ * in the process -- PyTorch's -- is reused); nothing else in the library depends on it.  Rank 0 creates the 128-byte id
+ * (ncclUniqueId) and hands it to the other ranks out of band (file, socket, MPI); every rank then calls mmvae_comm_init
+ * with its HIP device already selected.  A PyTorch host keeps torch.distributed. */
+typedef struct mmvae_comm mmvae_comm_t;
+int mmvae_comm_unique_id(void* out128);
+int mmvae_comm_init(mmvae_comm_t** out, int rank, int world, const void* unique_id128);
+int mmvae_allreduce_grads(mmvae_comm_t*, float* flat, size_t n, void* stream);
+int mmvae_comm_world(const mmvae_comm_t*);
+int mmvae_comm_destroy(mmvae_comm_t*);
+
 /* ---------------------------------------------------------------- MultiMNIST plan (multimnist/model.py:21-93) */
 typedef struct MMPlan mmvae_mm_t;
 mmvae_mm_t* mmvae_mm_create(int n_latents, int batch);      /* MultimodalVAE(n_latents) at a fixed batch size */

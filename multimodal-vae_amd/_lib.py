@@ -89,6 +89,11 @@ SIGNATURES = {
     "mmvae_last_error": (C.c_char_p, []),
     "mmvae_version": (C.c_char_p, []),
     "mmvae_set_stream_policy": (_I, [_I]),
+    "mmvae_comm_unique_id": (_I, [_P]),
+    "mmvae_comm_init": (_I, [C.POINTER(C.c_void_p), _I, _I, _P]),
+    "mmvae_allreduce_grads": (_I, [_P, _P, C.c_size_t, _P]),
+    "mmvae_comm_world": (_I, [_P]),
+    "mmvae_comm_destroy": (_I, [_P]),
     "mmvae_mm_create": (_P, [_I, _I]),
     "mmvae_mm_destroy": (None, [_P]),
     "mmvae_mm_param_count": (_LL, [_P]),
@@ -201,7 +206,7 @@ SIGNATURES["mmvae_coco_text_encoder_fwd"] = (_I, [_P, _P, _SZ, _P, _P, _P])
 SIGNATURES["mmvae_coco_text_encoder_bwd"] = (_I, [_P, _P, _SZ, _P, _P, _P])
 SIGNATURES["mmvae_coco_text_decoder_fwd"] = (_I, [_P, _P, _SZ, _P, _P, _P, _I, _P, _P])
 SIGNATURES["mmvae_coco_text_decoder_bwd"] = (_I, [_P, _P, _SZ, _P, _P, _P, _P, _P, _P, _P])
-_STATUS = {n for n, (r, _) in SIGNATURES.items() if r is _I and not n.endswith(("_num_params", "_num_bn", "_precision", "_coco_steps"))}
+_STATUS = {n for n, (r, _) in SIGNATURES.items() if r is _I and not n.endswith(("_num_params", "_num_bn", "_precision", "_coco_steps", "_comm_world"))}
 
 _lib = None
 _inited = set()

@@ -163,3 +163,28 @@ def test_single_rank_rccl_group_runs_the_data_parallel_step():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_c_abi_collective_face_single_rank():
+    """mmvae_comm_* (SURVEY 8b collective face): RCCL bound with dlopen, a communicator of one rank, the in-place SUM
+    all-reduce of a flat fp32 buffer on the caller's stream, then the data-parallel update through mmvae_adam_step with
+    grad_scale = 1/world -- the three calls a C++ host makes per step."""
+    import ctypes as C
+    from multimodal_vae_amd._lib import call, ptr
+    dev = _dev()
+    torch.cuda.set_device(dev)
+    uid = (C.c_char * 128)()
+    call("mmvae_comm_unique_id", C.cast(uid, C.c_void_p))
+    comm = C.c_void_p()
+    call("mmvae_comm_init", C.byref(comm), 0, 1, C.cast(uid, C.c_void_p))
+    try:
+        assert call("mmvae_comm_world", comm) == 1
+        g = torch.randn(1 << 20, device=dev)
+        want = g.clone()
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        call("mmvae_allreduce_grads", comm, ptr(g), g.numel(), s)
+        torch.cuda.synchronize()
+        assert torch.equal(g, want)                       # the sum over one rank
+        call("mmvae_allreduce_grads", comm, ptr(g), 0, s)  # empty message: a no-op, not an error
+    finally:
+        call("mmvae_comm_destroy", comm)
