@@ -40,7 +40,9 @@ struct CocoEncFwdArgs {
     int B, T;
     const float* gi;         // [B][T][600] input projection of every step (+ b_ih)
     const bf16* w_hh;        // packed [608][224]; resident form: three per-gate [208][224] matrices back to back
-    int resident;            // 1: the weights stay in registers / LDS for the whole recurrence (coco_enc_fwd_res_kernel)
+    int resident;            // 1: the weights stay in registers / LDS for the whole recurrence (coco_enc_fwd_res_kernel);
+                             // gi is then [T][600][B], sav [T][4][200][B], h_all [T][200][B] (batch row fastest, B % 4 == 0)
+    float* h_last;           // resident form: h after the last step, [B][200]
     const float* bhh;
     float* h_all;            // [T][B][200] h after each step
     float* sav;              // [T][B][4*200] (r, z, n, W_hn h + b_hn) or null (inference)
@@ -51,10 +53,12 @@ struct CocoEncBwdArgs {
     const float* dh_init;    // [B][200] gradient wrt h[T-1]
     const float *sav, *h_all;
     const bf16* w_hhT;       // packed [208][608]
+    int resident;            // 1: coco_enc_bwd_res_kernel (sav / h_all in the layouts of the resident forward kernel)
     bf16 *dgi_b, *dgh_b;     // [T][B][608] gradients wrt the input / hidden projections
 };
 int launch_coco_enc_fwd(const CocoEncFwdArgs& a, hipStream_t s);
 int launch_coco_enc_bwd(const CocoEncBwdArgs& a, hipStream_t s);
+int launch_coco_gi_transpose(const float* gi_bt, int B, int T, float* gi_tb, hipStream_t s);     // [B][T][600] -> [T][600][B]
 // dst[(t*B + b)*ld + e] = bf16(text[(b*T + t)*300 + e]); column 300 = 1.0
 int launch_coco_text_tb(const float* text, int B, int T, int ld, bf16* dst, hipStream_t s);
 int launch_coco_dec_fwd(const CocoDecFwdArgs& a, hipStream_t s);
@@ -99,6 +103,7 @@ struct CocoPlan : PlanBase {
         // bf16 persistent decoder: operands of the batched weight gradients, [t][row] layout
         bf16 *tb_x, *tb_h0, *tb_mid, *tb_h1, *tb_dout, *tb_dgi0, *tb_dgh0, *tb_dgi1, *tb_dgh1;
         bf16 *te_xb, *te_hb_all, *te_dgi_b, *te_dgh_b;
+        float *te_giT, *te_hlast;
     } w;
 };
 

@@ -373,9 +373,16 @@ void coco_text_carve(CocoPlan& P, Workspace& ws) {
         w.tb_h1 = ws.take<bf16>((T + 1) * R * CTB_HP); w.tb_dout = ws.take<bf16>(T * R * CTB_EP);
         w.tb_dgi0 = ws.take<bf16>(T * R * CTB_GP); w.tb_dgh0 = ws.take<bf16>(T * R * CTB_GP);
         w.tb_dgi1 = ws.take<bf16>(T * R * CTB_GP); w.tb_dgh1 = ws.take<bf16>(T * R * CTB_GP);
+        w.te_giT = ws.take<float>(B * T * G); w.te_hlast = ws.take<float>(B * H);
         w.te_xb = ws.take<bf16>(T * B * CTB_XP); w.te_hb_all = ws.take<bf16>(T * B * CTB_HP);
         w.te_dgi_b = ws.take<bf16>(T * B * CTB_GP); w.te_dgh_b = ws.take<bf16>(T * B * CTB_GP);
     }
+}
+
+// the weight-resident encoder kernels (coco_text_bf16.hip) need 4-row vectors of the batch
+static bool coco_enc_resident(const CocoPlan& P) {
+    static const bool streamed = getenv("MMVAE_COCO_ENC_STREAMED") != nullptr;      // A/B aid: the weight-streaming kernels
+    return P.text_bf16 && !streamed && P.B % 4 == 0;
 }
 
 // ================================================================== caption encoder (coco/model.py:236-245)
@@ -387,12 +394,16 @@ int coco_text_enc_fwd(CocoPlan& P, const float* text, int save, float* out, hipS
     MMVAE_TRY(lin(text, E, B * T, p + P.te_f.wih, G, E, E, 0, p + P.te_f.bih, nullptr, 0, w.te_gi, G, s));
     if (bf16_path && P.text_bf16) {      // the recurrence in ONE persistent launch (coco_text_bf16.hip)
         CocoEncFwdArgs a{};
-        static const bool streamed = getenv("MMVAE_COCO_ENC_STREAMED") != nullptr;      // A/B aid: the weight-streaming kernel
+        const bool res = coco_enc_resident(P);
         a.B = B; a.T = T; a.gi = w.te_gi; a.bhh = p + P.te_f.bhh;
-        a.resident = !streamed;
-        a.w_hh = P.buf.packed + P.pk.d[streamed ? P.tb_e_hh : P.tb_e_hhg[0]].dst_off;
-        MMVAE_REQUIRE(P.pk.d[P.tb_e_hhg[1]].dst_off == P.pk.d[P.tb_e_hhg[0]].dst_off + 208ll * CTB_HP &&
-                      P.pk.d[P.tb_e_hhg[2]].dst_off == P.pk.d[P.tb_e_hhg[0]].dst_off + 2 * 208ll * CTB_HP, "per-gate packs not contiguous");
+        a.resident = res;
+        a.w_hh = P.buf.packed + P.pk.d[res ? P.tb_e_hhg[0] : P.tb_e_hh].dst_off;
+        if (res) {      // the resident kernels read / write with the batch row fastest: [T][600][B] and friends
+            MMVAE_REQUIRE(P.pk.d[P.tb_e_hhg[1]].dst_off == P.pk.d[P.tb_e_hhg[0]].dst_off + 208ll * CTB_HP &&
+                          P.pk.d[P.tb_e_hhg[2]].dst_off == P.pk.d[P.tb_e_hhg[0]].dst_off + 2 * 208ll * CTB_HP, "per-gate packs not contiguous");
+            MMVAE_TRY(launch_coco_gi_transpose(w.te_gi, B, T, w.te_giT, s));
+            a.gi = w.te_giT; a.h_last = w.te_hlast;
+        }
         a.h_all = w.te_h;
         if (save) { a.sav = w.te_sav; a.hb_all = w.te_hb_all; }
         MMVAE_TRY(launch_coco_enc_fwd(a, s));
@@ -411,7 +422,8 @@ int coco_text_enc_fwd(CocoPlan& P, const float* text, int save, float* out, hipS
         a.gi = w.te_gi_r; a.ldgi = G; a.gh = w.te_gh; a.hprev = w.zeros_h; a.h = w.te_hb; a.sav = save ? w.te_sav_r : nullptr; a.rows = B;
         MMVAE_TRY(gru_fwd(a, s));
     }
-    MMVAE_TRY(add2(w.te_h + (size_t)(T - 1) * B * H, w.te_hb, (long long)B * H, w.te_sum, s));
+    const float* h_last = bf16_path && P.text_bf16 && coco_enc_resident(P) ? w.te_hlast : w.te_h + (size_t)(T - 1) * B * H;
+    MMVAE_TRY(add2(h_last, w.te_hb, (long long)B * H, w.te_sum, s));
     return lin(w.te_sum, H, B, p + P.te_h2p_w, D2, H, H, 0, p + P.te_h2p_b, nullptr, 0, out, D2, s);
 }
 
@@ -428,6 +440,7 @@ int coco_text_enc_bwd(CocoPlan& P, const float* text, const float* d_out, hipStr
         CocoEncBwdArgs a{};
         a.B = B; a.T = T; a.dh_init = w.te_dsum; a.sav = w.te_sav; a.h_all = w.te_h;
         a.w_hhT = P.buf.packed + P.pk.d[P.tb_e_hhT].dst_off; a.dgi_b = w.te_dgi_b; a.dgh_b = w.te_dgh_b;
+        a.resident = coco_enc_resident(P);
         MMVAE_TRY(launch_coco_enc_bwd(a, s));
         MMVAE_TRY(coco_text_dec_wgrads(P, so));      // the caption decoder's weight gradients, deferred to here by the step
     }

@@ -426,7 +426,10 @@ __global__ __launch_bounds__(NTHR) void coco_enc_fwd_kernel(const CocoEncFwdArgs
 // nothing.  The weights are packed per gate (three fragment-major [208][224] matrices), a wave owns unit blocks
 // wave and wave + 8 of ALL THREE gates, so r, z and n of a hidden unit meet in the accumulators of one lane (MFMA C layout:
 // rows 4*(lane/16) .. +3 of column lane%16) and the gate math runs in registers -- the state h lives there too, in fp32.
-// One barrier per step (the bf16 copy of h that feeds the next step's A operand is double-buffered in LDS).
+// What a lane owns is 4 consecutive ROWS of one unit, so the per-step operands and saves of this path are laid out with
+// the batch row as the fastest index ([t][gate][unit][B]): one 16-byte load / store per (gate, unit) instead of four
+// scattered ones.  The bf16 copy of h (next step's A operand, and the row-major operand of the batched weight gradient)
+// is double-buffered in LDS and written out by all threads as 16-byte vectors one step later.  One barrier per step.
 template <bool SAVE>
 __global__ __launch_bounds__(NTHR) void coco_enc_fwd_res_kernel(const CocoEncFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -435,7 +438,6 @@ __global__ __launch_bounds__(NTHR) void coco_enc_fwd_res_kernel(const CocoEncFwd
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
     const int r0 = blockIdx.x * TR, R = a.B, T = a.T;
-    const size_t RH = (size_t)R * H;
     constexpr int KS = HP / 32, NB = (H + 15) / 16;                 // 7 k-steps, 13 unit blocks
     constexpr size_t GATE = (size_t)NB * 16 * HP;                   // elements of one packed gate matrix
     const bool two = wave + NW < NB;                                // waves 0-4 own a second block
@@ -457,29 +459,31 @@ __global__ __launch_bounds__(NTHR) void coco_enc_fwd_res_kernel(const CocoEncFwd
         const int j = min(ju[i], H - 1);
         br[i] = a.bhh[j]; bz[i] = a.bhh[H + j]; bn[i] = a.bhh[2 * H + j];
     }
-    size_t grow[4]; bool rok[4];
-#pragma unroll
-    for (int jr = 0; jr < 4; ++jr) { rok[jr] = r0 + fq * 4 + jr < R; grow[jr] = rok[jr] ? r0 + fq * 4 + jr : 0; }
-    if (SAVE && tid < TR && r0 + tid < R) {      // slice 0 of the saved operand: h before the first step (zeros) + the 1.0 column
-        bf16* p = a.hb_all + (size_t)(r0 + tid) * HP;
-        for (int j = 0; j < H; ++j) p[j] = (bf16)0.f;
-        p[H] = (bf16)1.f;
-    }
+    const int row4 = r0 + fq * 4;                                   // this lane's 4 rows (B is a multiple of 4: all or none exist)
+    const bool rok = row4 < R;
+    const size_t rbase = rok ? row4 : 0;
+    // copy of a finished 16-row bf16 state tile to the [t][row] operand of the weight gradient: thread -> (row, 16-byte vector)
+    const int crow = tid / (HP / 8), cvec = tid - crow * (HP / 8);
+    auto put_rows = [&](const bf16* src, int slice) {
+        if (tid < TR * (HP / 8) && r0 + crow < R) {
+            bf16x8 v = *reinterpret_cast<const bf16x8*>(src + crow * LDH + cvec * 8);
+            if (cvec == H / 8) v[0] = (bf16)1.f;                    // column H = 1.0: the bias gradient rides in the weight gradient
+            *reinterpret_cast<bf16x8*>(a.hb_all + ((size_t)slice * R + r0 + crow) * HP + cvec * 8) = v;
+        }
+    };
     float hst[2][4] = {};
     __syncthreads();
     for (int t = 0; t < T; ++t) {
         const bf16* hc = hb + (t & 1) * TR * LDH;
         bf16* hn_b = hb + ((t + 1) & 1) * TR * LDH;
-        // this step's input projection (+ b_ih), requested before the MFMAs
-        float gi[2][3][4];
+        // this step's input projection (+ b_ih), [t][gate*H + unit][B]: requested before the MFMAs
+        f32x4 gi[2][3];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int jr = 0; jr < 4; ++jr) {
-                const float* p = a.gi + (grow[jr] * T + t) * G + min(ju[i], H - 1);
-#pragma unroll
-                for (int g = 0; g < 3; ++g) gi[i][g][jr] = p[g * H];
-            }
+            for (int g = 0; g < 3; ++g)
+                gi[i][g] = *reinterpret_cast<const f32x4*>(a.gi + ((size_t)t * G + g * H + min(ju[i], H - 1)) * R + rbase);
+        if (SAVE) put_rows(hc, t);                                  // h BEFORE this step (slice 0 = zeros)
         bf16x8 af[KS];
 #pragma unroll
         for (int s = 0; s < KS; ++s) af[s] = *reinterpret_cast<const bf16x8*>(hc + fr * LDH + s * 32 + fq * 8);
@@ -498,6 +502,7 @@ __global__ __launch_bounds__(NTHR) void coco_enc_fwd_res_kernel(const CocoEncFwd
             }
             if (uok[i]) {
                 const int j = ju[i];
+                f32x4 vr, vz, vn, vg, vh;
 #pragma unroll
                 for (int jr = 0; jr < 4; ++jr) {
                     const float r = sigm(gi[i][0][jr] + acc[0][jr] + br[i]);
@@ -506,24 +511,140 @@ __global__ __launch_bounds__(NTHR) void coco_enc_fwd_res_kernel(const CocoEncFwd
                     const float n = tanh_fast(gi[i][2][jr] + r * ghn);
                     const float hn = (1.0f - z) * n + z * hst[i][jr];
                     hst[i][jr] = hn;
-                    hn_b[(fq * 4 + jr) * LDH + j] = (bf16)hn;
-                    if (rok[jr]) {
-                        a.h_all[(size_t)t * RH + grow[jr] * H + j] = hn;
-                        if (SAVE) {
-                            float* sv = a.sav + ((size_t)t * R + grow[jr]) * 4 * H;
-                            sv[j] = r; sv[H + j] = z; sv[2 * H + j] = n; sv[3 * H + j] = ghn;
-                            if (t + 1 < T) a.hb_all[((size_t)(t + 1) * R + grow[jr]) * HP + j] = (bf16)hn;
-                        }
-                    }
+                    hn_b[(fq * 4 + jr) * LDH + j] = (bf16)(rok ? hn : 0.f);
+                    vr[jr] = r; vz[jr] = z; vn[jr] = n; vg[jr] = ghn; vh[jr] = hn;
+                    if (rok && t + 1 == T) a.h_last[(rbase + jr) * H + j] = hn;
+                }
+                if (SAVE && rok) {
+                    float* sv = a.sav + ((size_t)t * 4 * H + j) * R + rbase;          // [t][gate][unit][B]
+                    *reinterpret_cast<f32x4*>(sv) = vr;
+                    *reinterpret_cast<f32x4*>(sv + (size_t)H * R) = vz;
+                    *reinterpret_cast<f32x4*>(sv + (size_t)2 * H * R) = vn;
+                    *reinterpret_cast<f32x4*>(sv + (size_t)3 * H * R) = vg;
+                    *reinterpret_cast<f32x4*>(a.h_all + ((size_t)t * H + j) * R + rbase) = vh;    // [t][unit][B]
                 }
             }
         }
-        if (SAVE && wave == 0 && fr == 0 && t + 1 < T) {
+        __syncthreads();
+    }
+}
+
+// BPTT with W_hh^T resident (253 KB: a wave's first 16-unit tile in 76 VGPRs, the second one of waves 0-4 in 97 KB of
+// LDS).  The product dgh[t] * W_hh lands in the MFMA C layout, i.e. with the lane that owns (4 rows, unit j) of the gate
+// backward: the carried gradient never leaves registers.  dgh / dgi are written to LDS row-major (the next product's A
+// operand) and copied from there to the [t][row] operands of the batched weight gradients with 16-byte stores.
+__global__ __launch_bounds__(NTHR) void coco_enc_bwd_res_kernel(const CocoEncBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* dgb = reinterpret_cast<bf16*>(smem);                      // [2][16][LDGK] dgh (r | z | n*r)
+    bf16* dnb = dgb + 2 * TR * LDGK;                                // [2][16][LDH]  dn (the n-columns of dgi)
+    bf16* wl = dnb + 2 * TR * LDH;                                  // [5 waves][19 k-steps][64 lanes][8]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int r0 = blockIdx.x * TR, R = a.B, T = a.T;
+    constexpr int KS = GP / 32, NB = (H + 15) / 16;                 // 19 k-steps, 13 unit tiles
+    const bool two = wave + NW < NB;
+    bf16x8 w0[KS];
 #pragma unroll
-            for (int jr = 0; jr < 4; ++jr)
-                if (rok[jr]) a.hb_all[((size_t)(t + 1) * R + grow[jr]) * HP + H] = (bf16)1.f;
+    for (int s = 0; s < KS; ++s) {
+        w0[s] = *reinterpret_cast<const bf16x8*>(a.w_hhT + ((size_t)(wave * KS + s) * 64 + lane) * 8);
+        if (two) *reinterpret_cast<bf16x8*>(wl + ((size_t)(wave * KS + s) * 64 + lane) * 8) =
+            *reinterpret_cast<const bf16x8*>(a.w_hhT + ((size_t)((wave + NW) * KS + s) * 64 + lane) * 8);
+    }
+    for (int i = tid; i < 2 * TR * LDGK + 2 * TR * LDH; i += NTHR) dgb[i] = (bf16)0.f;
+    int ju[2]; bool uok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { ju[i] = (wave + NW * i) * 16 + fr; uok[i] = (i == 0 || two) && ju[i] < H; }
+    const int row4 = r0 + fq * 4;
+    const bool rok = row4 < R;
+    const size_t rbase = rok ? row4 : 0;
+    float dcar[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jr = 0; jr < 4; ++jr) dcar[i][jr] = rok && uok[i] ? a.dh_init[(rbase + jr) * H + ju[i]] : 0.f;
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    f32x4 sv[2][4], hp[2];
+    auto fetch = [&](int t) {           // saved gates of step t and h[t-1], [..][unit][B]
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int j = min(ju[i], H - 1);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) sv[i][g] = *reinterpret_cast<const f32x4*>(a.sav + ((size_t)(t * 4 + g) * H + j) * R + rbase);
+            hp[i] = t > 0 ? *reinterpret_cast<const f32x4*>(a.h_all + ((size_t)(t - 1) * H + j) * R + rbase) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    fetch(T - 1);
+    __syncthreads();
+    for (int t = T - 1; t >= 0; --t) {
+        bf16* dg = dgb + (t & 1) * TR * LDGK;
+        bf16* dn_s = dnb + (t & 1) * TR * LDH;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if (!uok[i]) continue;
+            const int j = ju[i];
+#pragma unroll
+            for (int jr = 0; jr < 4; ++jr) {
+                float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f, dd = 0.f;
+                if (rok) {
+                    const float r = sv[i][0][jr], z = sv[i][1][jr], n = sv[i][2][jr], ghn = sv[i][3][jr];
+                    const float d = dcar[i][jr] + acc[i][jr];
+                    dn = d * (1.0f - z) * (1.0f - n * n);
+                    dz = d * (hp[i][jr] - n) * z * (1.0f - z);
+                    dr = dn * ghn * r * (1.0f - r);
+                    dnr = dn * r;
+                    dd = d * z;
+                }
+                dcar[i][jr] = dd;
+                bf16* p = dg + (fq * 4 + jr) * LDGK;
+                p[j] = (bf16)dr; p[H + j] = (bf16)dz; p[2 * H + j] = (bf16)dnr;
+                dn_s[(fq * 4 + jr) * LDH + j] = (bf16)dn;
+            }
         }
         __syncthreads();
+        if (t > 0) fetch(t - 1);
+        // [t][row] operands of the batched weight gradients: dgh as it stands, dgi = dgh with the n-columns replaced by dn
+        for (int v = tid; v < TR * (GP / 8); v += NTHR) {
+            const int row = v / (GP / 8), c = v - row * (GP / 8);
+            if (r0 + row < R) {
+                const bf16x8 x = *reinterpret_cast<const bf16x8*>(dg + row * LDGK + c * 8);
+                const size_t o = ((size_t)t * R + r0 + row) * GP + c * 8;
+                *reinterpret_cast<bf16x8*>(a.dgh_b + o) = x;
+                const bool ncol = c * 8 >= 2 * H && c * 8 < 3 * H;
+                *reinterpret_cast<bf16x8*>(a.dgi_b + o) = ncol ? *reinterpret_cast<const bf16x8*>(dn_s + row * LDH + c * 8 - 2 * H) : x;
+            }
+        }
+        if (t > 0) {        // dh[t-1] += dgh[t] * W_hh
+            bf16x8 af[KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) af[s] = *reinterpret_cast<const bf16x8*>(dg + fr * LDGK + s * 32 + fq * 8);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (i == 1 && !two) break;
+                f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const bf16x8 wv = i == 0 ? w0[s] : *reinterpret_cast<const bf16x8*>(wl + ((size_t)(wave * KS + s) * 64 + lane) * 8);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s], wv, c, 0, 0, 0);
+                }
+                acc[i] = c;
+            }
+        }
+    }
+}
+
+// [B][T][G] -> [T][G][B] (the weight-resident encoder kernels read 4 consecutive rows of one column as one vector)
+__global__ __launch_bounds__(256) void gi_transpose_kernel(const float* src, int B, int T, float* dst) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z, g0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int b = b0 + r, g = g0 + tx;
+        tile[r][tx] = (b < B && g < G) ? src[((size_t)b * T + t) * G + g] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int g = g0 + r, b = b0 + tx;
+        if (g < G && b < B) dst[((size_t)t * G + g) * B + b] = tile[tx][r];
     }
 }
 
@@ -663,7 +784,8 @@ int launch_coco_enc_fwd(const CocoEncFwdArgs& a, hipStream_t s) {
         big(&coco_enc_fwd_kernel<true>); big(&coco_enc_fwd_kernel<false>);
         big(&coco_enc_fwd_res_kernel<true>); big(&coco_enc_fwd_res_kernel<false>);
     }
-    if (a.resident) {       // a.w_hh = three per-gate matrices, back to back
+    if (a.resident) {       // a.w_hh = three per-gate matrices, back to back; gi / sav / h_all with the batch row fastest
+        MMVAE_REQUIRE(a.B % 4 == 0 && a.h_last, "coco_enc_fwd (resident): batch must be a multiple of 4");
         const size_t lds = (size_t)(2 * TR * LDH + 5 * 3 * (HP / 32) * 64 * 8) * sizeof(bf16);
         if (a.sav) hipLaunchKernelGGL(coco_enc_fwd_res_kernel<true>, dim3(ceil_div(a.B, TR)), dim3(NTHR), lds, s, a);
         else hipLaunchKernelGGL(coco_enc_fwd_res_kernel<false>, dim3(ceil_div(a.B, TR)), dim3(NTHR), lds, s, a);
@@ -675,12 +797,24 @@ int launch_coco_enc_fwd(const CocoEncFwdArgs& a, hipStream_t s) {
     return mmvae_check_launch("coco_enc_fwd");
 }
 int launch_coco_enc_bwd(const CocoEncBwdArgs& a, hipStream_t s) {
-    const size_t lds = (size_t)(TR * H + TR * LDT) * sizeof(float) + (size_t)(TR * LDGK) * sizeof(bf16);
     static std::atomic<unsigned> once{0};
-    if (mmvae_first_use_on_device(once))
+    if (mmvae_first_use_on_device(once)) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&coco_enc_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&coco_enc_bwd_res_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    if (a.resident) {
+        MMVAE_REQUIRE(a.B % 4 == 0, "coco_enc_bwd (resident): batch must be a multiple of 4");
+        const size_t lds = (size_t)(2 * TR * LDGK + 2 * TR * LDH + 5 * (GP / 32) * 64 * 8) * sizeof(bf16);
+        hipLaunchKernelGGL(coco_enc_bwd_res_kernel, dim3(ceil_div(a.B, TR)), dim3(NTHR), lds, s, a);
+        return mmvae_check_launch("coco_enc_bwd_res");
+    }
+    const size_t lds = (size_t)(TR * H + TR * LDT) * sizeof(float) + (size_t)(TR * LDGK) * sizeof(bf16);
     hipLaunchKernelGGL(coco_enc_bwd_kernel, dim3(ceil_div(a.B, TR)), dim3(NTHR), lds, s, a);
     return mmvae_check_launch("coco_enc_bwd");
+}
+int launch_coco_gi_transpose(const float* src, int B, int T, float* dst, hipStream_t s) {
+    hipLaunchKernelGGL(gi_transpose_kernel, dim3(ceil_div(G, 32), ceil_div(B, 32), T), dim3(256), 0, s, src, B, T, dst);
+    return mmvae_check_launch("coco_gi_transpose");
 }
 int launch_coco_text_tb(const float* text, int B, int T, int ld, bf16* dst, hipStream_t s) {
     hipLaunchKernelGGL(text_tb_kernel, dim3((unsigned)(((long long)B * T * E + 255) / 256)), dim3(256), 0, s, text, B, T, ld, dst);
