@@ -472,17 +472,26 @@ __global__ __launch_bounds__(NTHR) void coco_enc_fwd_res_kernel(const CocoEncFwd
         }
     };
     float hst[2][4] = {};
-    __syncthreads();
-    for (int t = 0; t < T; ++t) {
-        const bf16* hc = hb + (t & 1) * TR * LDH;
-        bf16* hn_b = hb + ((t + 1) & 1) * TR * LDH;
-        // this step's input projection (+ b_ih), [t][gate*H + unit][B]: requested before the MFMAs
-        f32x4 gi[2][3];
+    // the input projection (+ b_ih) of a step, [t][gate*H + unit][B], is requested a whole step ahead: it comes from HBM /
+    // Infinity Cache (31 MB per pass), and one MFMA phase does not cover that latency
+    f32x4 gi[2][3], gnx[2][3];
+    auto fetch = [&](f32x4 (&dst)[2][3], int t) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int g = 0; g < 3; ++g)
-                gi[i][g] = *reinterpret_cast<const f32x4*>(a.gi + ((size_t)t * G + g * H + min(ju[i], H - 1)) * R + rbase);
+                dst[i][g] = *reinterpret_cast<const f32x4*>(a.gi + ((size_t)t * G + g * H + min(ju[i], H - 1)) * R + rbase);
+    };
+    fetch(gnx, 0);
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const bf16* hc = hb + (t & 1) * TR * LDH;
+        bf16* hn_b = hb + ((t + 1) & 1) * TR * LDH;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 3; ++g) gi[i][g] = gnx[i][g];
+        if (t + 1 < T) fetch(gnx, t + 1);
         if (SAVE) put_rows(hc, t);                                  // h BEFORE this step (slice 0 = zeros)
         bf16x8 af[KS];
 #pragma unroll
@@ -563,21 +572,29 @@ __global__ __launch_bounds__(NTHR) void coco_enc_bwd_res_kernel(const CocoEncBwd
 #pragma unroll
         for (int jr = 0; jr < 4; ++jr) dcar[i][jr] = rok && uok[i] ? a.dh_init[(rbase + jr) * H + ju[i]] : 0.f;
     f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    f32x4 sv[2][4], hp[2];
-    auto fetch = [&](int t) {           // saved gates of step t and h[t-1], [..][unit][B]
+    // saved gates of a step and h[t-1] ([..][unit][B]) are requested a whole step ahead (HBM / Infinity Cache latency)
+    f32x4 sv[2][4], hp[2], svn[2][4], hpn[2];
+    auto fetch = [&](f32x4 (&s4)[2][4], f32x4 (&h4)[2], int t) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int j = min(ju[i], H - 1);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) sv[i][g] = *reinterpret_cast<const f32x4*>(a.sav + ((size_t)(t * 4 + g) * H + j) * R + rbase);
-            hp[i] = t > 0 ? *reinterpret_cast<const f32x4*>(a.h_all + ((size_t)(t - 1) * H + j) * R + rbase) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int g = 0; g < 4; ++g) s4[i][g] = *reinterpret_cast<const f32x4*>(a.sav + ((size_t)(t * 4 + g) * H + j) * R + rbase);
+            h4[i] = t > 0 ? *reinterpret_cast<const f32x4*>(a.h_all + ((size_t)(t - 1) * H + j) * R + rbase) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
-    fetch(T - 1);
+    fetch(svn, hpn, T - 1);
     __syncthreads();
     for (int t = T - 1; t >= 0; --t) {
         bf16* dg = dgb + (t & 1) * TR * LDGK;
         bf16* dn_s = dnb + (t & 1) * TR * LDH;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            hp[i] = hpn[i];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) sv[i][g] = svn[i][g];
+        }
+        if (t > 0) fetch(svn, hpn, t - 1);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             if (!uok[i]) continue;
@@ -601,7 +618,6 @@ __global__ __launch_bounds__(NTHR) void coco_enc_bwd_res_kernel(const CocoEncBwd
             }
         }
         __syncthreads();
-        if (t > 0) fetch(t - 1);
         // [t][row] operands of the batched weight gradients: dgh as it stands, dgi = dgh with the n-columns replaced by dn
         for (int v = tid; v < TR * (GP / 8); v += NTHR) {
             const int row = v / (GP / 8), c = v - row * (GP / 8);
@@ -613,21 +629,28 @@ __global__ __launch_bounds__(NTHR) void coco_enc_bwd_res_kernel(const CocoEncBwd
                 *reinterpret_cast<bf16x8*>(a.dgi_b + o) = ncol ? *reinterpret_cast<const bf16x8*>(dn_s + row * LDH + c * 8 - 2 * H) : x;
             }
         }
-        if (t > 0) {        // dh[t-1] += dgh[t] * W_hh
-            bf16x8 af[KS];
+        if (t > 0) {        // dh[t-1] += dgh[t] * W_hh  (A fragments in two halves: registers)
+            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s = 0; s < KS; ++s) af[s] = *reinterpret_cast<const bf16x8*>(dg + fr * LDGK + s * 32 + fq * 8);
+            for (int half = 0; half < 2; ++half) {
+                constexpr int HS = (KS + 1) / 2;
+                bf16x8 af[HS];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                if (i == 1 && !two) break;
-                f32x4 c = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    const bf16x8 wv = i == 0 ? w0[s] : *reinterpret_cast<const bf16x8*>(wl + ((size_t)(wave * KS + s) * 64 + lane) * 8);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s], wv, c, 0, 0, 0);
+                for (int q = 0; q < HS; ++q) {
+                    const int s = half * HS + q;
+                    if (s < KS) af[q] = *reinterpret_cast<const bf16x8*>(dg + fr * LDGK + s * 32 + fq * 8);
                 }
-                acc[i] = c;
+#pragma unroll
+                for (int q = 0; q < HS; ++q) {
+                    const int s = half * HS + q;
+                    if (s < KS) {
+                        c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[q], w0[s], c0, 0, 0, 0);
+                        if (two) c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                     af[q], *reinterpret_cast<const bf16x8*>(wl + ((size_t)(wave * KS + s) * 64 + lane) * 8), c1, 0, 0, 0);
+                    }
+                }
             }
+            acc[0] = c0; acc[1] = c1;
         }
     }
 }
