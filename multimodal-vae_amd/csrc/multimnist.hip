@@ -148,9 +148,10 @@ void build_plan(MMPlan& P) {
         f.pk_dgrad = P.pk.add(t);
     }
     // ---- text packs (row-tile kernels): [round16(N)][round32(K)] bf16, plus transposed copies for backward
-    auto rt = [&](long long w, int N, int K, bool transpose) {
-        if (!transpose) return P.pk.add(pack_dense(w, N, K, round_up(N, 16), round_up(K, 32), K, 1));
-        return P.pk.add(pack_dense(w, K, N, round_up(K, 16), round_up(N, 32), 1, K));
+    auto rt = [&](long long w, int N, int K, bool transpose) {       // fragment-major: text.hip rowtile_gemm
+        PackDesc d = transpose ? pack_dense(w, K, N, round_up(K, 16), round_up(N, 32), 1, K) : pack_dense(w, N, K, round_up(N, 16), round_up(K, 32), K, 1);
+        d.frag = 1;
+        return P.pk.add(d);
     };
     auto gw = [&](long long w, int N, int K, int Kc) {   // wgrad target: [round64(N)][round64(Kc)] with K valid columns
         return P.gk.add(pack_dense(w, N, K, round_up(N, 64), round_up(Kc, 64), K, 1));

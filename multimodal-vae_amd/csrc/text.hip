@@ -19,7 +19,7 @@ constexpr int GK = TXT_G3K;  // 320
 __device__ __forceinline__ float sigm(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanh_fast(float x) { return 2.0f * __frcp_rn(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
-// out[16][ldo] = A[16][32*ksteps] * Wp[16*ntiles][kpad]^T
+// out[16][ldo] = A[16][32*ksteps] * Wp[16*ntiles][kpad]^T   (Wp fragment-major)
 // Each wave owns the column tiles wave, wave+NW, ... (at most MAXT).  ALL of its weight fragments (MAXT x ksteps
 // independent 16-byte loads, clamped so that no branch surrounds a load) are issued before the first MFMA: one L2
 // round trip per GEMM instead of one per tile -- the recurrence is a latency chain, not a bandwidth problem.
@@ -33,9 +33,11 @@ __device__ __forceinline__ void rowtile_gemm(const bf16* A, int lda, int ksteps,
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
         const int nt = min(wave + t * NW, ntiles - 1);
-        const bf16* w = Wp + (size_t)(nt * 16 + fr) * kpad + fq * 8;
+        // fragment-major packs (PackDesc::frag): the 64 lanes' vectors of one (tile, k-step) are one contiguous 1 KB block, so
+        // a wave's load is fully coalesced (row-major rows touched 16 half-used cache lines per instruction)
+        const bf16* w = Wp + ((size_t)nt * (kpad >> 5) * 64 + lane) * 8;
 #pragma unroll
-        for (int ks = 0; ks < MAXKS; ++ks) bw[t][ks] = *reinterpret_cast<const bf16x8*>(w + min(ks, ksteps - 1) * 32);
+        for (int ks = 0; ks < MAXKS; ++ks) bw[t][ks] = *reinterpret_cast<const bf16x8*>(w + min(ks, ksteps - 1) * 512);
     }
     bf16x8 af[MAXKS];
 #pragma unroll
