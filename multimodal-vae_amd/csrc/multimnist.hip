@@ -417,7 +417,10 @@ int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const
         GatherPlan pl = dense_plan(B * 625, 16, 16, 32);
         WgradParams g = wgrad_of(P, pl, P.conv[0].gk, 1, B * 625);
         g.c.A = w.patches1; g.P = w.d1e; g.ldp = 32;
-        MMVAE_TRY(launch_wgrad(g, s, &P.slab));
+        // fp32 atomics into the (zeroed) packed gradient instead of slab copies + a reduce launch: this is the last kernel in
+        // front of the optimizer, a second launch here is pure tail latency (the tile is 32 x 16)
+        static const bool slab_last = getenv("MMVAE_CONV1_WGRAD_SLAB") != nullptr;      // A/B aid
+        MMVAE_TRY(launch_wgrad(g, s, slab_last ? &P.slab : nullptr));
     }
     return MMVAE_OK;
 }
