@@ -95,6 +95,13 @@ def build_parser() -> argparse.ArgumentParser:
 
 
 def main(argv=None) -> dict:
+    """Single GPU: ``python -m multimodal_vae_amd.train --cuda ...``.  Data parallel (BASELINE configuration 4, one process
+    per GPU): ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 -m
+    multimodal_vae_amd.train --cuda ...`` -- every rank trains on its own shard of the training set with the per-GPU
+    ``--batch_size``, gradients are summed over RCCL (1/world inside Adam), rank 0 prints and writes checkpoints, the
+    BatchNorm running statistics are averaged over the ranks before every test pass / checkpoint."""
+    from . import dp
+    dp.ensure_ipc_env()                  # before the first GPU call (torch.cuda.is_available() below is one)
     args = build_parser().parse_args(argv)
     args.cuda = args.cuda and torch.cuda.is_available()
     if not args.cuda:
@@ -103,7 +110,15 @@ def main(argv=None) -> dict:
     from .multimnist import FusedTrainer, MultimodalVAE
     from .utils import tensor_to_string
 
+    world, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local)
     dev = torch.device("cuda", torch.cuda.current_device())
+    rank, world, _ = dp.init_distributed("nccl", dev)
+    chief = rank == 0
+    if not chief:
+        global print
+        print = lambda *a, **k: None     # noqa: E731  (rank 0 reports)
     torch.manual_seed(args.seed)
     if args.synthetic > 0:
         n_test = max(args.batch_size, args.synthetic // 6)
@@ -114,11 +129,20 @@ def main(argv=None) -> dict:
     else:
         tr_x, tr_t = D.load_multimnist(args.data, train=True)
         te_x, te_t = D.load_multimnist(args.data, train=False)
-    train_loader = D.DeviceBatcher(tr_x, tr_t, args.batch_size, dev, shuffle=True, seed=args.seed)
-    test_loader = D.DeviceBatcher(te_x, te_t, args.batch_size, dev, shuffle=True, seed=args.seed + 7)
+    if world > 1:                        # rank r trains / tests on samples r, r + world, ... (equal shard sizes)
+        n_tr, n_te = len(tr_x) // world * world, len(te_x) // world * world
+        tr_x, tr_t, te_x, te_t = tr_x[rank:n_tr:world], tr_t[rank:n_tr:world], te_x[rank:n_te:world], te_t[rank:n_te:world]
+    train_loader = D.DeviceBatcher(tr_x, tr_t, args.batch_size, dev, shuffle=True, seed=dp.rank_seed(args.seed, rank))
+    test_loader = D.DeviceBatcher(te_x, te_t, args.batch_size, dev, shuffle=True, seed=dp.rank_seed(args.seed + 7, rank))
 
     vae = MultimodalVAE(args.n_latents, use_cuda=True).cuda()
-    trainer = FusedTrainer(vae, args.batch_size, lr=args.lr, kl_lambda=1e-3, seed=args.seed)
+    trainer = FusedTrainer(vae, args.batch_size, lr=args.lr, kl_lambda=1e-3, seed=dp.rank_seed(args.seed, rank), world_size=world,
+                           all_reduce=dp.GradAllReduce() if world > 1 else None)
+    state = trainer.engine.state
+    dp.broadcast_flat(state.params)      # identical replicas (every rank seeds the same initialisation anyway)
+    dp.broadcast_flat(state.bn_stats)
+    if world > 1:
+        state.pack_weights()
 
     def train(epoch, kl_lambda):
         vae.train()
@@ -149,12 +173,17 @@ def main(argv=None) -> dict:
     def test(kl_lambda):
         vae.eval()
         trainer.engine.kl_lambda = kl_lambda
+        dp.sync_bn_buffers(state.bn_stats, state.bn_nbt)     # eval (and the checkpoint below) see the ranks' average
         acc = torch.zeros(3, device=dev)
         nb = 0
         for image, text in test_loader:
             acc += trainer.evaluate(image, text).losses()
             nb += 1
-        j, i, t = (acc / max(nb, 1)).cpu().tolist()
+        acc = acc / max(nb, 1)
+        if world > 1:
+            torch.distributed.all_reduce(acc)
+            acc = acc / world
+        j, i, t = acc.cpu().tolist()
         print('====> Test Epoch\tJoint loss: {:.4f}\tImage loss: {:.4f}\tText loss:{:.4f}'.format(j, i, t))
         return j + i + t, (j, i, t)
 
@@ -179,17 +208,18 @@ def main(argv=None) -> dict:
         is_best = loss < best_loss
         best_loss = min(loss, best_loss)
         eng = trainer.engine
-        save_checkpoint({
-            'state_dict': vae.state_dict(),
-            'best_loss': best_loss,
-            'joint_loss': joint_loss,
-            'image_loss': image_loss,
-            'text_loss': text_loss,
-            'n_latents': args.n_latents,
-            # torch.optim.Adam.state_dict() layout, so that optim.Adam(...).load_state_dict() accepts it
-            'optimizer': adam_state_dict(vae, eng),
-        }, is_best, folder=args.out)
-        if args.results:
+        if chief:
+            save_checkpoint({
+                'state_dict': vae.state_dict(),
+                'best_loss': best_loss,
+                'joint_loss': joint_loss,
+                'image_loss': image_loss,
+                'text_loss': text_loss,
+                'n_latents': args.n_latents,
+                # torch.optim.Adam.state_dict() layout, so that optim.Adam(...).load_state_dict() accepts it
+                'optimizer': adam_state_dict(vae, eng),
+            }, is_best, folder=args.out)
+        if args.results and chief:
             os.makedirs(args.results, exist_ok=True)
             sample = torch.randn(64, args.n_latents, device=dev)
             vae.eval()
@@ -203,6 +233,9 @@ def main(argv=None) -> dict:
             with open(os.path.join(args.results, 'sample_text_epoch%d.txt' % epoch), 'w') as fp:
                 for i in range(text_sample.size(0)):
                     fp.write('%s\n' % tensor_to_string(text_sample[i]))
+    if world > 1:
+        dp.barrier(dev)
+        torch.distributed.destroy_process_group()
     return history
 
 
