@@ -319,6 +319,12 @@ int try_launch_gemm_small(const GemmParams& pin, hipStream_t stream) {
     // only problems that leave most of the chip idle under 128-row tiles
     const long long tiles128 = (long long)max_tiles128 * c.groups * c.nclasses * ceil_div(c.N, 128);
     if (tiles128 > 128) return 0;
+    {   // ... and not the long-K giants: one wave per 32x32 tile re-reads both operands from L2 with no reuse
+        static const double cap = getenv("MMVAE_SMALL_MAX_GFLOP") ? atof(getenv("MMVAE_SMALL_MAX_GFLOP")) : 8.0;   // CelebA classifier.0 (13.4 GFLOP): 107 us here, ~35 us tiled + split-K
+        double fl = 0.0;
+        for (int i = 0; i < c.nclasses; ++i) fl += 2.0 * pin.cls[i].rows_per_group * c.groups * c.N * pin.cls[i].K;
+        if (cap > 0.0 && fl > cap * 1e9) return 0;
+    }
     const long long nimg_a = c.a_bcast_n > 0 ? c.a_bcast_n : (long long)c.groups * c.group_n;
     if (nimg_a * c.AH * c.AW * c.Ald * 2 >= (1ll << 31)) return 0;                 // 32-bit buffer offsets
     if ((long long)c.groups * c.group_n * c.OH * c.OW >= (1ll << 31) || rows_total >= (1ll << 23)) return 0;
