@@ -324,6 +324,7 @@ typedef struct {
     float* recon_text;                      /* out [3][B][steps][300] or NULL */
     float* mu; float* logvar;               /* out [3][B][D] or NULL */
     int pass_skip[3];                       /* 1: pass k absent from this step */
+    int defer_unpack;                       /* 1: the optimizer consumes the packed gradients itself (see the MultiMNIST step) */
 } mmvae_coco_step_io;
 int mmvae_coco_step(mmvae_coco_t*, const mmvae_coco_step_io*, int training, int do_backward, void* stream);
 /* Granular modules (forward + autograd backward), workspace rules as for mmvae_mm_*_fwd/bwd */

@@ -61,6 +61,7 @@ class CocoStepIO(C.Structure):
         ("sums", C.c_void_p), ("recon_image", C.c_void_p), ("recon_text", C.c_void_p),
         ("mu", C.c_void_p), ("logvar", C.c_void_p),
         ("pass_skip", C.c_int * 3),
+        ("defer_unpack", C.c_int),
     ]
 
 

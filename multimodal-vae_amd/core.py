@@ -523,9 +523,12 @@ class FusedCocoStep(_FusedStepBase):
         passes, lxy, lyx = self._last
         return StepOutputs(self.sums, self.B * 3 * 32 * 32, self.B * self.T * self.EMB, self.kl_lambda / self.B, lxy, lyx, passes)
 
+    def __call__(self, image, text, **kw) -> StepOutputs:
+        return self._call_packed(image, text, **kw)
+
     def forward_backward(self, image, text, training=True, backward=True, eps=None, enc_mask1=None, enc_mask2=None,
                          gru_keep=None, recon_image=None, recon_text=None, mu=None, logvar=None, passes=None,
-                         lambda_xy=None, lambda_yx=None) -> StepOutputs:
+                         lambda_xy=None, lambda_yx=None, _defer_unpack=False) -> StepOutputs:
         assert image.is_contiguous() and text.is_contiguous() and image.dtype == torch.float32 and text.dtype == torch.float32
         assert image.shape == (self.B, 3, 32, 32) and text.shape == (self.B, self.T, self.EMB)
         io = _lib.CocoStepIO()
@@ -539,6 +542,7 @@ class FusedCocoStep(_FusedStepBase):
         io.kl_lambda = self.kl_lambda
         self._pass_config(io, passes, lambda_xy, lambda_yx, "lambda_xy", "lambda_yx")
         io.seed = self.seed
+        io.defer_unpack = int(bool(_defer_unpack))
         io.sums = self.sums.data_ptr()
         call("mmvae_coco_step", self.h, C.byref(io), int(training), int(backward), _stream())
         return self._outputs()

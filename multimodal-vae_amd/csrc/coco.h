@@ -26,6 +26,7 @@ struct CocoStepIO {
     float* recon_text = nullptr;        // [3][B][T][300] or null
     float* mu = nullptr; float* logvar = nullptr;   // [3][B][D] or null
     int pass_skip[3] = {0, 0, 0};       // 1: pass k is absent from this step
+    int defer_unpack = 0;               // 1: leave the GEMM-weight gradients packed (mmvae_adam_step_packed gathers them)
 };
 
 struct CocoPlan;

@@ -495,6 +495,7 @@ static int coco_step_body(CocoPlan* Pp, const CocoStepIO& io, int training, int 
     if (P.st_wgrad2 != P.st_wgrad) MMVAE_TRY(edge(P, P.st_wgrad2, s));
     hipLaunchKernelGGL(sum_slots_kernel, dim3(1), dim3(64), 0, s, w.sums, io.sums);
     MMVAE_TRY(mmvae_check_launch("sum_slots"));
+    if (io.defer_unpack) return launch_wgrad_reduce(&P.slab, s);      // the packed gradients are complete; Adam gathers them
     return unpack(P, s);
 }
 
