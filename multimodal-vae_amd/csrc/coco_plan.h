@@ -18,6 +18,10 @@ struct CocoDecFwdArgs {
     const float* sos;        // [300]
     const uint8_t* keep; float keep_scale;        // [T][R][200] inter-layer dropout keep flags or null
     const bf16 *w_ih0, *w_hh0, *w_ih1, *w_hh1, *w_ho;       // packed [608][320], [608][224] x3, [304][224]
+    // cluster form (coco_dec_fwd_cl_kernel): per-gate packs [3][208][K] of the four GRU matrices, exchange granules
+    // [row blocks][3 phases][16][200] (zeroed before the launch), timeout word; cluster = ranks per row block (0 / 1: off)
+    const bf16 *wg_ih0, *wg_hh0, *wg_ih1, *wg_hh1;
+    unsigned long long* cl_xchg; unsigned* cl_timeout; int cluster;
     const float *bhh0, *bih1, *bhh1;
     float* sentence;         // [R][T][300]
     // saved for the backward pass (null: inference)
@@ -78,7 +82,7 @@ struct CocoPlan : PlanBase {
     // bf16 persistent caption decoder: packed weights (forward and transposed forms) and packed-gradient descriptors
     bool text_bf16 = true;
     bool dec_wg_pending = false; const float* dec_wg_z = nullptr; int dec_wg_groups = 0;   // deferred weight gradients of the bf16 decoder
-    int tb_ih0, tb_hh0, tb_ih1, tb_hh1, tb_ho, tb_hoT, tb_ih1T, tb_hh1T, tb_hh0T, tb_ih0T, tb_e_hh, tb_e_hhT, tb_e_hhg[3];
+    int tb_ih0, tb_hh0, tb_ih1, tb_hh1, tb_ho, tb_hoT, tb_ih1T, tb_hh1T, tb_hh0T, tb_ih0T, tb_e_hh, tb_e_hhT, tb_e_hhg[3], tb_g_ih0[3], tb_g_hh0[3], tb_g_ih1[3], tb_g_hh1[3];
     int tg_ih0, tg_hh0, tg_ih1, tg_hh1, tg_ho, tg_e_ih, tg_e_hh;
     struct W {
         char* zero_begin; size_t zero_bytes;
@@ -104,6 +108,7 @@ struct CocoPlan : PlanBase {
         bf16 *tb_x, *tb_h0, *tb_mid, *tb_h1, *tb_dout, *tb_dgi0, *tb_dgh0, *tb_dgi1, *tb_dgh1;
         bf16 *te_xb, *te_hb_all, *te_dgi_b, *te_dgh_b;
         float *te_giT, *te_hlast;
+        char* cl_xchg; size_t cl_bytes;
     } w;
 };
 

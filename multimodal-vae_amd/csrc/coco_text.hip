@@ -337,6 +337,11 @@ void coco_text_build(CocoPlan& P) {
     P.tb_e_hhT = trp(P.te_f.whh, H, G, H, 208, CTB_GP);
     for (int g3 = 0; g3 < 3; ++g3)                               // per-gate copies for the weight-resident forward kernel
         P.tb_e_hhg[g3] = fwdp(P.te_f.whh + (long long)g3 * H * H, H, H, H, 208, CTB_HP);
+    // per-gate copies of the decoder GRUs (cluster form): the three gates of a matrix back to back
+    for (int g3 = 0; g3 < 3; ++g3) P.tb_g_ih0[g3] = fwdp(P.td0.wih + (long long)g3 * H * in0, H, E, in0, 208, CTB_XP);
+    for (int g3 = 0; g3 < 3; ++g3) P.tb_g_hh0[g3] = fwdp(P.td0.whh + (long long)g3 * H * H, H, H, H, 208, CTB_HP);
+    for (int g3 = 0; g3 < 3; ++g3) P.tb_g_ih1[g3] = fwdp(P.td1.wih + (long long)g3 * H * H, H, H, H, 208, CTB_HP);
+    for (int g3 = 0; g3 < 3; ++g3) P.tb_g_hh1[g3] = fwdp(P.td1.whh + (long long)g3 * H * H, H, H, H, 208, CTB_HP);
     // packed gradients [round64(N)][Kpad of the wgrad operand] -> scattered back by the unpack kernel
     // bias >= 0: the saved operand carries 1.0 in column K, so column K of the packed gradient is the bias gradient
     auto gkp = [&](long long w, int N, int K, int ld, int Kc, long long bias) {
@@ -374,6 +379,8 @@ void coco_text_carve(CocoPlan& P, Workspace& ws) {
         w.tb_dgi0 = ws.take<bf16>(T * R * CTB_GP); w.tb_dgh0 = ws.take<bf16>(T * R * CTB_GP);
         w.tb_dgi1 = ws.take<bf16>(T * R * CTB_GP); w.tb_dgh1 = ws.take<bf16>(T * R * CTB_GP);
         w.te_giT = ws.take<float>(B * T * G); w.te_hlast = ws.take<float>(B * H);
+        w.cl_bytes = ((R + 15) / 16) * 3 * 16 * 200 * sizeof(unsigned long long) + 64;      // cluster exchange granules + timeout word
+        w.cl_xchg = ws.take<char>(w.cl_bytes);
         w.te_xb = ws.take<bf16>(T * B * CTB_XP); w.te_hb_all = ws.take<bf16>(T * B * CTB_HP);
         w.te_dgi_b = ws.take<bf16>(T * B * CTB_GP); w.te_dgh_b = ws.take<bf16>(T * B * CTB_GP);
     }
@@ -510,6 +517,26 @@ int coco_text_dec_fwd(CocoPlan& P, const float* z, int groups, const float* sos,
         a.w_ih0 = pw(P.tb_ih0); a.w_hh0 = pw(P.tb_hh0); a.w_ih1 = pw(P.tb_ih1); a.w_hh1 = pw(P.tb_hh1); a.w_ho = pw(P.tb_ho);
         a.bhh0 = p + P.td0.bhh; a.bih1 = p + P.td1.bih; a.bhh1 = p + P.td1.bhh;
         a.sentence = sentence;
+        {   // cluster form: P workgroups per 16-row block when the row blocks leave most of the chip idle
+            const char* cl_env = getenv("MMVAE_COCO_CLUSTER");                  // (read per call: tools/coco_cluster_check.py toggles it)
+            const int want = cl_env ? atoi(cl_env) : 4;
+            const int nblk_pad = ((R + 15) / 16 + 7) / 8 * 8;
+            int Pc = want;
+            while (Pc > 1 && nblk_pad * Pc > 224) Pc /= 2;
+            if (Pc == 4 || Pc == 8) {
+                a.cluster = Pc;
+                a.wg_ih0 = pw(P.tb_g_ih0[0]); a.wg_hh0 = pw(P.tb_g_hh0[0]); a.wg_ih1 = pw(P.tb_g_ih1[0]); a.wg_hh1 = pw(P.tb_g_hh1[0]);
+                for (int g3 = 1; g3 < 3; ++g3)
+                    MMVAE_REQUIRE(P.pk.d[P.tb_g_ih0[g3]].dst_off == P.pk.d[P.tb_g_ih0[0]].dst_off + (long long)g3 * 208 * CTB_XP &&
+                                  P.pk.d[P.tb_g_hh0[g3]].dst_off == P.pk.d[P.tb_g_hh0[0]].dst_off + (long long)g3 * 208 * CTB_HP &&
+                                  P.pk.d[P.tb_g_ih1[g3]].dst_off == P.pk.d[P.tb_g_ih1[0]].dst_off + (long long)g3 * 208 * CTB_HP &&
+                                  P.pk.d[P.tb_g_hh1[g3]].dst_off == P.pk.d[P.tb_g_hh1[0]].dst_off + (long long)g3 * 208 * CTB_HP,
+                                  "per-gate decoder packs not contiguous");
+                a.cl_xchg = reinterpret_cast<unsigned long long*>(w.cl_xchg);
+                a.cl_timeout = reinterpret_cast<unsigned*>(w.cl_xchg + w.cl_bytes - 64);
+                MMVAE_TRY(launch_fill_zero(w.cl_xchg, w.cl_bytes, s));      // tags and the timeout word: zero before EVERY launch
+            }
+        }
         if (save) {
             a.h0_all = w.td_h0; a.h1_all = w.td_h1; a.sav0 = w.td_sav0; a.sav1 = w.td_sav1;
             a.xb_all = w.tb_x; a.h0b_all = w.tb_h0; a.midb_all = w.tb_mid; a.h1b_all = w.tb_h1;

@@ -178,6 +178,275 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_kernel(const CocoDecFwdArgs
     }
 }
 
+// ================================================================== forward, CLUSTER form
+// At the per-GPU batch of configuration 5 (R = 384 rows = 24 row blocks) a decoder step is bound by what ONE CU can pull out
+// of L2 (1.34 MB at ~55 GB/s = 24 us) while 230 CUs idle.  Here P workgroups (ranks) share a row block: rank r owns the
+// hidden-unit blocks r, r + P, ... of EVERY gate GEMM (weights packed per gate, so r, z and n of a unit stay together) and
+// the embedding tiles r, r + P, ... of the output projection, i.e. streams 1/P of the weights, computes the new state of
+// its units, and the ranks all-gather the new state after each of the three phases of a step through global memory:
+// 8-byte granules {epoch tag, two bf16 values} written and read with device-scope atomics -- the data is the flag, no
+// fence, one hop (guide recipe R2).  Epoch = 3 t + phase + 1, one buffer per phase: a rank can be at most one phase ahead
+// of the slowest one.  Every spin is bounded (timeout word; the kernel then runs on with NaNs, which surface in the losses).
+// Results are bit-identical to the single-workgroup kernel (same k order and the same roundings per output element).
+typedef unsigned long long u64;
+constexpr int CL_NG = 200;                          // granules per row and phase buffer
+constexpr unsigned CL_SPIN_MAX = 1u << 22;
+
+__device__ __forceinline__ void cl_put(u64* g, unsigned epoch, bf16 lo, bf16 hi) {
+    const unsigned short a = __builtin_bit_cast(unsigned short, lo), b = __builtin_bit_cast(unsigned short, hi);
+    __hip_atomic_store(g, ((u64)epoch << 32) | ((u64)b << 16) | a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void cl_get(const u64* g, unsigned epoch, bf16& lo, bf16& hi, unsigned* tmo) {
+    for (unsigned spin = 0; spin < CL_SPIN_MAX; ++spin) {
+        const u64 x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(x >> 32) == epoch) {
+            lo = __builtin_bit_cast(bf16, (unsigned short)(x & 0xffff));
+            hi = __builtin_bit_cast(bf16, (unsigned short)((x >> 16) & 0xffff));
+            return;
+        }
+        if ((spin & 31) == 31) __builtin_amdgcn_s_sleep(1);
+    }
+    // gave up: a rank of this cluster never published.  No hang: the kernel runs on, but with NaNs, so the step's losses and
+    // gradients come out NaN (loud), and the timeout word keeps the epoch for a post-mortem
+    atomicExch(tmo, epoch);
+    lo = hi = __builtin_bit_cast(bf16, (unsigned short)0x7FC0);
+}
+
+struct ClMat { __amdgpu_buffer_rsrc_t r; int ks; };     // gate matrices: per-gate packs, tile g * 13 + ub; ho: tile et
+
+// chunk `pos` (= tile slot of this wave; one chunk per tile, every K here is <= 10 k-steps) of the rank's tile list
+template <bool GATES, int P>
+__device__ __forceinline__ void cl_load(bf16x8 (&dst)[KCH], const ClMat& m, int pos, int nown, int rank, int wave, int lane) {
+    const int li = wave + NW * pos;
+    if (li >= nown) return;
+    const int tile = GATES ? (li % 3) * 13 + rank + P * (li / 3) : rank + P * li;
+    const int ub = tile * m.ks * 1024;
+#pragma unroll
+    for (int s = 0; s < KCH; ++s)
+        if (s < m.ks) dst[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(m.r, lane * 16, ub + s * 1024, 0));
+}
+
+// out[16][ldo], columns li*16 .. of this wave's tiles, = A * W^T (+ cinit).  KS = k-steps of THIS matrix.
+template <int KS, int MAXT, int MAXTN, int D, int SLOT0, bool GATES, bool GATESN, int P, bool CINIT>
+__device__ __forceinline__ void cl_gemm(const bf16* A, int lda, const ClMat& m, int nown, float* out, int ldo, bf16x8 (&ring)[D][KCH],
+                                        const ClMat& mn, int nown_n, bool has_next, int rank, int wave, int lane,
+                                        const float* cinit, int ldc, int climit, int gstride, int rows_ok) {
+    const int fr = lane & 15, fq = lane >> 4;
+    f32x4 ci[MAXT];
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+        ci[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (CINIT) {
+            const int li = wave + NW * i;
+            const int within = (GATES ? rank + P * (li / 3) : rank + P * li) * 16 + fr;     // unit / embedding column
+            const bool ok = li < nown && within < climit;
+            const int col = ok ? (GATES ? (li % 3) * gstride + within : within) : 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ci[i][j] = cinit[(size_t)min(fq * 4 + j, rows_ok - 1) * ldc + col];
+        }
+    }
+    bf16x8 af[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) af[s] = *reinterpret_cast<const bf16x8*>(A + fr * lda + s * 32 + fq * 8);
+#pragma unroll
+    for (int i = 0; i < MAXT; ++i) {
+        const int li = wave + NW * i;
+        const int slot = (SLOT0 + i) % D;
+        f32x4 acc = ci[i];
+        if (li < nown) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s], ring[slot][s], acc, 0, 0, 0);
+        }
+        if (i + D < MAXT) cl_load<GATES, P>(ring[slot], m, i + D, nown, rank, wave, lane);
+        else if (has_next && i + D - MAXT < MAXTN) cl_load<GATESN, P>(ring[slot], mn, i + D - MAXT, nown_n, rank, wave, lane);
+        if (li < nown) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[(fq * 4 + j) * ldo + li * 16 + fr] = acc[j];
+        }
+    }
+}
+
+template <bool KEEP, bool SAVE, int P>
+__global__ __launch_bounds__(NTHR) void coco_dec_fwd_cl_kernel(const CocoDecFwdArgs a) {
+    constexpr int NUBMAX = (13 + P - 1) / P, NOEMAX = (19 + P - 1) / P;           // unit blocks / embedding tiles per rank (max)
+    constexpr int MT = (3 * NUBMAX + NW - 1) / NW, MTO = (NOEMAX + NW - 1) / NW;    // tile slots per wave
+    constexpr int D = MT;                                                          // ring depth = one gate GEMM ahead
+    static_assert(MTO <= MT, "output projection slots");
+    constexpr int LDC = 3 * NUBMAX * 16 + 4;                                       // fp32 LDS row stride of the GEMM results
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ga = reinterpret_cast<float*>(smem);                     // [16][LDC]
+    float* gb = ga + TR * LDC;
+    float* bias = gb + TR * LDC;                                    // b_hh0 | b_ih1 | b_hh1, [3][G]
+    bf16* xb = reinterpret_cast<bf16*>(bias + 3 * G);               // [16][LDX]
+    bf16* h0b = xb + TR * LDX;
+    bf16* midb = h0b + TR * LDH;
+    bf16* h1b = midb + TR * LDH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nblk = (a.R + TR - 1) / TR, nblk_pad = (nblk + 7) / 8 * 8;           // ranks of a cluster: equal blockIdx % 8 (one XCD
+    const int rank = blockIdx.x / nblk_pad, blk = blockIdx.x - rank * nblk_pad;    //  under round-robin placement; speed only)
+    if (blk >= nblk) return;
+    const int r0 = blk * TR, R = a.R, T = a.T;
+    const size_t RH = (size_t)R * H;
+    const int rows_ok = min(TR, R - r0);
+    const int nub = (13 - rank + P - 1) / P, noe = (19 - rank + P - 1) / P;        // owned unit blocks / embedding tiles
+    const int ng = 3 * nub;
+    const int grow = tid >> 5, pl = tid & 31;
+    const bool gok = r0 + grow < R;
+    const size_t gr = gok ? r0 + grow : 0;
+    // this thread's pair of owned units (gate phases): local units 2*pl, 2*pl + 1 of the rank's nub*16
+    const int uk = (2 * pl) >> 4, uu = (2 * pl) & 15;
+    const int j0 = (rank + P * uk) * 16 + uu;
+    const bool uok = uk < nub && j0 < H;
+    u64* xA = a.cl_xchg + (size_t)(blk * 3 + 0) * TR * CL_NG;       // phase buffers of this cluster
+    u64* xB = a.cl_xchg + (size_t)(blk * 3 + 1) * TR * CL_NG;
+    u64* xC = a.cl_xchg + (size_t)(blk * 3 + 2) * TR * CL_NG;
+    unsigned* tmo = a.cl_timeout;
+
+    for (int i = tid; i < TR * LDX; i += NTHR) xb[i] = (bf16)0.f;
+    for (int i = tid; i < 3 * TR * LDH; i += NTHR) h0b[i] = (bf16)0.f;
+    for (int i = tid; i < G; i += NTHR) { bias[i] = a.bhh0[i]; bias[G + i] = a.bih1[i]; bias[2 * G + i] = a.bhh1[i]; }
+    __syncthreads();
+    for (int i = tid; i < TR * H; i += NTHR) {
+        const int row = i / H, j = i - row * H;
+        const float v = r0 + row < R ? a.hinit[(size_t)(r0 + row) * H + j] : 0.f;
+        h0b[row * LDH + j] = (bf16)v; h1b[row * LDH + j] = (bf16)v;
+        if (SAVE && rank == 0 && r0 + row < R) {
+            a.h0b_all[(size_t)(r0 + row) * HP + j] = (bf16)v; a.h1b_all[(size_t)(r0 + row) * HP + j] = (bf16)v;
+        }
+    }
+    for (int i = tid; i < TR * E; i += NTHR) {
+        const int row = i / E, e = i - row * E;
+        const bf16 v = (bf16)a.sos[e];
+        xb[row * LDX + e] = v;
+        if (SAVE && rank == 0 && r0 + row < R) a.xb_all[(size_t)(r0 + row) * XP + e] = v;
+    }
+    if (SAVE && rank == 0 && pl == 0 && gok) { a.h0b_all[gr * HP + H] = (bf16)1.f; a.h1b_all[gr * HP + H] = (bf16)1.f; }
+    float h0f[2] = {0.f, 0.f}, h1f[2] = {0.f, 0.f};
+    if (uok && gok) {
+        h0f[0] = h1f[0] = a.hinit[gr * H + j0]; h0f[1] = h1f[1] = a.hinit[gr * H + j0 + 1];
+    }
+    const ClMat m_ih0{__builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.wg_ih0), 0, 39 * (XP / 32) * 1024, 0x00020000), XP / 32};
+    const ClMat m_hh0{__builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.wg_hh0), 0, 39 * (HP / 32) * 1024, 0x00020000), HP / 32};
+    const ClMat m_ih1{__builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.wg_ih1), 0, 39 * (HP / 32) * 1024, 0x00020000), HP / 32};
+    const ClMat m_hh1{__builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.wg_hh1), 0, 39 * (HP / 32) * 1024, 0x00020000), HP / 32};
+    const ClMat m_ho{__builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w_ho), 0, 19 * (HP / 32) * 1024, 0x00020000), HP / 32};
+    bf16x8 ring[D][KCH];
+#pragma unroll
+    for (int q = 0; q < D; ++q) cl_load<true, P>(ring[q], m_ih0, q, ng, rank, wave, lane);
+    __syncthreads();
+    const float* zi0 = a.zi0 + (size_t)r0 * G;
+    const float* zo = a.zo + (size_t)r0 * E;
+    // chunk list of a step: ih0 MT, hh0 MT, ih1 MT, hh1 MT, ho MT (MTO real + padding); D = MT: every GEMM starts in slot 0 and
+    // requests exactly the chunks of the NEXT GEMM of the list while it computes
+    for (int t = 0; t < T; ++t) {
+        const unsigned ep = 3u * (unsigned)t + 1u;
+        // ---- layer 0
+        cl_gemm<XP / 32, MT, MT, D, 0, true, true, P, true>(xb, LDX, m_ih0, ng, ga, LDC, ring, m_hh0, ng, true, rank, wave, lane, zi0, G, H, H, rows_ok);
+        cl_gemm<HP / 32, MT, MT, D, 0, true, true, P, false>(h0b, LDH, m_hh0, ng, gb, LDC, ring, m_ih1, ng, true, rank, wave, lane, nullptr, 0, 0, H, rows_ok);
+        unsigned short kpo = 0x0101;
+        if (KEEP && uok) kpo = gok ? *reinterpret_cast<const unsigned short*>(a.keep + (size_t)t * RH + gr * H + j0) : (unsigned short)0;
+        __syncthreads();
+        if (uok) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int j = j0 + q, lc = (3 * uk) * 16 + uu + q;          // local column of gate g: lc + 16 g
+                const float* pa = ga + grow * LDC; const float* pb = gb + grow * LDC;
+                const float r = sigm(pa[lc] + pb[lc] + bias[j]);
+                const float z = sigm(pa[lc + 16] + pb[lc + 16] + bias[H + j]);
+                const float ghn = pb[lc + 32] + bias[2 * H + j];
+                const float n = tanh_fast(pa[lc + 32] + r * ghn);
+                const float hn = (1.0f - z) * n + z * h0f[q];
+                h0f[q] = hn;
+                float mid = hn;
+                if (KEEP) mid = ((kpo >> (8 * q)) & 0xff) ? hn * a.keep_scale : 0.f;
+                if (SAVE && gok) {
+                    a.h0_all[(size_t)(t + 1) * RH + gr * H + j] = hn;
+                    float* s = a.sav0 + ((size_t)t * R + gr) * 4 * H;
+                    s[j] = r; s[H + j] = z; s[2 * H + j] = n; s[3 * H + j] = ghn;
+                    a.h0b_all[((size_t)(t + 1) * R + gr) * HP + j] = (bf16)hn;
+                    a.midb_all[((size_t)t * R + gr) * HP + j] = (bf16)mid;
+                }
+                cl_put(xA + (size_t)grow * CL_NG + j, ep, (bf16)hn, (bf16)mid);       // granule (row, unit) = {h0, dropout(h0)}
+            }
+        }
+        if (SAVE && rank == 0 && pl == 0 && gok) {
+            a.h0b_all[((size_t)(t + 1) * R + gr) * HP + H] = (bf16)1.f;
+            a.midb_all[((size_t)t * R + gr) * HP + H] = (bf16)1.f;
+            a.h1b_all[((size_t)(t + 1) * R + gr) * HP + H] = (bf16)1.f;
+        }
+        // all-gather: every rank's units of the new h0 and of mid (own ones included: same path)
+        for (int gi = tid; gi < TR * H; gi += NTHR) {
+            const int row = gi / H, j = gi - row * H;
+            bf16 lo, hi;
+            cl_get(xA + (size_t)row * CL_NG + j, ep, lo, hi, tmo);
+            h0b[row * LDH + j] = lo; midb[row * LDH + j] = hi;
+        }
+        __syncthreads();
+        // ---- layer 1
+        cl_gemm<HP / 32, MT, MT, D, 0, true, true, P, false>(midb, LDH, m_ih1, ng, ga, LDC, ring, m_hh1, ng, true, rank, wave, lane, nullptr, 0, 0, H, rows_ok);
+        cl_gemm<HP / 32, MT, MTO, D, 0, true, false, P, false>(h1b, LDH, m_hh1, ng, gb, LDC, ring, m_ho, noe, true, rank, wave, lane, nullptr, 0, 0, H, rows_ok);
+        __syncthreads();
+        if (uok) {
+            bf16 hb2[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int j = j0 + q, lc = (3 * uk) * 16 + uu + q;
+                const float* pa = ga + grow * LDC; const float* pb = gb + grow * LDC;
+                const float r = sigm(pa[lc] + bias[G + j] + pb[lc] + bias[2 * G + j]);
+                const float z = sigm(pa[lc + 16] + bias[G + H + j] + pb[lc + 16] + bias[2 * G + H + j]);
+                const float ghn = pb[lc + 32] + bias[2 * G + 2 * H + j];
+                const float n = tanh_fast(pa[lc + 32] + bias[G + 2 * H + j] + r * ghn);
+                const float hn = (1.0f - z) * n + z * h1f[q];
+                h1f[q] = hn; hb2[q] = (bf16)hn;
+                if (SAVE && gok) {
+                    a.h1_all[(size_t)(t + 1) * RH + gr * H + j] = hn;
+                    float* s = a.sav1 + ((size_t)t * R + gr) * 4 * H;
+                    s[j] = r; s[H + j] = z; s[2 * H + j] = n; s[3 * H + j] = ghn;
+                    a.h1b_all[((size_t)(t + 1) * R + gr) * HP + j] = (bf16)hn;
+                }
+            }
+            cl_put(xB + (size_t)grow * CL_NG + (j0 >> 1), ep + 1, hb2[0], hb2[1]);       // granule (row, unit pair)
+        }
+        for (int gi = tid; gi < TR * (H / 2); gi += NTHR) {
+            const int row = gi / (H / 2), pr = gi - row * (H / 2);
+            bf16 lo, hi;
+            cl_get(xB + (size_t)row * CL_NG + pr, ep + 1, lo, hi, tmo);
+            h1b[row * LDH + 2 * pr] = lo; h1b[row * LDH + 2 * pr + 1] = hi;
+        }
+        __syncthreads();
+        // ---- output projection (own embedding tiles), fed back as the next input
+        const bool last = t + 1 == T;
+        cl_gemm<HP / 32, MT, MT, D, 0, false, true, P, true>(h1b, LDH, m_ho, noe, ga, LDC, ring, m_ih0, ng, !last, rank, wave, lane, zo, E, E, 0, rows_ok);
+        __syncthreads();
+        // own columns: local pair lp -> tile lp / 8, columns 2 (lp % 8), +1 ; up to NOEMAX * 8 pairs per row
+        for (int gi = tid; gi < TR * NOEMAX * 8; gi += NTHR) {
+            const int row = gi / (NOEMAX * 8), lp = gi - row * (NOEMAX * 8);
+            const int lt = lp >> 3, e = (rank + P * lt) * 16 + 2 * (lp & 7);
+            if (lt < noe && e < E) {
+                const float v0 = ga[row * LDC + lt * 16 + 2 * (lp & 7)], v1 = ga[row * LDC + lt * 16 + 2 * (lp & 7) + 1];
+                if (r0 + row < R) {
+                    float* sp = a.sentence + ((size_t)(r0 + row) * T + t) * E + e;
+                    sp[0] = v0; sp[1] = v1;
+                    if (SAVE && !last) {
+                        bf16* xp = a.xb_all + ((size_t)(t + 1) * R + r0 + row) * XP + e;
+                        xp[0] = (bf16)v0; xp[1] = (bf16)v1;
+                    }
+                }
+                cl_put(xC + (size_t)row * CL_NG + (e >> 1), ep + 2, (bf16)v0, (bf16)v1);
+            }
+        }
+        if (!last) {
+            for (int gi = tid; gi < TR * (E / 2); gi += NTHR) {
+                const int row = gi / (E / 2), pr = gi - row * (E / 2);
+                bf16 lo, hi;
+                cl_get(xC + (size_t)row * CL_NG + pr, ep + 2, lo, hi, tmo);
+                xb[row * LDX + 2 * pr] = lo; xb[row * LDX + 2 * pr + 1] = hi;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ================================================================== backward (BPTT)
 // Thread (row, c0) keeps the time sum of the output gradient of its 10 columns in registers; the time sum of the layer-0
 // input-projection gradient (what the z-columns and the bias see) is taken from the saved operand afterwards.
@@ -781,6 +1050,27 @@ int launch_coco_dec_fwd(const CocoDecFwdArgs& a, hipStream_t s) {
     }
     const bool save = a.sav0 != nullptr;
     if (save) MMVAE_REQUIRE(a.sav1 && a.h0_all && a.h1_all && a.xb_all && a.h0b_all && a.midb_all && a.h1b_all, "coco_dec_fwd: save buffers");
+    if (a.cluster > 1) {        // P ranks per row block (coco_dec_fwd_cl_kernel); the caller zeroed cl_xchg / cl_timeout
+        MMVAE_REQUIRE((a.cluster == 4 || a.cluster == 8) && a.wg_ih0 && a.wg_hh0 && a.wg_ih1 && a.wg_hh1 && a.cl_xchg && a.cl_timeout,
+                      "coco_dec_fwd: cluster arguments");
+        const int nblk = ceil_div(a.R, TR), nblk_pad = (nblk + 7) / 8 * 8;
+        auto lds_of = [](int P) {
+            const int nubmax = (13 + P - 1) / P;
+            return (size_t)(2 * TR * (3 * nubmax * 16 + 4) + 3 * G) * sizeof(float) + (size_t)(TR * LDX + 3 * TR * LDH) * sizeof(bf16);
+        };
+        // every rank of a cluster must be resident for the exchange to complete: one workgroup per CU (LDS > 80 KB is not
+        // needed for that: the grid never exceeds the CU count)
+        MMVAE_REQUIRE(nblk_pad * a.cluster <= 256, "coco_dec_fwd: %d x %d workgroups do not fit the chip", nblk_pad, a.cluster);
+        auto gc = [&](auto kern, int P) { hipLaunchKernelGGL(kern, dim3(nblk_pad * P), dim3(NTHR), lds_of(P), s, a); };
+        if (a.cluster == 4) {
+            if (a.keep) { if (save) gc(&coco_dec_fwd_cl_kernel<true, true, 4>, 4); else gc(&coco_dec_fwd_cl_kernel<true, false, 4>, 4); }
+            else { if (save) gc(&coco_dec_fwd_cl_kernel<false, true, 4>, 4); else gc(&coco_dec_fwd_cl_kernel<false, false, 4>, 4); }
+        } else {
+            if (a.keep) { if (save) gc(&coco_dec_fwd_cl_kernel<true, true, 8>, 8); else gc(&coco_dec_fwd_cl_kernel<true, false, 8>, 8); }
+            else { if (save) gc(&coco_dec_fwd_cl_kernel<false, true, 8>, 8); else gc(&coco_dec_fwd_cl_kernel<false, false, 8>, 8); }
+        }
+        return mmvae_check_launch("coco_dec_fwd_cl");
+    }
     auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(ceil_div(a.R, TR)), dim3(NTHR), lds, s, a); };
     if (a.keep) { if (save) go(&coco_dec_fwd_kernel<true, true>); else go(&coco_dec_fwd_kernel<true, false>); }
     else { if (save) go(&coco_dec_fwd_kernel<false, true>); else go(&coco_dec_fwd_kernel<false, false>); }
