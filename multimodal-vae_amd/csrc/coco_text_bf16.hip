@@ -212,6 +212,38 @@ __device__ __forceinline__ void cl_get(const u64* g, unsigned epoch, bf16& lo, b
     lo = hi = __builtin_bit_cast(bf16, (unsigned short)0x7FC0);
 }
 
+// All-gather of `total` granules of one phase buffer: thread tid owns granules tid, tid + 512, ... (at most NG); ALL of its
+// loads are in flight before the first tag is looked at, and only granules whose tag is still old are polled again (a
+// single granule per round trip would serialise NG L2 latencies).  sink(index, lo, hi) consumes a granule.
+template <int NG, class Sink>
+__device__ __forceinline__ void cl_gather(const u64* base, int total, unsigned epoch, unsigned* tmo, int tid, Sink sink) {
+    u64 x[NG];
+    unsigned pending = 0;
+#pragma unroll
+    for (int q = 0; q < NG; ++q)
+        if (tid + q * NTHR < total) pending |= 1u << q;
+    for (unsigned spin = 0; pending != 0; ++spin) {
+#pragma unroll
+        for (int q = 0; q < NG; ++q)
+            if (pending & (1u << q)) x[q] = __hip_atomic_load(base + tid + q * NTHR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int q = 0; q < NG; ++q)
+            if ((pending & (1u << q)) && (unsigned)(x[q] >> 32) == epoch) {
+                pending &= ~(1u << q);
+                sink(tid + q * NTHR, __builtin_bit_cast(bf16, (unsigned short)(x[q] & 0xffff)),
+                     __builtin_bit_cast(bf16, (unsigned short)((x[q] >> 16) & 0xffff)));
+            }
+        if (pending && spin >= CL_SPIN_MAX) {           // gave up (see cl_get): NaNs, loud
+            atomicExch(tmo, epoch);
+#pragma unroll
+            for (int q = 0; q < NG; ++q)
+                if (pending & (1u << q)) sink(tid + q * NTHR, __builtin_bit_cast(bf16, (unsigned short)0x7FC0), __builtin_bit_cast(bf16, (unsigned short)0x7FC0));
+            pending = 0;
+        }
+        if (pending && (spin & 15) == 15) __builtin_amdgcn_s_sleep(1);
+    }
+}
+
 struct ClMat { __amdgpu_buffer_rsrc_t r; int ks; };     // gate matrices: per-gate packs, tile g * 13 + ub; ho: tile et
 
 // chunk `pos` (= tile slot of this wave; one chunk per tile, every K here is <= 10 k-steps) of the rank's tile list
@@ -366,7 +398,7 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_cl_kernel(const CocoDecFwdA
                     a.h0b_all[((size_t)(t + 1) * R + gr) * HP + j] = (bf16)hn;
                     a.midb_all[((size_t)t * R + gr) * HP + j] = (bf16)mid;
                 }
-                cl_put(xA + (size_t)grow * CL_NG + j, ep, (bf16)hn, (bf16)mid);       // granule (row, unit) = {h0, dropout(h0)}
+                cl_put(xA + (size_t)grow * H + j, ep, (bf16)hn, (bf16)mid);           // granule (row, unit) = {h0, dropout(h0)}
             }
         }
         if (SAVE && rank == 0 && pl == 0 && gok) {
@@ -375,12 +407,10 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_cl_kernel(const CocoDecFwdA
             a.h1b_all[((size_t)(t + 1) * R + gr) * HP + H] = (bf16)1.f;
         }
         // all-gather: every rank's units of the new h0 and of mid (own ones included: same path)
-        for (int gi = tid; gi < TR * H; gi += NTHR) {
+        cl_gather<(TR * H + NTHR - 1) / NTHR>(xA, TR * H, ep, tmo, tid, [&](int gi, bf16 lo, bf16 hi) {
             const int row = gi / H, j = gi - row * H;
-            bf16 lo, hi;
-            cl_get(xA + (size_t)row * CL_NG + j, ep, lo, hi, tmo);
             h0b[row * LDH + j] = lo; midb[row * LDH + j] = hi;
-        }
+        });
         __syncthreads();
         // ---- layer 1
         cl_gemm<HP / 32, MT, MT, D, 0, true, true, P, false>(midb, LDH, m_ih1, ng, ga, LDC, ring, m_hh1, ng, true, rank, wave, lane, nullptr, 0, 0, H, rows_ok);
@@ -405,14 +435,12 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_cl_kernel(const CocoDecFwdA
                     a.h1b_all[((size_t)(t + 1) * R + gr) * HP + j] = (bf16)hn;
                 }
             }
-            cl_put(xB + (size_t)grow * CL_NG + (j0 >> 1), ep + 1, hb2[0], hb2[1]);       // granule (row, unit pair)
+            cl_put(xB + (size_t)grow * (H / 2) + (j0 >> 1), ep + 1, hb2[0], hb2[1]);     // granule (row, unit pair)
         }
-        for (int gi = tid; gi < TR * (H / 2); gi += NTHR) {
+        cl_gather<(TR * (H / 2) + NTHR - 1) / NTHR>(xB, TR * (H / 2), ep + 1, tmo, tid, [&](int gi, bf16 lo, bf16 hi) {
             const int row = gi / (H / 2), pr = gi - row * (H / 2);
-            bf16 lo, hi;
-            cl_get(xB + (size_t)row * CL_NG + pr, ep + 1, lo, hi, tmo);
             h1b[row * LDH + 2 * pr] = lo; h1b[row * LDH + 2 * pr + 1] = hi;
-        }
+        });
         __syncthreads();
         // ---- output projection (own embedding tiles), fed back as the next input
         const bool last = t + 1 == T;
@@ -432,16 +460,14 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_cl_kernel(const CocoDecFwdA
                         xp[0] = (bf16)v0; xp[1] = (bf16)v1;
                     }
                 }
-                cl_put(xC + (size_t)row * CL_NG + (e >> 1), ep + 2, (bf16)v0, (bf16)v1);
+                cl_put(xC + (size_t)row * (E / 2) + (e >> 1), ep + 2, (bf16)v0, (bf16)v1);
             }
         }
         if (!last) {
-            for (int gi = tid; gi < TR * (E / 2); gi += NTHR) {
+            cl_gather<(TR * (E / 2) + NTHR - 1) / NTHR>(xC, TR * (E / 2), ep + 2, tmo, tid, [&](int gi, bf16 lo, bf16 hi) {
                 const int row = gi / (E / 2), pr = gi - row * (E / 2);
-                bf16 lo, hi;
-                cl_get(xC + (size_t)row * CL_NG + pr, ep + 2, lo, hi, tmo);
                 xb[row * LDX + 2 * pr] = lo; xb[row * LDX + 2 * pr + 1] = hi;
-            }
+            });
         }
         __syncthreads();
     }
