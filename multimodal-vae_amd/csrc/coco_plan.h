@@ -39,6 +39,8 @@ struct CocoDecBwdArgs {
     bf16 *dgi0_b, *dgh0_b, *dgi1_b, *dgh1_b;               // [T][R][608]
     float *dhinit;           // [R][200]
     float *dwsum;            // [R][300] time sum of the output gradient
+    // cluster form (coco_dec_bwd_cl_kernel): exchange granules [row blocks][2*2*16*200 + 16*150] (zeroed before the launch)
+    unsigned long long* cl_xchg; unsigned* cl_timeout; int cluster;
 };
 struct CocoEncFwdArgs {
     int B, T;
@@ -108,7 +110,7 @@ struct CocoPlan : PlanBase {
         bf16 *tb_x, *tb_h0, *tb_mid, *tb_h1, *tb_dout, *tb_dgi0, *tb_dgh0, *tb_dgi1, *tb_dgh1;
         bf16 *te_xb, *te_hb_all, *te_dgi_b, *te_dgh_b;
         float *te_giT, *te_hlast;
-        char* cl_xchg; size_t cl_bytes;
+        char* cl_xchg; size_t cl_bytes; char* clb_xchg; size_t clb_bytes;
     } w;
 };
 

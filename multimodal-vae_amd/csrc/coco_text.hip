@@ -381,9 +381,20 @@ void coco_text_carve(CocoPlan& P, Workspace& ws) {
         w.te_giT = ws.take<float>(B * T * G); w.te_hlast = ws.take<float>(B * H);
         w.cl_bytes = ((R + 15) / 16) * 3 * 16 * 200 * sizeof(unsigned long long) + 64;      // cluster exchange granules + timeout word
         w.cl_xchg = ws.take<char>(w.cl_bytes);
+        w.clb_bytes = ((R + 15) / 16) * (2 * 2 * 16 * 200 + 16 * 150) * sizeof(unsigned long long) + 64;    // ... of the BPTT launch
+        w.clb_xchg = ws.take<char>(w.clb_bytes);
         w.te_xb = ws.take<bf16>(T * B * CTB_XP); w.te_hb_all = ws.take<bf16>(T * B * CTB_HP);
         w.te_dgi_b = ws.take<bf16>(T * B * CTB_GP); w.te_dgh_b = ws.take<bf16>(T * B * CTB_GP);
     }
+}
+
+// ranks per 16-row block of the caption decoder's persistent launches (cluster form), 0 / 1: one workgroup per block
+static int coco_dec_cluster(int R) {
+    const char* cl_env = getenv("MMVAE_COCO_CLUSTER");          // (read per call: tools/coco_cluster_check.py toggles it)
+    int Pc = cl_env ? atoi(cl_env) : 4;
+    const int nblk_pad = ((R + 15) / 16 + 7) / 8 * 8;
+    while (Pc > 1 && nblk_pad * Pc > 224) Pc /= 2;
+    return (Pc == 4 || Pc == 8) ? Pc : 0;
 }
 
 // the weight-resident encoder kernels (coco_text_bf16.hip) need 4-row vectors of the batch
@@ -518,11 +529,7 @@ int coco_text_dec_fwd(CocoPlan& P, const float* z, int groups, const float* sos,
         a.bhh0 = p + P.td0.bhh; a.bih1 = p + P.td1.bih; a.bhh1 = p + P.td1.bhh;
         a.sentence = sentence;
         {   // cluster form: P workgroups per 16-row block when the row blocks leave most of the chip idle
-            const char* cl_env = getenv("MMVAE_COCO_CLUSTER");                  // (read per call: tools/coco_cluster_check.py toggles it)
-            const int want = cl_env ? atoi(cl_env) : 4;
-            const int nblk_pad = ((R + 15) / 16 + 7) / 8 * 8;
-            int Pc = want;
-            while (Pc > 1 && nblk_pad * Pc > 224) Pc /= 2;
+            const int Pc = coco_dec_cluster(R);
             if (Pc == 4 || Pc == 8) {
                 a.cluster = Pc;
                 a.wg_ih0 = pw(P.tb_g_ih0[0]); a.wg_hh0 = pw(P.tb_g_hh0[0]); a.wg_ih1 = pw(P.tb_g_ih1[0]); a.wg_hh1 = pw(P.tb_g_hh1[0]);
@@ -579,6 +586,15 @@ static int coco_text_dec_bwd_bf16(CocoPlan& P, const float* z, int groups, const
     a.h0_all = w.td_h0; a.h1_all = w.td_h1; a.sav0 = w.td_sav0; a.sav1 = w.td_sav1;
     a.dout_b = w.tb_dout; a.dgi0_b = w.tb_dgi0; a.dgh0_b = w.tb_dgh0; a.dgi1_b = w.tb_dgi1; a.dgh1_b = w.tb_dgh1;
     a.dhinit = w.td_dhinit; a.dwsum = w.td_dwsum;
+    {
+        const int Pc = coco_dec_cluster(R);
+        if (Pc > 1) {
+            a.cluster = Pc;
+            a.cl_xchg = reinterpret_cast<unsigned long long*>(w.clb_xchg);
+            a.cl_timeout = reinterpret_cast<unsigned*>(w.clb_xchg + w.clb_bytes - 64);
+            MMVAE_TRY(launch_fill_zero(w.clb_xchg, w.clb_bytes, s));        // tags and the timeout word: zero before EVERY launch
+        }
+    }
     MMVAE_TRY(launch_coco_dec_bwd(a, s));
     MMVAE_TRY(launch_coco_time_sum_bf16(a.dgi0_b, T, R, CTB_GP, G, w.td_dzi0, s));
     // ---- what the rest of the step waits for: dz through the three z-terms (initial state, layer-0 input, output projection)

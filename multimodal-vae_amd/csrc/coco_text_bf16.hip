@@ -645,6 +645,278 @@ __global__ __launch_bounds__(NTHR) void coco_dec_bwd_kernel(const CocoDecBwdArgs
     }
 }
 
+// ================================================================== backward (BPTT), CLUSTER form
+// The same decomposition as coco_dec_fwd_cl_kernel: rank r of the P workgroups of a row block owns the hidden-unit tiles
+// r, r + P, ... of the four unit-indexed products (dOut W_ho, dgi1 W_ih1, dgh1 W_hh1, dgh0 W_hh0) and the embedding tiles
+// r, r + P, ... of the feedback product dgi0 W_ih0.  A rank has only NUBMAX <= 4 tiles per product, so the reduction
+// dimension of every tile is split over KH = 8 / NUBMAX waves whose partial tiles meet in LDS planes: all 8 waves stream,
+// one chunk per wave and product.  Three all-gathers per step (the gate gradients of layer 1, of layer 0, and the total
+// output gradient of the next step), tagged granules as in the forward kernel.
+template <bool KEEP, int P>
+__global__ __launch_bounds__(NTHR) void coco_dec_bwd_cl_kernel(const CocoDecBwdArgs a) {
+    constexpr int NUBMAX = (13 + P - 1) / P, NOEMAX = (19 + P - 1) / P;
+    constexpr int KH = NW / NUBMAX;                                   // K planes of the unit products
+    constexpr int MTE = (NOEMAX * KH + NW - 1) / NW;                  // wave slots of the feedback product
+    constexpr int NPOS = 4 + MTE;                                     // chunks per step and wave
+    constexpr int D = NPOS % 2 == 0 ? 2 : 3;                          // (3 chunks ahead spill: 256 VGPRs)
+    static_assert(NPOS % D == 0, "static ring slots");
+    constexpr int KSG = GP / 32, KSX = XP / 32;                       // 19, 10 k-steps
+    constexpr int KPG = (KSG + KH - 1) / KH, KPX = (KSX + KH - 1) / KH;   // k-steps per plane
+    static_assert(KPG <= KCH && KPX <= KCH, "one chunk per plane");
+    constexpr int LDU = NUBMAX * 16 + 4, LDE = NOEMAX * 16 + 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* o1 = reinterpret_cast<float*>(smem);                     // [KH][16][LDU]
+    float* o2 = o1 + KH * TR * LDU;                                 // [KH][16][LDU]
+    float* fbp = o2 + KH * TR * LDU;                                // [KH][16][LDE]
+    bf16* dob = reinterpret_cast<bf16*>(fbp + KH * TR * LDE);       // [16][LDX]
+    bf16* dgi = dob + TR * LDX;                                     // [16][LDGK]
+    bf16* dgh = dgi + TR * LDGK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int nblk = (a.R + TR - 1) / TR, nblk_pad = (nblk + 7) / 8 * 8;
+    const int rank = blockIdx.x / nblk_pad, blk = blockIdx.x - rank * nblk_pad;
+    if (blk >= nblk) return;
+    const int r0 = blk * TR, R = a.R, T = a.T;
+    const size_t RH = (size_t)R * H;
+    const int nub = (13 - rank + P - 1) / P, noe = (19 - rank + P - 1) / P;
+    const int grow = tid >> 5, pl = tid & 31;
+    const bool gok = r0 + grow < R;
+    const size_t gr = gok ? r0 + grow : 0;
+    const int uk = (2 * pl) >> 4, uu = (2 * pl) & 15;
+    const int j0 = (rank + P * uk) * 16 + uu;                       // own unit pair j0, j0 + 1
+    const bool uok = uk < nub && j0 < H;
+    u64* xA = a.cl_xchg + (size_t)blk * (2 * 2 * TR * H + TR * (E / 2));    // [2 kinds][16][H] gate gradients of layer 1
+    u64* xB = xA + 2 * TR * H;                                               // ... of layer 0
+    u64* xC = xB + 2 * TR * H;                                               // [16][E/2] total output gradient of the next step
+    unsigned* tmo = a.cl_timeout;
+
+    for (int i = tid; i < TR * LDX; i += NTHR) dob[i] = (bf16)0.f;
+    for (int i = tid; i < 2 * TR * LDGK; i += NTHR) dgi[i] = (bf16)0.f;
+    __syncthreads();
+    // own embedding pairs of this thread: q-th pair = local pair pl + 32 q -> tile lt, columns e, e + 1
+    int eo[2]; bool eok[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int lp = pl + 32 * q, lt = lp >> 3;
+        eo[q] = (rank + P * lt) * 16 + 2 * (lp & 7);
+        eok[q] = lt < noe && eo[q] < E;
+    }
+    float ws_sum[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    // step T-1: the total output gradient is the loss term alone, every rank reads all of it; the owner accounts for its columns
+    for (int i = tid; i < TR * E; i += NTHR) {
+        const int row = i / E, e = i - row * E;
+        dob[row * LDX + e] = (bf16)(r0 + row < R ? a.dw[((size_t)(r0 + row) * T + (T - 1)) * E + e] : 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+        if (eok[q] && gok) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float v = a.dw[(gr * T + (T - 1)) * E + eo[q] + c];
+                ws_sum[q][c] += v;
+                a.dout_b[((size_t)(T - 1) * R + gr) * EP + eo[q] + c] = (bf16)v;
+            }
+        }
+    float dh0f[2] = {0.f, 0.f}, dh1f[2] = {0.f, 0.f};
+
+    const __amdgpu_buffer_rsrc_t r_hoT = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w_hoT), 0, 13 * KSX * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_ih1T = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w_ih1T), 0, 13 * KSG * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_hh1T = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w_hh1T), 0, 13 * KSG * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_hh0T = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w_hh0T), 0, 13 * KSG * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_ih0T = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w_ih0T), 0, 19 * KSG * 1024, 0x00020000);
+    // a unit product: this wave's item = (tile li = wave % NUBMAX, plane kh = wave / NUBMAX)
+    const int uli = wave % NUBMAX, ukh = wave / NUBMAX;
+    const bool uitem = uli < nub;
+    const int utile = rank + P * uli;
+    auto load_pos = [&](bf16x8 (&dst)[KCH], int pos) {      // pos is a compile-time constant at every call site
+        if (pos < 4) {
+            if (!uitem) return;
+            const int ks = pos == 0 ? KSX : KSG, kp = pos == 0 ? KPX : KPG;
+            const __amdgpu_buffer_rsrc_t& rs = pos == 0 ? r_hoT : pos == 1 ? r_ih1T : pos == 2 ? r_hh1T : r_hh0T;
+            const int k0 = ukh * kp, kc = min(kp, ks - k0);
+            const int ub = (utile * ks + k0) * 1024;
+#pragma unroll
+            for (int s = 0; s < KCH; ++s)
+                if (s < kc) dst[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, ub + s * 1024, 0));
+        } else {
+            const int it = wave + NW * (pos - 4), li = it % NOEMAX, kh = it / NOEMAX;
+            if (li >= noe || kh >= KH) return;
+            const int k0 = kh * KPG, kc = min(KPG, KSG - k0);
+            const int ub = ((rank + P * li) * KSG + k0) * 1024;
+#pragma unroll
+            for (int s = 0; s < KCH; ++s)
+                if (s < kc) dst[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r_ih0T, lane * 16, ub + s * 1024, 0));
+        }
+    };
+    // consume chunk `pos` from ring slot pos % D: partial tile -> plane kh of `out`; then request chunk pos + D of the list
+    bf16x8 ring[D][KCH];
+    auto gemm_pos = [&](int pos, const bf16* A, int lda, float* out, int ldo, bool more) {
+        int li, kh, k0, kc;
+        bool ok;
+        if (pos < 4) {
+            const int ks = pos == 0 ? KSX : KSG, kp = pos == 0 ? KPX : KPG;
+            li = uli; kh = ukh; k0 = kh * kp; kc = min(kp, ks - k0); ok = uitem && kc > 0;
+        } else {
+            const int it = wave + NW * (pos - 4);
+            li = it % NOEMAX; kh = it / NOEMAX; k0 = kh * KPG; kc = min(KPG, KSG - k0); ok = li < noe && kh < KH && kc > 0;
+        }
+        if (ok) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KCH; ++s)
+                if (s < kc) {
+                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(A + fr * lda + (k0 + s) * 32 + fq * 8);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, ring[pos % D][s], acc, 0, 0, 0);
+                }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[(kh * TR + fq * 4 + j) * ldo + li * 16 + fr] = acc[j];
+        }
+        const int np = pos + D;
+        if (np < NPOS) load_pos(ring[pos % D], np);
+        else if (more) load_pos(ring[pos % D], np - NPOS);
+    };
+#pragma unroll
+    for (int q = 0; q < D; ++q) load_pos(ring[q], q);
+    __syncthreads();
+
+    for (int t = T - 1; t >= 0; --t) {
+        const unsigned ep = 3u * (unsigned)(T - 1 - t) + 1u;
+        const bool first = t == 0;
+        // saved gates of both layers for the own unit pair: requested before the products
+        float s1[2][4], s0[2][4], hp1[2], hp0[2];
+        unsigned short kpo = 0x0101;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int j = min(j0 + q, H - 1);
+            const float* p1 = a.sav1 + ((size_t)t * R + gr) * 4 * H;
+            const float* p0 = a.sav0 + ((size_t)t * R + gr) * 4 * H;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { s1[q][g] = p1[g * H + j]; s0[q][g] = p0[g * H + j]; }
+            hp1[q] = a.h1_all[(size_t)t * RH + gr * H + j];
+            hp0[q] = a.h0_all[(size_t)t * RH + gr * H + j];
+        }
+        if (KEEP && uok) kpo = gok ? *reinterpret_cast<const unsigned short*>(a.keep + (size_t)t * RH + gr * H + j0) : (unsigned short)0;
+        // ---- dh1 += dOut * W_ho (own units)
+        gemm_pos(0, dob, LDX, o1, LDU, true);
+        __syncthreads();
+        if (uok) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int j = j0 + q, lc = uk * 16 + uu + q;
+                float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f, dd = 0.f;
+                if (gok) {
+                    float o = 0.f;
+#pragma unroll
+                    for (int k = 0; k < KH; ++k) o += o1[(k * TR + grow) * LDU + lc];
+                    const float r = s1[q][0], z = s1[q][1], n = s1[q][2], ghn = s1[q][3];
+                    const float d = dh1f[q] + o;
+                    dn = d * (1.0f - z) * (1.0f - n * n);
+                    dz = d * (hp1[q] - n) * z * (1.0f - z);
+                    dr = dn * ghn * r * (1.0f - r);
+                    dnr = dn * r;
+                    dd = d * z;
+                    bf16* gi = a.dgi1_b + ((size_t)t * R + gr) * GP;
+                    bf16* gh = a.dgh1_b + ((size_t)t * R + gr) * GP;
+                    gi[j] = (bf16)dr; gi[H + j] = (bf16)dz; gi[2 * H + j] = (bf16)dn;
+                    gh[j] = (bf16)dr; gh[H + j] = (bf16)dz; gh[2 * H + j] = (bf16)dnr;
+                }
+                dh1f[q] = dd;
+                cl_put(xA + (size_t)grow * H + j, ep, (bf16)dr, (bf16)dz);
+                cl_put(xA + (size_t)(TR + grow) * H + j, ep, (bf16)dn, (bf16)dnr);
+            }
+        }
+        cl_gather<(2 * TR * H + NTHR - 1) / NTHR>(xA, 2 * TR * H, ep, tmo, tid, [&](int gi, bf16 lo, bf16 hi) {
+            const int kind = gi / (TR * H), rem = gi - kind * TR * H, row = rem / H, j = rem - row * H;
+            if (kind == 0) { dgi[row * LDGK + j] = lo; dgh[row * LDGK + j] = lo; dgi[row * LDGK + H + j] = hi; dgh[row * LDGK + H + j] = hi; }
+            else { dgi[row * LDGK + 2 * H + j] = lo; dgh[row * LDGK + 2 * H + j] = hi; }
+        });
+        __syncthreads();
+        // ---- dmid = dgi1 * W_ih1 ; dh1[t-1] += dgh1 * W_hh1 (own units)
+        gemm_pos(1, dgi, LDGK, o1, LDU, true);
+        gemm_pos(2, dgh, LDGK, o2, LDU, true);
+        __syncthreads();
+        if (uok) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int j = j0 + q, lc = uk * 16 + uu + q;
+                float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f, dd = 0.f;
+                float om = 0.f, oh = 0.f;
+#pragma unroll
+                for (int k = 0; k < KH; ++k) { om += o1[(k * TR + grow) * LDU + lc]; oh += o2[(k * TR + grow) * LDU + lc]; }
+                dh1f[q] += gok ? oh : 0.f;
+                if (gok) {
+                    const float r = s0[q][0], z = s0[q][1], n = s0[q][2], ghn = s0[q][3];
+                    float dm = om;
+                    if (KEEP) dm = ((kpo >> (8 * q)) & 0xff) ? dm * a.keep_scale : 0.f;
+                    const float d = dh0f[q] + dm;
+                    dn = d * (1.0f - z) * (1.0f - n * n);
+                    dz = d * (hp0[q] - n) * z * (1.0f - z);
+                    dr = dn * ghn * r * (1.0f - r);
+                    dnr = dn * r;
+                    dd = d * z;
+                    bf16* gi = a.dgi0_b + ((size_t)t * R + gr) * GP;
+                    bf16* gh = a.dgh0_b + ((size_t)t * R + gr) * GP;
+                    gi[j] = (bf16)dr; gi[H + j] = (bf16)dz; gi[2 * H + j] = (bf16)dn;
+                    gh[j] = (bf16)dr; gh[H + j] = (bf16)dz; gh[2 * H + j] = (bf16)dnr;
+                }
+                dh0f[q] = dd;
+                cl_put(xB + (size_t)grow * H + j, ep + 1, (bf16)dr, (bf16)dz);
+                cl_put(xB + (size_t)(TR + grow) * H + j, ep + 1, (bf16)dn, (bf16)dnr);
+            }
+        }
+        cl_gather<(2 * TR * H + NTHR - 1) / NTHR>(xB, 2 * TR * H, ep + 1, tmo, tid, [&](int gi, bf16 lo, bf16 hi) {
+            const int kind = gi / (TR * H), rem = gi - kind * TR * H, row = rem / H, j = rem - row * H;
+            if (kind == 0) { dgi[row * LDGK + j] = lo; dgh[row * LDGK + j] = lo; dgi[row * LDGK + H + j] = hi; dgh[row * LDGK + H + j] = hi; }
+            else { dgi[row * LDGK + 2 * H + j] = lo; dgh[row * LDGK + 2 * H + j] = hi; }
+        });
+        __syncthreads();
+        // ---- dh0[t-1] += dgh0 * W_hh0 (own units) ; feedback into the previous output = dgi0 * W_ih0[:, :300] (own embedding tiles)
+        gemm_pos(3, dgh, LDGK, o2, LDU, true);
+#pragma unroll
+        for (int sl = 0; sl < MTE; ++sl) gemm_pos(4 + sl, dgi, LDGK, fbp, LDE, !first);
+        __syncthreads();
+        if (uok && gok) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float oh = 0.f;
+#pragma unroll
+                for (int k = 0; k < KH; ++k) oh += o2[(k * TR + grow) * LDU + uk * 16 + uu + q];
+                dh0f[q] += oh;
+            }
+        }
+        if (!first) {
+            // total output gradient of step t-1 for the own columns: loss term + feedback; accounted, saved, published
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                if (eok[q]) {
+                    const int lp = pl + 32 * q, lt = lp >> 3, lcol = lt * 16 + 2 * (lp & 7);
+                    float v[2];
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        float f = 0.f;
+#pragma unroll
+                        for (int k = 0; k < KH; ++k) f += fbp[(k * TR + grow) * LDE + lcol + c];
+                        v[c] = (gok ? a.dw[(gr * T + (t - 1)) * E + eo[q] + c] : 0.f) + f;
+                        if (gok) { ws_sum[q][c] += v[c]; a.dout_b[((size_t)(t - 1) * R + gr) * EP + eo[q] + c] = (bf16)v[c]; }
+                    }
+                    cl_put(xC + (size_t)grow * (E / 2) + (eo[q] >> 1), ep + 2, (bf16)v[0], (bf16)v[1]);
+                }
+            cl_gather<(TR * (E / 2) + NTHR - 1) / NTHR>(xC, TR * (E / 2), ep + 2, tmo, tid, [&](int gi, bf16 lo, bf16 hi) {
+                const int row = gi / (E / 2), pr = gi - row * (E / 2);
+                dob[row * LDX + 2 * pr] = lo; dob[row * LDX + 2 * pr + 1] = hi;
+            });
+        }
+        __syncthreads();
+    }
+    if (uok && gok) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) a.dhinit[gr * H + j0 + q] = dh0f[q] + dh1f[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+        if (eok[q] && gok) { a.dwsum[gr * E + eo[q]] = ws_sum[q][0]; a.dwsum[gr * E + eo[q] + 1] = ws_sum[q][1]; }
+}
+
 // ================================================================== caption encoder (forward direction of the bi-GRU)
 // coco/model.py:236-245.  The input projection of all T steps is one batched GEMM done by the caller; what is sequential is
 // h[t] = GRU(gi[t], h[t-1]): one hidden projection (W_hh, 272 KB bf16) and the gate math per step.  Same scheme as the
@@ -1109,6 +1381,20 @@ int launch_coco_dec_bwd(const CocoDecBwdArgs& a, hipStream_t s) {
     {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&coco_dec_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&coco_dec_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    if (a.cluster > 1) {        // P ranks per row block (coco_dec_bwd_cl_kernel); the caller zeroed cl_xchg / cl_timeout
+        MMVAE_REQUIRE((a.cluster == 4 || a.cluster == 8) && a.cl_xchg && a.cl_timeout, "coco_dec_bwd: cluster arguments");
+        const int nblk = ceil_div(a.R, TR), nblk_pad = (nblk + 7) / 8 * 8;
+        MMVAE_REQUIRE(nblk_pad * a.cluster <= 256, "coco_dec_bwd: %d x %d workgroups do not fit the chip", nblk_pad, a.cluster);
+        auto lds_of = [](int P) {
+            const int nubmax = (13 + P - 1) / P, noemax = (19 + P - 1) / P, kh = NW / nubmax;
+            return (size_t)(2 * kh * TR * (nubmax * 16 + 4) + kh * TR * (noemax * 16 + 4)) * sizeof(float) +
+                   (size_t)(TR * LDX + 2 * TR * LDGK) * sizeof(bf16);
+        };
+        auto gc = [&](auto kern, int P) { hipLaunchKernelGGL(kern, dim3(nblk_pad * P), dim3(NTHR), lds_of(P), s, a); };
+        if (a.cluster == 4) { if (a.keep) gc(&coco_dec_bwd_cl_kernel<true, 4>, 4); else gc(&coco_dec_bwd_cl_kernel<false, 4>, 4); }
+        else { if (a.keep) gc(&coco_dec_bwd_cl_kernel<true, 8>, 8); else gc(&coco_dec_bwd_cl_kernel<false, 8>, 8); }
+        return mmvae_check_launch("coco_dec_bwd_cl");
     }
     if (a.keep) hipLaunchKernelGGL(coco_dec_bwd_kernel<true>, dim3(ceil_div(a.R, TR)), dim3(NTHR), lds, s, a);
     else hipLaunchKernelGGL(coco_dec_bwd_kernel<false>, dim3(ceil_div(a.R, TR)), dim3(NTHR), lds, s, a);
