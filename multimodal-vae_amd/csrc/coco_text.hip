@@ -379,9 +379,10 @@ void coco_text_carve(CocoPlan& P, Workspace& ws) {
         w.tb_dgi0 = ws.take<bf16>(T * R * CTB_GP); w.tb_dgh0 = ws.take<bf16>(T * R * CTB_GP);
         w.tb_dgi1 = ws.take<bf16>(T * R * CTB_GP); w.tb_dgh1 = ws.take<bf16>(T * R * CTB_GP);
         w.te_giT = ws.take<float>(B * T * G); w.te_hlast = ws.take<float>(B * H);
-        w.cl_bytes = ((R + 15) / 16) * 3 * 16 * 200 * sizeof(unsigned long long) + 64;      // cluster exchange granules + timeout word
+        // cluster exchange buffers (coco_text_bf16.hip CLF_BYTES / CLB_BYTES per row block) + a timeout word each
+        w.cl_bytes = ((R + 15) / 16) * (size_t)(16 * 200 * 4 + 16 * 200 * 2 + 16 * 300 * 2 + 256) + 64;
         w.cl_xchg = ws.take<char>(w.cl_bytes);
-        w.clb_bytes = ((R + 15) / 16) * (2 * 2 * 16 * 200 + 16 * 150) * sizeof(unsigned long long) + 64;    // ... of the BPTT launch
+        w.clb_bytes = ((R + 15) / 16) * (size_t)(2 * 16 * 200 * 8 + 16 * 300 * 2 + 256) + 64;
         w.clb_xchg = ws.take<char>(w.clb_bytes);
         w.te_xb = ws.take<bf16>(T * B * CTB_XP); w.te_hb_all = ws.take<bf16>(T * B * CTB_HP);
         w.te_dgi_b = ws.take<bf16>(T * B * CTB_GP); w.te_dgh_b = ws.take<bf16>(T * B * CTB_GP);
@@ -391,7 +392,7 @@ void coco_text_carve(CocoPlan& P, Workspace& ws) {
 // ranks per 16-row block of the caption decoder's persistent launches (cluster form), 0 / 1: one workgroup per block
 static int coco_dec_cluster(int R) {
     const char* cl_env = getenv("MMVAE_COCO_CLUSTER");          // (read per call: tools/coco_cluster_check.py toggles it)
-    int Pc = cl_env ? atoi(cl_env) : 4;
+    int Pc = cl_env ? atoi(cl_env) : 8;
     const int nblk_pad = ((R + 15) / 16 + 7) / 8 * 8;
     while (Pc > 1 && nblk_pad * Pc > 224) Pc /= 2;
     return (Pc == 4 || Pc == 8) ? Pc : 0;

@@ -244,6 +244,56 @@ __device__ __forceinline__ void cl_gather(const u64* base, int total, unsigned e
     }
 }
 
+// Bulk form of the exchange (guide recipe R1): the granule form above costs one uncached 8-byte load per granule and reader
+// -- 15,200 per BPTT step, which made the exchange, not the weight stream, the bound.  Here every rank writes its slice of a
+// phase buffer with write-through (sc1) stores, drains them (s_waitcnt vmcnt(0), workgroup barrier), and ONE lane stores
+// the rank's flag = epoch; a reader polls the P flags (one lane each), passes a barrier, and reads the whole buffer with
+// 16-byte sc1 loads (every load of handed-off bytes is sc1: no acquire fence needed).  4x fewer memory instructions for one
+// more hop.
+struct ClX {
+    __amdgpu_buffer_rsrc_t rs;      // this cluster's phase buffer
+    unsigned* flags;                // [P] epochs
+};
+__device__ __forceinline__ ClX cl_x(char* base, int bytes, unsigned* flags) {
+    return ClX{__builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, 0x00020000), flags};
+}
+__device__ __forceinline__ void cl_signal(const ClX& x, int rank, unsigned epoch, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every storing wave: its payload stores have left
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(x.flags + rank, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int P>
+__device__ __forceinline__ void cl_wait(const ClX& x, unsigned epoch, unsigned* tmo, int tid) {
+    if (tid < P) {
+        unsigned spin = 0;
+        while (__hip_atomic_load(x.flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+            if (++spin >= CL_SPIN_MAX) { atomicExch(tmo, epoch); break; }       // gave up: the step's results are garbage, the word says so
+            if ((spin & 7) == 7) __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // (no instruction: keeps the sc1 loads below the poll)
+}
+__device__ __forceinline__ bf16x8 cl_load16(const ClX& x, int byte_off) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(x.rs, byte_off, 0, 16));     // aux 16 = sc1
+}
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(4))) int i32x4c;
+__device__ __forceinline__ void cl_store4(const ClX& x, int byte_off, bf16 a, bf16 b) {
+    const unsigned v = ((unsigned)__builtin_bit_cast(unsigned short, b) << 16) | __builtin_bit_cast(unsigned short, a);
+    __builtin_amdgcn_raw_buffer_store_b32(v, x.rs, byte_off, 0, 16);
+}
+__device__ __forceinline__ void cl_store8(const ClX& x, int byte_off, bf16 a, bf16 b, bf16 c, bf16 d) {
+    u32x2 v;
+    v[0] = ((unsigned)__builtin_bit_cast(unsigned short, b) << 16) | __builtin_bit_cast(unsigned short, a);
+    v[1] = ((unsigned)__builtin_bit_cast(unsigned short, d) << 16) | __builtin_bit_cast(unsigned short, c);
+    __builtin_amdgcn_raw_buffer_store_b64(v, x.rs, byte_off, 0, 16);
+}
+constexpr int CLF_A = TR * H * 4, CLF_B = TR * H * 2, CLF_C = TR * E * 2;        // forward phase buffers (bytes)
+constexpr int CLF_BYTES = CLF_A + CLF_B + CLF_C + 256;                         // + flags [3][P <= 8] (padded)
+constexpr int CLB_G = TR * H * 8, CLB_C = TR * E * 2;                          // BPTT: gate gradients (x2), output gradient
+constexpr int CLB_BYTES = 2 * CLB_G + CLB_C + 256;
+
 struct ClMat { __amdgpu_buffer_rsrc_t r; int ks; };     // gate matrices: per-gate packs, tile g * 13 + ub; ho: tile et
 
 // chunk `pos` (= tile slot of this wave; one chunk per tile, every K here is <= 10 k-steps) of the rank's tile list
@@ -329,9 +379,11 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_cl_kernel(const CocoDecFwdA
     const int uk = (2 * pl) >> 4, uu = (2 * pl) & 15;
     const int j0 = (rank + P * uk) * 16 + uu;
     const bool uok = uk < nub && j0 < H;
-    u64* xA = a.cl_xchg + (size_t)(blk * 3 + 0) * TR * CL_NG;       // phase buffers of this cluster
-    u64* xB = a.cl_xchg + (size_t)(blk * 3 + 1) * TR * CL_NG;
-    u64* xC = a.cl_xchg + (size_t)(blk * 3 + 2) * TR * CL_NG;
+    char* xbase = reinterpret_cast<char*>(a.cl_xchg) + (size_t)blk * CLF_BYTES;     // phase buffers + flags of this cluster
+    unsigned* xflags = reinterpret_cast<unsigned*>(xbase + CLF_A + CLF_B + CLF_C);
+    const ClX xA = cl_x(xbase, CLF_A, xflags);                      // [16][200] {h0, dropout(h0)}
+    const ClX xB = cl_x(xbase + CLF_A, CLF_B, xflags + 8);          // [16][200] h1
+    const ClX xC = cl_x(xbase + CLF_A + CLF_B, CLF_C, xflags + 16); // [16][300] output vector
     unsigned* tmo = a.cl_timeout;
 
     for (int i = tid; i < TR * LDX; i += NTHR) xb[i] = (bf16)0.f;
@@ -379,6 +431,7 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_cl_kernel(const CocoDecFwdA
         if (KEEP && uok) kpo = gok ? *reinterpret_cast<const unsigned short*>(a.keep + (size_t)t * RH + gr * H + j0) : (unsigned short)0;
         __syncthreads();
         if (uok) {
+            bf16 pub[4];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int j = j0 + q, lc = (3 * uk) * 16 + uu + q;          // local column of gate g: lc + 16 g
@@ -398,8 +451,9 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_cl_kernel(const CocoDecFwdA
                     a.h0b_all[((size_t)(t + 1) * R + gr) * HP + j] = (bf16)hn;
                     a.midb_all[((size_t)t * R + gr) * HP + j] = (bf16)mid;
                 }
-                cl_put(xA + (size_t)grow * H + j, ep, (bf16)hn, (bf16)mid);           // granule (row, unit) = {h0, dropout(h0)}
+                pub[2 * q] = (bf16)hn; pub[2 * q + 1] = (bf16)mid;
             }
+            cl_store8(xA, (grow * H + j0) * 4, pub[0], pub[1], pub[2], pub[3]);      // (row, unit pair) = {h0, dropout(h0)} x 2
         }
         if (SAVE && rank == 0 && pl == 0 && gok) {
             a.h0b_all[((size_t)(t + 1) * R + gr) * HP + H] = (bf16)1.f;
@@ -407,10 +461,14 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_cl_kernel(const CocoDecFwdA
             a.h1b_all[((size_t)(t + 1) * R + gr) * HP + H] = (bf16)1.f;
         }
         // all-gather: every rank's units of the new h0 and of mid (own ones included: same path)
-        cl_gather<(TR * H + NTHR - 1) / NTHR>(xA, TR * H, ep, tmo, tid, [&](int gi, bf16 lo, bf16 hi) {
-            const int row = gi / H, j = gi - row * H;
-            h0b[row * LDH + j] = lo; midb[row * LDH + j] = hi;
-        });
+        cl_signal(xA, rank, ep, tid);
+        cl_wait<P>(xA, ep, tmo, tid);
+        for (int v = tid; v < TR * H / 4; v += NTHR) {              // 16 bytes = 4 units x {h0, mid}
+            const bf16x8 x = cl_load16(xA, v * 16);
+            const int row = v / (H / 4), j = (v - row * (H / 4)) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { h0b[row * LDH + j + u] = x[2 * u]; midb[row * LDH + j + u] = x[2 * u + 1]; }
+        }
         __syncthreads();
         // ---- layer 1
         cl_gemm<HP / 32, MT, MT, D, 0, true, true, P, false>(midb, LDH, m_ih1, ng, ga, LDC, ring, m_hh1, ng, true, rank, wave, lane, nullptr, 0, 0, H, rows_ok);
@@ -435,12 +493,15 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_cl_kernel(const CocoDecFwdA
                     a.h1b_all[((size_t)(t + 1) * R + gr) * HP + j] = (bf16)hn;
                 }
             }
-            cl_put(xB + (size_t)grow * (H / 2) + (j0 >> 1), ep + 1, hb2[0], hb2[1]);     // granule (row, unit pair)
+            cl_store4(xB, (grow * H + j0) * 2, hb2[0], hb2[1]);
         }
-        cl_gather<(TR * (H / 2) + NTHR - 1) / NTHR>(xB, TR * (H / 2), ep + 1, tmo, tid, [&](int gi, bf16 lo, bf16 hi) {
-            const int row = gi / (H / 2), pr = gi - row * (H / 2);
-            h1b[row * LDH + 2 * pr] = lo; h1b[row * LDH + 2 * pr + 1] = hi;
-        });
+        cl_signal(xB, rank, ep + 1, tid);
+        cl_wait<P>(xB, ep + 1, tmo, tid);
+        for (int v = tid; v < TR * H / 8; v += NTHR) {              // 16 bytes = 8 units
+            const bf16x8 x = cl_load16(xB, v * 16);
+            const int row = v / (H / 8), j = (v - row * (H / 8)) * 8;
+            *reinterpret_cast<bf16x8*>(h1b + row * LDH + j) = x;
+        }
         __syncthreads();
         // ---- output projection (own embedding tiles), fed back as the next input
         const bool last = t + 1 == T;
@@ -460,14 +521,17 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_cl_kernel(const CocoDecFwdA
                         xp[0] = (bf16)v0; xp[1] = (bf16)v1;
                     }
                 }
-                cl_put(xC + (size_t)row * (E / 2) + (e >> 1), ep + 2, (bf16)v0, (bf16)v1);
+                if (!last) cl_store4(xC, (row * E + e) * 2, (bf16)v0, (bf16)v1);
             }
         }
         if (!last) {
-            cl_gather<(TR * (E / 2) + NTHR - 1) / NTHR>(xC, TR * (E / 2), ep + 2, tmo, tid, [&](int gi, bf16 lo, bf16 hi) {
-                const int row = gi / (E / 2), pr = gi - row * (E / 2);
-                xb[row * LDX + 2 * pr] = lo; xb[row * LDX + 2 * pr + 1] = hi;
-            });
+            cl_signal(xC, rank, ep + 2, tid);
+            cl_wait<P>(xC, ep + 2, tmo, tid);
+            for (int v = tid; v < TR * E / 4; v += NTHR) {          // 8 bytes = 4 columns (E * 2 bytes per row is not a multiple of 16)
+                const int row = v / (E / 4), e = (v - row * (E / 4)) * 4;
+                const u32x2 x = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(xC.rs, (row * E + e) * 2, 0, 16));
+                *reinterpret_cast<u32x2*>(xb + row * LDX + e) = x;
+            }
         }
         __syncthreads();
     }
@@ -685,10 +749,25 @@ __global__ __launch_bounds__(NTHR) void coco_dec_bwd_cl_kernel(const CocoDecBwdA
     const int uk = (2 * pl) >> 4, uu = (2 * pl) & 15;
     const int j0 = (rank + P * uk) * 16 + uu;                       // own unit pair j0, j0 + 1
     const bool uok = uk < nub && j0 < H;
-    u64* xA = a.cl_xchg + (size_t)blk * (2 * 2 * TR * H + TR * (E / 2));    // [2 kinds][16][H] gate gradients of layer 1
-    u64* xB = xA + 2 * TR * H;                                               // ... of layer 0
-    u64* xC = xB + 2 * TR * H;                                               // [16][E/2] total output gradient of the next step
+    char* xbase = reinterpret_cast<char*>(a.cl_xchg) + (size_t)blk * CLB_BYTES;
+    unsigned* xflags = reinterpret_cast<unsigned*>(xbase + 2 * CLB_G + CLB_C);
+    const ClX xA = cl_x(xbase, CLB_G, xflags);                      // [16][200] {dr, dz, dn, dn*r} of layer 1
+    const ClX xB = cl_x(xbase + CLB_G, CLB_G, xflags + 8);          // ... of layer 0
+    const ClX xC = cl_x(xbase + 2 * CLB_G, CLB_C, xflags + 16);     // [16][300] total output gradient of the next step
     unsigned* tmo = a.cl_timeout;
+    // a 16-byte piece of a gate-gradient buffer = 2 units x {dr, dz, dn, dn*r}: scatter into the two A operands
+    auto take_gates = [&](const ClX& x) {
+        for (int v = tid; v < TR * H / 2; v += NTHR) {
+            const bf16x8 q = cl_load16(x, v * 16);
+            const int row = v / (H / 2), j = (v - row * (H / 2)) * 2;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                dgi[row * LDGK + j + u] = q[4 * u]; dgh[row * LDGK + j + u] = q[4 * u];
+                dgi[row * LDGK + H + j + u] = q[4 * u + 1]; dgh[row * LDGK + H + j + u] = q[4 * u + 1];
+                dgi[row * LDGK + 2 * H + j + u] = q[4 * u + 2]; dgh[row * LDGK + 2 * H + j + u] = q[4 * u + 3];
+            }
+        }
+    };
 
     for (int i = tid; i < TR * LDX; i += NTHR) dob[i] = (bf16)0.f;
     for (int i = tid; i < 2 * TR * LDGK; i += NTHR) dgi[i] = (bf16)0.f;
@@ -800,6 +879,7 @@ __global__ __launch_bounds__(NTHR) void coco_dec_bwd_cl_kernel(const CocoDecBwdA
         gemm_pos(0, dob, LDX, o1, LDU, true);
         __syncthreads();
         if (uok) {
+            bf16x8 pub;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int j = j0 + q, lc = uk * 16 + uu + q;
@@ -821,21 +901,20 @@ __global__ __launch_bounds__(NTHR) void coco_dec_bwd_cl_kernel(const CocoDecBwdA
                     gh[j] = (bf16)dr; gh[H + j] = (bf16)dz; gh[2 * H + j] = (bf16)dnr;
                 }
                 dh1f[q] = dd;
-                cl_put(xA + (size_t)grow * H + j, ep, (bf16)dr, (bf16)dz);
-                cl_put(xA + (size_t)(TR + grow) * H + j, ep, (bf16)dn, (bf16)dnr);
+                pub[4 * q] = (bf16)dr; pub[4 * q + 1] = (bf16)dz; pub[4 * q + 2] = (bf16)dn; pub[4 * q + 3] = (bf16)dnr;
             }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4c, pub), xA.rs, (grow * H + j0) * 8, 0, 16);
         }
-        cl_gather<(2 * TR * H + NTHR - 1) / NTHR>(xA, 2 * TR * H, ep, tmo, tid, [&](int gi, bf16 lo, bf16 hi) {
-            const int kind = gi / (TR * H), rem = gi - kind * TR * H, row = rem / H, j = rem - row * H;
-            if (kind == 0) { dgi[row * LDGK + j] = lo; dgh[row * LDGK + j] = lo; dgi[row * LDGK + H + j] = hi; dgh[row * LDGK + H + j] = hi; }
-            else { dgi[row * LDGK + 2 * H + j] = lo; dgh[row * LDGK + 2 * H + j] = hi; }
-        });
+        cl_signal(xA, rank, ep, tid);
+        cl_wait<P>(xA, ep, tmo, tid);
+        take_gates(xA);
         __syncthreads();
         // ---- dmid = dgi1 * W_ih1 ; dh1[t-1] += dgh1 * W_hh1 (own units)
         gemm_pos(1, dgi, LDGK, o1, LDU, true);
         gemm_pos(2, dgh, LDGK, o2, LDU, true);
         __syncthreads();
         if (uok) {
+            bf16x8 pub;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int j = j0 + q, lc = uk * 16 + uu + q;
@@ -860,15 +939,13 @@ __global__ __launch_bounds__(NTHR) void coco_dec_bwd_cl_kernel(const CocoDecBwdA
                     gh[j] = (bf16)dr; gh[H + j] = (bf16)dz; gh[2 * H + j] = (bf16)dnr;
                 }
                 dh0f[q] = dd;
-                cl_put(xB + (size_t)grow * H + j, ep + 1, (bf16)dr, (bf16)dz);
-                cl_put(xB + (size_t)(TR + grow) * H + j, ep + 1, (bf16)dn, (bf16)dnr);
+                pub[4 * q] = (bf16)dr; pub[4 * q + 1] = (bf16)dz; pub[4 * q + 2] = (bf16)dn; pub[4 * q + 3] = (bf16)dnr;
             }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4c, pub), xB.rs, (grow * H + j0) * 8, 0, 16);
         }
-        cl_gather<(2 * TR * H + NTHR - 1) / NTHR>(xB, 2 * TR * H, ep + 1, tmo, tid, [&](int gi, bf16 lo, bf16 hi) {
-            const int kind = gi / (TR * H), rem = gi - kind * TR * H, row = rem / H, j = rem - row * H;
-            if (kind == 0) { dgi[row * LDGK + j] = lo; dgh[row * LDGK + j] = lo; dgi[row * LDGK + H + j] = hi; dgh[row * LDGK + H + j] = hi; }
-            else { dgi[row * LDGK + 2 * H + j] = lo; dgh[row * LDGK + 2 * H + j] = hi; }
-        });
+        cl_signal(xB, rank, ep + 1, tid);
+        cl_wait<P>(xB, ep + 1, tmo, tid);
+        take_gates(xB);
         __syncthreads();
         // ---- dh0[t-1] += dgh0 * W_hh0 (own units) ; feedback into the previous output = dgi0 * W_ih0[:, :300] (own embedding tiles)
         gemm_pos(3, dgh, LDGK, o2, LDU, true);
@@ -899,12 +976,15 @@ __global__ __launch_bounds__(NTHR) void coco_dec_bwd_cl_kernel(const CocoDecBwdA
                         v[c] = (gok ? a.dw[(gr * T + (t - 1)) * E + eo[q] + c] : 0.f) + f;
                         if (gok) { ws_sum[q][c] += v[c]; a.dout_b[((size_t)(t - 1) * R + gr) * EP + eo[q] + c] = (bf16)v[c]; }
                     }
-                    cl_put(xC + (size_t)grow * (E / 2) + (eo[q] >> 1), ep + 2, (bf16)v[0], (bf16)v[1]);
+                    cl_store4(xC, (grow * E + eo[q]) * 2, (bf16)v[0], (bf16)v[1]);
                 }
-            cl_gather<(TR * (E / 2) + NTHR - 1) / NTHR>(xC, TR * (E / 2), ep + 2, tmo, tid, [&](int gi, bf16 lo, bf16 hi) {
-                const int row = gi / (E / 2), pr = gi - row * (E / 2);
-                dob[row * LDX + 2 * pr] = lo; dob[row * LDX + 2 * pr + 1] = hi;
-            });
+            cl_signal(xC, rank, ep + 2, tid);
+            cl_wait<P>(xC, ep + 2, tmo, tid);
+            for (int v = tid; v < TR * E / 4; v += NTHR) {          // 8 bytes = 4 columns
+                const int row = v / (E / 4), e = (v - row * (E / 4)) * 4;
+                const u32x2 x = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(xC.rs, (row * E + e) * 2, 0, 16));
+                *reinterpret_cast<u32x2*>(dob + row * LDX + e) = x;
+            }
         }
         __syncthreads();
     }
