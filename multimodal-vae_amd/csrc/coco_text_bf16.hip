@@ -426,7 +426,7 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_cl_kernel(const CocoDecFwdA
         const unsigned ep = 3u * (unsigned)t + 1u;
         // ---- layer 0
         cl_gemm<XP / 32, MT, MT, D, 0, true, true, P, true>(xb, LDX, m_ih0, ng, ga, LDC, ring, m_hh0, ng, true, rank, wave, lane, zi0, G, H, H, rows_ok);
-        cl_gemm<HP / 32, MT, MT, D, 0, true, true, P, false>(h0b, LDH, m_hh0, ng, gb, LDC, ring, m_ih1, ng, true, rank, wave, lane, nullptr, 0, 0, H, rows_ok);
+        cl_gemm<HP / 32, MT, MT, D, 0, true, true, P, false>(h0b, LDH, m_hh0, ng, gb, LDC, ring, m_ih1, ng, false, rank, wave, lane, nullptr, 0, 0, H, rows_ok);
         unsigned short kpo = 0x0101;
         if (KEEP && uok) kpo = gok ? *reinterpret_cast<const unsigned short*>(a.keep + (size_t)t * RH + gr * H + j0) : (unsigned short)0;
         __syncthreads();
@@ -463,16 +463,28 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_cl_kernel(const CocoDecFwdA
         // all-gather: every rank's units of the new h0 and of mid (own ones included: same path)
         cl_signal(xA, rank, ep, tid);
         cl_wait<P>(xA, ep, tmo, tid);
-        for (int v = tid; v < TR * H / 4; v += NTHR) {              // 16 bytes = 4 units x {h0, mid}
-            const bf16x8 x = cl_load16(xA, v * 16);
-            const int row = v / (H / 4), j = (v - row * (H / 4)) * 4;
+        {   // 16 bytes = 4 units x {h0, mid}.  All pieces are requested, THEN the weights of the next phase (they are not in
+            // flight while the payload stores drain, and they travel while the exchange completes), then the pieces are used
+            constexpr int NPC = (TR * H / 4 + NTHR - 1) / NTHR;
+            bf16x8 x[NPC];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { h0b[row * LDH + j + u] = x[2 * u]; midb[row * LDH + j + u] = x[2 * u + 1]; }
+            for (int q = 0; q < NPC; ++q) { const int v = tid + q * NTHR; if (v < TR * H / 4) x[q] = cl_load16(xA, v * 16); }
+#pragma unroll
+            for (int q = 0; q < D; ++q) cl_load<true, P>(ring[q], m_ih1, q, ng, rank, wave, lane);
+#pragma unroll
+            for (int q = 0; q < NPC; ++q) {
+                const int v = tid + q * NTHR;
+                if (v < TR * H / 4) {
+                    const int row = v / (H / 4), j = (v - row * (H / 4)) * 4;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { h0b[row * LDH + j + u] = x[q][2 * u]; midb[row * LDH + j + u] = x[q][2 * u + 1]; }
+                }
+            }
         }
         __syncthreads();
         // ---- layer 1
         cl_gemm<HP / 32, MT, MT, D, 0, true, true, P, false>(midb, LDH, m_ih1, ng, ga, LDC, ring, m_hh1, ng, true, rank, wave, lane, nullptr, 0, 0, H, rows_ok);
-        cl_gemm<HP / 32, MT, MTO, D, 0, true, false, P, false>(h1b, LDH, m_hh1, ng, gb, LDC, ring, m_ho, noe, true, rank, wave, lane, nullptr, 0, 0, H, rows_ok);
+        cl_gemm<HP / 32, MT, MTO, D, 0, true, false, P, false>(h1b, LDH, m_hh1, ng, gb, LDC, ring, m_ho, noe, false, rank, wave, lane, nullptr, 0, 0, H, rows_ok);
         __syncthreads();
         if (uok) {
             bf16 hb2[2];
@@ -497,15 +509,20 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_cl_kernel(const CocoDecFwdA
         }
         cl_signal(xB, rank, ep + 1, tid);
         cl_wait<P>(xB, ep + 1, tmo, tid);
-        for (int v = tid; v < TR * H / 8; v += NTHR) {              // 16 bytes = 8 units
-            const bf16x8 x = cl_load16(xB, v * 16);
-            const int row = v / (H / 8), j = (v - row * (H / 8)) * 8;
-            *reinterpret_cast<bf16x8*>(h1b + row * LDH + j) = x;
+        {   // 16 bytes = 8 units (400 pieces: one per thread)
+            bf16x8 x = {};
+            if (tid < TR * H / 8) x = cl_load16(xB, tid * 16);
+#pragma unroll
+            for (int q = 0; q < MTO; ++q) cl_load<false, P>(ring[q], m_ho, q, noe, rank, wave, lane);
+            if (tid < TR * H / 8) {
+                const int row = tid / (H / 8), j = (tid - row * (H / 8)) * 8;
+                *reinterpret_cast<bf16x8*>(h1b + row * LDH + j) = x;
+            }
         }
         __syncthreads();
         // ---- output projection (own embedding tiles), fed back as the next input
         const bool last = t + 1 == T;
-        cl_gemm<HP / 32, MT, MT, D, 0, false, true, P, true>(h1b, LDH, m_ho, noe, ga, LDC, ring, m_ih0, ng, !last, rank, wave, lane, zo, E, E, 0, rows_ok);
+        cl_gemm<HP / 32, MT, MT, D, 0, false, true, P, true>(h1b, LDH, m_ho, noe, ga, LDC, ring, m_ih0, ng, false, rank, wave, lane, zo, E, E, 0, rows_ok);
         __syncthreads();
         // own columns: local pair lp -> tile lp / 8, columns 2 (lp % 8), +1 ; up to NOEMAX * 8 pairs per row
         for (int gi = tid; gi < TR * NOEMAX * 8; gi += NTHR) {
@@ -527,10 +544,20 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_cl_kernel(const CocoDecFwdA
         if (!last) {
             cl_signal(xC, rank, ep + 2, tid);
             cl_wait<P>(xC, ep + 2, tmo, tid);
-            for (int v = tid; v < TR * E / 4; v += NTHR) {          // 8 bytes = 4 columns (E * 2 bytes per row is not a multiple of 16)
-                const int row = v / (E / 4), e = (v - row * (E / 4)) * 4;
-                const u32x2 x = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(xC.rs, (row * E + e) * 2, 0, 16));
-                *reinterpret_cast<u32x2*>(xb + row * LDX + e) = x;
+            // 8 bytes = 4 columns (E * 2 bytes per row is not a multiple of 16)
+            constexpr int NPC = (TR * E / 4 + NTHR - 1) / NTHR;
+            u32x2 x[NPC];
+#pragma unroll
+            for (int q = 0; q < NPC; ++q) {
+                const int v = tid + q * NTHR;
+                if (v < TR * E / 4) { const int row = v / (E / 4), e = (v - row * (E / 4)) * 4; x[q] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(xC.rs, (row * E + e) * 2, 0, 16)); }
+            }
+#pragma unroll
+            for (int q = 0; q < D; ++q) cl_load<true, P>(ring[q], m_ih0, q, ng, rank, wave, lane);
+#pragma unroll
+            for (int q = 0; q < NPC; ++q) {
+                const int v = tid + q * NTHR;
+                if (v < TR * E / 4) { const int row = v / (E / 4), e = (v - row * (E / 4)) * 4; *reinterpret_cast<u32x2*>(xb + row * LDX + e) = x[q]; }
             }
         }
         __syncthreads();
