@@ -783,15 +783,23 @@ __global__ __launch_bounds__(NTHR) void coco_dec_bwd_cl_kernel(const CocoDecBwdA
     const ClX xC = cl_x(xbase + 2 * CLB_G, CLB_C, xflags + 16);     // [16][300] total output gradient of the next step
     unsigned* tmo = a.cl_timeout;
     // a 16-byte piece of a gate-gradient buffer = 2 units x {dr, dz, dn, dn*r}: scatter into the two A operands
-    auto take_gates = [&](const ClX& x) {
-        for (int v = tid; v < TR * H / 2; v += NTHR) {
-            const bf16x8 q = cl_load16(x, v * 16);
-            const int row = v / (H / 2), j = (v - row * (H / 2)) * 2;
+    constexpr int NPG = (TR * H / 2 + NTHR - 1) / NTHR;
+    auto load_gates = [&](const ClX& x, bf16x8 (&pc)[NPG]) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                dgi[row * LDGK + j + u] = q[4 * u]; dgh[row * LDGK + j + u] = q[4 * u];
-                dgi[row * LDGK + H + j + u] = q[4 * u + 1]; dgh[row * LDGK + H + j + u] = q[4 * u + 1];
-                dgi[row * LDGK + 2 * H + j + u] = q[4 * u + 2]; dgh[row * LDGK + 2 * H + j + u] = q[4 * u + 3];
+        for (int q = 0; q < NPG; ++q) { const int v = tid + q * NTHR; if (v < TR * H / 2) pc[q] = cl_load16(x, v * 16); }
+    };
+    auto put_gates = [&](const bf16x8 (&pc)[NPG]) {
+#pragma unroll
+        for (int q = 0; q < NPG; ++q) {
+            const int v = tid + q * NTHR;
+            if (v < TR * H / 2) {
+                const int row = v / (H / 2), j = (v - row * (H / 2)) * 2;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    dgi[row * LDGK + j + u] = pc[q][4 * u]; dgh[row * LDGK + j + u] = pc[q][4 * u];
+                    dgi[row * LDGK + H + j + u] = pc[q][4 * u + 1]; dgh[row * LDGK + H + j + u] = pc[q][4 * u + 1];
+                    dgi[row * LDGK + 2 * H + j + u] = pc[q][4 * u + 2]; dgh[row * LDGK + 2 * H + j + u] = pc[q][4 * u + 3];
+                }
             }
         }
     };
@@ -854,9 +862,12 @@ __global__ __launch_bounds__(NTHR) void coco_dec_bwd_cl_kernel(const CocoDecBwdA
                 if (s < kc) dst[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r_ih0T, lane * 16, ub + s * 1024, 0));
         }
     };
-    // consume chunk `pos` from ring slot pos % D: partial tile -> plane kh of `out`; then request chunk pos + D of the list
+    // consume chunk `pos` from ring slot pos % D: partial tile -> plane kh of `out`.  Chunks are requested explicitly
+    // (request(pos)): the ones a phase starts with go out behind the loads of the exchange that precedes it, so that no
+    // weight load is in flight while payload stores drain, and the stream travels while the exchange completes
     bf16x8 ring[D][KCH];
-    auto gemm_pos = [&](int pos, const bf16* A, int lda, float* out, int ldo, bool more) {
+    auto request = [&](int pos) { load_pos(ring[pos % D], pos); };
+    auto gemm_pos = [&](int pos, const bf16* A, int lda, float* out, int ldo) {
         int li, kh, k0, kc;
         bool ok;
         if (pos < 4) {
@@ -877,12 +888,9 @@ __global__ __launch_bounds__(NTHR) void coco_dec_bwd_cl_kernel(const CocoDecBwdA
 #pragma unroll
             for (int j = 0; j < 4; ++j) out[(kh * TR + fq * 4 + j) * ldo + li * 16 + fr] = acc[j];
         }
-        const int np = pos + D;
-        if (np < NPOS) load_pos(ring[pos % D], np);
-        else if (more) load_pos(ring[pos % D], np - NPOS);
     };
-#pragma unroll
-    for (int q = 0; q < D; ++q) load_pos(ring[q], q);
+    static_assert(D == 2, "explicit request schedule below is written for two ring slots");
+    request(0);
     __syncthreads();
 
     for (int t = T - 1; t >= 0; --t) {
@@ -903,7 +911,7 @@ __global__ __launch_bounds__(NTHR) void coco_dec_bwd_cl_kernel(const CocoDecBwdA
         }
         if (KEEP && uok) kpo = gok ? *reinterpret_cast<const unsigned short*>(a.keep + (size_t)t * RH + gr * H + j0) : (unsigned short)0;
         // ---- dh1 += dOut * W_ho (own units)
-        gemm_pos(0, dob, LDX, o1, LDU, true);
+        gemm_pos(0, dob, LDX, o1, LDU);
         __syncthreads();
         if (uok) {
             bf16x8 pub;
@@ -934,11 +942,16 @@ __global__ __launch_bounds__(NTHR) void coco_dec_bwd_cl_kernel(const CocoDecBwdA
         }
         cl_signal(xA, rank, ep, tid);
         cl_wait<P>(xA, ep, tmo, tid);
-        take_gates(xA);
+        {
+            bf16x8 pc[NPG];
+            load_gates(xA, pc);
+            request(1); request(2);
+            put_gates(pc);
+        }
         __syncthreads();
         // ---- dmid = dgi1 * W_ih1 ; dh1[t-1] += dgh1 * W_hh1 (own units)
-        gemm_pos(1, dgi, LDGK, o1, LDU, true);
-        gemm_pos(2, dgh, LDGK, o2, LDU, true);
+        gemm_pos(1, dgi, LDGK, o1, LDU);
+        gemm_pos(2, dgh, LDGK, o2, LDU);
         __syncthreads();
         if (uok) {
             bf16x8 pub;
@@ -972,12 +985,18 @@ __global__ __launch_bounds__(NTHR) void coco_dec_bwd_cl_kernel(const CocoDecBwdA
         }
         cl_signal(xB, rank, ep + 1, tid);
         cl_wait<P>(xB, ep + 1, tmo, tid);
-        take_gates(xB);
+        {
+            bf16x8 pc[NPG];
+            load_gates(xB, pc);
+            request(3); request(4);
+            put_gates(pc);
+        }
         __syncthreads();
         // ---- dh0[t-1] += dgh0 * W_hh0 (own units) ; feedback into the previous output = dgi0 * W_ih0[:, :300] (own embedding tiles)
-        gemm_pos(3, dgh, LDGK, o2, LDU, true);
+        gemm_pos(3, dgh, LDGK, o2, LDU);
+        if (NPOS > 5) request(5);                      // (slot of chunk 3 is free again)
 #pragma unroll
-        for (int sl = 0; sl < MTE; ++sl) gemm_pos(4 + sl, dgi, LDGK, fbp, LDE, !first);
+        for (int sl = 0; sl < MTE; ++sl) gemm_pos(4 + sl, dgi, LDGK, fbp, LDE);
         __syncthreads();
         if (uok && gok) {
 #pragma unroll
@@ -1007,10 +1026,18 @@ __global__ __launch_bounds__(NTHR) void coco_dec_bwd_cl_kernel(const CocoDecBwdA
                 }
             cl_signal(xC, rank, ep + 2, tid);
             cl_wait<P>(xC, ep + 2, tmo, tid);
-            for (int v = tid; v < TR * E / 4; v += NTHR) {          // 8 bytes = 4 columns
-                const int row = v / (E / 4), e = (v - row * (E / 4)) * 4;
-                const u32x2 x = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(xC.rs, (row * E + e) * 2, 0, 16));
-                *reinterpret_cast<u32x2*>(dob + row * LDX + e) = x;
+            constexpr int NPC = (TR * E / 4 + NTHR - 1) / NTHR;     // 8 bytes = 4 columns
+            u32x2 x[NPC];
+#pragma unroll
+            for (int q = 0; q < NPC; ++q) {
+                const int v = tid + q * NTHR;
+                if (v < TR * E / 4) { const int row = v / (E / 4), e = (v - row * (E / 4)) * 4; x[q] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(xC.rs, (row * E + e) * 2, 0, 16)); }
+            }
+            request(0);
+#pragma unroll
+            for (int q = 0; q < NPC; ++q) {
+                const int v = tid + q * NTHR;
+                if (v < TR * E / 4) { const int row = v / (E / 4), e = (v - row * (E / 4)) * 4; *reinterpret_cast<u32x2*>(dob + row * LDX + e) = x[q]; }
             }
         }
         __syncthreads();
