@@ -21,7 +21,7 @@ struct CocoDecFwdArgs {
     // cluster form (coco_dec_fwd_cl_kernel): per-gate packs [3][208][K] of the four GRU matrices, exchange granules
     // [row blocks][3 phases][16][200] (zeroed before the launch), timeout word; cluster = ranks per row block (0 / 1: off)
     const bf16 *wg_ih0, *wg_hh0, *wg_ih1, *wg_hh1;
-    unsigned long long* cl_xchg; unsigned* cl_timeout; int cluster;
+    unsigned long long* cl_xchg; unsigned* cl_timeout; int cluster;   // (cl_xchg: raw bytes, 16-byte aligned)
     const float *bhh0, *bih1, *bhh1;
     float* sentence;         // [R][T][300]
     // saved for the backward pass (null: inference)
@@ -40,7 +40,7 @@ struct CocoDecBwdArgs {
     float *dhinit;           // [R][200]
     float *dwsum;            // [R][300] time sum of the output gradient
     // cluster form (coco_dec_bwd_cl_kernel): exchange granules [row blocks][2*2*16*200 + 16*150] (zeroed before the launch)
-    unsigned long long* cl_xchg; unsigned* cl_timeout; int cluster;
+    unsigned long long* cl_xchg; unsigned* cl_timeout; int cluster;   // (cl_xchg: raw bytes, 16-byte aligned)
 };
 struct CocoEncFwdArgs {
     int B, T;

@@ -1,15 +1,16 @@
-// Caption decoder of the COCO MMVAE (coco/model.py:256-312) as TWO persistent launches: one for the 102-step forward
-// recurrence, one for backpropagation through time.
+// Caption recurrences of the COCO MMVAE (coco/model.py:219-312) as persistent launches: decoder forward, decoder BPTT,
+// encoder forward, encoder BPTT -- four launches where the fp32 path (coco_text.hip) issues 3 dependent launches per forward
+// step and 5 per backward step of each recurrence (17 ms per training step at the per-GPU batch of configuration 5, all of it
+// dependent-launch latency).
 //
-// The fp32 path (coco_text.hip) issues 3 dependent launches per forward step and 5 per backward step: 17 ms per training
-// step at the per-GPU batch of configuration 5, all of it dependent-launch latency.  Here one workgroup (8 waves) owns 16
-// rows of the 3B-row decoder batch for the WHOLE recurrence:
-//   * state (h0, h1, the fed-back output vector, the carried gradients) lives in LDS / registers, nothing synchronises
-//     across workgroups;
-//   * the weights (1.24 MB bf16 per step: 5 matrices forward, 6 backward) stream from L2 as MFMA-fragment-shaped 16-byte
-//     loads; the stream never stalls on the recurrence: while a wave runs the MFMAs of one 16-column tile it already holds
-//     the loads of its next tile in flight -- ACROSS the barriers between the GEMMs of a step (the weights do not depend on
-//     the data), so a step costs the L2 stream, not a latency chain;
+//   * single-workgroup form (coco_dec_fwd/bwd_kernel): one 8-wave workgroup owns 16 rows of the 3B-row decoder batch for the
+//     WHOLE recurrence; state lives in LDS / registers; the weights (1.34 MB bf16 per step forward, 1.26 MB backward) stream
+//     from L2 through a register ring (stream_gemm.h) as fragment-major 16-byte loads, ACROSS the barriers between the GEMMs
+//     of a step: a step costs the L2 stream of one CU (24 us), not a latency chain.  Used when the row blocks fill the chip.
+//   * cluster form (coco_dec_fwd/bwd_cl_kernel): P = 8 or 4 workgroups per row block, each owning a slice of the hidden
+//     units / embedding columns of every product, three all-gathers per step through global memory (12-13 us per step).
+//   * caption encoder (coco_enc_fwd/bwd_res_kernel): W_hh resident in registers + LDS, gate math in the MFMA accumulators;
+//     the streamed form (coco_enc_fwd/bwd_kernel) is kept for batches that are not a multiple of 4.
 //   * bf16 MFMA operands, fp32 accumulation, gate math and state in fp32.  Measured against the reference (oracle with the
 //     GEMM operands of the caption GRUs rounded to bf16, 102 steps, B=16): losses move by <= 1e-4 relative, gradient
 //     tensors by <= 3e-3 -- inside the 1e-3 ELBO bound, so the 1/16-rate fp32 MFMA is not needed.
@@ -183,73 +184,18 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_kernel(const CocoDecFwdArgs
 // of L2 (1.34 MB at ~55 GB/s = 24 us) while 230 CUs idle.  Here P workgroups (ranks) share a row block: rank r owns the
 // hidden-unit blocks r, r + P, ... of EVERY gate GEMM (weights packed per gate, so r, z and n of a unit stay together) and
 // the embedding tiles r, r + P, ... of the output projection, i.e. streams 1/P of the weights, computes the new state of
-// its units, and the ranks all-gather the new state after each of the three phases of a step through global memory:
-// 8-byte granules {epoch tag, two bf16 values} written and read with device-scope atomics -- the data is the flag, no
-// fence, one hop (guide recipe R2).  Epoch = 3 t + phase + 1, one buffer per phase: a rank can be at most one phase ahead
-// of the slowest one.  Every spin is bounded (timeout word; the kernel then runs on with NaNs, which surface in the losses).
-// Results are bit-identical to the single-workgroup kernel (same k order and the same roundings per output element).
-typedef unsigned long long u64;
-constexpr int CL_NG = 200;                          // granules per row and phase buffer
+// its units, and the ranks all-gather the new state after each of the three phases of a step through global memory.
+// Exchange (guide Guideline 16, recipe R1): every rank writes its slice of a phase buffer with write-through (sc1) stores,
+// drains them (s_waitcnt vmcnt(0), workgroup barrier), and ONE lane stores the rank's flag = epoch; a reader polls the P
+// flags (one lane each), passes a barrier, and reads the whole buffer with 16-byte sc1 loads (every load of handed-off
+// bytes is sc1: no acquire fence).  Epoch = 3 t + phase + 1, one buffer per phase: a rank can be at most one phase ahead
+// of the slowest one; buffers and flags are zeroed before every launch; every spin is bounded (timeout word: the step's
+// results are then garbage, loudly, instead of a hang).  The first version exchanged 8-byte {epoch, 2 x bf16} granules
+// with device-scope atomics (the data is the flag, one hop): correct, but one uncached load per granule and reader --
+// 15,200 per BPTT step -- made the exchange, not the weight stream, the bound.
+// Results equal the single-workgroup kernels up to the fp32 summation order of split reductions.
 constexpr unsigned CL_SPIN_MAX = 1u << 22;
 
-__device__ __forceinline__ void cl_put(u64* g, unsigned epoch, bf16 lo, bf16 hi) {
-    const unsigned short a = __builtin_bit_cast(unsigned short, lo), b = __builtin_bit_cast(unsigned short, hi);
-    __hip_atomic_store(g, ((u64)epoch << 32) | ((u64)b << 16) | a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void cl_get(const u64* g, unsigned epoch, bf16& lo, bf16& hi, unsigned* tmo) {
-    for (unsigned spin = 0; spin < CL_SPIN_MAX; ++spin) {
-        const u64 x = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((unsigned)(x >> 32) == epoch) {
-            lo = __builtin_bit_cast(bf16, (unsigned short)(x & 0xffff));
-            hi = __builtin_bit_cast(bf16, (unsigned short)((x >> 16) & 0xffff));
-            return;
-        }
-        if ((spin & 31) == 31) __builtin_amdgcn_s_sleep(1);
-    }
-    // gave up: a rank of this cluster never published.  No hang: the kernel runs on, but with NaNs, so the step's losses and
-    // gradients come out NaN (loud), and the timeout word keeps the epoch for a post-mortem
-    atomicExch(tmo, epoch);
-    lo = hi = __builtin_bit_cast(bf16, (unsigned short)0x7FC0);
-}
-
-// All-gather of `total` granules of one phase buffer: thread tid owns granules tid, tid + 512, ... (at most NG); ALL of its
-// loads are in flight before the first tag is looked at, and only granules whose tag is still old are polled again (a
-// single granule per round trip would serialise NG L2 latencies).  sink(index, lo, hi) consumes a granule.
-template <int NG, class Sink>
-__device__ __forceinline__ void cl_gather(const u64* base, int total, unsigned epoch, unsigned* tmo, int tid, Sink sink) {
-    u64 x[NG];
-    unsigned pending = 0;
-#pragma unroll
-    for (int q = 0; q < NG; ++q)
-        if (tid + q * NTHR < total) pending |= 1u << q;
-    for (unsigned spin = 0; pending != 0; ++spin) {
-#pragma unroll
-        for (int q = 0; q < NG; ++q)
-            if (pending & (1u << q)) x[q] = __hip_atomic_load(base + tid + q * NTHR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int q = 0; q < NG; ++q)
-            if ((pending & (1u << q)) && (unsigned)(x[q] >> 32) == epoch) {
-                pending &= ~(1u << q);
-                sink(tid + q * NTHR, __builtin_bit_cast(bf16, (unsigned short)(x[q] & 0xffff)),
-                     __builtin_bit_cast(bf16, (unsigned short)((x[q] >> 16) & 0xffff)));
-            }
-        if (pending && spin >= CL_SPIN_MAX) {           // gave up (see cl_get): NaNs, loud
-            atomicExch(tmo, epoch);
-#pragma unroll
-            for (int q = 0; q < NG; ++q)
-                if (pending & (1u << q)) sink(tid + q * NTHR, __builtin_bit_cast(bf16, (unsigned short)0x7FC0), __builtin_bit_cast(bf16, (unsigned short)0x7FC0));
-            pending = 0;
-        }
-        if (pending && (spin & 15) == 15) __builtin_amdgcn_s_sleep(1);
-    }
-}
-
-// Bulk form of the exchange (guide recipe R1): the granule form above costs one uncached 8-byte load per granule and reader
-// -- 15,200 per BPTT step, which made the exchange, not the weight stream, the bound.  Here every rank writes its slice of a
-// phase buffer with write-through (sc1) stores, drains them (s_waitcnt vmcnt(0), workgroup barrier), and ONE lane stores
-// the rank's flag = epoch; a reader polls the P flags (one lane each), passes a barrier, and reads the whole buffer with
-// 16-byte sc1 loads (every load of handed-off bytes is sc1: no acquire fence needed).  4x fewer memory instructions for one
-// more hop.
 struct ClX {
     __amdgpu_buffer_rsrc_t rs;      // this cluster's phase buffer
     unsigned* flags;                // [P] epochs
