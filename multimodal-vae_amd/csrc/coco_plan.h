@@ -44,10 +44,11 @@ struct CocoDecBwdArgs {
 };
 struct CocoEncFwdArgs {
     int B, T;
-    const float* gi;         // [B][T][600] input projection of every step (+ b_ih)
+    const float* gi;         // [B][T][600] input projection of every step (+ b_ih); resident form: [600][T][B] WITHOUT b_ih
+    const float* bih;        // resident form: b_ih, added in fp32 by the kernel
     const bf16* w_hh;        // packed [608][224]; resident form: three per-gate [208][224] matrices back to back
     int resident;            // 1: the weights stay in registers / LDS for the whole recurrence (coco_enc_fwd_res_kernel);
-                             // gi is then [T][600][B], sav [T][4][200][B], h_all [T][200][B] (batch row fastest, B % 4 == 0)
+                             // gi is then [600][T][B] (no bias), sav [T][4][200][B], h_all [T][200][B] (batch row fastest, B % 4 == 0)
     float* h_last;           // resident form: h after the last step, [B][200]
     const float* bhh;
     float* h_all;            // [T][B][200] h after each step
@@ -64,7 +65,6 @@ struct CocoEncBwdArgs {
 };
 int launch_coco_enc_fwd(const CocoEncFwdArgs& a, hipStream_t s);
 int launch_coco_enc_bwd(const CocoEncBwdArgs& a, hipStream_t s);
-int launch_coco_gi_transpose(const float* gi_bt, int B, int T, float* gi_tb, hipStream_t s);     // [B][T][600] -> [T][600][B]
 // dst[(t*B + b)*ld + e] = bf16(text[(b*T + t)*300 + e]); column 300 = 1.0
 int launch_coco_text_tb(const float* text, int B, int T, int ld, bf16* dst, hipStream_t s);
 int launch_coco_dec_fwd(const CocoDecFwdArgs& a, hipStream_t s);
@@ -84,7 +84,7 @@ struct CocoPlan : PlanBase {
     // bf16 persistent caption decoder: packed weights (forward and transposed forms) and packed-gradient descriptors
     bool text_bf16 = true;
     bool dec_wg_pending = false; const float* dec_wg_z = nullptr; int dec_wg_groups = 0;   // deferred weight gradients of the bf16 decoder
-    int tb_ih0, tb_hh0, tb_ih1, tb_hh1, tb_ho, tb_hoT, tb_ih1T, tb_hh1T, tb_hh0T, tb_ih0T, tb_e_hh, tb_e_hhT, tb_e_hhg[3], tb_g_ih0[3], tb_g_hh0[3], tb_g_ih1[3], tb_g_hh1[3];
+    int tb_ih0, tb_hh0, tb_ih1, tb_hh1, tb_ho, tb_hoT, tb_ih1T, tb_hh1T, tb_hh0T, tb_ih0T, tb_e_hh, tb_e_hhT, tb_e_ihA, tb_e_hhg[3], tb_g_ih0[3], tb_g_hh0[3], tb_g_ih1[3], tb_g_hh1[3];
     int tg_ih0, tg_hh0, tg_ih1, tg_hh1, tg_ho, tg_e_ih, tg_e_hh;
     struct W {
         char* zero_begin; size_t zero_bytes;

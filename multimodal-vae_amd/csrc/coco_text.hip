@@ -335,6 +335,8 @@ void coco_text_build(CocoPlan& P) {
     P.tb_ih0T = trp(P.td0.wih, E, G, in0, CTB_EP, CTB_GP);      // [e][g] = weight_ih_l0[g][e]
     P.tb_e_hh = fwdp(P.te_f.whh, G, H, H, CTB_GP, CTB_HP);      // caption encoder, forward direction
     P.tb_e_hhT = trp(P.te_f.whh, H, G, H, 208, CTB_GP);
+    // weight_ih of the encoder as the ROW operand of the transposed input projection gi^T[600][T*B] = W_ih x^T (row-major)
+    P.tb_e_ihA = P.pk.add(pack_dense(P.te_f.wih, G, E, round_up(G, 128), CTB_XP, E, 1));
     for (int g3 = 0; g3 < 3; ++g3)                               // per-gate copies for the weight-resident forward kernel
         P.tb_e_hhg[g3] = fwdp(P.te_f.whh + (long long)g3 * H * H, H, H, H, 208, CTB_HP);
     // per-gate copies of the decoder GRUs (cluster form): the three gates of a matrix back to back
@@ -384,7 +386,7 @@ void coco_text_carve(CocoPlan& P, Workspace& ws) {
         w.cl_xchg = ws.take<char>(w.cl_bytes);
         w.clb_bytes = ((R + 15) / 16) * (size_t)(2 * 16 * 200 * 8 + 16 * 300 * 2 + 256) + 64;
         w.clb_xchg = ws.take<char>(w.clb_bytes);
-        w.te_xb = ws.take<bf16>(T * B * CTB_XP); w.te_hb_all = ws.take<bf16>(T * B * CTB_HP);
+        w.te_xb = ws.take<bf16>((size_t)round_up((int)(T * B), 128) * CTB_XP); w.te_hb_all = ws.take<bf16>(T * B * CTB_HP);
         w.te_dgi_b = ws.take<bf16>(T * B * CTB_GP); w.te_dgh_b = ws.take<bf16>(T * B * CTB_GP);
     }
 }
@@ -409,8 +411,22 @@ int coco_text_enc_fwd(CocoPlan& P, const float* text, int save, float* out, hipS
     CocoPlan::W& w = P.w;
     const int B = P.B, T = P.T, D2 = 2 * P.D;
     const float* p = P.buf.params;
-    // input projection of every time step at once: rows (b, t)
-    MMVAE_TRY(lin(text, E, B * T, p + P.te_f.wih, G, E, E, 0, p + P.te_f.bih, nullptr, 0, w.te_gi, G, s));
+    const bool res_path = bf16_path && P.text_bf16 && coco_enc_resident(P);
+    if (res_path) {
+        // input projection of every time step at once, TRANSPOSED: gi^T[600][T*B] = W_ih (rows) x captions^T, one bf16 GEMM with
+        // the captions in the [t][row] bf16 layout the weight gradient needs anyway as its "weight" operand (b_ih is added in
+        // fp32 by the recurrence kernel).  Replaces an fp32 GEMM (83 us at B=128, 590 us at B=1024) + a transpose.
+        MMVAE_TRY(launch_coco_text_tb(text, B, T, CTB_XP, w.te_xb, s));
+        GatherPlan pl = dense_plan(G, CTB_XP, CTB_XP, T * B);
+        GemmParams g = gemm_of(P, pl, &P.tb_e_ihA, 1, G);
+        g.c.A = P.buf.packed + P.pk.d[P.tb_e_ihA].dst_off;
+        g.cls[0].Wp = w.te_xb; g.cls[0].Kpad = CTB_XP; g.npad = round_up(T * B, 128);
+        g.out_f = w.te_giT; g.ldo = T * B;
+        MMVAE_TRY(launch_gemm_gather(g, s));
+    } else {
+        // input projection of every time step at once: rows (b, t)
+        MMVAE_TRY(lin(text, E, B * T, p + P.te_f.wih, G, E, E, 0, p + P.te_f.bih, nullptr, 0, w.te_gi, G, s));
+    }
     if (bf16_path && P.text_bf16) {      // the recurrence in ONE persistent launch (coco_text_bf16.hip)
         CocoEncFwdArgs a{};
         const bool res = coco_enc_resident(P);
@@ -420,8 +436,7 @@ int coco_text_enc_fwd(CocoPlan& P, const float* text, int save, float* out, hipS
         if (res) {      // the resident kernels read / write with the batch row fastest: [T][600][B] and friends
             MMVAE_REQUIRE(P.pk.d[P.tb_e_hhg[1]].dst_off == P.pk.d[P.tb_e_hhg[0]].dst_off + 208ll * CTB_HP &&
                           P.pk.d[P.tb_e_hhg[2]].dst_off == P.pk.d[P.tb_e_hhg[0]].dst_off + 2 * 208ll * CTB_HP, "per-gate packs not contiguous");
-            MMVAE_TRY(launch_coco_gi_transpose(w.te_gi, B, T, w.te_giT, s));
-            a.gi = w.te_giT; a.h_last = w.te_hlast;
+            a.gi = w.te_giT; a.bih = p + P.te_f.bih; a.h_last = w.te_hlast;
         }
         a.h_all = w.te_h;
         if (save) { a.sav = w.te_sav; a.hb_all = w.te_hb_all; }
@@ -452,6 +467,7 @@ int coco_text_enc_bwd(CocoPlan& P, const float* text, const float* d_out, hipStr
     const float* p = P.buf.params;
     float* g = P.buf.grads;
     const bool bf = bf16_path && P.text_bf16;
+    const bool a_res_done = bf && coco_enc_resident(P);
     hipStream_t so = bf ? sw : s;        // where everything that only feeds the optimizer goes
     MMVAE_TRY(lin_dx(d_out, D2, B, p + P.te_h2p_w, D2, H, H, 0, w.te_dsum, H, 0, s));
     if (bf) {       // BPTT of the forward direction in one launch; it is the critical chain, everything else goes behind it
@@ -474,7 +490,7 @@ int coco_text_enc_bwd(CocoPlan& P, const float* text, const float* d_out, hipStr
         MMVAE_TRY(lin_dw(w.te_dgi_r, G, text + (size_t)(T - 1) * E, (long long)T * E, B, g + P.te_r.wih, G, E, E, 0, so));
     }
     if (bf) {       // weight gradients of the forward direction as batched bf16 GEMMs over all T*B rows
-        MMVAE_TRY(launch_coco_text_tb(text, B, T, CTB_XP, w.te_xb, so));
+        if (!a_res_done) MMVAE_TRY(launch_coco_text_tb(text, B, T, CTB_XP, w.te_xb, so));    // (the resident forward path made it already)
         if (so != s) MMVAE_TRY(edge(P, s, so));
         WgradParams list[2];
         int n = 0;

@@ -1074,7 +1074,8 @@ __global__ __launch_bounds__(NTHR) void coco_enc_fwd_kernel(const CocoEncFwdArgs
 // wave and wave + 8 of ALL THREE gates, so r, z and n of a hidden unit meet in the accumulators of one lane (MFMA C layout:
 // rows 4*(lane/16) .. +3 of column lane%16) and the gate math runs in registers -- the state h lives there too, in fp32.
 // What a lane owns is 4 consecutive ROWS of one unit, so the per-step operands and saves of this path are laid out with
-// the batch row as the fastest index ([t][gate][unit][B]): one 16-byte load / store per (gate, unit) instead of four
+// the batch row as the fastest index ([gate*H + unit][t][B] for the input projection, [t][gate][unit][B] for the saves): one
+// 16-byte load / store per (gate, unit) instead of four
 // scattered ones.  The bf16 copy of h (next step's A operand, and the row-major operand of the batched weight gradient)
 // is double-buffered in LDS and written out by all threads as 16-byte vectors one step later.  One barrier per step.
 template <bool SAVE>
@@ -1098,13 +1099,13 @@ __global__ __launch_bounds__(NTHR) void coco_enc_fwd_res_kernel(const CocoEncFwd
                 *reinterpret_cast<const bf16x8*>(a.w_hh + g * GATE + ((size_t)((wave + NW) * KS + s) * 64 + lane) * 8);
         }
     for (int i = tid; i < 2 * TR * LDH; i += NTHR) hb[i] = (bf16)0.f;
-    int ju[2]; bool uok[2]; float br[2], bz[2], bn[2];
+    int ju[2]; bool uok[2]; float br[2], bz[2], bn[2], bin[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         ju[i] = (wave + NW * i) * 16 + fr;
         uok[i] = (i == 0 || two) && ju[i] < H;
         const int j = min(ju[i], H - 1);
-        br[i] = a.bhh[j]; bz[i] = a.bhh[H + j]; bn[i] = a.bhh[2 * H + j];
+        br[i] = a.bhh[j] + a.bih[j]; bz[i] = a.bhh[H + j] + a.bih[H + j]; bn[i] = a.bhh[2 * H + j]; bin[i] = a.bih[2 * H + j];
     }
     const int row4 = r0 + fq * 4;                                   // this lane's 4 rows (B is a multiple of 4: all or none exist)
     const bool rok = row4 < R;
@@ -1119,7 +1120,7 @@ __global__ __launch_bounds__(NTHR) void coco_enc_fwd_res_kernel(const CocoEncFwd
         }
     };
     float hst[2][4] = {};
-    // the input projection (+ b_ih) of a step, [t][gate*H + unit][B], is requested a whole step ahead: it comes from HBM /
+    // the input projection of a step, [gate*H + unit][t][B] (no bias), is requested a whole step ahead: it comes from HBM /
     // Infinity Cache (31 MB per pass), and one MFMA phase does not cover that latency
     f32x4 gi[2][3], gnx[2][3];
     auto fetch = [&](f32x4 (&dst)[2][3], int t) {
@@ -1127,7 +1128,7 @@ __global__ __launch_bounds__(NTHR) void coco_enc_fwd_res_kernel(const CocoEncFwd
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int g = 0; g < 3; ++g)
-                dst[i][g] = *reinterpret_cast<const f32x4*>(a.gi + ((size_t)t * G + g * H + min(ju[i], H - 1)) * R + rbase);
+                dst[i][g] = *reinterpret_cast<const f32x4*>(a.gi + ((size_t)(g * H + min(ju[i], H - 1)) * T + t) * R + rbase);
     };
     fetch(gnx, 0);
     __syncthreads();
@@ -1164,7 +1165,7 @@ __global__ __launch_bounds__(NTHR) void coco_enc_fwd_res_kernel(const CocoEncFwd
                     const float r = sigm(gi[i][0][jr] + acc[0][jr] + br[i]);
                     const float z = sigm(gi[i][1][jr] + acc[1][jr] + bz[i]);
                     const float ghn = acc[2][jr] + bn[i];
-                    const float n = tanh_fast(gi[i][2][jr] + r * ghn);
+                    const float n = tanh_fast(gi[i][2][jr] + bin[i] + r * ghn);
                     const float hn = (1.0f - z) * n + z * hst[i][jr];
                     hst[i][jr] = hn;
                     hn_b[(fq * 4 + jr) * LDH + j] = (bf16)(rok ? hn : 0.f);
@@ -1302,22 +1303,6 @@ __global__ __launch_bounds__(NTHR) void coco_enc_bwd_res_kernel(const CocoEncBwd
     }
 }
 
-// [B][T][G] -> [T][G][B] (the weight-resident encoder kernels read 4 consecutive rows of one column as one vector)
-__global__ __launch_bounds__(256) void gi_transpose_kernel(const float* src, int B, int T, float* dst) {
-    __shared__ float tile[32][33];
-    const int t = blockIdx.z, g0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int r = ty; r < 32; r += 8) {
-        const int b = b0 + r, g = g0 + tx;
-        tile[r][tx] = (b < B && g < G) ? src[((size_t)b * T + t) * G + g] : 0.f;
-    }
-    __syncthreads();
-    for (int r = ty; r < 32; r += 8) {
-        const int g = g0 + r, b = b0 + tx;
-        if (g < G && b < B) dst[((size_t)t * G + g) * B + b] = tile[tx][r];
-    }
-}
-
 // BPTT of the same recurrence: per step the gate backward and dh[t-1] += dgh[t] * W_hh (253 KB bf16 streamed).
 __global__ __launch_bounds__(NTHR) void coco_enc_bwd_kernel(const CocoEncBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1389,15 +1374,17 @@ __global__ __launch_bounds__(NTHR) void coco_enc_bwd_kernel(const CocoEncBwdArgs
     }
 }
 
-// dst[(t*B + b)*ld + e] = bf16(src[(b*T + t)*E + e]): the captions as the [t][row] bf16 operand of the batched weight gradient
+// dst[(t*B + b)*ld + e] = bf16(src[(b*T + t)*E + e]) for e < E, 1.0 at e == E (the bias gradient rides in the weight gradient),
+// 0 in the remaining pad columns: the rows are also the K-contiguous operand of the transposed input-projection GEMM, where a
+// stale NaN in a pad column would poison the dot product even against a zero weight
 __global__ __launch_bounds__(256) void text_tb_kernel(const float* src, int B, int T, int ld, bf16* dst) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long long)B * T * E) return;
-    const int e = (int)(i % E);
-    const long long bt = i / E;
+    if (i >= (long long)B * T * ld) return;
+    const int e = (int)(i % ld);
+    const long long bt = i / ld;
     const int t = (int)(bt % T), b = (int)(bt / T);
-    dst[((size_t)t * B + b) * ld + e] = (bf16)src[i];
-    if (e == 0) dst[((size_t)t * B + b) * ld + E] = (bf16)1.f;          // 1.0 column: the bias gradient rides in the weight gradient
+    const float v = e < E ? src[bt * E + e] : (e == E ? 1.f : 0.f);
+    dst[((size_t)t * B + b) * ld + e] = (bf16)v;
 }
 
 // out[r][c] = sum_t in[(t*R + r)*ld + c]
@@ -1490,7 +1477,7 @@ int launch_coco_enc_fwd(const CocoEncFwdArgs& a, hipStream_t s) {
         big(&coco_enc_fwd_res_kernel<true>); big(&coco_enc_fwd_res_kernel<false>);
     }
     if (a.resident) {       // a.w_hh = three per-gate matrices, back to back; gi / sav / h_all with the batch row fastest
-        MMVAE_REQUIRE(a.B % 4 == 0 && a.h_last, "coco_enc_fwd (resident): batch must be a multiple of 4");
+        MMVAE_REQUIRE(a.B % 4 == 0 && a.h_last && a.bih, "coco_enc_fwd (resident): batch must be a multiple of 4");
         const size_t lds = (size_t)(2 * TR * LDH + 5 * 3 * (HP / 32) * 64 * 8) * sizeof(bf16);
         if (a.sav) hipLaunchKernelGGL(coco_enc_fwd_res_kernel<true>, dim3(ceil_div(a.B, TR)), dim3(NTHR), lds, s, a);
         else hipLaunchKernelGGL(coco_enc_fwd_res_kernel<false>, dim3(ceil_div(a.B, TR)), dim3(NTHR), lds, s, a);
@@ -1517,11 +1504,7 @@ int launch_coco_enc_bwd(const CocoEncBwdArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(coco_enc_bwd_kernel, dim3(ceil_div(a.B, TR)), dim3(NTHR), lds, s, a);
     return mmvae_check_launch("coco_enc_bwd");
 }
-int launch_coco_gi_transpose(const float* src, int B, int T, float* dst, hipStream_t s) {
-    hipLaunchKernelGGL(gi_transpose_kernel, dim3(ceil_div(G, 32), ceil_div(B, 32), T), dim3(256), 0, s, src, B, T, dst);
-    return mmvae_check_launch("coco_gi_transpose");
-}
 int launch_coco_text_tb(const float* text, int B, int T, int ld, bf16* dst, hipStream_t s) {
-    hipLaunchKernelGGL(text_tb_kernel, dim3((unsigned)(((long long)B * T * E + 255) / 256)), dim3(256), 0, s, text, B, T, ld, dst);
+    hipLaunchKernelGGL(text_tb_kernel, dim3((unsigned)(((long long)B * T * ld + 255) / 256)), dim3(256), 0, s, text, B, T, ld, dst);
     return mmvae_check_launch("coco_text_tb");
 }
