@@ -402,7 +402,7 @@ static int coco_dec_cluster(int R) {
 
 // the weight-resident encoder kernels (coco_text_bf16.hip) need 4-row vectors of the batch
 static bool coco_enc_resident(const CocoPlan& P) {
-    static const bool streamed = getenv("MMVAE_COCO_ENC_STREAMED") != nullptr;      // A/B aid: the weight-streaming kernels
+    const bool streamed = getenv("MMVAE_COCO_ENC_STREAMED") != nullptr;     // A/B aid: the weight-streaming kernels (read per call)
     return P.text_bf16 && !streamed && P.B % 4 == 0;
 }
 

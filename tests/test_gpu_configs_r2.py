@@ -188,3 +188,51 @@ def test_c_abi_collective_face_single_rank():
         call("mmvae_allreduce_grads", comm, ptr(g), 0, s)  # empty message: a no-op, not an error
     finally:
         call("mmvae_comm_destroy", comm)
+
+
+def test_coco_caption_kernel_forms_agree():
+    """The forms of the COCO caption recurrences must compute the same step: decoder with 8 / 4 workgroups per row block
+    (cluster form: slices of the hidden units per rank, all-gathers through global memory) against one workgroup per block,
+    encoder with resident against streamed W_hh.  Same inputs, same draws; what may differ is fp32 summation order (split
+    reductions) and the step's own run-to-run noise from fp32 atomics upstream, both far below the gates."""
+    from multimodal_vae_amd.core import CocoState, FusedCocoStep
+    from multimodal_vae_amd.init import default_init_
+    dev = _dev()
+    B, T = 32, 102
+    g = torch.Generator().manual_seed(5)
+    image = torch.rand(B, 3, 32, 32, generator=g).to(dev)
+    text = (0.4 * torch.randn(B, T, 300, generator=g)).to(dev)
+    eps = torch.randn(3, B, D, generator=g).to(dev)
+    keep = (torch.rand(T, 3 * B, 200, generator=g) > 0.1).to(torch.uint8).to(dev)
+    st = CocoState(D, dev, steps=T); default_init_(st, 21)
+    eng = FusedCocoStep(st, B, 0.4 * torch.randn(300, generator=g), seed=3)
+    old = {k: os.environ.get(k) for k in ("MMVAE_COCO_CLUSTER", "MMVAE_COCO_ENC_STREAMED")}
+
+    def run(cluster, streamed):
+        os.environ["MMVAE_COCO_CLUSTER"] = str(cluster)
+        if streamed:
+            os.environ["MMVAE_COCO_ENC_STREAMED"] = "1"
+        else:
+            os.environ.pop("MMVAE_COCO_ENC_STREAMED", None)
+        rt = torch.zeros(3, B, T, 300, device=dev)
+        out = eng.forward_backward(image, text, True, True, eps=eps, gru_keep=keep, recon_text=rt)
+        torch.cuda.synchronize()
+        return rt, st.grads.clone(), out.losses().cpu().numpy()
+
+    try:
+        r0, g0, l0 = run(0, True)
+        for cluster, streamed in ((0, False), (4, False), (8, False), (8, True)):
+            r, gg, l = run(cluster, streamed)
+            np.testing.assert_allclose(l, l0, rtol=2e-4)
+            assert float((r - r0).abs().max()) < 1e-2, (cluster, streamed)
+            assert float((gg - g0).norm() / g0.norm()) < 1e-2, (cluster, streamed)
+            for n, shape, off in st.table:        # every tensor, so that a slice of units left out cannot hide in the norm
+                k = int(np.prod(shape))
+                a, b = gg[off:off + k], g0[off:off + k]
+                assert float((a - b).norm()) <= 5e-2 * float(b.norm()) + 1e-7, (cluster, streamed, n)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
