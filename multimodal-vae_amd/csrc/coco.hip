@@ -374,6 +374,7 @@ int use_ws(CocoPlan* P, void* ws, size_t bytes, bool module = true) {
     P->dec_skip_mask = 0;
     P->slab.reset(P->w.slab, P->w.slab_floats);
     P->dec_wg_pending = false;
+    P->cl_alarm_f = P->cl_alarm_b = nullptr;
     return MMVAE_OK;
 }
 int unpack(CocoPlan& P, hipStream_t s) {
@@ -468,7 +469,7 @@ static int coco_step_body(CocoPlan* Pp, const CocoStepIO& io, int training, int 
     MMVAE_TRY(dec_fwd(P, 3, training, &last, s));
     if (!do_backward) {
         MMVAE_TRY(edge(P, Tx, s));
-        hipLaunchKernelGGL(sum_slots_kernel, dim3(1), dim3(64), 0, s, w.sums, io.sums);
+        hipLaunchKernelGGL(sum_slots_kernel, dim3(1), dim3(64), 0, s, w.sums, io.sums, P.cl_alarm_f, (const unsigned*)nullptr);
         return mmvae_check_launch("sum_slots");
     }
     // =============================== backward ===============================
@@ -493,7 +494,8 @@ static int coco_step_body(CocoPlan* Pp, const CocoStepIO& io, int training, int 
     MMVAE_TRY(edge(P, Tx, s));
     MMVAE_TRY(edge(P, P.st_wgrad, s));
     if (P.st_wgrad2 != P.st_wgrad) MMVAE_TRY(edge(P, P.st_wgrad2, s));
-    hipLaunchKernelGGL(sum_slots_kernel, dim3(1), dim3(64), 0, s, w.sums, io.sums);
+    // (timeout words of the decoder's cluster launches of THIS step: zeroed before each of them, set only when an exchange gave up)
+    hipLaunchKernelGGL(sum_slots_kernel, dim3(1), dim3(64), 0, s, w.sums, io.sums, P.cl_alarm_f, P.cl_alarm_b);
     MMVAE_TRY(mmvae_check_launch("sum_slots"));
     if (io.defer_unpack) return launch_wgrad_reduce(&P.slab, s);      // the packed gradients are complete; Adam gathers them
     return unpack(P, s);

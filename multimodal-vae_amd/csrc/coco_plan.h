@@ -83,6 +83,7 @@ struct CocoPlan : PlanBase {
     long long te_h2p_w, te_h2p_b, td_z2h_w, td_z2h_b, td_h2o_w, td_h2o_b;
     // bf16 persistent caption decoder: packed weights (forward and transposed forms) and packed-gradient descriptors
     bool text_bf16 = true;
+    const unsigned *cl_alarm_f = nullptr, *cl_alarm_b = nullptr;   // timeout words of this step's cluster launches (null: not used)
     bool dec_wg_pending = false; const float* dec_wg_z = nullptr; int dec_wg_groups = 0;   // deferred weight gradients of the bf16 decoder
     int tb_ih0, tb_hh0, tb_ih1, tb_hh1, tb_ho, tb_hoT, tb_ih1T, tb_hh1T, tb_hh0T, tb_ih0T, tb_e_hh, tb_e_hhT, tb_e_ihA, tb_e_hhg[3], tb_g_ih0[3], tb_g_hh0[3], tb_g_ih1[3], tb_g_hh1[3];
     int tg_ih0, tg_hh0, tg_ih1, tg_hh1, tg_ho, tg_e_ih, tg_e_hh;

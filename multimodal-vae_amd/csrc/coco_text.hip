@@ -558,7 +558,8 @@ int coco_text_dec_fwd(CocoPlan& P, const float* z, int groups, const float* sos,
                                   "per-gate decoder packs not contiguous");
                 a.cl_xchg = reinterpret_cast<unsigned long long*>(w.cl_xchg);
                 a.cl_timeout = reinterpret_cast<unsigned*>(w.cl_xchg + w.cl_bytes - 64);
-                MMVAE_TRY(launch_fill_zero(w.cl_xchg, w.cl_bytes, s));      // tags and the timeout word: zero before EVERY launch
+                P.cl_alarm_f = a.cl_timeout;
+                MMVAE_TRY(launch_fill_zero(w.cl_xchg, w.cl_bytes, s));      // flags and the timeout word: zero before EVERY launch
             }
         }
         if (save) {
@@ -609,7 +610,8 @@ static int coco_text_dec_bwd_bf16(CocoPlan& P, const float* z, int groups, const
             a.cluster = Pc;
             a.cl_xchg = reinterpret_cast<unsigned long long*>(w.clb_xchg);
             a.cl_timeout = reinterpret_cast<unsigned*>(w.clb_xchg + w.clb_bytes - 64);
-            MMVAE_TRY(launch_fill_zero(w.clb_xchg, w.clb_bytes, s));        // tags and the timeout word: zero before EVERY launch
+            P.cl_alarm_b = a.cl_timeout;
+            MMVAE_TRY(launch_fill_zero(w.clb_xchg, w.clb_bytes, s));        // flags and the timeout word: zero before EVERY launch
         }
     }
     MMVAE_TRY(launch_coco_dec_bwd(a, s));

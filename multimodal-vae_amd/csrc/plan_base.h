@@ -422,12 +422,15 @@ inline int check_bound(const PlanBase* P) {
 }
 
 
-// out[16] = sum over the MMVAE_LOSS_SLOTS replicated rows of the loss accumulators
-static __global__ void sum_slots_kernel(const float* slots, float* out) {
+// out[16] = sum over the MMVAE_LOSS_SLOTS replicated rows of the loss accumulators.  alarm0 / alarm1 (optional): words a
+// kernel of the step sets when it gave up waiting for a peer (the cluster exchange of the COCO caption decoder): the
+// step's numbers are then garbage, and the loss sums say so (NaN) instead of looking plausible.
+static __global__ void sum_slots_kernel(const float* slots, float* out, const unsigned* alarm0 = nullptr, const unsigned* alarm1 = nullptr) {
     const int j = threadIdx.x;
     if (j >= 16) return;
     float s = 0.f;
     for (int q = 0; q < MMVAE_LOSS_SLOTS; ++q) s += slots[q * 16 + j];
+    if ((alarm0 && *alarm0) || (alarm1 && *alarm1)) s = __builtin_nanf("");
     out[j] = s;
 }
 static __global__ void cast_z_kernel(const float* z, int rows, int D, bf16* out, int ldz) {
