@@ -361,18 +361,24 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_cl_kernel(const CocoDecFwdA
     const ClMat m_hh1{__builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.wg_hh1), 0, 39 * (HP / 32) * 1024, 0x00020000), HP / 32};
     const ClMat m_ho{__builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w_ho), 0, 19 * (HP / 32) * 1024, 0x00020000), HP / 32};
     bf16x8 ring[D][KCH];
+    auto request = [&](const ClMat& m, bool gates, int n) {      // the chunks of ONE product (its tile slots) into the ring
 #pragma unroll
-    for (int q = 0; q < D; ++q) cl_load<true, P>(ring[q], m_ih0, q, ng, rank, wave, lane);
-    __syncthreads();
+        for (int q = 0; q < D; ++q) { if (gates) cl_load<true, P>(ring[q], m, q, n, rank, wave, lane); else cl_load<false, P>(ring[q], m, q, n, rank, wave, lane); }
+    };
     const float* zi0 = a.zi0 + (size_t)r0 * G;
     const float* zo = a.zo + (size_t)r0 * E;
-    // chunk list of a step: ih0 MT, hh0 MT, ih1 MT, hh1 MT, ho MT (MTO real + padding); D = MT: every GEMM starts in slot 0 and
-    // requests exactly the chunks of the NEXT GEMM of the list while it computes
+    // Order of a step.  The hidden-state products do not depend on the exchange that is in flight when they run, so each of
+    // them hides one:   ih0 x | gates 0, publish A | hh1 h1 (during A) | ih1 mid | gates 1, publish B | hh0 h0' for the NEXT
+    // step (during B) | ho h1' | output, publish C | (wait C).  One product's chunks sit in the ring at a time, requested
+    // right behind the flag store (overlapped products) or behind the loads of the exchange in front of the product.
+    request(m_hh0, true, ng);
+    __syncthreads();
+    cl_gemm<HP / 32, MT, MT, D, 0, true, true, P, false>(h0b, LDH, m_hh0, ng, gb, LDC, ring, m_ih0, ng, true, rank, wave, lane, nullptr, 0, 0, H, rows_ok);
     for (int t = 0; t < T; ++t) {
         const unsigned ep = 3u * (unsigned)t + 1u;
-        // ---- layer 0
-        cl_gemm<XP / 32, MT, MT, D, 0, true, true, P, true>(xb, LDX, m_ih0, ng, ga, LDC, ring, m_hh0, ng, true, rank, wave, lane, zi0, G, H, H, rows_ok);
-        cl_gemm<HP / 32, MT, MT, D, 0, true, true, P, false>(h0b, LDH, m_hh0, ng, gb, LDC, ring, m_ih1, ng, false, rank, wave, lane, nullptr, 0, 0, H, rows_ok);
+        const bool last = t + 1 == T;
+        // ---- layer 0 (its hidden product is in gb already)
+        cl_gemm<XP / 32, MT, MT, D, 0, true, true, P, true>(xb, LDX, m_ih0, ng, ga, LDC, ring, m_hh1, ng, false, rank, wave, lane, zi0, G, H, H, rows_ok);
         unsigned short kpo = 0x0101;
         if (KEEP && uok) kpo = gok ? *reinterpret_cast<const unsigned short*>(a.keep + (size_t)t * RH + gr * H + j0) : (unsigned short)0;
         __syncthreads();
@@ -408,6 +414,8 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_cl_kernel(const CocoDecFwdA
         }
         // all-gather: every rank's units of the new h0 and of mid (own ones included: same path)
         cl_signal(xA, rank, ep, tid);
+        request(m_hh1, true, ng);        // layer 1's hidden product reads last step's h1: it runs while exchange A completes
+        cl_gemm<HP / 32, MT, MT, D, 0, true, true, P, false>(h1b, LDH, m_hh1, ng, gb, LDC, ring, m_ih1, ng, false, rank, wave, lane, nullptr, 0, 0, H, rows_ok);
         cl_wait<P>(xA, ep, tmo, tid);
         {   // 16 bytes = 4 units x {h0, mid}.  All pieces are requested, THEN the weights of the next phase (they are not in
             // flight while the payload stores drain, and they travel while the exchange completes), then the pieces are used
@@ -429,8 +437,7 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_cl_kernel(const CocoDecFwdA
         }
         __syncthreads();
         // ---- layer 1
-        cl_gemm<HP / 32, MT, MT, D, 0, true, true, P, false>(midb, LDH, m_ih1, ng, ga, LDC, ring, m_hh1, ng, true, rank, wave, lane, nullptr, 0, 0, H, rows_ok);
-        cl_gemm<HP / 32, MT, MTO, D, 0, true, false, P, false>(h1b, LDH, m_hh1, ng, gb, LDC, ring, m_ho, noe, false, rank, wave, lane, nullptr, 0, 0, H, rows_ok);
+        cl_gemm<HP / 32, MT, MT, D, 0, true, true, P, false>(midb, LDH, m_ih1, ng, ga, LDC, ring, m_hh1, ng, false, rank, wave, lane, nullptr, 0, 0, H, rows_ok);
         __syncthreads();
         if (uok) {
             bf16 hb2[2];
@@ -454,6 +461,10 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_cl_kernel(const CocoDecFwdA
             cl_store4(xB, (grow * H + j0) * 2, hb2[0], hb2[1]);
         }
         cl_signal(xB, rank, ep + 1, tid);
+        if (!last) {                     // layer 0's hidden product of the NEXT step reads the h0 of exchange A: it runs during B
+            request(m_hh0, true, ng);
+            cl_gemm<HP / 32, MT, MT, D, 0, true, true, P, false>(h0b, LDH, m_hh0, ng, gb, LDC, ring, m_ih0, ng, false, rank, wave, lane, nullptr, 0, 0, H, rows_ok);
+        }
         cl_wait<P>(xB, ep + 1, tmo, tid);
         {   // 16 bytes = 8 units (400 pieces: one per thread)
             bf16x8 x = {};
@@ -467,7 +478,6 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_cl_kernel(const CocoDecFwdA
         }
         __syncthreads();
         // ---- output projection (own embedding tiles), fed back as the next input
-        const bool last = t + 1 == T;
         cl_gemm<HP / 32, MT, MT, D, 0, false, true, P, true>(h1b, LDH, m_ho, noe, ga, LDC, ring, m_ih0, ng, false, rank, wave, lane, zo, E, E, 0, rows_ok);
         __syncthreads();
         // own columns: local pair lp -> tile lp / 8, columns 2 (lp % 8), +1 ; up to NOEMAX * 8 pairs per row
