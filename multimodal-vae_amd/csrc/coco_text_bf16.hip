@@ -714,7 +714,8 @@ __global__ __launch_bounds__(NTHR) void coco_dec_bwd_cl_kernel(const CocoDecBwdA
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* o1 = reinterpret_cast<float*>(smem);                     // [KH][16][LDU]
     float* o2 = o1 + KH * TR * LDU;                                 // [KH][16][LDU]
-    float* fbp = o2 + KH * TR * LDU;                                // [KH][16][LDE]
+    float* o3 = o2 + KH * TR * LDU;                                 // [KH][16][LDU]
+    float* fbp = o3 + KH * TR * LDU;                                // [KH][16][LDE]
     bf16* dob = reinterpret_cast<bf16*>(fbp + KH * TR * LDE);       // [16][LDX]
     bf16* dgi = dob + TR * LDX;                                     // [16][LDGK]
     bf16* dgh = dgi + TR * LDGK;
@@ -822,8 +823,8 @@ __global__ __launch_bounds__(NTHR) void coco_dec_bwd_cl_kernel(const CocoDecBwdA
     // (request(pos)): the ones a phase starts with go out behind the loads of the exchange that precedes it, so that no
     // weight load is in flight while payload stores drain, and the stream travels while the exchange completes
     bf16x8 ring[D][KCH];
-    auto request = [&](int pos) { load_pos(ring[pos % D], pos); };
-    auto gemm_pos = [&](int pos, const bf16* A, int lda, float* out, int ldo) {
+    auto request = [&](int pos, int slot) { load_pos(ring[slot], pos); };
+    auto gemm_pos = [&](int pos, int slot, const bf16* A, int lda, float* out, int ldo) {
         int li, kh, k0, kc;
         bool ok;
         if (pos < 4) {
@@ -839,14 +840,18 @@ __global__ __launch_bounds__(NTHR) void coco_dec_bwd_cl_kernel(const CocoDecBwdA
             for (int s = 0; s < KCH; ++s)
                 if (s < kc) {
                     const bf16x8 af = *reinterpret_cast<const bf16x8*>(A + fr * lda + (k0 + s) * 32 + fq * 8);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, ring[pos % D][s], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, ring[slot][s], acc, 0, 0, 0);
                 }
 #pragma unroll
             for (int j = 0; j < 4; ++j) out[(kh * TR + fq * 4 + j) * ldo + li * 16 + fr] = acc[j];
         }
     };
-    static_assert(D == 2, "explicit request schedule below is written for two ring slots");
-    request(0);
+    static_assert(D == 2 && MTE == 2, "the explicit request schedule below is written for two ring slots and two feedback chunks");
+    // Order of a step (chunk, ring slot):  hoT (0, s0) | gates 1, publish X1 | ih1T (1, s1) | gates 0, publish X2 | hh1T (2, s0)
+    // DURING X2 | ih0T (4, s1) (5, s0) | output gradient of the next step, publish X3 | hh0T (3, s1) DURING X3 | carried
+    // gradients += the two hidden-state products.  Those two products feed nothing but the carried gradients, so each of
+    // them hides one exchange.
+    request(0, 0);
     __syncthreads();
 
     for (int t = T - 1; t >= 0; --t) {
@@ -867,7 +872,7 @@ __global__ __launch_bounds__(NTHR) void coco_dec_bwd_cl_kernel(const CocoDecBwdA
         }
         if (KEEP && uok) kpo = gok ? *reinterpret_cast<const unsigned short*>(a.keep + (size_t)t * RH + gr * H + j0) : (unsigned short)0;
         // ---- dh1 += dOut * W_ho (own units)
-        gemm_pos(0, dob, LDX, o1, LDU);
+        gemm_pos(0, 0, dob, LDX, o1, LDU);
         __syncthreads();
         if (uok) {
             bf16x8 pub;
@@ -901,13 +906,12 @@ __global__ __launch_bounds__(NTHR) void coco_dec_bwd_cl_kernel(const CocoDecBwdA
         {
             bf16x8 pc[NPG];
             load_gates(xA, pc);
-            request(1); request(2);
+            request(1, 1);
             put_gates(pc);
         }
         __syncthreads();
         // ---- dmid = dgi1 * W_ih1 ; dh1[t-1] += dgh1 * W_hh1 (own units)
-        gemm_pos(1, dgi, LDGK, o1, LDU);
-        gemm_pos(2, dgh, LDGK, o2, LDU);
+        gemm_pos(1, 1, dgi, LDGK, o1, LDU);
         __syncthreads();
         if (uok) {
             bf16x8 pub;
@@ -915,10 +919,9 @@ __global__ __launch_bounds__(NTHR) void coco_dec_bwd_cl_kernel(const CocoDecBwdA
             for (int q = 0; q < 2; ++q) {
                 const int j = j0 + q, lc = uk * 16 + uu + q;
                 float dr = 0.f, dz = 0.f, dn = 0.f, dnr = 0.f, dd = 0.f;
-                float om = 0.f, oh = 0.f;
+                float om = 0.f;
 #pragma unroll
-                for (int k = 0; k < KH; ++k) { om += o1[(k * TR + grow) * LDU + lc]; oh += o2[(k * TR + grow) * LDU + lc]; }
-                dh1f[q] += gok ? oh : 0.f;
+                for (int k = 0; k < KH; ++k) om += o1[(k * TR + grow) * LDU + lc];
                 if (gok) {
                     const float r = s0[q][0], z = s0[q][1], n = s0[q][2], ghn = s0[q][3];
                     float dm = om;
@@ -940,28 +943,24 @@ __global__ __launch_bounds__(NTHR) void coco_dec_bwd_cl_kernel(const CocoDecBwdA
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4c, pub), xB.rs, (grow * H + j0) * 8, 0, 16);
         }
         cl_signal(xB, rank, ep + 1, tid);
-        cl_wait<P>(xB, ep + 1, tmo, tid);
+        // dh1[t-1] += dgh1 * W_hh1 (own units): still layer 1's gate gradients in dgh -- it runs while exchange X2 completes
+        request(2, 0);
+        gemm_pos(2, 0, dgh, LDGK, o3, LDU);
+        cl_wait<P>(xB, ep + 1, tmo, tid);           // (its barrier: every wave is done with the old dgh)
         {
             bf16x8 pc[NPG];
             load_gates(xB, pc);
-            request(3); request(4);
+            request(4, 1); request(5, 0);
             put_gates(pc);
         }
         __syncthreads();
-        // ---- dh0[t-1] += dgh0 * W_hh0 (own units) ; feedback into the previous output = dgi0 * W_ih0[:, :300] (own embedding tiles)
-        gemm_pos(3, dgh, LDGK, o2, LDU);
-        if (NPOS > 5) request(5);                      // (slot of chunk 3 is free again)
-#pragma unroll
-        for (int sl = 0; sl < MTE; ++sl) gemm_pos(4 + sl, dgi, LDGK, fbp, LDE);
+        // ---- feedback into the previous output = dgi0 * W_ih0[:, :300] (own embedding tiles)
+        gemm_pos(4, 1, dgi, LDGK, fbp, LDE);
+        gemm_pos(5, 0, dgi, LDGK, fbp, LDE);
         __syncthreads();
-        if (uok && gok) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                float oh = 0.f;
-#pragma unroll
-                for (int k = 0; k < KH; ++k) oh += o2[(k * TR + grow) * LDU + uk * 16 + uu + q];
-                dh0f[q] += oh;
-            }
+        if (first) {                                // last step of the loop: no exchange left to hide the product behind
+            request(3, 1);
+            gemm_pos(3, 1, dgh, LDGK, o2, LDU);
         }
         if (!first) {
             // total output gradient of step t-1 for the own columns: loss term + feedback; accounted, saved, published
@@ -981,6 +980,9 @@ __global__ __launch_bounds__(NTHR) void coco_dec_bwd_cl_kernel(const CocoDecBwdA
                     cl_store4(xC, (grow * E + eo[q]) * 2, (bf16)v[0], (bf16)v[1]);
                 }
             cl_signal(xC, rank, ep + 2, tid);
+            // dh0[t-1] += dgh0 * W_hh0 (own units) runs while exchange X3 completes
+            request(3, 1);
+            gemm_pos(3, 1, dgh, LDGK, o2, LDU);
             cl_wait<P>(xC, ep + 2, tmo, tid);
             constexpr int NPC = (TR * E / 4 + NTHR - 1) / NTHR;     // 8 bytes = 4 columns
             u32x2 x[NPC];
@@ -989,7 +991,7 @@ __global__ __launch_bounds__(NTHR) void coco_dec_bwd_cl_kernel(const CocoDecBwdA
                 const int v = tid + q * NTHR;
                 if (v < TR * E / 4) { const int row = v / (E / 4), e = (v - row * (E / 4)) * 4; x[q] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(xC.rs, (row * E + e) * 2, 0, 16)); }
             }
-            request(0);
+            request(0, 0);
 #pragma unroll
             for (int q = 0; q < NPC; ++q) {
                 const int v = tid + q * NTHR;
@@ -997,6 +999,15 @@ __global__ __launch_bounds__(NTHR) void coco_dec_bwd_cl_kernel(const CocoDecBwdA
             }
         }
         __syncthreads();
+        if (uok && gok) {                           // carried gradients += the two hidden-state products of this step
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float oh0 = 0.f, oh1 = 0.f;
+#pragma unroll
+                for (int k = 0; k < KH; ++k) { oh0 += o2[(k * TR + grow) * LDU + uk * 16 + uu + q]; oh1 += o3[(k * TR + grow) * LDU + uk * 16 + uu + q]; }
+                dh0f[q] += oh0; dh1f[q] += oh1;
+            }
+        }
     }
     if (uok && gok) {
 #pragma unroll
@@ -1465,7 +1476,7 @@ int launch_coco_dec_bwd(const CocoDecBwdArgs& a, hipStream_t s) {
         MMVAE_REQUIRE(nblk_pad * a.cluster <= 256, "coco_dec_bwd: %d x %d workgroups do not fit the chip", nblk_pad, a.cluster);
         auto lds_of = [](int P) {
             const int nubmax = (13 + P - 1) / P, noemax = (19 + P - 1) / P, kh = NW / nubmax;
-            return (size_t)(2 * kh * TR * (nubmax * 16 + 4) + kh * TR * (noemax * 16 + 4)) * sizeof(float) +
+            return (size_t)(3 * kh * TR * (nubmax * 16 + 4) + kh * TR * (noemax * 16 + 4)) * sizeof(float) +
                    (size_t)(TR * LDX + 2 * TR * LDGK) * sizeof(bf16);
         };
         auto gc = [&](auto kern, int P) { hipLaunchKernelGGL(kern, dim3(nblk_pad * P), dim3(NTHR), lds_of(P), s, a); };
