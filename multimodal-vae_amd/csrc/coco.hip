@@ -374,6 +374,7 @@ int use_ws(CocoPlan* P, void* ws, size_t bytes, bool module = true) {
     P->dec_skip_mask = 0;
     P->slab.reset(P->w.slab, P->w.slab_floats);
     P->dec_wg_pending = false;
+    P->comb_fresh = false;
     P->cl_alarm_f = P->cl_alarm_b = nullptr;
     return MMVAE_OK;
 }
@@ -447,6 +448,7 @@ static int coco_step_body(CocoPlan* Pp, const CocoStepIO& io, int training, int 
     MMVAE_TRY(edge(P, s, Tx));
     MMVAE_TRY(coco_text_enc_fwd(P, io.text, do_backward, w.txtout, Tx, true));
     MMVAE_TRY(enc_fwd(P, io.image, 2, m1, m2, enc_drop, training, 2 - sk[0] - sk[1], w.encout, s));
+    MMVAE_TRY(coco_text_dec_prepare(P, io.sos, s));      // (main stream: idle here until the caption encoder is through)
     MMVAE_TRY(edge(P, Tx, s));
     Latent3Args la{};
     la.B = B; la.D = D; la.img_out = w.encout; la.txt_out = w.txtout; la.eps = eps;

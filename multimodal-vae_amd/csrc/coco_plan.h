@@ -21,6 +21,9 @@ struct CocoDecFwdArgs {
     // cluster form (coco_dec_fwd_cl_kernel): per-gate packs [3][208][K] of the four GRU matrices, exchange granules
     // [row blocks][3 phases][16][200] (zeroed before the launch), timeout word; cluster = ranks per row block (0 / 1: off)
     const bf16 *wg_ih0, *wg_hh0, *wg_ih1, *wg_hh1;
+    // composed form (coco_dec_fwd_c8_kernel, cluster == 8): per-gate packs [3][208][224] of W_comb = W_ih0[:, :300] W_ho[:, :200],
+    // zi0p = zi0 + zo W_ih0[:, :300]^T ([R][600]), sosv = W_ih0[:, :300] sos ([600]); null: the three-exchange form
+    const bf16* wg_comb; const float *zi0p, *sosv;
     unsigned long long* cl_xchg; unsigned* cl_timeout; int cluster;   // (cl_xchg: raw bytes, 16-byte aligned)
     const float *bhh0, *bih1, *bhh1;
     float* sentence;         // [R][T][300]
@@ -68,6 +71,8 @@ int launch_coco_enc_bwd(const CocoEncBwdArgs& a, hipStream_t s);
 // dst[(t*B + b)*ld + e] = bf16(text[(b*T + t)*300 + e]); column 300 = 1.0
 int launch_coco_text_tb(const float* text, int B, int T, int ld, bf16* dst, hipStream_t s);
 int launch_coco_dec_fwd(const CocoDecFwdArgs& a, hipStream_t s);
+// comb: [3][208][224], combT: [208][608] (fragment-major bf16), sosv: [600]; wih0 / who: the fp32 parameters, row strides in0 / ino
+int launch_coco_comb(const float* wih0, int in0, const float* who, int ino, const float* sos, bf16* comb, bf16* combT, float* sosv, hipStream_t s);
 int launch_coco_dec_bwd(const CocoDecBwdArgs& a, hipStream_t s);
 // out[r][c] (fp32, [R][cols]) = sum over t of in[(t*R + r)*ld + c]
 int launch_coco_time_sum_bf16(const bf16* in, int T, int R, int ld, int cols, float* out, hipStream_t s);
@@ -84,6 +89,7 @@ struct CocoPlan : PlanBase {
     // bf16 persistent caption decoder: packed weights (forward and transposed forms) and packed-gradient descriptors
     bool text_bf16 = true;
     const unsigned *cl_alarm_f = nullptr, *cl_alarm_b = nullptr;   // timeout words of this step's cluster launches (null: not used)
+    bool comb_fresh = false;                                       // W_comb / sosv made from the CURRENT parameters (reset by use_ws)
     bool dec_wg_pending = false; const float* dec_wg_z = nullptr; int dec_wg_groups = 0;   // deferred weight gradients of the bf16 decoder
     int tb_ih0, tb_hh0, tb_ih1, tb_hh1, tb_ho, tb_hoT, tb_ih1T, tb_hh1T, tb_hh0T, tb_ih0T, tb_e_hh, tb_e_hhT, tb_e_ihA, tb_e_hhg[3], tb_g_ih0[3], tb_g_hh0[3], tb_g_ih1[3], tb_g_hh1[3];
     int tg_ih0, tg_hh0, tg_ih1, tg_hh1, tg_ho, tg_e_ih, tg_e_hh;
@@ -111,6 +117,7 @@ struct CocoPlan : PlanBase {
         bf16 *tb_x, *tb_h0, *tb_mid, *tb_h1, *tb_dout, *tb_dgi0, *tb_dgh0, *tb_dgi1, *tb_dgh1;
         bf16 *te_xb, *te_hb_all, *te_dgi_b, *te_dgh_b;
         float *te_giT, *te_hlast;
+        bf16 *tb_comb, *tb_combT; float *td_sosv, *td_zi0p;
         char* cl_xchg; size_t cl_bytes; char* clb_xchg; size_t clb_bytes;
     } w;
 };
@@ -121,6 +128,9 @@ void coco_text_carve(CocoPlan& P, Workspace& ws);       // the non-zeroed captio
 // text: [B][T][300]; out: [B][2D]
 // issues the caption decoder's deferred weight gradients (bf16 path) on `sw`; no-op when none are pending
 int coco_text_dec_wgrads(CocoPlan& P, hipStream_t sw);
+// composed decoder weights (W_comb, sosv) from the current parameters, once per step, on any stream the decoder's stream is
+// ordered behind; the decoder makes them itself (on its own stream) when nobody did
+int coco_text_dec_prepare(CocoPlan& P, const float* sos, hipStream_t s);
 int coco_text_enc_fwd(CocoPlan& P, const float* text, int save, float* out, hipStream_t s, bool bf16_path);
 // d_out: [B][2D] (the h2p bias gradient is added here); accumulates every caption-encoder gradient into P.buf.grads
 int coco_text_enc_bwd(CocoPlan& P, const float* text, const float* d_out, hipStream_t s, hipStream_t sw, bool bf16_path);

@@ -388,6 +388,8 @@ void coco_text_carve(CocoPlan& P, Workspace& ws) {
         w.clb_xchg = ws.take<char>(w.clb_bytes);
         w.te_xb = ws.take<bf16>((size_t)round_up((int)(T * B), 128) * CTB_XP); w.te_hb_all = ws.take<bf16>(T * B * CTB_HP);
         w.te_dgi_b = ws.take<bf16>(T * B * CTB_GP); w.te_dgh_b = ws.take<bf16>(T * B * CTB_GP);
+        w.tb_comb = ws.take<bf16>(3 * 208 * CTB_HP); w.tb_combT = ws.take<bf16>(208 * CTB_GP);
+        w.td_sosv = ws.take<float>(G); w.td_zi0p = ws.take<float>(R * G);
     }
 }
 
@@ -398,6 +400,19 @@ static int coco_dec_cluster(int R) {
     const int nblk_pad = ((R + 15) / 16 + 7) / 8 * 8;
     while (Pc > 1 && nblk_pad * Pc > 224) Pc /= 2;
     return (Pc == 4 || Pc == 8) ? Pc : 0;
+}
+
+// composed form of the cluster-of-8 decoder (two exchanges per step): MMVAE_COCO_NO_COMB=1 keeps the three-exchange kernels (A/B aid)
+static bool coco_dec_composed(int Pc) {
+    const bool off = getenv("MMVAE_COCO_NO_COMB") != nullptr;   // (read per call)
+    return Pc == 8 && !off;
+}
+int coco_text_dec_prepare(CocoPlan& P, const float* sos, hipStream_t s) {
+    if (!P.text_bf16 || P.comb_fresh) return MMVAE_OK;
+    const float* p = P.buf.params;
+    MMVAE_TRY(launch_coco_comb(p + P.td0.wih, E + P.D, p + P.td_h2o_w, H + P.D, sos, P.w.tb_comb, P.w.tb_combT, P.w.td_sosv, s));
+    P.comb_fresh = true;
+    return MMVAE_OK;
 }
 
 // the weight-resident encoder kernels (coco_text_bf16.hip) need 4-row vectors of the batch
@@ -560,6 +575,12 @@ int coco_text_dec_fwd(CocoPlan& P, const float* z, int groups, const float* sos,
                 a.cl_timeout = reinterpret_cast<unsigned*>(w.cl_xchg + w.cl_bytes - 64);
                 P.cl_alarm_f = a.cl_timeout;
                 MMVAE_TRY(launch_fill_zero(w.cl_xchg, w.cl_bytes, s));      // flags and the timeout word: zero before EVERY launch
+                if (coco_dec_composed(Pc)) {
+                    MMVAE_TRY(coco_text_dec_prepare(P, sos, s));            // (no-op when the step made W_comb already)
+                    // zi0p = zi0 + zo W_ih0x^T: what the composed input projection adds to W_comb h1
+                    MMVAE_TRY(lin(w.td_zo, E, R, p + P.td0.wih, G, E, in0, 0, nullptr, w.td_zi0, G, w.td_zi0p, G, s));
+                    a.wg_comb = w.tb_comb; a.zi0p = w.td_zi0p; a.sosv = w.td_sosv;
+                }
             }
         }
         if (save) {

@@ -520,6 +520,305 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_cl_kernel(const CocoDecFwdA
     }
 }
 
+// ================================================================== forward, COMPOSED cluster form (8 ranks, weights resident)
+// The decoder feeds its own output back: x[t+1] = W_ho h1[t] + zo, and the only consumer of x[t+1] inside the recurrence is
+// layer 0's input projection W_ih0x x[t+1].  With W_comb = W_ih0x W_ho ([600][200], recomputed from the fp32 parameters by
+// coco_comb_kernel whenever they change) that projection is W_comb h1[t] + (W_ih0x zo + zi0): it reads the h1 every rank holds
+// after exchange B, so the third all-gather of a step (the output vector) disappears from the chain, and the output projection
+// itself -- still needed: the sentence is the result, and its bf16 copy the operand of the weight gradient -- moves into the
+// window of exchange A of the NEXT step.  K of the composed product is 224 instead of 320, and with 8 ranks a wave owns ONE
+// tile of each of the five matrices: 5 x 7 k-steps x 4 VGPRs = 140 registers hold every weight the workgroup ever needs, so
+// nothing streams inside the loop.  Step: gates 0, publish A | hh1 h1 and ho h1 (step t-1's output) during A | ih1 mid |
+// gates 1, publish B | hh0 h0' during B | comb h1'.
+template <bool KEEP, bool SAVE>
+__global__ __launch_bounds__(NTHR) void coco_dec_fwd_c8_kernel(const CocoDecFwdArgs a) {
+    constexpr int P = 8, NUBMAX = 2, NOEMAX = 3, KS = HP / 32;
+    constexpr int LDC = 3 * NUBMAX * 16 + 4, LDOE = NOEMAX * 16 + 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ga = reinterpret_cast<float*>(smem);                     // [16][LDC] input-side gate pre-activations (own units)
+    float* gb = ga + TR * LDC;                                      // [16][LDC] hidden-side
+    float* go = gb + TR * LDC;                                      // [16][LDOE] own output columns
+    float* bias = go + TR * LDOE;                                   // b_hh0 | b_ih1 | b_hh1, [3][G]
+    bf16* h0b = reinterpret_cast<bf16*>(bias + 3 * G);              // [16][LDH]
+    bf16* midb = h0b + TR * LDH;
+    bf16* h1b = midb + TR * LDH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int nblk = (a.R + TR - 1) / TR, nblk_pad = (nblk + 7) / 8 * 8;
+    const int rank = blockIdx.x / nblk_pad, blk = blockIdx.x - rank * nblk_pad;
+    if (blk >= nblk) return;
+    const int r0 = blk * TR, R = a.R, T = a.T;
+    const size_t RH = (size_t)R * H;
+    const int rows_ok = min(TR, R - r0);
+    const int nub = (13 - rank + P - 1) / P, noe = (19 - rank + P - 1) / P;
+    const int ng = 3 * nub;
+    const int grow = tid >> 5, pl = tid & 31;
+    const bool gok = r0 + grow < R;
+    const size_t gr = gok ? r0 + grow : 0;
+    const int uk = (2 * pl) >> 4, uu = (2 * pl) & 15;
+    const int j0 = (rank + P * uk) * 16 + uu;
+    const bool uok = uk < nub && j0 < H;
+    char* xbase = reinterpret_cast<char*>(a.cl_xchg) + (size_t)blk * CLF_BYTES;
+    unsigned* xflags = reinterpret_cast<unsigned*>(xbase + CLF_A + CLF_B + CLF_C);
+    const ClX xA = cl_x(xbase, CLF_A, xflags);                      // [16][200] {h0, dropout(h0)}
+    const ClX xB = cl_x(xbase + CLF_A, CLF_B, xflags + 8);          // [16][200] h1
+    unsigned* tmo = a.cl_timeout;
+
+    for (int i = tid; i < 3 * TR * LDH; i += NTHR) h0b[i] = (bf16)0.f;
+    for (int i = tid; i < G; i += NTHR) { bias[i] = a.bhh0[i]; bias[G + i] = a.bih1[i]; bias[2 * G + i] = a.bhh1[i]; }
+    __syncthreads();
+    for (int i = tid; i < TR * H; i += NTHR) {
+        const int row = i / H, j = i - row * H;
+        const float v = r0 + row < R ? a.hinit[(size_t)(r0 + row) * H + j] : 0.f;
+        h0b[row * LDH + j] = (bf16)v; h1b[row * LDH + j] = (bf16)v;
+        if (SAVE && rank == 0 && r0 + row < R) {
+            a.h0b_all[(size_t)(r0 + row) * HP + j] = (bf16)v; a.h1b_all[(size_t)(r0 + row) * HP + j] = (bf16)v;
+        }
+    }
+    if (SAVE && rank == 0)
+        for (int i = tid; i < TR * E; i += NTHR) {
+            const int row = i / E, e = i - row * E;
+            if (r0 + row < R) a.xb_all[(size_t)(r0 + row) * XP + e] = (bf16)a.sos[e];
+        }
+    if (SAVE && rank == 0 && pl == 0 && gok) { a.h0b_all[gr * HP + H] = (bf16)1.f; a.h1b_all[gr * HP + H] = (bf16)1.f; }
+    float h0f[2] = {0.f, 0.f}, h1f[2] = {0.f, 0.f};
+    if (uok && gok) {
+        h0f[0] = h1f[0] = a.hinit[gr * H + j0]; h0f[1] = h1f[1] = a.hinit[gr * H + j0 + 1];
+    }
+    // ---- resident weights: this wave's tile of the four gate matrices (tile list index = wave) and of the output projection
+    // (list index 7 - wave: the waves the gate products leave idle)
+    const bool gact = wave < ng;
+    const int lo = NW - 1 - wave;
+    const bool oact = lo < noe;
+    bf16x8 wc[KS], w_hh0[KS], w_ih1[KS], w_hh1[KS], w_o[KS];
+    {
+        auto rs = [](const bf16* p, int tiles) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p), 0, tiles * KS * 1024, 0x00020000); };
+        const __amdgpu_buffer_rsrc_t r_c = rs(a.wg_comb, 39), r_0 = rs(a.wg_hh0, 39), r_1 = rs(a.wg_ih1, 39), r_2 = rs(a.wg_hh1, 39), r_o = rs(a.w_ho, 19);
+        const int gt = gact ? ((wave % 3) * 13 + rank + P * (wave / 3)) * KS * 1024 : 0;
+        const int ot = oact ? (rank + P * lo) * KS * 1024 : 0;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            wc[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r_c, lane * 16, gt + s * 1024, 0));
+            w_hh0[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r_0, lane * 16, gt + s * 1024, 0));
+            w_ih1[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r_1, lane * 16, gt + s * 1024, 0));
+            w_hh1[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r_2, lane * 16, gt + s * 1024, 0));
+            w_o[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r_o, lane * 16, ot + s * 1024, 0));
+        }
+    }
+    // time-invariant addends of the two products with one, in the accumulator layout (rows 4 fq + j, column fr of the tile)
+    f32x4 zc = {0.f, 0.f, 0.f, 0.f}, zof = {0.f, 0.f, 0.f, 0.f};
+    {
+        const int within = (rank + P * (wave / 3)) * 16 + fr;
+        if (gact && within < H) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) zc[j] = a.zi0p[(size_t)(r0 + min(fq * 4 + j, rows_ok - 1)) * G + (wave % 3) * H + within];
+        }
+        const int e = (rank + P * lo) * 16 + fr;
+        if (oact && e < E) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) zof[j] = a.zo[(size_t)(r0 + min(fq * 4 + j, rows_ok - 1)) * E + e];
+        }
+    }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto rgemm = [&](const bf16* A, const bf16x8 (&w)[KS], f32x4 acc, float* out, int ldo, int li) {
+        bf16x8 af[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) af[s] = *reinterpret_cast<const bf16x8*>(A + fr * LDH + s * 32 + fq * 8);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s], w[s], acc, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[(fq * 4 + j) * ldo + li * 16 + fr] = acc[j];
+    };
+    // own output columns of step ts: go -> the sentence and (as the bf16 operand of the weight gradient) slice ts + 1 of xb_all
+    auto put_output = [&](int ts) {
+        if (tid < TR * NOEMAX * 8) {
+            const int row = tid / (NOEMAX * 8), lp = tid - row * (NOEMAX * 8);
+            const int lt = lp >> 3, e = (rank + P * lt) * 16 + 2 * (lp & 7);
+            if (lt < noe && e < E && r0 + row < R) {
+                const float v0 = go[row * LDOE + lt * 16 + 2 * (lp & 7)], v1 = go[row * LDOE + lt * 16 + 2 * (lp & 7) + 1];
+                float* sp = a.sentence + ((size_t)(r0 + row) * T + ts) * E + e;
+                sp[0] = v0; sp[1] = v1;
+                if (SAVE && ts + 1 < T) {
+                    bf16* xp = a.xb_all + ((size_t)(ts + 1) * R + r0 + row) * XP + e;
+                    xp[0] = (bf16)v0; xp[1] = (bf16)v1;
+                }
+            }
+        }
+    };
+    // step 0: the input is '<s>' for every row: ga = zi0 + W_ih0x sos (a.sosv, made with W_comb); gb = W_hh0 h(init)
+    for (int i = tid; i < TR * 3 * NUBMAX * 16; i += NTHR) {
+        const int row = i / (3 * NUBMAX * 16), c = i - row * (3 * NUBMAX * 16);
+        const int li = c >> 4, within = (rank + P * (li / 3)) * 16 + (c & 15);
+        float v = 0.f;
+        if (li < ng && within < H) {
+            const int col = (li % 3) * H + within;
+            v = a.zi0[(size_t)(r0 + min(row, rows_ok - 1)) * G + col] + a.sosv[col];
+        }
+        ga[row * LDC + c] = v;
+    }
+    __syncthreads();
+    if (gact) rgemm(h0b, w_hh0, zero4, gb, LDC, wave);
+    __syncthreads();
+    for (int t = 0; t < T; ++t) {
+        const unsigned ep = (unsigned)t + 1u;
+        const bool last = t + 1 == T;
+        // ---- layer 0
+        {
+            unsigned short kpo = 0x0101;
+            if (KEEP && uok) kpo = gok ? *reinterpret_cast<const unsigned short*>(a.keep + (size_t)t * RH + gr * H + j0) : (unsigned short)0;
+            float sr[2], sz[2], sn[2], sg[2], sh[2], sm[2];
+            if (uok) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int j = j0 + q, lc = (3 * uk) * 16 + uu + q;          // local column of gate g: lc + 16 g
+                    const float* pa = ga + grow * LDC; const float* pb = gb + grow * LDC;
+                    const float r = sigm(pa[lc] + pb[lc] + bias[j]);
+                    const float z = sigm(pa[lc + 16] + pb[lc + 16] + bias[H + j]);
+                    const float ghn = pb[lc + 32] + bias[2 * H + j];
+                    const float n = tanh_fast(pa[lc + 32] + r * ghn);
+                    const float hn = (1.0f - z) * n + z * h0f[q];
+                    h0f[q] = hn;
+                    float mid = hn;
+                    if (KEEP) mid = ((kpo >> (8 * q)) & 0xff) ? hn * a.keep_scale : 0.f;
+                    sr[q] = r; sz[q] = z; sn[q] = n; sg[q] = ghn; sh[q] = hn; sm[q] = mid;
+                }
+                cl_store8(xA, (grow * H + j0) * 4, (bf16)sh[0], (bf16)sm[0], (bf16)sh[1], (bf16)sm[1]);
+            }
+            cl_signal(xA, rank, ep, tid);
+            if (SAVE && uok && gok) {        // (behind the flag: the exchange does not wait for these)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int j = j0 + q;
+                    a.h0_all[(size_t)(t + 1) * RH + gr * H + j] = sh[q];
+                    float* s = a.sav0 + ((size_t)t * R + gr) * 4 * H;
+                    s[j] = sr[q]; s[H + j] = sz[q]; s[2 * H + j] = sn[q]; s[3 * H + j] = sg[q];
+                    a.h0b_all[((size_t)(t + 1) * R + gr) * HP + j] = (bf16)sh[q];
+                    a.midb_all[((size_t)t * R + gr) * HP + j] = (bf16)sm[q];
+                }
+            }
+            if (SAVE && rank == 0 && pl == 0 && gok) {
+                a.h0b_all[((size_t)(t + 1) * R + gr) * HP + H] = (bf16)1.f;
+                a.midb_all[((size_t)t * R + gr) * HP + H] = (bf16)1.f;
+                a.h1b_all[((size_t)(t + 1) * R + gr) * HP + H] = (bf16)1.f;
+            }
+        }
+        // during exchange A: layer 1's hidden product and the output projection of the previous step (both read last step's h1)
+        if (gact) rgemm(h1b, w_hh1, zero4, gb, LDC, wave);
+        if (t > 0 && oact) rgemm(h1b, w_o, zof, go, LDOE, lo);
+        cl_wait<P>(xA, ep, tmo, tid);
+        {   // 16 bytes = 4 units x {h0, mid}
+            constexpr int NPC = (TR * H / 4 + NTHR - 1) / NTHR;
+            bf16x8 x[NPC];
+#pragma unroll
+            for (int q = 0; q < NPC; ++q) { const int v = tid + q * NTHR; if (v < TR * H / 4) x[q] = cl_load16(xA, v * 16); }
+            if (t > 0) put_output(t - 1);
+#pragma unroll
+            for (int q = 0; q < NPC; ++q) {
+                const int v = tid + q * NTHR;
+                if (v < TR * H / 4) {
+                    const int row = v / (H / 4), j = (v - row * (H / 4)) * 4;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { h0b[row * LDH + j + u] = x[q][2 * u]; midb[row * LDH + j + u] = x[q][2 * u + 1]; }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- layer 1
+        if (gact) rgemm(midb, w_ih1, zero4, ga, LDC, wave);
+        __syncthreads();
+        {
+            float sr[2], sz[2], sn[2], sg[2], sh[2];
+            if (uok) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int j = j0 + q, lc = (3 * uk) * 16 + uu + q;
+                    const float* pa = ga + grow * LDC; const float* pb = gb + grow * LDC;
+                    const float r = sigm(pa[lc] + bias[G + j] + pb[lc] + bias[2 * G + j]);
+                    const float z = sigm(pa[lc + 16] + bias[G + H + j] + pb[lc + 16] + bias[2 * G + H + j]);
+                    const float ghn = pb[lc + 32] + bias[2 * G + 2 * H + j];
+                    const float n = tanh_fast(pa[lc + 32] + bias[G + 2 * H + j] + r * ghn);
+                    const float hn = (1.0f - z) * n + z * h1f[q];
+                    h1f[q] = hn;
+                    sr[q] = r; sz[q] = z; sn[q] = n; sg[q] = ghn; sh[q] = hn;
+                }
+                cl_store4(xB, (grow * H + j0) * 2, (bf16)sh[0], (bf16)sh[1]);
+            }
+            cl_signal(xB, rank, ep, tid);
+            if (SAVE && uok && gok) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int j = j0 + q;
+                    a.h1_all[(size_t)(t + 1) * RH + gr * H + j] = sh[q];
+                    float* s = a.sav1 + ((size_t)t * R + gr) * 4 * H;
+                    s[j] = sr[q]; s[H + j] = sz[q]; s[2 * H + j] = sn[q]; s[3 * H + j] = sg[q];
+                    a.h1b_all[((size_t)(t + 1) * R + gr) * HP + j] = (bf16)sh[q];
+                }
+            }
+        }
+        // during exchange B: layer 0's hidden product of the NEXT step (reads the h0 of exchange A)
+        if (!last && gact) rgemm(h0b, w_hh0, zero4, gb, LDC, wave);
+        cl_wait<P>(xB, ep, tmo, tid);
+        if (tid < TR * H / 8) {     // 16 bytes = 8 units (400 pieces: one per thread)
+            const bf16x8 x = cl_load16(xB, tid * 16);
+            const int row = tid / (H / 8), j = (tid - row * (H / 8)) * 8;
+            *reinterpret_cast<bf16x8*>(h1b + row * LDH + j) = x;
+        }
+        __syncthreads();
+        // ---- layer 0's input projection of the next step, straight from h1
+        if (!last && gact) rgemm(h1b, wc, zc, ga, LDC, wave);
+        __syncthreads();
+    }
+    if (oact) rgemm(h1b, w_o, zof, go, LDOE, lo);
+    __syncthreads();
+    put_output(T - 1);
+}
+
+// W_comb = W_ih0[:, :300] W_ho[:, :200] in fp32, written as the per-gate forward packs [3][208][224] and the transposed pack
+// [208][608] (fragment-major, pads zero), and sosv = W_ih0[:, :300] sos.  4 gate rows per workgroup, thread = hidden column.
+__global__ __launch_bounds__(256) void coco_comb_kernel(const float* __restrict__ wih0, int in0, const float* __restrict__ who, int ino,
+                                                        const float* __restrict__ sos, bf16* comb, bf16* combT, float* sosv) {
+    __shared__ float wr[4][E];
+    const int c0 = blockIdx.x * 4, k = threadIdx.x;
+    for (int i = k; i < 4 * E; i += 256) {
+        const int r = i / E, e = i - r * E;
+        wr[r][e] = c0 + r < G ? wih0[(size_t)(c0 + r) * in0 + e] : 0.f;
+    }
+    __syncthreads();
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (k < H) {
+#pragma unroll 4
+        for (int e = 0; e < E; ++e) {
+            const float v = who[(size_t)e * ino + k];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] += wr[r][e] * v;
+        }
+    }
+    auto frag = [](int n, int kk, int kpad) {
+        const int kv = kk >> 3;
+        return ((size_t)((n >> 4) * (kpad >> 5) + (kv >> 2)) * 64 + (kv & 3) * 16 + (n & 15)) * 8 + (kk & 7);
+    };
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int c = c0 + r;
+        if (c < G) {
+            const int g = c / H, n = c - g * H;
+            if (k < HP) comb[(size_t)g * 208 * HP + frag(n, k, HP)] = (bf16)(k < H ? acc[r] : 0.f);
+        } else if (c < GP) {                 // rows 200..207 of the three gates: zero
+            const int n = H + (c - G);
+            if (k < HP) for (int g = 0; g < 3; ++g) comb[(size_t)g * 208 * HP + frag(n, k, HP)] = (bf16)0.f;
+        }
+        if (c < GP && k < 208) combT[frag(k, c, GP)] = (bf16)((c < G && k < H) ? acc[r] : 0.f);
+    }
+    const int w = k >> 6, lane = k & 63, c = c0 + w;
+    if (c < G) {
+        float t = 0.f;
+        for (int e = lane; e < E; e += 64) t += wr[w][e] * sos[e];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+        if (lane == 0) sosv[c] = t;
+    }
+}
+
 // ================================================================== backward (BPTT)
 // Thread (row, c0) keeps the time sum of the output gradient of its 10 columns in registers; the time sum of the layer-0
 // input-projection gradient (what the z-columns and the bias see) is taken from the saved operand afterwards.
@@ -1426,6 +1725,10 @@ int launch_coco_time_sum_bf16(const bf16* in, int T, int R, int ld, int cols, fl
     return mmvae_check_launch("coco_time_sum_bf16");
 }
 
+int launch_coco_comb(const float* wih0, int in0, const float* who, int ino, const float* sos, bf16* comb, bf16* combT, float* sosv, hipStream_t s) {
+    hipLaunchKernelGGL(coco_comb_kernel, dim3(GP / 4), dim3(256), 0, s, wih0, in0, who, ino, sos, comb, combT, sosv);
+    return mmvae_check_launch("coco_comb");
+}
 int launch_coco_dec_fwd(const CocoDecFwdArgs& a, hipStream_t s) {
     const size_t lds = (size_t)(2 * TR * LDG + 2 * TR * H + 3 * G) * sizeof(float) + (size_t)(TR * LDX + 3 * TR * LDH) * sizeof(bf16);
     static std::atomic<unsigned> once{0};
@@ -1448,6 +1751,14 @@ int launch_coco_dec_fwd(const CocoDecFwdArgs& a, hipStream_t s) {
         // needed for that: the grid never exceeds the CU count)
         MMVAE_REQUIRE(nblk_pad * a.cluster <= 256, "coco_dec_fwd: %d x %d workgroups do not fit the chip", nblk_pad, a.cluster);
         auto gc = [&](auto kern, int P) { hipLaunchKernelGGL(kern, dim3(nblk_pad * P), dim3(NTHR), lds_of(P), s, a); };
+        if (a.cluster == 8 && a.wg_comb) {      // composed form: two exchanges per step, weights resident
+            MMVAE_REQUIRE(a.zi0p && a.sosv, "coco_dec_fwd: composed-form arguments");
+            const size_t lds8 = (size_t)(2 * TR * (3 * 2 * 16 + 4) + TR * (3 * 16 + 4) + 3 * G) * sizeof(float) + (size_t)(3 * TR * LDH) * sizeof(bf16);
+            auto g8 = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(nblk_pad * 8), dim3(NTHR), lds8, s, a); };
+            if (a.keep) { if (save) g8(&coco_dec_fwd_c8_kernel<true, true>); else g8(&coco_dec_fwd_c8_kernel<true, false>); }
+            else { if (save) g8(&coco_dec_fwd_c8_kernel<false, true>); else g8(&coco_dec_fwd_c8_kernel<false, false>); }
+            return mmvae_check_launch("coco_dec_fwd_c8");
+        }
         if (a.cluster == 4) {
             if (a.keep) { if (save) gc(&coco_dec_fwd_cl_kernel<true, true, 4>, 4); else gc(&coco_dec_fwd_cl_kernel<true, false, 4>, 4); }
             else { if (save) gc(&coco_dec_fwd_cl_kernel<false, true, 4>, 4); else gc(&coco_dec_fwd_cl_kernel<false, false, 4>, 4); }
