@@ -374,7 +374,7 @@ int use_ws(CocoPlan* P, void* ws, size_t bytes, bool module = true) {
     P->dec_skip_mask = 0;
     P->slab.reset(P->w.slab, P->w.slab_floats);
     P->dec_wg_pending = false;
-    P->comb_fresh = false;
+    P->comb_fresh = false; P->dw16_fresh = false; P->dec_wg_composed = false;
     P->cl_alarm_f = P->cl_alarm_b = nullptr;
     return MMVAE_OK;
 }
@@ -462,7 +462,9 @@ static int coco_step_body(CocoPlan* Pp, const CocoStepIO& io, int training, int 
     {
         float coef[3];
         for (int k = 0; k < 3; ++k) coef[k] = sk[k] ? 0.f : io.lambda_yx[k] / ((float)B * (float)T * (float)COCO_E);
-        MMVAE_TRY(coco_mse3(sentence, io.text, 3, (long long)B * T * COCO_E, coef, w.sums, do_backward ? w.td_dw : nullptr, Tx));
+        MMVAE_TRY(coco_mse3(sentence, io.text, 3, (long long)B * T * COCO_E, coef, w.sums, do_backward ? w.td_dw : nullptr, Tx,
+                            P.text_bf16 ? w.tb_dw16 : nullptr));
+        P.dw16_fresh = do_backward && P.text_bf16;
     }
     if (do_backward) MMVAE_TRY(coco_text_dec_bwd(P, w.z_f32, 3, io.sos, gk, sentence, w.td_dw, w.dz_txt, Tx, serial ? Tx : P.st_wgrad2, true));
     ConvTLastFwdArgs last{};

@@ -44,6 +44,10 @@ struct CocoDecBwdArgs {
     float *dwsum;            // [R][300] time sum of the output gradient
     // cluster form (coco_dec_bwd_cl_kernel): exchange granules [row blocks][2*2*16*200 + 16*150] (zeroed before the launch)
     unsigned long long* cl_xchg; unsigned* cl_timeout; int cluster;   // (cl_xchg: raw bytes, 16-byte aligned)
+    // composed form (coco_dec_bwd_c8_kernel, cluster == 8; null: three exchanges): packed [208][608] W_comb^T and the bf16 copy
+    // [R][T][320] of dw (pad columns zero).  That kernel leaves dout_b to the caller (dOut[t] = dw[t] + dgi0[t+1] W_ih0x) and
+    // writes only the time sum of dw into dwsum
+    const bf16 *w_combT, *dw16;
 };
 struct CocoEncFwdArgs {
     int B, T;
@@ -75,7 +79,12 @@ int launch_coco_dec_fwd(const CocoDecFwdArgs& a, hipStream_t s);
 int launch_coco_comb(const float* wih0, int in0, const float* who, int ino, const float* sos, bf16* comb, bf16* combT, float* sosv, hipStream_t s);
 int launch_coco_dec_bwd(const CocoDecBwdArgs& a, hipStream_t s);
 // out[r][c] (fp32, [R][cols]) = sum over t of in[(t*R + r)*ld + c]
-int launch_coco_time_sum_bf16(const bf16* in, int T, int R, int ld, int cols, float* out, hipStream_t s);
+// out2 (or null): the same sum without the first slice
+int launch_coco_time_sum_bf16(const bf16* in, int T, int R, int ld, int cols, float* out, hipStream_t s, float* out2 = nullptr);
+// dout[(t*R + r)*304 + e] = bf16(dw[(r*T + t)*300 + e] + (t < T-1 ? fb[(t*R + r)*300 + e] : 0)): total gradient wrt each step's output
+int launch_coco_dout_combine(const float* dw, const float* fb, int T, int R, bf16* dout, hipStream_t s);
+// dw16[r*320 + e] = bf16(dw[r*300 + e]), pad columns zero (rows = R*T)
+int launch_coco_dw16(const float* dw, long long rows, bf16* dw16, hipStream_t s);
 
 struct CocoPlan : PlanBase {
     int ldz, T;
@@ -89,6 +98,9 @@ struct CocoPlan : PlanBase {
     // bf16 persistent caption decoder: packed weights (forward and transposed forms) and packed-gradient descriptors
     bool text_bf16 = true;
     const unsigned *cl_alarm_f = nullptr, *cl_alarm_b = nullptr;   // timeout words of this step's cluster launches (null: not used)
+    const float* dec_wg_dw = nullptr;
+    bool dw16_fresh = false, dec_wg_composed = false;             // bf16 copy of dw made by this step's MSE kernel; dOut left to the wgrads
+    int tb_ih0xT_rm = -1;                                          // row-major pack of W_ih0[:, :300]^T ([300][600]) for the batched dOut GEMM
     bool comb_fresh = false;                                       // W_comb / sosv made from the CURRENT parameters (reset by use_ws)
     bool dec_wg_pending = false; const float* dec_wg_z = nullptr; int dec_wg_groups = 0;   // deferred weight gradients of the bf16 decoder
     int tb_ih0, tb_hh0, tb_ih1, tb_hh1, tb_ho, tb_hoT, tb_ih1T, tb_hh1T, tb_hh0T, tb_ih0T, tb_e_hh, tb_e_hhT, tb_e_ihA, tb_e_hhg[3], tb_g_ih0[3], tb_g_hh0[3], tb_g_ih1[3], tb_g_hh1[3];
@@ -118,6 +130,7 @@ struct CocoPlan : PlanBase {
         bf16 *te_xb, *te_hb_all, *te_dgi_b, *te_dgh_b;
         float *te_giT, *te_hlast;
         bf16 *tb_comb, *tb_combT; float *td_sosv, *td_zi0p;
+        bf16* tb_dw16; float* td_dzi1;
         char* cl_xchg; size_t cl_bytes; char* clb_xchg; size_t clb_bytes;
     } w;
 };
@@ -142,4 +155,6 @@ int coco_text_dec_fwd(CocoPlan& P, const float* z, int groups, const float* sos,
 int coco_text_dec_bwd(CocoPlan& P, const float* z, int groups, const float* sos, const uint8_t* keep, const float* sentence, float* dw, float* dz, hipStream_t s, hipStream_t sw,
                       bool bf16_path = false);
 // recon [G*B][T][300] vs target [B][T][300]: loss_sum[slot][4+g] += sum sq err ; dw = coef[g] * 2 (recon - target) (or null)
-int coco_mse3(const float* recon, const float* target, int G, long long per_group, const float* coef, float* loss_sum, float* dw, hipStream_t s);
+// dw16 (or null): bf16 copy of dw with rows of 320 (pad columns zero)
+int coco_mse3(const float* recon, const float* target, int G, long long per_group, const float* coef, float* loss_sum, float* dw, hipStream_t s,
+              bf16* dw16 = nullptr);

@@ -250,9 +250,10 @@ int sum_mid(const float* in, long long outer, int T, long long inner, float* out
     return mmvae_check_launch("sum_mid");
 }
 
-// grid.y = group; recon rows of group g compare with the same target
+// grid.y = group; recon rows of group g compare with the same target.  dw16 (or null): bf16 copy of dw with rows of 320
+// (the A operand of dw W_ho in the composed caption-decoder BPTT kernel), pad columns zero
 __global__ __launch_bounds__(TPBT) void mse3_kernel(const float* recon, const float* target, long long per_group, float c0, float c1,
-                                                    float c2, float* loss_sum, float* dw) {
+                                                    float c2, float* loss_sum, float* dw, bf16* dw16) {
     const int g = blockIdx.y;
     const float coef = g == 0 ? c0 : (g == 1 ? c1 : c2);
     float acc = 0.f;
@@ -260,6 +261,12 @@ __global__ __launch_bounds__(TPBT) void mse3_kernel(const float* recon, const fl
         const float d = recon[g * per_group + i] - target[i];
         acc += d * d;
         if (dw) dw[g * per_group + i] = coef * 2.f * d;
+        if (dw16) {
+            const long long m = (g * per_group + i) / COCO_E;
+            const int e = (int)(g * per_group + i - m * COCO_E);
+            dw16[m * CTB_XP + e] = (bf16)(coef * 2.f * d);
+            if (e < CTB_XP - COCO_E) dw16[m * CTB_XP + COCO_E + e] = (bf16)0.f;
+        }
     }
     acc = wave_sum(acc);
     if (loss_sum && (threadIdx.x & 63) == 0) atomicAdd(loss_sum + (blockIdx.x % MMVAE_LOSS_SLOTS) * 16 + 4 + g, acc);
@@ -344,6 +351,8 @@ void coco_text_build(CocoPlan& P) {
     for (int g3 = 0; g3 < 3; ++g3) P.tb_g_hh0[g3] = fwdp(P.td0.whh + (long long)g3 * H * H, H, H, H, 208, CTB_HP);
     for (int g3 = 0; g3 < 3; ++g3) P.tb_g_ih1[g3] = fwdp(P.td1.wih + (long long)g3 * H * H, H, H, H, 208, CTB_HP);
     for (int g3 = 0; g3 < 3; ++g3) P.tb_g_hh1[g3] = fwdp(P.td1.whh + (long long)g3 * H * H, H, H, H, 208, CTB_HP);
+    // W_ih0[:, :300]^T row-major ([300][600]): the batched GEMM dgi0[t+1] W_ih0x behind the composed BPTT kernel
+    P.tb_ih0xT_rm = P.pk.add(pack_dense(P.td0.wih, E, G, npad_for(E), round_up(G, 64), 1, in0));
     // packed gradients [round64(N)][Kpad of the wgrad operand] -> scattered back by the unpack kernel
     // bias >= 0: the saved operand carries 1.0 in column K, so column K of the packed gradient is the bias gradient
     auto gkp = [&](long long w, int N, int K, int ld, int Kc, long long bias) {
@@ -390,6 +399,7 @@ void coco_text_carve(CocoPlan& P, Workspace& ws) {
         w.te_dgi_b = ws.take<bf16>(T * B * CTB_GP); w.te_dgh_b = ws.take<bf16>(T * B * CTB_GP);
         w.tb_comb = ws.take<bf16>(3 * 208 * CTB_HP); w.tb_combT = ws.take<bf16>(208 * CTB_GP);
         w.td_sosv = ws.take<float>(G); w.td_zi0p = ws.take<float>(R * G);
+        w.tb_dw16 = ws.take<bf16>(R * T * CTB_XP); w.td_dzi1 = ws.take<float>(R * G);
     }
 }
 
@@ -612,8 +622,8 @@ int coco_text_dec_fwd(CocoPlan& P, const float* z, int groups, const float* sos,
 }
 
 // bf16 persistent path: BPTT in one launch, then the weight gradients as batched bf16 GEMMs over all T*R rows
-static int coco_text_dec_bwd_bf16(CocoPlan& P, const float* z, int groups, const uint8_t* keep, float* dw, float* dz, hipStream_t s,
-                                  hipStream_t sw) {
+static int coco_text_dec_bwd_bf16(CocoPlan& P, const float* z, int groups, const float* sos, const uint8_t* keep, float* dw, float* dz,
+                                  hipStream_t s, hipStream_t sw) {
     CocoPlan::W& w = P.w;
     const int R = groups * P.B, T = P.T, D = P.D, in0 = E + D, ino = H + D;
     const float* p = P.buf.params;
@@ -633,10 +643,19 @@ static int coco_text_dec_bwd_bf16(CocoPlan& P, const float* z, int groups, const
             a.cl_timeout = reinterpret_cast<unsigned*>(w.clb_xchg + w.clb_bytes - 64);
             P.cl_alarm_b = a.cl_timeout;
             MMVAE_TRY(launch_fill_zero(w.clb_xchg, w.clb_bytes, s));        // flags and the timeout word: zero before EVERY launch
+            if (coco_dec_composed(Pc) && !getenv("MMVAE_COCO_NO_COMB_BWD")) {
+                MMVAE_TRY(coco_text_dec_prepare(P, sos, s));                // (no-op inside a step: the forward pass made W_comb)
+                if (!P.dw16_fresh) MMVAE_TRY(launch_coco_dw16(dw, (long long)R * T, w.tb_dw16, s));    // (the step's MSE kernel makes it)
+                a.w_combT = w.tb_combT; a.dw16 = w.tb_dw16;
+            }
         }
     }
     MMVAE_TRY(launch_coco_dec_bwd(a, s));
-    MMVAE_TRY(launch_coco_time_sum_bf16(a.dgi0_b, T, R, CTB_GP, G, w.td_dzi0, s));
+    const bool composed = a.w_combT != nullptr;
+    MMVAE_TRY(launch_coco_time_sum_bf16(a.dgi0_b, T, R, CTB_GP, G, w.td_dzi0, s, composed ? w.td_dzi1 : nullptr));
+    // composed form: the kernel left the time sum of dw in dwsum; the feedback part of sum_t dOut[t] is (sum_{t>=1} dgi0[t]) W_ih0x
+    if (composed) MMVAE_TRY(lin_dx(w.td_dzi1, G, R, p + P.td0.wih, G, E, in0, 0, w.td_dwsum, E, 1, s));
+    P.dec_wg_composed = composed; P.dec_wg_dw = dw;
     // ---- what the rest of the step waits for: dz through the three z-terms (initial state, layer-0 input, output projection)
     MMVAE_TRY(lin_dx(w.td_dhinit, H, R, p + P.td_z2h_w, H, D, D, 0, dz, D, 0, s));
     MMVAE_TRY(lin_dx(w.td_dzi0, G, R, p + P.td0.wih, G, D, in0, E, dz, D, 1, s));
@@ -665,6 +684,18 @@ int coco_text_dec_wgrads(CocoPlan& P, hipStream_t sw) {
         list[i] = q;
     };
     const size_t RHP = (size_t)R * CTB_HP;
+    if (P.dec_wg_composed) {
+        // dOut[t] = dw[t] + dgi0[t+1] W_ih0x for every step at once: one bf16 GEMM over the saved gate gradients (slices 1 .. T-1,
+        // fp32 result in a buffer of the fp32 path) + a pass that adds the loss term and lays dOut out as the wgrad operand
+        const int M = (T - 1) * R;
+        if (M > 0) {
+            GatherPlan pl = dense_plan(M, G, CTB_GP, E);
+            GemmParams q = gemm_of(P, pl, &P.tb_ih0xT_rm, 1, M);
+            q.c.A = w.tb_dgi0 + (size_t)R * CTB_GP; q.out_f = w.td_dgi0; q.ldo = E;
+            MMVAE_TRY(launch_gemm_gather(q, sw));
+        }
+        MMVAE_TRY(launch_coco_dout_combine(P.dec_wg_dw, w.td_dgi0, T, R, w.tb_dout, sw));
+    }
     wg(0, P.tg_ih0, w.tb_dgi0, G, CTB_GP, w.tb_x, CTB_XP);
     wg(1, P.tg_hh0, w.tb_dgh0, G, CTB_GP, w.tb_h0, CTB_HP);                    // h0 BEFORE each step: slices 0 .. T-1
     wg(2, P.tg_ih1, w.tb_dgi1, G, CTB_GP, w.tb_mid, CTB_HP);
@@ -684,7 +715,7 @@ int coco_text_dec_wgrads(CocoPlan& P, hipStream_t sw) {
 
 int coco_text_dec_bwd(CocoPlan& P, const float* z, int groups, const float* sos, const uint8_t* keep, const float* sentence, float* dw,
                       float* dz, hipStream_t s, hipStream_t sw, bool bf16_path) {
-    if (bf16_path && P.text_bf16) return coco_text_dec_bwd_bf16(P, z, groups, keep, dw, dz, s, sw);
+    if (bf16_path && P.text_bf16) return coco_text_dec_bwd_bf16(P, z, groups, sos, keep, dw, dz, s, sw);
     CocoPlan::W& w = P.w;
     const int R = groups * P.B, T = P.T, D = P.D, in0 = E + D, ino = H + D;
     const float* p = P.buf.params;
@@ -759,9 +790,9 @@ int coco_text_dec_bwd(CocoPlan& P, const float* z, int groups, const float* sos,
 }
 
 int coco_mse3(const float* recon, const float* target, int Gn, long long per_group, const float* coef, float* loss_sum, float* dw,
-              hipStream_t s) {
+              hipStream_t s, bf16* dw16) {
     MMVAE_REQUIRE(Gn >= 1 && Gn <= 3, "mse3: groups=%d", Gn);
     const unsigned nb = (unsigned)std::min<long long>((per_group + TPBT - 1) / TPBT, 4096);
-    hipLaunchKernelGGL(mse3_kernel, dim3(nb, Gn), dim3(TPBT), 0, s, recon, target, per_group, coef[0], coef[1], coef[2], loss_sum, dw);
+    hipLaunchKernelGGL(mse3_kernel, dim3(nb, Gn), dim3(TPBT), 0, s, recon, target, per_group, coef[0], coef[1], coef[2], loss_sum, dw, dw ? dw16 : nullptr);
     return mmvae_check_launch("mse3");
 }

@@ -1317,6 +1317,259 @@ __global__ __launch_bounds__(NTHR) void coco_dec_bwd_cl_kernel(const CocoDecBwdA
         if (eok[q] && gok) { a.dwsum[gr * E + eo[q]] = ws_sum[q][0]; a.dwsum[gr * E + eo[q] + 1] = ws_sum[q][1]; }
 }
 
+// ================================================================== backward (BPTT), COMPOSED cluster form (8 ranks, resident)
+// Mirror of coco_dec_fwd_c8_kernel.  The gradient entering h1[t] through the output is dOut[t] W_ho with
+// dOut[t] = dw[t] + dgi0[t+1] W_ih0x; composed: dw[t] W_ho (no recurrence in it: its operand comes straight from the bf16 copy
+// of the loss gradient the MSE kernel leaves, a step ahead) + dgi0[t+1] W_comb (reads the layer-0 gate gradients every rank
+// holds after exchange X2).  The all-gather of the total output gradient disappears, and so does everything that only needs
+// dOut: W_ho's weight gradient and the z-term of the output projection get it from ONE batched GEMM over the saved dgi0
+// afterwards (coco_text.hip), the kernel only keeps the time sum of dw for its own embedding columns.  What is left is the
+// recurrence proper -- chain of a step: gates 1, publish X1 | (hh0T of the step before, during X1) | ih1T | gates 0, publish
+// X2 | (hh1T and hoT dw[t-1], during X2) | combT -- with every weight fragment resident: 4 x 5 + 3 k-steps x 4 VGPRs a wave.
+template <bool KEEP>
+__global__ __launch_bounds__(NTHR) void coco_dec_bwd_c8_kernel(const CocoDecBwdArgs a) {
+    constexpr int P = 8, NUBMAX = 2, KH = NW / NUBMAX;
+    constexpr int KSG = GP / 32, KSX = XP / 32;                       // 19, 10 k-steps
+    constexpr int KPG = (KSG + KH - 1) / KH, KPX = (KSX + KH - 1) / KH;   // 5, 3 k-steps per plane
+    constexpr int LDU = NUBMAX * 16 + 4, PLU = KH * TR * LDU;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* o1 = reinterpret_cast<float*>(smem);                     // [KH][16][LDU] dgi1 W_ih1
+    float* o2 = o1 + PLU;                                           // dgh0 W_hh0 (of the step before)
+    float* o3 = o2 + PLU;                                           // dgh1 W_hh1 + dw W_ho
+    float* oc = o3 + PLU;                                           // dgi0 W_comb
+    bf16* dgi = reinterpret_cast<bf16*>(oc + PLU);                  // [16][LDGK]
+    bf16* dgh = dgi + TR * LDGK;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int nblk = (a.R + TR - 1) / TR, nblk_pad = (nblk + 7) / 8 * 8;
+    const int rank = blockIdx.x / nblk_pad, blk = blockIdx.x - rank * nblk_pad;
+    if (blk >= nblk) return;
+    const int r0 = blk * TR, R = a.R, T = a.T;
+    const int nub = (13 - rank + P - 1) / P, noe = (19 - rank + P - 1) / P;
+    const int grow = tid >> 5, pl = tid & 31;
+    const bool gok = r0 + grow < R;
+    const int gr = gok ? r0 + grow : 0;
+    // ONE own unit per thread (a rank has at most 32): local column pl of the planes
+    const int uk = pl >> 4, ju = (rank + P * uk) * 16 + (pl & 15);
+    const bool uok = uk < nub && ju < H, act = uok && gok;
+    // own embedding columns (time sum of the loss gradient): pair pl of the rank's noe * 8
+    const int eo = (rank + P * (pl >> 3)) * 16 + 2 * (pl & 7);
+    const bool eact = (pl >> 3) < noe && eo < E && gok;
+    char* xbase = reinterpret_cast<char*>(a.cl_xchg) + (size_t)blk * CLB_BYTES;
+    unsigned* xflags = reinterpret_cast<unsigned*>(xbase + 2 * CLB_G + CLB_C);
+    const ClX xA = cl_x(xbase, CLB_G, xflags);                      // [16][200] {dr, dz, dn, dn*r} of layer 1
+    const ClX xB = cl_x(xbase + CLB_G, CLB_G, xflags + 8);          // ... of layer 0
+    unsigned* tmo = a.cl_timeout;
+    // every per-step global access goes through a buffer descriptor: per-thread byte offset (loop-invariant, 32 bits) + a scalar
+    // offset for the step (64-bit addresses per access cost two registers each)
+    auto mkrs = [](const void* p, size_t bytes) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000); };
+    const size_t TRn = (size_t)T * R;
+    const __amdgpu_buffer_rsrc_t q_dw = mkrs(a.dw, TRn * E * 4), q_dw16 = mkrs(a.dw16, TRn * XP * 2),
+                                 q_sav0 = mkrs(a.sav0, TRn * 4 * H * 4), q_sav1 = mkrs(a.sav1, TRn * 4 * H * 4),
+                                 q_h0 = mkrs(a.h0_all, (TRn + R) * H * 4), q_h1 = mkrs(a.h1_all, (TRn + R) * H * 4),
+                                 q_gi0 = mkrs(a.dgi0_b, TRn * GP * 2), q_gh0 = mkrs(a.dgh0_b, TRn * GP * 2),
+                                 q_gi1 = mkrs(a.dgi1_b, TRn * GP * 2), q_gh1 = mkrs(a.dgh1_b, TRn * GP * 2);
+    const int vo_g = (gr * GP + ju) * 2, vo_s = (gr * 4 * H + ju) * 4, vo_h = (gr * H + ju) * 4;
+    auto ldf = [](const __amdgpu_buffer_rsrc_t& rs, int vo, int so) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0)); };
+    auto stb = [](const __amdgpu_buffer_rsrc_t& rs, int vo, int so, float x) {
+        const bf16 b = (bf16)x;
+        __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, b), rs, vo, so, 0);
+    };
+    // gate gradients of the own unit, step t: gi = (dr, dz, dn), gh = (dr, dz, dn r)
+    auto put_gv = [&](const __amdgpu_buffer_rsrc_t& qi, const __amdgpu_buffer_rsrc_t& qh, int t, const float (&gv)[4]) {
+        const int so = t * R * GP * 2;
+        stb(qi, vo_g, so, gv[0]); stb(qi, vo_g + H * 2, so, gv[1]); stb(qi, vo_g + 2 * H * 2, so, gv[2]);
+        stb(qh, vo_g, so, gv[0]); stb(qh, vo_g + H * 2, so, gv[1]); stb(qh, vo_g + 2 * H * 2, so, gv[3]);
+    };
+    // saved gates (r, z, n, W_hn h + b_hn) and previous hidden state of the own unit, step t
+    auto get_sav = [&](const __amdgpu_buffer_rsrc_t& qs, const __amdgpu_buffer_rsrc_t& qh, int t, float (&sv)[4], float& hp) {
+        const int so = t * R * 4 * H * 4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) sv[g] = ldf(qs, vo_s + g * H * 4, so);
+        hp = ldf(qh, vo_h, t * R * H * 4);
+    };
+    constexpr int NPG = (TR * H / 2 + NTHR - 1) / NTHR;
+    auto load_gates = [&](const ClX& x, bf16x8 (&pc)[NPG]) {
+#pragma unroll
+        for (int q = 0; q < NPG; ++q) { const int v = tid + q * NTHR; if (v < TR * H / 2) pc[q] = cl_load16(x, v * 16); }
+    };
+    auto put_gates = [&](const bf16x8 (&pc)[NPG]) {       // a 16-byte piece = 2 units x {dr, dz, dn, dn*r}: into the two A operands
+#pragma unroll
+        for (int q = 0; q < NPG; ++q) {
+            const int v = tid + q * NTHR;
+            if (v < TR * H / 2) {
+                const int row = v / (H / 2), j = (v - row * (H / 2)) * 2;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    dgi[row * LDGK + j + u] = pc[q][4 * u]; dgh[row * LDGK + j + u] = pc[q][4 * u];
+                    dgi[row * LDGK + H + j + u] = pc[q][4 * u + 1]; dgh[row * LDGK + H + j + u] = pc[q][4 * u + 1];
+                    dgi[row * LDGK + 2 * H + j + u] = pc[q][4 * u + 2]; dgh[row * LDGK + 2 * H + j + u] = pc[q][4 * u + 3];
+                }
+            }
+        }
+    };
+    for (int i = tid; i < 2 * TR * LDGK; i += NTHR) dgi[i] = (bf16)0.f;
+    for (int i = tid; i < 4 * PLU; i += NTHR) o1[i] = 0.f;
+    float ws_sum[2] = {0.f, 0.f};
+    float dh0f = 0.f, dh1f = 0.f;
+    // ---- resident weights: this wave's item of a unit product = (tile uli = wave % 2, K plane ukh = wave / 2)
+    const int uli = wave % NUBMAX, ukh = wave / NUBMAX;
+    const bool uitem = uli < nub;
+    const int kcx = uitem ? max(0, min(KPX, KSX - ukh * KPX)) : 0, kcg = uitem ? max(0, min(KPG, KSG - ukh * KPG)) : 0;
+    bf16x8 w_ho[KPX], w_c[KPG], w_ih1[KPG], w_hh1[KPG], w_hh0[KPG];
+    {
+        auto rs = [](const bf16* p, int tiles, int ks) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p), 0, tiles * ks * 1024, 0x00020000); };
+        const __amdgpu_buffer_rsrc_t r_ho = rs(a.w_hoT, 13, KSX), r_c = rs(a.w_combT, 13, KSG), r_1 = rs(a.w_ih1T, 13, KSG), r_2 = rs(a.w_hh1T, 13, KSG),
+                                     r_0 = rs(a.w_hh0T, 13, KSG);
+        const int utile = uitem ? rank + P * uli : 0;
+        const bf16x8 z8 = {};
+#pragma unroll
+        for (int s = 0; s < KPX; ++s)
+            w_ho[s] = s < kcx ? __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r_ho, lane * 16, (utile * KSX + ukh * KPX + s) * 1024, 0)) : z8;
+#pragma unroll
+        for (int s = 0; s < KPG; ++s) {
+            const int ub = (utile * KSG + ukh * KPG + s) * 1024;
+            const bool ok = s < kcg;
+            w_c[s] = ok ? __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r_c, lane * 16, ub, 0)) : z8;
+            w_ih1[s] = ok ? __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r_1, lane * 16, ub, 0)) : z8;
+            w_hh1[s] = ok ? __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r_2, lane * 16, ub, 0)) : z8;
+            w_hh0[s] = ok ? __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r_0, lane * 16, ub, 0)) : z8;
+        }
+    }
+    // A fragments of dw[t] W_ho straight from the bf16 copy of the loss gradient ([row][t][320], pad columns zero): row fr of
+    // the block, this wave's K plane
+    const int vo_a = ((min(r0 + fr, R - 1) * T) * XP + ukh * KPX * 32 + fq * 8) * 2;
+    bf16x8 dwa[KPX];
+    auto load_dwa = [&](int t) {
+#pragma unroll
+        for (int s = 0; s < KPX; ++s)
+            if (s < kcx) dwa[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(q_dw16, vo_a + s * 64, t * XP * 2, 0));
+    };
+    // partial tile of this wave's item: k-steps [k0, k0 + kc) of the LDS operand against resident fragments, on top of `acc`
+    auto umma = [&](const auto& w, const bf16* A, f32x4 acc) {
+        constexpr int N = sizeof(w) / sizeof(w[0]);
+#pragma unroll
+        for (int s = 0; s < N; ++s)
+            if (s < kcg) {
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(A + fr * LDGK + (ukh * KPG + s) * 32 + fq * 8);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, w[s], acc, 0, 0, 0);
+            }
+        return acc;
+    };
+    auto uput = [&](float* out, f32x4 acc) {
+        if (kcg > 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[(ukh * TR + fq * 4 + j) * LDU + uli * 16 + fr] = acc[j];
+        }
+    };
+    auto homma = [&](f32x4 acc) {           // += dw W_ho, K plane of this wave (fragments in dwa)
+#pragma unroll
+        for (int s = 0; s < KPX; ++s)
+            if (s < kcx) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dwa[s], w_ho[s], acc, 0, 0, 0);
+        return acc;
+    };
+    auto usum = [&](const float* o) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < KH; ++k) t += o[(k * TR + grow) * LDU + pl];
+        return t;
+    };
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, hp1 = 0.f;
+    if (act) get_sav(q_sav1, q_h1, T - 1, s1, hp1);
+    load_dwa(T - 1);
+    __syncthreads();
+    uput(o3, homma(zero4));
+    __syncthreads();
+
+    for (int t = T - 1; t >= 0; --t) {
+        const unsigned ep = (unsigned)(T - t);
+        const bool newest = t == T - 1, first = t == 0;
+        float s0[4] = {0.f, 0.f, 0.f, 0.f}, hp0 = 0.f, dwo[2] = {0.f, 0.f};
+        unsigned kp = 1;
+        // ---- layer-1 gates backward: dh1 = carried + (dw W_ho + dgh1[t+1] W_hh1) + dgi0[t+1] W_comb
+        {
+            float gv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (uok) {
+                float dd = 0.f;
+                if (gok) {
+                    const float r = s1[0], z = s1[1], n = s1[2], ghn = s1[3];
+                    const float d = dh1f + usum(o3) + usum(oc);
+                    gv[2] = d * (1.0f - z) * (1.0f - n * n);
+                    gv[1] = d * (hp1 - n) * z * (1.0f - z);
+                    gv[0] = gv[2] * ghn * r * (1.0f - r);
+                    gv[3] = gv[2] * r;
+                    dd = d * z;
+                }
+                dh1f = dd;
+                cl_store8(xA, (grow * H + ju) * 8, (bf16)gv[0], (bf16)gv[1], (bf16)gv[2], (bf16)gv[3]);
+            }
+            cl_signal(xA, rank, ep, tid);
+            if (act) put_gv(q_gi1, q_gh1, t, gv);       // (behind the flag: the exchange does not wait for these)
+        }
+        // requests that have the window of X1 to arrive: saved gates of layer 0, the operand of the next dw W_ho, own columns of dw
+        if (act) get_sav(q_sav0, q_h0, t, s0, hp0);
+        if (KEEP && act) kp = a.keep[(size_t)t * R * H + (size_t)gr * H + ju];
+        if (!first) load_dwa(t - 1);
+        if (eact) { dwo[0] = ldf(q_dw, (gr * T * E + eo) * 4, t * E * 4); dwo[1] = ldf(q_dw, (gr * T * E + eo) * 4 + 4, t * E * 4); }
+        // during X1 (dgh still holds layer 0's gate gradients of step t+1): the dh0 carry
+        if (!newest) uput(o2, umma(w_hh0, dgh, zero4));
+        cl_wait<P>(xA, ep, tmo, tid);
+        {
+            bf16x8 pc[NPG];
+            load_gates(xA, pc);
+            ws_sum[0] += dwo[0]; ws_sum[1] += dwo[1];
+            put_gates(pc);
+        }
+        __syncthreads();
+        // ---- dmid = dgi1 W_ih1 (own units)
+        uput(o1, umma(w_ih1, dgi, zero4));
+        __syncthreads();
+        {
+            float gv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (uok) {
+                float dd = 0.f;
+                if (gok) {
+                    const float r = s0[0], z = s0[1], n = s0[2], ghn = s0[3];
+                    float dm = usum(o1);
+                    if (KEEP) dm = kp ? dm * a.keep_scale : 0.f;
+                    const float d = dh0f + usum(o2) + dm;
+                    gv[2] = d * (1.0f - z) * (1.0f - n * n);
+                    gv[1] = d * (hp0 - n) * z * (1.0f - z);
+                    gv[0] = gv[2] * ghn * r * (1.0f - r);
+                    gv[3] = gv[2] * r;
+                    dd = d * z;
+                }
+                dh0f = dd;
+                cl_store8(xB, (grow * H + ju) * 8, (bf16)gv[0], (bf16)gv[1], (bf16)gv[2], (bf16)gv[3]);
+            }
+            cl_signal(xB, rank, ep, tid);
+            if (act) put_gv(q_gi0, q_gh0, t, gv);
+        }
+        if (!first && act) get_sav(q_sav1, q_h1, t - 1, s1, hp1);
+        // during X2 (dgh still holds layer 1's gate gradients): the dh1 carry, and the loss term of the step below on top of it
+        {
+            f32x4 acc = umma(w_hh1, dgh, zero4);
+            if (!first) acc = homma(acc);
+            uput(o3, acc);
+        }
+        cl_wait<P>(xB, ep, tmo, tid);
+        {
+            bf16x8 pc[NPG];
+            load_gates(xB, pc);
+            put_gates(pc);
+        }
+        __syncthreads();
+        if (!first) uput(oc, umma(w_c, dgi, zero4));
+        __syncthreads();
+    }
+    // what the loop hides inside the next step's first window: dgh0[0] W_hh0
+    uput(o2, umma(w_hh0, dgh, zero4));
+    __syncthreads();
+    if (act) a.dhinit[(size_t)gr * H + ju] = dh0f + usum(o2) + dh1f + usum(o3);
+    if (eact) { a.dwsum[(size_t)gr * E + eo] = ws_sum[0]; a.dwsum[(size_t)gr * E + eo + 1] = ws_sum[1]; }
+}
+
 // ================================================================== caption encoder (forward direction of the bi-GRU)
 // coco/model.py:236-245.  The input projection of all T steps is one batched GEMM done by the caller; what is sequential is
 // h[t] = GRU(gi[t], h[t-1]): one hidden projection (W_hh, 272 KB bf16) and the gate math per step.  Same scheme as the
@@ -1707,22 +1960,47 @@ __global__ __launch_bounds__(256) void text_tb_kernel(const float* src, int B, i
     dst[((size_t)t * B + b) * ld + e] = (bf16)v;
 }
 
-// out[r][c] = sum_t in[(t*R + r)*ld + c]
-__global__ __launch_bounds__(256) void time_sum_bf16_kernel(const bf16* in, int T, int R, int ld, int cols, float* out) {
+// out[r][c] = sum_t in[(t*R + r)*ld + c]; out2 = the same without t = 0
+__global__ __launch_bounds__(256) void time_sum_bf16_kernel(const bf16* in, int T, int R, int ld, int cols, float* out, float* out2) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long long)R * cols) return;
     const int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
     const bf16* p = in + (size_t)r * ld + c;
     float acc = 0.f;
-    for (int t = 0; t < T; ++t) acc += (float)p[(size_t)t * R * ld];
-    out[i] = acc;
+    for (int t = 1; t < T; ++t) acc += (float)p[(size_t)t * R * ld];
+    if (out2) out2[i] = acc;
+    out[i] = acc + (float)p[0];
+}
+__global__ __launch_bounds__(256) void dout_combine_kernel(const float* __restrict__ dw, const float* __restrict__ fb, int T, int R, bf16* __restrict__ dout) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)T * R * E) return;
+    const long long m = i / E;                  // t * R + r
+    const int e = (int)(i - m * E), t = (int)(m / R), r = (int)(m - (long long)t * R);
+    float v = dw[((size_t)r * T + t) * E + e];
+    if (t + 1 < T) v += fb[i];
+    dout[m * EP + e] = (bf16)v;
+}
+__global__ __launch_bounds__(256) void dw16_kernel(const float* __restrict__ dw, long long rows, bf16* __restrict__ dw16) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * XP) return;
+    const long long r = i / XP;
+    const int e = (int)(i - r * XP);
+    dw16[i] = (bf16)(e < E ? dw[r * E + e] : 0.f);
 }
 
 }  // namespace
 
-int launch_coco_time_sum_bf16(const bf16* in, int T, int R, int ld, int cols, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(time_sum_bf16_kernel, dim3((unsigned)(((long long)R * cols + 255) / 256)), dim3(256), 0, s, in, T, R, ld, cols, out);
+int launch_coco_time_sum_bf16(const bf16* in, int T, int R, int ld, int cols, float* out, hipStream_t s, float* out2) {
+    hipLaunchKernelGGL(time_sum_bf16_kernel, dim3((unsigned)(((long long)R * cols + 255) / 256)), dim3(256), 0, s, in, T, R, ld, cols, out, out2);
     return mmvae_check_launch("coco_time_sum_bf16");
+}
+int launch_coco_dout_combine(const float* dw, const float* fb, int T, int R, bf16* dout, hipStream_t s) {
+    hipLaunchKernelGGL(dout_combine_kernel, dim3((unsigned)(((long long)T * R * E + 255) / 256)), dim3(256), 0, s, dw, fb, T, R, dout);
+    return mmvae_check_launch("coco_dout_combine");
+}
+int launch_coco_dw16(const float* dw, long long rows, bf16* dw16, hipStream_t s) {
+    hipLaunchKernelGGL(dw16_kernel, dim3((unsigned)((rows * XP + 255) / 256)), dim3(256), 0, s, dw, rows, dw16);
+    return mmvae_check_launch("coco_dw16");
 }
 
 int launch_coco_comb(const float* wih0, int in0, const float* who, int ino, const float* sos, bf16* comb, bf16* combT, float* sosv, hipStream_t s) {
@@ -1791,6 +2069,18 @@ int launch_coco_dec_bwd(const CocoDecBwdArgs& a, hipStream_t s) {
                    (size_t)(TR * LDX + 2 * TR * LDGK) * sizeof(bf16);
         };
         auto gc = [&](auto kern, int P) { hipLaunchKernelGGL(kern, dim3(nblk_pad * P), dim3(NTHR), lds_of(P), s, a); };
+        if (a.cluster == 8 && a.w_combT) {      // composed form: two exchanges per step, weights resident
+            MMVAE_REQUIRE(a.dw16, "coco_dec_bwd: the composed form needs the bf16 copy of the loss gradient");
+            const size_t lds8 = (size_t)(4 * 4 * TR * (2 * 16 + 4)) * sizeof(float) + (size_t)(2 * TR * LDGK) * sizeof(bf16);
+            static std::atomic<unsigned> once8{0};
+            if (mmvae_first_use_on_device(once8)) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&coco_dec_bwd_c8_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&coco_dec_bwd_c8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            }
+            if (a.keep) hipLaunchKernelGGL(coco_dec_bwd_c8_kernel<true>, dim3(nblk_pad * 8), dim3(NTHR), lds8, s, a);
+            else hipLaunchKernelGGL(coco_dec_bwd_c8_kernel<false>, dim3(nblk_pad * 8), dim3(NTHR), lds8, s, a);
+            return mmvae_check_launch("coco_dec_bwd_c8");
+        }
         if (a.cluster == 4) { if (a.keep) gc(&coco_dec_bwd_cl_kernel<true, 4>, 4); else gc(&coco_dec_bwd_cl_kernel<false, 4>, 4); }
         else { if (a.keep) gc(&coco_dec_bwd_cl_kernel<true, 8>, 8); else gc(&coco_dec_bwd_cl_kernel<false, 8>, 8); }
         return mmvae_check_launch("coco_dec_bwd_cl");
