@@ -325,6 +325,8 @@ typedef struct {
     float* mu; float* logvar;               /* out [3][B][D] or NULL */
     int pass_skip[3];                       /* 1: pass k absent from this step */
     int defer_unpack;                       /* 1: the optimizer consumes the packed gradients itself (see the MultiMNIST step) */
+    int pack_first;                         /* 1: the step refreshes the packed bf16 weights itself (the caller skipped mmvae_coco_pack_weights
+                                               after the optimizer step): caption half on the text stream, image half on the main one */
 } mmvae_coco_step_io;
 int mmvae_coco_step(mmvae_coco_t*, const mmvae_coco_step_io*, int training, int do_backward, void* stream);
 /* Granular modules (forward + autograd backward), workspace rules as for mmvae_mm_*_fwd/bwd */

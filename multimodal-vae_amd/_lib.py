@@ -62,6 +62,7 @@ class CocoStepIO(C.Structure):
         ("mu", C.c_void_p), ("logvar", C.c_void_p),
         ("pass_skip", C.c_int * 3),
         ("defer_unpack", C.c_int),
+        ("pack_first", C.c_int),
     ]
 
 

@@ -508,6 +508,7 @@ class FusedCocoStep(_FusedStepBase):
     LAMBDA_XY = (1.0, 1.0, 0.0)
     LAMBDA_YX = (1.0, 1.0, 1.0)
     EMB = 300
+    _DEFER_PACK = True          # the step refreshes the packed weights itself, the two halves on their own streams
 
     def __init__(self, state: PlanState, batch: int, sos: torch.Tensor, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8,
                  kl_lambda: float = 1e-3, seed: int = 1234, world_size: int = 1, all_reduce=None):
@@ -543,6 +544,8 @@ class FusedCocoStep(_FusedStepBase):
         self._pass_config(io, passes, lambda_xy, lambda_yx, "lambda_xy", "lambda_yx")
         io.seed = self.seed
         io.defer_unpack = int(bool(_defer_unpack))
+        io.pack_first = int(self.state.pack_pending)
         io.sums = self.sums.data_ptr()
         call("mmvae_coco_step", self.h, C.byref(io), int(training), int(backward), _stream())
+        self.state.pack_pending = False
         return self._outputs()

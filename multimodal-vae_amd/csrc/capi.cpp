@@ -390,7 +390,7 @@ int mmvae_coco_step(mmvae_coco_t* p, const mmvae_coco_step_io* io, int training,
     s.seed = io->seed; s.sums = io->sums; s.recon_image = io->recon_image; s.recon_text = io->recon_text;
     s.mu = io->mu; s.logvar = io->logvar;
     for (int k = 0; k < 3; ++k) s.pass_skip[k] = io->pass_skip[k];
-    s.defer_unpack = io->defer_unpack;
+    s.defer_unpack = io->defer_unpack; s.pack_first = io->pack_first;
     return coco_step(p, s, training, do_backward, S(stream));
     API_GUARD_END
 }

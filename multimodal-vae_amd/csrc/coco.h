@@ -26,6 +26,8 @@ struct CocoStepIO {
     float* recon_text = nullptr;        // [3][B][T][300] or null
     float* mu = nullptr; float* logvar = nullptr;   // [3][B][D] or null
     int pass_skip[3] = {0, 0, 0};       // 1: pass k is absent from this step
+    int pack_first = 0;                 // 1: the step refreshes the packed bf16 weights itself (after an optimizer step): the caption
+                                        //    GRUs' part on the text stream, the image half's on the main stream, side by side
     int defer_unpack = 0;               // 1: leave the GEMM-weight gradients packed (mmvae_adam_step_packed gathers them)
 };
 

@@ -100,6 +100,7 @@ void build(CocoPlan& P) {
         t.TW = 4; t.C = 512; t.s_ty = 0; t.s_tx = D; t.s_c = 4 * D;
         f.pk_dgrad = P.pk.add(t);
     }
+    P.pk_text_begin = (int)P.pk.d.size();
     coco_text_build(P);
 }
 
@@ -446,6 +447,11 @@ static int coco_step_body(CocoPlan* Pp, const CocoStepIO& io, int training, int 
     hipStream_t Tx = serial ? s : P.st_text;
     // ---- encoders: caption GRU on the side stream, image encoder on main
     MMVAE_TRY(edge(P, s, Tx));
+    if (io.pack_first && !P.no_pack) {      // the caption recurrences are the critical chain: their packs first, the image half's beside them
+        const int nd = (int)P.pk.d.size();
+        MMVAE_TRY(launch_pack_range(P.buf.desc_dev, P.pk.d.data(), nd, P.pk_text_begin, nd, P.buf.params, P.buf.packed, P.buf.packed_vec, Tx));
+        MMVAE_TRY(launch_pack_range(P.buf.desc_dev, P.pk.d.data(), nd, 0, P.pk_text_begin, P.buf.params, P.buf.packed, P.buf.packed_vec, s));
+    }
     MMVAE_TRY(coco_text_enc_fwd(P, io.text, do_backward, w.txtout, Tx, true));
     MMVAE_TRY(enc_fwd(P, io.image, 2, m1, m2, enc_drop, training, 2 - sk[0] - sk[1], w.encout, s));
     MMVAE_TRY(coco_text_dec_prepare(P, io.sos, s));      // (main stream: idle here until the caption encoder is through)
@@ -458,12 +464,13 @@ static int coco_step_body(CocoPlan* Pp, const CocoStepIO& io, int training, int 
     // ---- caption decoder (+ MSE, + its backward) on the side stream, image decoder on main
     MMVAE_TRY(edge(P, s, Tx));
     float* sentence = io.recon_text ? io.recon_text : w.td_recon;
-    MMVAE_TRY(coco_text_dec_fwd(P, w.z_f32, 3, io.sos, gk, do_backward, sentence, Tx, true));
     {
-        float coef[3];
-        for (int k = 0; k < 3; ++k) coef[k] = sk[k] ? 0.f : io.lambda_yx[k] / ((float)B * (float)T * (float)COCO_E);
-        MMVAE_TRY(coco_mse3(sentence, io.text, 3, (long long)B * T * COCO_E, coef, w.sums, do_backward ? w.td_dw : nullptr, Tx,
-                            P.text_bf16 ? w.tb_dw16 : nullptr));
+        CocoMseFuse mf{};
+        for (int k = 0; k < 3; ++k) mf.coef[k] = sk[k] ? 0.f : io.lambda_yx[k] / ((float)B * (float)T * (float)COCO_E);
+        mf.target = io.text; mf.loss_sum = w.sums; mf.dw = do_backward ? w.td_dw : nullptr; mf.dw16 = P.text_bf16 ? w.tb_dw16 : nullptr;
+        MMVAE_TRY(coco_text_dec_fwd(P, w.z_f32, 3, io.sos, gk, do_backward, sentence, Tx, true, &mf));
+        if (!P.mse_fused)
+            MMVAE_TRY(coco_mse3(sentence, io.text, 3, (long long)B * T * COCO_E, mf.coef, w.sums, mf.dw, Tx, mf.dw16));
         P.dw16_fresh = do_backward && P.text_bf16;
     }
     if (do_backward) MMVAE_TRY(coco_text_dec_bwd(P, w.z_f32, 3, io.sos, gk, sentence, w.td_dw, w.dz_txt, Tx, serial ? Tx : P.st_wgrad2, true));

@@ -24,6 +24,10 @@ struct CocoDecFwdArgs {
     // composed form (coco_dec_fwd_c8_kernel, cluster == 8): per-gate packs [3][208][224] of W_comb = W_ih0[:, :300] W_ho[:, :200],
     // zi0p = zi0 + zo W_ih0[:, :300]^T ([R][600]), sosv = W_ih0[:, :300] sos ([600]); null: the three-exchange form
     const bf16* wg_comb; const float *zi0p, *sosv;
+    // composed form only, optional: the reconstruction loss of the 3 passes fused into the output pass.  mse_target [B][T][300]
+    // (rows of pass g = g*B ..), mse_coef[g] the loss weights, mse_loss the loss slots (slot*16 + 4 + g, += squared error),
+    // mse_dw [R][T][300] / mse_dw16 [R][T][320] the loss gradient (null: loss only)
+    const float* mse_target; float mse_coef[3]; int mse_B; float* mse_loss; float* mse_dw; bf16* mse_dw16;
     unsigned long long* cl_xchg; unsigned* cl_timeout; int cluster;   // (cl_xchg: raw bytes, 16-byte aligned)
     const float *bhh0, *bih1, *bhh1;
     float* sentence;         // [R][T][300]
@@ -48,6 +52,7 @@ struct CocoDecBwdArgs {
     // [R][T][320] of dw (pad columns zero).  That kernel leaves dout_b to the caller (dOut[t] = dw[t] + dgi0[t+1] W_ih0x) and
     // writes only the time sum of dw into dwsum
     const bf16 *w_combT, *dw16;
+    float *dzi0, *dzi1;      // composed form: [R][600] time sum of dgi0 over all steps / over t >= 1 (made by the kernel)
 };
 struct CocoEncFwdArgs {
     int B, T;
@@ -79,8 +84,7 @@ int launch_coco_dec_fwd(const CocoDecFwdArgs& a, hipStream_t s);
 int launch_coco_comb(const float* wih0, int in0, const float* who, int ino, const float* sos, bf16* comb, bf16* combT, float* sosv, hipStream_t s);
 int launch_coco_dec_bwd(const CocoDecBwdArgs& a, hipStream_t s);
 // out[r][c] (fp32, [R][cols]) = sum over t of in[(t*R + r)*ld + c]
-// out2 (or null): the same sum without the first slice
-int launch_coco_time_sum_bf16(const bf16* in, int T, int R, int ld, int cols, float* out, hipStream_t s, float* out2 = nullptr);
+int launch_coco_time_sum_bf16(const bf16* in, int T, int R, int ld, int cols, float* out, hipStream_t s);
 // dout[(t*R + r)*304 + e] = bf16(dw[(r*T + t)*300 + e] + (t < T-1 ? fb[(t*R + r)*300 + e] : 0)): total gradient wrt each step's output
 int launch_coco_dout_combine(const float* dw, const float* fb, int T, int R, bf16* dout, hipStream_t s);
 // dw16[r*320 + e] = bf16(dw[r*300 + e]), pad columns zero (rows = R*T)
@@ -101,6 +105,8 @@ struct CocoPlan : PlanBase {
     const float* dec_wg_dw = nullptr;
     bool dw16_fresh = false, dec_wg_composed = false;             // bf16 copy of dw made by this step's MSE kernel; dOut left to the wgrads
     int tb_ih0xT_rm = -1;                                          // row-major pack of W_ih0[:, :300]^T ([300][600]) for the batched dOut GEMM
+    int pk_text_begin = 0;                                         // first pack descriptor of the caption half (the table's tail)
+    bool mse_fused = false;                                        // the last caption-decoder forward computed the MSE terms itself
     bool comb_fresh = false;                                       // W_comb / sosv made from the CURRENT parameters (reset by use_ws)
     bool dec_wg_pending = false; const float* dec_wg_z = nullptr; int dec_wg_groups = 0;   // deferred weight gradients of the bf16 decoder
     int tb_ih0, tb_hh0, tb_ih1, tb_hh1, tb_ho, tb_hoT, tb_ih1T, tb_hh1T, tb_hh0T, tb_ih0T, tb_e_hh, tb_e_hhT, tb_e_ihA, tb_e_hhg[3], tb_g_ih0[3], tb_g_hh0[3], tb_g_ih1[3], tb_g_hh1[3];
@@ -148,8 +154,11 @@ int coco_text_enc_fwd(CocoPlan& P, const float* text, int save, float* out, hipS
 // d_out: [B][2D] (the h2p bias gradient is added here); accumulates every caption-encoder gradient into P.buf.grads
 int coco_text_enc_bwd(CocoPlan& P, const float* text, const float* d_out, hipStream_t s, hipStream_t sw, bool bf16_path);
 // z: [rows][D] fp32, rows = groups*B; sentence: [rows][T][300]; keep: [T][rows][200] or null
+// mse (or null): target / loss weights / outputs of the reconstruction loss; when the kernel that runs can fuse it into its
+// output pass (composed cluster form) it does, and P.mse_fused tells the caller not to launch coco_mse3
+struct CocoMseFuse { const float* target; float coef[3]; float* loss_sum; float* dw; bf16* dw16; };
 int coco_text_dec_fwd(CocoPlan& P, const float* z, int groups, const float* sos, const uint8_t* keep, int save, float* sentence, hipStream_t s,
-                      bool bf16_path = false);
+                      bool bf16_path = false, const CocoMseFuse* mse = nullptr);
 // dw: [rows][T][300] gradient wrt the sentence (consumed: the feedback gradients are accumulated into it); dz: [rows][D]
 // sw: stream for the weight gradients (== s: in order; a side stream: the caller joins it before reading the gradients)
 int coco_text_dec_bwd(CocoPlan& P, const float* z, int groups, const float* sos, const uint8_t* keep, const float* sentence, float* dw, float* dz, hipStream_t s, hipStream_t sw,

@@ -551,7 +551,8 @@ int coco_text_enc_bwd(CocoPlan& P, const float* text, const float* d_out, hipStr
 
 // ================================================================== caption decoder (coco/model.py:266-312)
 int coco_text_dec_fwd(CocoPlan& P, const float* z, int groups, const float* sos, const uint8_t* keep, int save, float* sentence,
-                      hipStream_t s, bool bf16_path) {
+                      hipStream_t s, bool bf16_path, const CocoMseFuse* mse) {
+    P.mse_fused = false;
     CocoPlan::W& w = P.w;
     const int R = groups * P.B, T = P.T, D = P.D, in0 = E + D, ino = H + D;
     const float* p = P.buf.params;
@@ -590,6 +591,11 @@ int coco_text_dec_fwd(CocoPlan& P, const float* z, int groups, const float* sos,
                     // zi0p = zi0 + zo W_ih0x^T: what the composed input projection adds to W_comb h1
                     MMVAE_TRY(lin(w.td_zo, E, R, p + P.td0.wih, G, E, in0, 0, nullptr, w.td_zi0, G, w.td_zi0p, G, s));
                     a.wg_comb = w.tb_comb; a.zi0p = w.td_zi0p; a.sosv = w.td_sosv;
+                    if (mse && !getenv("MMVAE_COCO_NO_MSE_FUSE")) {         // (A/B aid, read per call)
+                        a.mse_target = mse->target; a.mse_B = P.B; a.mse_loss = mse->loss_sum; a.mse_dw = mse->dw; a.mse_dw16 = mse->dw16;
+                        for (int g3 = 0; g3 < 3; ++g3) a.mse_coef[g3] = g3 < groups ? mse->coef[g3] : 0.f;
+                        P.mse_fused = true;
+                    }
                 }
             }
         }
@@ -646,13 +652,13 @@ static int coco_text_dec_bwd_bf16(CocoPlan& P, const float* z, int groups, const
             if (coco_dec_composed(Pc) && !getenv("MMVAE_COCO_NO_COMB_BWD")) {
                 MMVAE_TRY(coco_text_dec_prepare(P, sos, s));                // (no-op inside a step: the forward pass made W_comb)
                 if (!P.dw16_fresh) MMVAE_TRY(launch_coco_dw16(dw, (long long)R * T, w.tb_dw16, s));    // (the step's MSE kernel makes it)
-                a.w_combT = w.tb_combT; a.dw16 = w.tb_dw16;
+                a.w_combT = w.tb_combT; a.dw16 = w.tb_dw16; a.dzi0 = w.td_dzi0; a.dzi1 = w.td_dzi1;
             }
         }
     }
     MMVAE_TRY(launch_coco_dec_bwd(a, s));
     const bool composed = a.w_combT != nullptr;
-    MMVAE_TRY(launch_coco_time_sum_bf16(a.dgi0_b, T, R, CTB_GP, G, w.td_dzi0, s, composed ? w.td_dzi1 : nullptr));
+    if (!composed) MMVAE_TRY(launch_coco_time_sum_bf16(a.dgi0_b, T, R, CTB_GP, G, w.td_dzi0, s));     // (the composed kernel keeps the sums itself)
     // composed form: the kernel left the time sum of dw in dwsum; the feedback part of sum_t dOut[t] is (sum_{t>=1} dgi0[t]) W_ih0x
     if (composed) MMVAE_TRY(lin_dx(w.td_dzi1, G, R, p + P.td0.wih, G, E, in0, 0, w.td_dwsum, E, 1, s));
     P.dec_wg_composed = composed; P.dec_wg_dw = dw;

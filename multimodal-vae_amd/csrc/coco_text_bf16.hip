@@ -555,9 +555,9 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_c8_kernel(const CocoDecFwdA
     const int grow = tid >> 5, pl = tid & 31;
     const bool gok = r0 + grow < R;
     const size_t gr = gok ? r0 + grow : 0;
-    const int uk = (2 * pl) >> 4, uu = (2 * pl) & 15;
-    const int j0 = (rank + P * uk) * 16 + uu;
-    const bool uok = uk < nub && j0 < H;
+    // ONE own unit per thread (a rank has at most 32): local column lc (+ 16 per gate) of the gate planes
+    const int uk = pl >> 4, ju = (rank + P * uk) * 16 + (pl & 15), lc = 3 * uk * 16 + (pl & 15);
+    const bool uok = uk < nub && ju < H;
     char* xbase = reinterpret_cast<char*>(a.cl_xchg) + (size_t)blk * CLF_BYTES;
     unsigned* xflags = reinterpret_cast<unsigned*>(xbase + CLF_A + CLF_B + CLF_C);
     const ClX xA = cl_x(xbase, CLF_A, xflags);                      // [16][200] {h0, dropout(h0)}
@@ -581,21 +581,19 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_c8_kernel(const CocoDecFwdA
             if (r0 + row < R) a.xb_all[(size_t)(r0 + row) * XP + e] = (bf16)a.sos[e];
         }
     if (SAVE && rank == 0 && pl == 0 && gok) { a.h0b_all[gr * HP + H] = (bf16)1.f; a.h1b_all[gr * HP + H] = (bf16)1.f; }
-    float h0f[2] = {0.f, 0.f}, h1f[2] = {0.f, 0.f};
-    if (uok && gok) {
-        h0f[0] = h1f[0] = a.hinit[gr * H + j0]; h0f[1] = h1f[1] = a.hinit[gr * H + j0 + 1];
-    }
+    float h0f = 0.f, h1f = 0.f;
+    if (uok && gok) h0f = h1f = a.hinit[gr * H + ju];
     // ---- resident weights: this wave's tile of the four gate matrices (tile list index = wave) and of the output projection
     // (list index 7 - wave: the waves the gate products leave idle)
     const bool gact = wave < ng;
     const int lo = NW - 1 - wave;
-    const bool oact = lo < noe;
+    const bool owave = lo < noe;
     bf16x8 wc[KS], w_hh0[KS], w_ih1[KS], w_hh1[KS], w_o[KS];
     {
         auto rs = [](const bf16* p, int tiles) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(p), 0, tiles * KS * 1024, 0x00020000); };
         const __amdgpu_buffer_rsrc_t r_c = rs(a.wg_comb, 39), r_0 = rs(a.wg_hh0, 39), r_1 = rs(a.wg_ih1, 39), r_2 = rs(a.wg_hh1, 39), r_o = rs(a.w_ho, 19);
         const int gt = gact ? ((wave % 3) * 13 + rank + P * (wave / 3)) * KS * 1024 : 0;
-        const int ot = oact ? (rank + P * lo) * KS * 1024 : 0;
+        const int ot = owave ? (rank + P * lo) * KS * 1024 : 0;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             wc[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r_c, lane * 16, gt + s * 1024, 0));
@@ -614,7 +612,7 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_c8_kernel(const CocoDecFwdA
             for (int j = 0; j < 4; ++j) zc[j] = a.zi0p[(size_t)(r0 + min(fq * 4 + j, rows_ok - 1)) * G + (wave % 3) * H + within];
         }
         const int e = (rank + P * lo) * 16 + fr;
-        if (oact && e < E) {
+        if (owave && e < E) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) zof[j] = a.zo[(size_t)(r0 + min(fq * 4 + j, rows_ok - 1)) * E + e];
         }
@@ -629,22 +627,45 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_c8_kernel(const CocoDecFwdA
 #pragma unroll
         for (int j = 0; j < 4; ++j) out[(fq * 4 + j) * ldo + li * 16 + fr] = acc[j];
     };
-    // own output columns of step ts: go -> the sentence and (as the bf16 operand of the weight gradient) slice ts + 1 of xb_all
+    // own output columns of step ts: go -> the sentence and (as the bf16 operand of the weight gradient) slice ts + 1 of xb_all.
+    // With a.mse_target the reconstruction loss rides along (coco/train.py:150-158: MSE against the caption's word vectors): the
+    // squared error is accumulated per thread, its gradient written in the two forms the BPTT kernel reads -- one pass over the
+    // sentence less between the two recurrences.
+    const int orow = tid / (NOEMAX * 8), olp = tid - orow * (NOEMAX * 8);
+    const int oe = (rank + P * (olp >> 3)) * 16 + 2 * (olp & 7);
+    const bool oact = tid < TR * NOEMAX * 8 && (olp >> 3) < noe && oe < E && r0 + orow < R;
+    const bool mse = a.mse_target != nullptr;
+    const int ogrp = oact && mse ? (r0 + orow) / a.mse_B : 0;
+    const float* tgt = mse ? a.mse_target + ((size_t)(r0 + orow - ogrp * a.mse_B) * T) * E + oe : nullptr;
+    const float c2 = mse ? 2.f * a.mse_coef[ogrp] : 0.f;
+    float sq = 0.f, tg[2] = {0.f, 0.f};
+    auto get_target = [&](int ts) { if (mse && oact) { tg[0] = tgt[(size_t)ts * E]; tg[1] = tgt[(size_t)ts * E + 1]; } };
     auto put_output = [&](int ts) {
-        if (tid < TR * NOEMAX * 8) {
-            const int row = tid / (NOEMAX * 8), lp = tid - row * (NOEMAX * 8);
-            const int lt = lp >> 3, e = (rank + P * lt) * 16 + 2 * (lp & 7);
-            if (lt < noe && e < E && r0 + row < R) {
-                const float v0 = go[row * LDOE + lt * 16 + 2 * (lp & 7)], v1 = go[row * LDOE + lt * 16 + 2 * (lp & 7) + 1];
-                float* sp = a.sentence + ((size_t)(r0 + row) * T + ts) * E + e;
-                sp[0] = v0; sp[1] = v1;
-                if (SAVE && ts + 1 < T) {
-                    bf16* xp = a.xb_all + ((size_t)(ts + 1) * R + r0 + row) * XP + e;
-                    xp[0] = (bf16)v0; xp[1] = (bf16)v1;
+        if (oact) {
+            const float v0 = go[orow * LDOE + (olp >> 3) * 16 + 2 * (olp & 7)], v1 = go[orow * LDOE + (olp >> 3) * 16 + 2 * (olp & 7) + 1];
+            float* sp = a.sentence + ((size_t)(r0 + orow) * T + ts) * E + oe;
+            sp[0] = v0; sp[1] = v1;
+            if (SAVE && ts + 1 < T) {
+                bf16* xp = a.xb_all + ((size_t)(ts + 1) * R + r0 + orow) * XP + oe;
+                xp[0] = (bf16)v0; xp[1] = (bf16)v1;
+            }
+            if (mse) {
+                const float d0 = v0 - tg[0], d1 = v1 - tg[1];
+                sq += d0 * d0 + d1 * d1;
+                if (a.mse_dw) {
+                    float* dp = a.mse_dw + ((size_t)(r0 + orow) * T + ts) * E + oe;
+                    dp[0] = c2 * d0; dp[1] = c2 * d1;
+                    bf16* hp = a.mse_dw16 + ((size_t)(r0 + orow) * T + ts) * XP + oe;
+                    hp[0] = (bf16)(c2 * d0); hp[1] = (bf16)(c2 * d1);
                 }
             }
         }
     };
+    if (mse && a.mse_dw && rank == 0)       // pad columns of the bf16 gradient rows (K padding of dw W_ho): zero
+        for (int i = tid; i < rows_ok * T * (XP - E); i += NTHR) {
+            const int rt = i / (XP - E), c = i - rt * (XP - E);
+            a.mse_dw16[((size_t)r0 * T + rt) * XP + E + c] = (bf16)0.f;
+        }
     // step 0: the input is '<s>' for every row: ga = zi0 + W_ih0x sos (a.sosv, made with W_comb); gb = W_hh0 h(init)
     for (int i = tid; i < TR * 3 * NUBMAX * 16; i += NTHR) {
         const int row = i / (3 * NUBMAX * 16), c = i - row * (3 * NUBMAX * 16);
@@ -662,39 +683,30 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_c8_kernel(const CocoDecFwdA
     for (int t = 0; t < T; ++t) {
         const unsigned ep = (unsigned)t + 1u;
         const bool last = t + 1 == T;
+        if (t > 0) get_target(t - 1);       // (for the output pass behind exchange A)
         // ---- layer 0
         {
-            unsigned short kpo = 0x0101;
-            if (KEEP && uok) kpo = gok ? *reinterpret_cast<const unsigned short*>(a.keep + (size_t)t * RH + gr * H + j0) : (unsigned short)0;
-            float sr[2], sz[2], sn[2], sg[2], sh[2], sm[2];
+            unsigned kp = 1;
+            if (KEEP && uok) kp = gok ? a.keep[(size_t)t * RH + gr * H + ju] : 0;
+            float sr = 0.f, sz = 0.f, sn = 0.f, sg = 0.f, sm = 0.f;
             if (uok) {
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int j = j0 + q, lc = (3 * uk) * 16 + uu + q;          // local column of gate g: lc + 16 g
-                    const float* pa = ga + grow * LDC; const float* pb = gb + grow * LDC;
-                    const float r = sigm(pa[lc] + pb[lc] + bias[j]);
-                    const float z = sigm(pa[lc + 16] + pb[lc + 16] + bias[H + j]);
-                    const float ghn = pb[lc + 32] + bias[2 * H + j];
-                    const float n = tanh_fast(pa[lc + 32] + r * ghn);
-                    const float hn = (1.0f - z) * n + z * h0f[q];
-                    h0f[q] = hn;
-                    float mid = hn;
-                    if (KEEP) mid = ((kpo >> (8 * q)) & 0xff) ? hn * a.keep_scale : 0.f;
-                    sr[q] = r; sz[q] = z; sn[q] = n; sg[q] = ghn; sh[q] = hn; sm[q] = mid;
-                }
-                cl_store8(xA, (grow * H + j0) * 4, (bf16)sh[0], (bf16)sm[0], (bf16)sh[1], (bf16)sm[1]);
+                const float* pa = ga + grow * LDC; const float* pb = gb + grow * LDC;
+                sr = sigm(pa[lc] + pb[lc] + bias[ju]);
+                sz = sigm(pa[lc + 16] + pb[lc + 16] + bias[H + ju]);
+                sg = pb[lc + 32] + bias[2 * H + ju];
+                sn = tanh_fast(pa[lc + 32] + sr * sg);
+                h0f = (1.0f - sz) * sn + sz * h0f;
+                sm = h0f;
+                if (KEEP) sm = kp ? h0f * a.keep_scale : 0.f;
+                cl_store4(xA, (grow * H + ju) * 4, (bf16)h0f, (bf16)sm);       // (row, unit) = {h0, dropout(h0)}
             }
             cl_signal(xA, rank, ep, tid);
             if (SAVE && uok && gok) {        // (behind the flag: the exchange does not wait for these)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int j = j0 + q;
-                    a.h0_all[(size_t)(t + 1) * RH + gr * H + j] = sh[q];
-                    float* s = a.sav0 + ((size_t)t * R + gr) * 4 * H;
-                    s[j] = sr[q]; s[H + j] = sz[q]; s[2 * H + j] = sn[q]; s[3 * H + j] = sg[q];
-                    a.h0b_all[((size_t)(t + 1) * R + gr) * HP + j] = (bf16)sh[q];
-                    a.midb_all[((size_t)t * R + gr) * HP + j] = (bf16)sm[q];
-                }
+                a.h0_all[(size_t)(t + 1) * RH + gr * H + ju] = h0f;
+                float* s = a.sav0 + ((size_t)t * R + gr) * 4 * H;
+                s[ju] = sr; s[H + ju] = sz; s[2 * H + ju] = sn; s[3 * H + ju] = sg;
+                a.h0b_all[((size_t)(t + 1) * R + gr) * HP + ju] = (bf16)h0f;
+                a.midb_all[((size_t)t * R + gr) * HP + ju] = (bf16)sm;
             }
             if (SAVE && rank == 0 && pl == 0 && gok) {
                 a.h0b_all[((size_t)(t + 1) * R + gr) * HP + H] = (bf16)1.f;
@@ -704,7 +716,7 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_c8_kernel(const CocoDecFwdA
         }
         // during exchange A: layer 1's hidden product and the output projection of the previous step (both read last step's h1)
         if (gact) rgemm(h1b, w_hh1, zero4, gb, LDC, wave);
-        if (t > 0 && oact) rgemm(h1b, w_o, zof, go, LDOE, lo);
+        if (t > 0 && owave) rgemm(h1b, w_o, zof, go, LDOE, lo);
         cl_wait<P>(xA, ep, tmo, tid);
         {   // 16 bytes = 4 units x {h0, mid}
             constexpr int NPC = (TR * H / 4 + NTHR - 1) / NTHR;
@@ -727,32 +739,23 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_c8_kernel(const CocoDecFwdA
         if (gact) rgemm(midb, w_ih1, zero4, ga, LDC, wave);
         __syncthreads();
         {
-            float sr[2], sz[2], sn[2], sg[2], sh[2];
+            float sr = 0.f, sz = 0.f, sn = 0.f, sg = 0.f;
             if (uok) {
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int j = j0 + q, lc = (3 * uk) * 16 + uu + q;
-                    const float* pa = ga + grow * LDC; const float* pb = gb + grow * LDC;
-                    const float r = sigm(pa[lc] + bias[G + j] + pb[lc] + bias[2 * G + j]);
-                    const float z = sigm(pa[lc + 16] + bias[G + H + j] + pb[lc + 16] + bias[2 * G + H + j]);
-                    const float ghn = pb[lc + 32] + bias[2 * G + 2 * H + j];
-                    const float n = tanh_fast(pa[lc + 32] + bias[G + 2 * H + j] + r * ghn);
-                    const float hn = (1.0f - z) * n + z * h1f[q];
-                    h1f[q] = hn;
-                    sr[q] = r; sz[q] = z; sn[q] = n; sg[q] = ghn; sh[q] = hn;
-                }
-                cl_store4(xB, (grow * H + j0) * 2, (bf16)sh[0], (bf16)sh[1]);
+                const float* pa = ga + grow * LDC; const float* pb = gb + grow * LDC;
+                sr = sigm(pa[lc] + bias[G + ju] + pb[lc] + bias[2 * G + ju]);
+                sz = sigm(pa[lc + 16] + bias[G + H + ju] + pb[lc + 16] + bias[2 * G + H + ju]);
+                sg = pb[lc + 32] + bias[2 * G + 2 * H + ju];
+                sn = tanh_fast(pa[lc + 32] + bias[G + 2 * H + ju] + sr * sg);
+                h1f = (1.0f - sz) * sn + sz * h1f;
+                const bf16 hb = (bf16)h1f;
+                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, hb), xB.rs, (grow * H + ju) * 2, 0, 16);
             }
             cl_signal(xB, rank, ep, tid);
             if (SAVE && uok && gok) {
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int j = j0 + q;
-                    a.h1_all[(size_t)(t + 1) * RH + gr * H + j] = sh[q];
-                    float* s = a.sav1 + ((size_t)t * R + gr) * 4 * H;
-                    s[j] = sr[q]; s[H + j] = sz[q]; s[2 * H + j] = sn[q]; s[3 * H + j] = sg[q];
-                    a.h1b_all[((size_t)(t + 1) * R + gr) * HP + j] = (bf16)sh[q];
-                }
+                a.h1_all[(size_t)(t + 1) * RH + gr * H + ju] = h1f;
+                float* s = a.sav1 + ((size_t)t * R + gr) * 4 * H;
+                s[ju] = sr; s[H + ju] = sz; s[2 * H + ju] = sn; s[3 * H + ju] = sg;
+                a.h1b_all[((size_t)(t + 1) * R + gr) * HP + ju] = (bf16)h1f;
             }
         }
         // during exchange B: layer 0's hidden product of the NEXT step (reads the h0 of exchange A)
@@ -768,9 +771,19 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_c8_kernel(const CocoDecFwdA
         if (!last && gact) rgemm(h1b, wc, zc, ga, LDC, wave);
         __syncthreads();
     }
-    if (oact) rgemm(h1b, w_o, zof, go, LDOE, lo);
+    get_target(T - 1);
+    if (owave) rgemm(h1b, w_o, zof, go, LDOE, lo);
     __syncthreads();
     put_output(T - 1);
+    if (mse) {      // squared error: rows of the block meet in LDS, one atomic per row into the row's pass
+        float* red = ga;
+        __syncthreads();
+        if (tid < TR) red[tid] = 0.f;
+        __syncthreads();
+        if (oact) atomicAdd(red + orow, sq);
+        __syncthreads();
+        if (tid < rows_ok) atomicAdd(a.mse_loss + (blockIdx.x % MMVAE_LOSS_SLOTS) * 16 + 4 + (r0 + tid) / a.mse_B, red[tid]);
+    }
 }
 
 // W_comb = W_ih0[:, :300] W_ho[:, :200] in fp32, written as the per-gate forward packs [3][208][224] and the transposed pack
@@ -1411,6 +1424,7 @@ __global__ __launch_bounds__(NTHR) void coco_dec_bwd_c8_kernel(const CocoDecBwdA
     for (int i = tid; i < 2 * TR * LDGK; i += NTHR) dgi[i] = (bf16)0.f;
     for (int i = tid; i < 4 * PLU; i += NTHR) o1[i] = 0.f;
     float ws_sum[2] = {0.f, 0.f};
+    float gsum[3] = {0.f, 0.f, 0.f};        // time sum of the own unit's layer-0 input-side gate gradients (as stored: bf16 values)
     float dh0f = 0.f, dh1f = 0.f;
     // ---- resident weights: this wave's item of a unit product = (tile uli = wave % 2, K plane ukh = wave / 2)
     const int uli = wave % NUBMAX, ukh = wave / NUBMAX;
@@ -1545,6 +1559,14 @@ __global__ __launch_bounds__(NTHR) void coco_dec_bwd_c8_kernel(const CocoDecBwdA
             }
             cl_signal(xB, rank, ep, tid);
             if (act) put_gv(q_gi0, q_gh0, t, gv);
+            if (!first) { gsum[0] += (float)(bf16)gv[0]; gsum[1] += (float)(bf16)gv[1]; gsum[2] += (float)(bf16)gv[2]; }
+            else if (act) {     // last step of the loop: the sums over t >= 1 (what the output projection's z-term sees) and over all t
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    a.dzi1[(size_t)gr * G + g * H + ju] = gsum[g];
+                    a.dzi0[(size_t)gr * G + g * H + ju] = gsum[g] + (float)(bf16)gv[g];
+                }
+            }
         }
         if (!first && act) get_sav(q_sav1, q_h1, t - 1, s1, hp1);
         // during X2 (dgh still holds layer 1's gate gradients): the dh1 carry, and the loss term of the step below on top of it
@@ -1960,16 +1982,15 @@ __global__ __launch_bounds__(256) void text_tb_kernel(const float* src, int B, i
     dst[((size_t)t * B + b) * ld + e] = (bf16)v;
 }
 
-// out[r][c] = sum_t in[(t*R + r)*ld + c]; out2 = the same without t = 0
-__global__ __launch_bounds__(256) void time_sum_bf16_kernel(const bf16* in, int T, int R, int ld, int cols, float* out, float* out2) {
+// out[r][c] = sum_t in[(t*R + r)*ld + c]
+__global__ __launch_bounds__(256) void time_sum_bf16_kernel(const bf16* in, int T, int R, int ld, int cols, float* out) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long long)R * cols) return;
     const int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
     const bf16* p = in + (size_t)r * ld + c;
     float acc = 0.f;
-    for (int t = 1; t < T; ++t) acc += (float)p[(size_t)t * R * ld];
-    if (out2) out2[i] = acc;
-    out[i] = acc + (float)p[0];
+    for (int t = 0; t < T; ++t) acc += (float)p[(size_t)t * R * ld];
+    out[i] = acc;
 }
 __global__ __launch_bounds__(256) void dout_combine_kernel(const float* __restrict__ dw, const float* __restrict__ fb, int T, int R, bf16* __restrict__ dout) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -1990,8 +2011,8 @@ __global__ __launch_bounds__(256) void dw16_kernel(const float* __restrict__ dw,
 
 }  // namespace
 
-int launch_coco_time_sum_bf16(const bf16* in, int T, int R, int ld, int cols, float* out, hipStream_t s, float* out2) {
-    hipLaunchKernelGGL(time_sum_bf16_kernel, dim3((unsigned)(((long long)R * cols + 255) / 256)), dim3(256), 0, s, in, T, R, ld, cols, out, out2);
+int launch_coco_time_sum_bf16(const bf16* in, int T, int R, int ld, int cols, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(time_sum_bf16_kernel, dim3((unsigned)(((long long)R * cols + 255) / 256)), dim3(256), 0, s, in, T, R, ld, cols, out);
     return mmvae_check_launch("coco_time_sum_bf16");
 }
 int launch_coco_dout_combine(const float* dw, const float* fb, int T, int R, bf16* dout, hipStream_t s) {
@@ -2070,7 +2091,7 @@ int launch_coco_dec_bwd(const CocoDecBwdArgs& a, hipStream_t s) {
         };
         auto gc = [&](auto kern, int P) { hipLaunchKernelGGL(kern, dim3(nblk_pad * P), dim3(NTHR), lds_of(P), s, a); };
         if (a.cluster == 8 && a.w_combT) {      // composed form: two exchanges per step, weights resident
-            MMVAE_REQUIRE(a.dw16, "coco_dec_bwd: the composed form needs the bf16 copy of the loss gradient");
+            MMVAE_REQUIRE(a.dw16 && a.dzi0 && a.dzi1, "coco_dec_bwd: the composed form needs the bf16 copy of the loss gradient and the sum buffers");
             const size_t lds8 = (size_t)(4 * 4 * TR * (2 * 16 + 4)) * sizeof(float) + (size_t)(2 * TR * LDGK) * sizeof(bf16);
             static std::atomic<unsigned> once8{0};
             if (mmvae_first_use_on_device(once8)) {

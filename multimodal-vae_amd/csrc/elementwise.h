@@ -24,6 +24,9 @@ struct PackDesc {
 
 int launch_pack(const PackDesc* table_dev, const PackDesc* table_host, int ndesc, const float* params,
                 bf16* packed_bf, float* packed_f32, hipStream_t s);
+// the descriptors [d0, d1) of the table only (a plan whose streams need different parts of the packed weights first)
+int launch_pack_range(const PackDesc* table_dev, const PackDesc* table_host, int ndesc, int d0, int d1, const float* params,
+                      bf16* packed_bf, float* packed_f32, hipStream_t s);
 // grads_flat[src] += packed_grad[dst]  (inverse of the matrix packing, fp32 -> fp32)
 // part >= 0: only the descriptors with PackDesc::part == part (the data-parallel step hands the early part to the collective
 // while the rest of the backward pass runs)

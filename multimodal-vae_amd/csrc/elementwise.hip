@@ -88,8 +88,8 @@ __device__ __forceinline__ void pack_block(const PackDesc* __restrict__ table, i
 // MAP = false: grads[flat] += packed value.  MAP = true: map[flat] = where that value lives (index into gmat, or
 // -(index + 2) into gvec) -- built once per plan for the optimizer kernel that consumes the packed gradients directly.
 __global__ __launch_bounds__(TPB) void pack_kernel(const PackDesc* __restrict__ table, int nd, const float* __restrict__ params,
-                                                   bf16* __restrict__ packed_bf, float* __restrict__ packed_f32) {
-    pack_block(table, nd, params, packed_bf, packed_f32, blockIdx.x);
+                                                   bf16* __restrict__ packed_bf, float* __restrict__ packed_f32, int block0) {
+    pack_block(table, nd, params, packed_bf, packed_f32, block0 + blockIdx.x);
 }
 
 template <bool MAP>
@@ -891,7 +891,15 @@ int launch_pack(const PackDesc* table_dev, const PackDesc* table_host, int nd, c
     MMVAE_REQUIRE(nd > 0, "pack: empty table");
     for (int i = 0; i < nd; ++i)
         MMVAE_REQUIRE((long long)table_host[i].Npad * (table_host[i].Kpad / 8) < (1 << 23), "pack: matrix %d too large for 32-bit index math", i);
-    hipLaunchKernelGGL(pack_kernel, dim3(table_blocks(table_host, nd)), dim3(TPB), 0, s, table_dev, nd, params, packed_bf, packed_f32);
+    hipLaunchKernelGGL(pack_kernel, dim3(table_blocks(table_host, nd)), dim3(TPB), 0, s, table_dev, nd, params, packed_bf, packed_f32, 0);
+    return mmvae_check_launch("pack");
+}
+int launch_pack_range(const PackDesc* table_dev, const PackDesc* table_host, int nd, int d0, int d1, const float* params, bf16* packed_bf,
+                      float* packed_f32, hipStream_t s) {
+    MMVAE_REQUIRE(0 <= d0 && d0 <= d1 && d1 <= nd, "pack: descriptor range [%d, %d) of %d", d0, d1, nd);
+    if (d0 == d1) return MMVAE_OK;
+    const int b0 = (int)table_host[d0].first_block, b1 = d1 < nd ? (int)table_host[d1].first_block : table_blocks(table_host, nd);
+    hipLaunchKernelGGL(pack_kernel, dim3(b1 - b0), dim3(TPB), 0, s, table_dev, nd, params, packed_bf, packed_f32, b0);
     return mmvae_check_launch("pack");
 }
 int launch_unpack_grads(const PackDesc* table_dev, const PackDesc* table_host, int nd, const float* gmat, const float* gvec,
