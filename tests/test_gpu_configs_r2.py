@@ -192,7 +192,8 @@ def test_c_abi_collective_face_single_rank():
 
 def test_coco_caption_kernel_forms_agree():
     """The forms of the COCO caption recurrences must compute the same step: decoder with 8 / 4 workgroups per row block
-    (cluster form: slices of the hidden units per rank, all-gathers through global memory) against one workgroup per block,
+    (cluster form: slices of the hidden units per rank, all-gathers through global memory; at 8 the COMPOSED form, whose
+    layer-0 input projection reads h1 through W_ih0x W_ho, against the three-exchange kernels) against one workgroup per block,
     encoder with resident against streamed W_hh.  Same inputs, same draws; what may differ is fp32 summation order (split
     reductions) and the step's own run-to-run noise from fp32 atomics upstream, both far below the gates."""
     from multimodal_vae_amd.core import CocoState, FusedCocoStep
@@ -206,9 +207,16 @@ def test_coco_caption_kernel_forms_agree():
     keep = (torch.rand(T, 3 * B, 200, generator=g) > 0.1).to(torch.uint8).to(dev)
     st = CocoState(D, dev, steps=T); default_init_(st, 21)
     eng = FusedCocoStep(st, B, 0.4 * torch.randn(300, generator=g), seed=3)
-    old = {k: os.environ.get(k) for k in ("MMVAE_COCO_CLUSTER", "MMVAE_COCO_ENC_STREAMED")}
+    switches = ("MMVAE_COCO_CLUSTER", "MMVAE_COCO_ENC_STREAMED", "MMVAE_COCO_NO_COMB", "MMVAE_COCO_NO_COMB_BWD", "MMVAE_COCO_NO_MSE_FUSE")
+    old = {k: os.environ.get(k) for k in switches}
 
-    def run(cluster, streamed):
+    def run(cluster, streamed, *off):
+        """off: switches that take parts of the composed cluster-of-8 form out (W_comb = W_ih0x W_ho, two exchanges per step,
+        the MSE fused into the forward kernel's output pass); the default at cluster == 8 has all of them in."""
+        for k in switches[2:]:
+            os.environ.pop(k, None)
+        for k in off:
+            os.environ[k] = "1"
         os.environ["MMVAE_COCO_CLUSTER"] = str(cluster)
         if streamed:
             os.environ["MMVAE_COCO_ENC_STREAMED"] = "1"
@@ -221,15 +229,16 @@ def test_coco_caption_kernel_forms_agree():
 
     try:
         r0, g0, l0 = run(0, True)
-        for cluster, streamed in ((0, False), (4, False), (8, False), (8, True)):
-            r, gg, l = run(cluster, streamed)
+        for cluster, streamed, *off in ((0, False), (4, False), (8, False), (8, True), (8, False, "MMVAE_COCO_NO_COMB"),
+                                        (8, False, "MMVAE_COCO_NO_COMB_BWD"), (8, False, "MMVAE_COCO_NO_MSE_FUSE")):
+            r, gg, l = run(cluster, streamed, *off)
             np.testing.assert_allclose(l, l0, rtol=2e-4)
-            assert float((r - r0).abs().max()) < 1e-2, (cluster, streamed)
-            assert float((gg - g0).norm() / g0.norm()) < 1e-2, (cluster, streamed)
+            assert float((r - r0).abs().max()) < 1e-2, (cluster, streamed, off)
+            assert float((gg - g0).norm() / g0.norm()) < 1e-2, (cluster, streamed, off)
             for n, shape, off in st.table:        # every tensor, so that a slice of units left out cannot hide in the norm
                 k = int(np.prod(shape))
                 a, b = gg[off:off + k], g0[off:off + k]
-                assert float((a - b).norm()) <= 5e-2 * float(b.norm()) + 1e-7, (cluster, streamed, n)
+                assert float((a - b).norm()) <= 5e-2 * float(b.norm()) + 1e-7, (cluster, streamed, off, n)
     finally:
         for k, v in old.items():
             if v is None:
