@@ -447,12 +447,19 @@ static int coco_step_body(CocoPlan* Pp, const CocoStepIO& io, int training, int 
     hipStream_t Tx = serial ? s : P.st_text;
     // ---- encoders: caption GRU on the side stream, image encoder on main
     MMVAE_TRY(edge(P, s, Tx));
-    if (io.pack_first && !P.no_pack) {      // the caption recurrences are the critical chain: their packs first, the image half's beside them
+    hipStream_t Sd = serial ? s : P.st_wgrad;       // idle until the backward pass: the caption decoder's packs
+    const bool packing = io.pack_first && !P.no_pack;
+    if (packing) {      // the caption encoder's recurrence opens the critical chain: its (few) packs first, everything else beside them
         const int nd = (int)P.pk.d.size();
-        MMVAE_TRY(launch_pack_range(P.buf.desc_dev, P.pk.d.data(), nd, P.pk_text_begin, nd, P.buf.params, P.buf.packed, P.buf.packed_vec, Tx));
-        MMVAE_TRY(launch_pack_range(P.buf.desc_dev, P.pk.d.data(), nd, 0, P.pk_text_begin, P.buf.params, P.buf.packed, P.buf.packed_vec, s));
+        auto range = [&](int d0, int d1, hipStream_t st) {
+            return launch_pack_range(P.buf.desc_dev, P.pk.d.data(), nd, d0, d1, P.buf.params, P.buf.packed, P.buf.packed_vec, st);
+        };
+        MMVAE_TRY(range(P.pk_text_begin, P.pk_textdec_begin, Tx));
+        if (Sd != s) MMVAE_TRY(edge(P, s, Sd));
+        MMVAE_TRY(range(P.pk_textdec_begin, nd, Sd));
+        MMVAE_TRY(range(0, P.pk_text_begin, s));
     }
-    MMVAE_TRY(coco_text_enc_fwd(P, io.text, do_backward, w.txtout, Tx, true));
+    MMVAE_TRY(coco_text_enc_fwd(P, io.text, do_backward, w.txtout, Tx, true, serial ? nullptr : &s));
     MMVAE_TRY(enc_fwd(P, io.image, 2, m1, m2, enc_drop, training, 2 - sk[0] - sk[1], w.encout, s));
     MMVAE_TRY(coco_text_dec_prepare(P, io.sos, s));      // (main stream: idle here until the caption encoder is through)
     MMVAE_TRY(edge(P, Tx, s));
@@ -463,6 +470,7 @@ static int coco_step_body(CocoPlan* Pp, const CocoStepIO& io, int training, int 
     MMVAE_TRY(launch_latent3_fwd(la, s));
     // ---- caption decoder (+ MSE, + its backward) on the side stream, image decoder on main
     MMVAE_TRY(edge(P, s, Tx));
+    if (packing && Sd != Tx) MMVAE_TRY(edge(P, Sd, Tx));
     float* sentence = io.recon_text ? io.recon_text : w.td_recon;
     {
         CocoMseFuse mf{};

@@ -80,8 +80,10 @@ int launch_coco_enc_bwd(const CocoEncBwdArgs& a, hipStream_t s);
 // dst[(t*B + b)*ld + e] = bf16(text[(b*T + t)*300 + e]); column 300 = 1.0
 int launch_coco_text_tb(const float* text, int B, int T, int ld, bf16* dst, hipStream_t s);
 int launch_coco_dec_fwd(const CocoDecFwdArgs& a, hipStream_t s);
-// comb: [3][208][224], combT: [208][608] (fragment-major bf16), sosv: [600]; wih0 / who: the fp32 parameters, row strides in0 / ino
-int launch_coco_comb(const float* wih0, int in0, const float* who, int ino, const float* sos, bf16* comb, bf16* combT, float* sosv, hipStream_t s);
+// comb: [3][208][224], combT: [208][608] (fragment-major bf16), sosv: [600], wz: [600][D] = W_ih0z + W_ih0x W_hoz, bz: [600] =
+// b_ih + W_ih0x b_ho; wih0 [600][300 + D] / who [300][200 + D] and their biases: the fp32 parameters
+int launch_coco_comb(const float* wih0, const float* bih0, const float* who, const float* bho, int D, const float* sos, bf16* comb, bf16* combT,
+                     float* sosv, float* wz, float* bz, hipStream_t s);
 int launch_coco_dec_bwd(const CocoDecBwdArgs& a, hipStream_t s);
 // out[r][c] (fp32, [R][cols]) = sum over t of in[(t*R + r)*ld + c]
 int launch_coco_time_sum_bf16(const bf16* in, int T, int R, int ld, int cols, float* out, hipStream_t s);
@@ -105,6 +107,7 @@ struct CocoPlan : PlanBase {
     const float* dec_wg_dw = nullptr;
     bool dw16_fresh = false, dec_wg_composed = false;             // bf16 copy of dw made by this step's MSE kernel; dOut left to the wgrads
     int tb_ih0xT_rm = -1;                                          // row-major pack of W_ih0[:, :300]^T ([300][600]) for the batched dOut GEMM
+    int pk_textdec_begin = 0;                                      // ... of the caption DECODER (the encoder's come first)
     int pk_text_begin = 0;                                         // first pack descriptor of the caption half (the table's tail)
     bool mse_fused = false;                                        // the last caption-decoder forward computed the MSE terms itself
     bool comb_fresh = false;                                       // W_comb / sosv made from the CURRENT parameters (reset by use_ws)
@@ -137,6 +140,7 @@ struct CocoPlan : PlanBase {
         float *te_giT, *te_hlast;
         bf16 *tb_comb, *tb_combT; float *td_sosv, *td_zi0p;
         bf16* tb_dw16; float* td_dzi1;
+        float *td_wz, *td_bz;
         char* cl_xchg; size_t cl_bytes; char* clb_xchg; size_t clb_bytes;
     } w;
 };
@@ -150,7 +154,8 @@ int coco_text_dec_wgrads(CocoPlan& P, hipStream_t sw);
 // composed decoder weights (W_comb, sosv) from the current parameters, once per step, on any stream the decoder's stream is
 // ordered behind; the decoder makes them itself (on its own stream) when nobody did
 int coco_text_dec_prepare(CocoPlan& P, const float* sos, hipStream_t s);
-int coco_text_enc_fwd(CocoPlan& P, const float* text, int save, float* out, hipStream_t s, bool bf16_path);
+// side (or null): a stream ordered behind the step's prologue on which the reverse direction's single step runs
+int coco_text_enc_fwd(CocoPlan& P, const float* text, int save, float* out, hipStream_t s, bool bf16_path, const hipStream_t* side = nullptr);
 // d_out: [B][2D] (the h2p bias gradient is added here); accumulates every caption-encoder gradient into P.buf.grads
 int coco_text_enc_bwd(CocoPlan& P, const float* text, const float* d_out, hipStream_t s, hipStream_t sw, bool bf16_path);
 // z: [rows][D] fp32, rows = groups*B; sentence: [rows][T][300]; keep: [T][rows][200] or null

@@ -330,6 +330,14 @@ void coco_text_build(CocoPlan& P) {
     auto fragd = [&](PackDesc d) { d.frag = 1; return P.pk.add(d); };
     auto fwdp = [&](long long w, int N, int K, int ld, int Npad, int Kpad) { return fragd(pack_dense(w, N, K, Npad, Kpad, ld, 1)); };
     auto trp = [&](long long w, int Nout, int Kin, int ld, int Npad, int Kpad) { return fragd(pack_dense(w, Nout, Kin, Npad, Kpad, 1, ld)); };
+    // the caption ENCODER's packs first: the step's critical chain starts with them (pack ranges: CocoPlan::pk_textdec_begin)
+    P.tb_e_hh = fwdp(P.te_f.whh, G, H, H, CTB_GP, CTB_HP);      // caption encoder, forward direction
+    P.tb_e_hhT = trp(P.te_f.whh, H, G, H, 208, CTB_GP);
+    // weight_ih of the encoder as the ROW operand of the transposed input projection gi^T[600][T*B] = W_ih x^T (row-major)
+    P.tb_e_ihA = P.pk.add(pack_dense(P.te_f.wih, G, E, round_up(G, 128), CTB_XP, E, 1));
+    for (int g3 = 0; g3 < 3; ++g3)                               // per-gate copies for the weight-resident forward kernel
+        P.tb_e_hhg[g3] = fwdp(P.te_f.whh + (long long)g3 * H * H, H, H, H, 208, CTB_HP);
+    P.pk_textdec_begin = (int)P.pk.d.size();
     P.tb_ih0 = fwdp(P.td0.wih, G, E, in0, CTB_GP, CTB_XP);      // columns 0..299 of weight_ih_l0 (the word vector part)
     P.tb_hh0 = fwdp(P.td0.whh, G, H, H, CTB_GP, CTB_HP);
     P.tb_ih1 = fwdp(P.td1.wih, G, H, H, CTB_GP, CTB_HP);
@@ -340,12 +348,6 @@ void coco_text_build(CocoPlan& P) {
     P.tb_hh1T = trp(P.td1.whh, H, G, H, 208, CTB_GP);
     P.tb_hh0T = trp(P.td0.whh, H, G, H, 208, CTB_GP);
     P.tb_ih0T = trp(P.td0.wih, E, G, in0, CTB_EP, CTB_GP);      // [e][g] = weight_ih_l0[g][e]
-    P.tb_e_hh = fwdp(P.te_f.whh, G, H, H, CTB_GP, CTB_HP);      // caption encoder, forward direction
-    P.tb_e_hhT = trp(P.te_f.whh, H, G, H, 208, CTB_GP);
-    // weight_ih of the encoder as the ROW operand of the transposed input projection gi^T[600][T*B] = W_ih x^T (row-major)
-    P.tb_e_ihA = P.pk.add(pack_dense(P.te_f.wih, G, E, round_up(G, 128), CTB_XP, E, 1));
-    for (int g3 = 0; g3 < 3; ++g3)                               // per-gate copies for the weight-resident forward kernel
-        P.tb_e_hhg[g3] = fwdp(P.te_f.whh + (long long)g3 * H * H, H, H, H, 208, CTB_HP);
     // per-gate copies of the decoder GRUs (cluster form): the three gates of a matrix back to back
     for (int g3 = 0; g3 < 3; ++g3) P.tb_g_ih0[g3] = fwdp(P.td0.wih + (long long)g3 * H * in0, H, E, in0, 208, CTB_XP);
     for (int g3 = 0; g3 < 3; ++g3) P.tb_g_hh0[g3] = fwdp(P.td0.whh + (long long)g3 * H * H, H, H, H, 208, CTB_HP);
@@ -400,6 +402,7 @@ void coco_text_carve(CocoPlan& P, Workspace& ws) {
         w.tb_comb = ws.take<bf16>(3 * 208 * CTB_HP); w.tb_combT = ws.take<bf16>(208 * CTB_GP);
         w.td_sosv = ws.take<float>(G); w.td_zi0p = ws.take<float>(R * G);
         w.tb_dw16 = ws.take<bf16>(R * T * CTB_XP); w.td_dzi1 = ws.take<float>(R * G);
+        w.td_wz = ws.take<float>((size_t)G * D); w.td_bz = ws.take<float>(G);
     }
 }
 
@@ -420,7 +423,8 @@ static bool coco_dec_composed(int Pc) {
 int coco_text_dec_prepare(CocoPlan& P, const float* sos, hipStream_t s) {
     if (!P.text_bf16 || P.comb_fresh) return MMVAE_OK;
     const float* p = P.buf.params;
-    MMVAE_TRY(launch_coco_comb(p + P.td0.wih, E + P.D, p + P.td_h2o_w, H + P.D, sos, P.w.tb_comb, P.w.tb_combT, P.w.td_sosv, s));
+    MMVAE_TRY(launch_coco_comb(p + P.td0.wih, p + P.td0.bih, p + P.td_h2o_w, p + P.td_h2o_b, P.D, sos, P.w.tb_comb, P.w.tb_combT, P.w.td_sosv,
+                               P.w.td_wz, P.w.td_bz, s));
     P.comb_fresh = true;
     return MMVAE_OK;
 }
@@ -432,11 +436,22 @@ static bool coco_enc_resident(const CocoPlan& P) {
 }
 
 // ================================================================== caption encoder (coco/model.py:236-245)
-int coco_text_enc_fwd(CocoPlan& P, const float* text, int save, float* out, hipStream_t s, bool bf16_path) {
+int coco_text_enc_fwd(CocoPlan& P, const float* text, int save, float* out, hipStream_t s, bool bf16_path, const hipStream_t* side) {
     CocoPlan::W& w = P.w;
     const int B = P.B, T = P.T, D2 = 2 * P.D;
     const float* p = P.buf.params;
     const bool res_path = bf16_path && P.text_bf16 && coco_enc_resident(P);
+    // reverse direction: its output at the last position is its FIRST step (input T-1, h = 0) -- three small launches that need
+    // nothing of the forward recurrence.  With a side stream (ordered behind the step's prologue) they leave the chain.
+    const hipStream_t sr = side ? *side : s;        // (a pointer: the default stream's handle is null)
+    auto reverse_dir = [&]() -> int {
+        MMVAE_TRY(lin(text + (size_t)(T - 1) * E, (long long)T * E, B, p + P.te_r.wih, G, E, E, 0, p + P.te_r.bih, nullptr, 0, w.te_gi_r, G, sr));
+        MMVAE_TRY(lin(w.zeros_h, H, B, p + P.te_r.whh, G, H, H, 0, p + P.te_r.bhh, nullptr, 0, w.te_gh, G, sr));
+        GruFwd a{};
+        a.gi = w.te_gi_r; a.ldgi = G; a.gh = w.te_gh; a.hprev = w.zeros_h; a.h = w.te_hb; a.sav = save ? w.te_sav_r : nullptr; a.rows = B;
+        return gru_fwd(a, sr);
+    };
+    if (sr != s) MMVAE_TRY(reverse_dir());
     if (res_path) {
         // input projection of every time step at once, TRANSPOSED: gi^T[600][T*B] = W_ih (rows) x captions^T, one bf16 GEMM with
         // the captions in the [t][row] bf16 layout the weight gradient needs anyway as its "weight" operand (b_ih is added in
@@ -474,13 +489,8 @@ int coco_text_enc_fwd(CocoPlan& P, const float* text, int save, float* out, hipS
         a.h = w.te_h + (size_t)t * B * H; a.sav = save ? w.te_sav + (size_t)t * B * 4 * H : nullptr; a.rows = B;
         MMVAE_TRY(gru_layer_fwd(a, s));
     }
-    {   // reverse direction: its output at the last position is its FIRST step (input T-1, h = 0)
-        MMVAE_TRY(lin(text + (size_t)(T - 1) * E, (long long)T * E, B, p + P.te_r.wih, G, E, E, 0, p + P.te_r.bih, nullptr, 0, w.te_gi_r, G, s));
-        MMVAE_TRY(lin(w.zeros_h, H, B, p + P.te_r.whh, G, H, H, 0, p + P.te_r.bhh, nullptr, 0, w.te_gh, G, s));
-        GruFwd a{};
-        a.gi = w.te_gi_r; a.ldgi = G; a.gh = w.te_gh; a.hprev = w.zeros_h; a.h = w.te_hb; a.sav = save ? w.te_sav_r : nullptr; a.rows = B;
-        MMVAE_TRY(gru_fwd(a, s));
-    }
+    if (sr == s) MMVAE_TRY(reverse_dir());
+    else MMVAE_TRY(edge(P, sr, s));
     const float* h_last = bf16_path && P.text_bf16 && coco_enc_resident(P) ? w.te_hlast : w.te_h + (size_t)(T - 1) * B * H;
     MMVAE_TRY(add2(h_last, w.te_hb, (long long)B * H, w.te_sum, s));
     return lin(w.te_sum, H, B, p + P.te_h2p_w, D2, H, H, 0, p + P.te_h2p_b, nullptr, 0, out, D2, s);
@@ -562,7 +572,8 @@ int coco_text_dec_fwd(CocoPlan& P, const float* z, int groups, const float* sos,
     MMVAE_TRY(lin(z, D, R, p + P.td0.wih, G, D, in0, E, p + P.td0.bih, nullptr, 0, w.td_zi0, G, s));
     MMVAE_TRY(lin(z, D, R, p + P.td_h2o_w, E, D, ino, H, p + P.td_h2o_b, nullptr, 0, w.td_zo, E, s));
     MMVAE_TRY(lin(z, D, R, p + P.td_z2h_w, H, D, D, 0, p + P.td_z2h_b, nullptr, 0, w.td_h0, H, s));
-    hipMemcpyAsync(w.td_h1, w.td_h0, RH * sizeof(float), hipMemcpyDeviceToDevice, s);
+    const bool composed = bf16_path && P.text_bf16 && coco_dec_composed(coco_dec_cluster(R));
+    if (!composed) hipMemcpyAsync(w.td_h1, w.td_h0, RH * sizeof(float), hipMemcpyDeviceToDevice, s);   // (the composed kernel writes slice 0 of h1 itself)
     const float scale = 1.f / (1.f - DROP_P);
     if (bf16_path && P.text_bf16) {      // the whole recurrence in ONE persistent launch (coco_text_bf16.hip)
         CocoDecFwdArgs a{};
@@ -588,8 +599,9 @@ int coco_text_dec_fwd(CocoPlan& P, const float* z, int groups, const float* sos,
                 MMVAE_TRY(launch_fill_zero(w.cl_xchg, w.cl_bytes, s));      // flags and the timeout word: zero before EVERY launch
                 if (coco_dec_composed(Pc)) {
                     MMVAE_TRY(coco_text_dec_prepare(P, sos, s));            // (no-op when the step made W_comb already)
-                    // zi0p = zi0 + zo W_ih0x^T: what the composed input projection adds to W_comb h1
-                    MMVAE_TRY(lin(w.td_zo, E, R, p + P.td0.wih, G, E, in0, 0, nullptr, w.td_zi0, G, w.td_zi0p, G, s));
+                    // zi0p = zi0 + zo W_ih0x^T, what the composed input projection adds to W_comb h1, straight from z through the
+                    // composed z-weights the preparation left: W_ih0z + W_ih0x W_hoz and b_ih + W_ih0x b_ho
+                    MMVAE_TRY(lin(z, D, R, w.td_wz, G, D, D, 0, w.td_bz, nullptr, 0, w.td_zi0p, G, s));
                     a.wg_comb = w.tb_comb; a.zi0p = w.td_zi0p; a.sosv = w.td_sosv;
                     if (mse && !getenv("MMVAE_COCO_NO_MSE_FUSE")) {         // (A/B aid, read per call)
                         a.mse_target = mse->target; a.mse_B = P.B; a.mse_loss = mse->loss_sum; a.mse_dw = mse->dw; a.mse_dw16 = mse->dw16;
@@ -673,6 +685,21 @@ static int coco_text_dec_bwd_bf16(CocoPlan& P, const float* z, int groups, const
     return MMVAE_OK;
 }
 
+// composed BPTT form: dOut[t] = dw[t] + dgi0[t+1] W_ih0x for every step at once -- one bf16 GEMM over the saved gate gradients
+// (slices 1 .. T-1, fp32 result in a buffer of the fp32 path) + a pass that adds the loss term and lays dOut out as the
+// operand of W_ho's weight gradient
+static int coco_text_dec_dout(CocoPlan& P, const float* dw, int R, hipStream_t sw) {
+    CocoPlan::W& w = P.w;
+    const int T = P.T, M = (T - 1) * R;
+    if (M > 0) {
+        GatherPlan pl = dense_plan(M, G, CTB_GP, E);
+        GemmParams q = gemm_of(P, pl, &P.tb_ih0xT_rm, 1, M);
+        q.c.A = w.tb_dgi0 + (size_t)R * CTB_GP; q.out_f = w.td_dgi0; q.ldo = E;
+        MMVAE_TRY(launch_gemm_gather(q, sw));
+    }
+    return launch_coco_dout_combine(dw, w.td_dgi0, T, R, w.tb_dout, sw);
+}
+
 // weight gradients of the bf16 caption decoder: dW[N][K] = P[T*R][N]^T G[T*R][K], bf16 operands saved in [t][row] layout.
 // The caller has ordered `sw` behind the decoder's BPTT launch and its time sums.
 int coco_text_dec_wgrads(CocoPlan& P, hipStream_t sw) {
@@ -690,18 +717,7 @@ int coco_text_dec_wgrads(CocoPlan& P, hipStream_t sw) {
         list[i] = q;
     };
     const size_t RHP = (size_t)R * CTB_HP;
-    if (P.dec_wg_composed) {
-        // dOut[t] = dw[t] + dgi0[t+1] W_ih0x for every step at once: one bf16 GEMM over the saved gate gradients (slices 1 .. T-1,
-        // fp32 result in a buffer of the fp32 path) + a pass that adds the loss term and lays dOut out as the wgrad operand
-        const int M = (T - 1) * R;
-        if (M > 0) {
-            GatherPlan pl = dense_plan(M, G, CTB_GP, E);
-            GemmParams q = gemm_of(P, pl, &P.tb_ih0xT_rm, 1, M);
-            q.c.A = w.tb_dgi0 + (size_t)R * CTB_GP; q.out_f = w.td_dgi0; q.ldo = E;
-            MMVAE_TRY(launch_gemm_gather(q, sw));
-        }
-        MMVAE_TRY(launch_coco_dout_combine(P.dec_wg_dw, w.td_dgi0, T, R, w.tb_dout, sw));
-    }
+    if (P.dec_wg_composed) MMVAE_TRY(coco_text_dec_dout(P, P.dec_wg_dw, R, sw));
     wg(0, P.tg_ih0, w.tb_dgi0, G, CTB_GP, w.tb_x, CTB_XP);
     wg(1, P.tg_hh0, w.tb_dgh0, G, CTB_GP, w.tb_h0, CTB_HP);                    // h0 BEFORE each step: slices 0 .. T-1
     wg(2, P.tg_ih1, w.tb_dgi1, G, CTB_GP, w.tb_mid, CTB_HP);

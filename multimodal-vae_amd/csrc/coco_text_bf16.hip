@@ -573,6 +573,7 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_c8_kernel(const CocoDecFwdA
         h0b[row * LDH + j] = (bf16)v; h1b[row * LDH + j] = (bf16)v;
         if (SAVE && rank == 0 && r0 + row < R) {
             a.h0b_all[(size_t)(r0 + row) * HP + j] = (bf16)v; a.h1b_all[(size_t)(r0 + row) * HP + j] = (bf16)v;
+            a.h1_all[(size_t)(r0 + row) * H + j] = v;       // (slice 0 of h0_all IS hinit; this form's caller leaves h1's to us)
         }
     }
     if (SAVE && rank == 0)
@@ -787,18 +788,23 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_c8_kernel(const CocoDecFwdA
 }
 
 // W_comb = W_ih0[:, :300] W_ho[:, :200] in fp32, written as the per-gate forward packs [3][208][224] and the transposed pack
-// [208][608] (fragment-major, pads zero), and sosv = W_ih0[:, :300] sos.  4 gate rows per workgroup, thread = hidden column.
-__global__ __launch_bounds__(256) void coco_comb_kernel(const float* __restrict__ wih0, int in0, const float* __restrict__ who, int ino,
-                                                        const float* __restrict__ sos, bf16* comb, bf16* combT, float* sosv) {
+// [208][608] (fragment-major, pads zero); sosv = W_ih0[:, :300] sos; and the z-side of the same composition, fp32:
+// wz = W_ih0[:, 300:] + W_ih0[:, :300] W_ho[:, 200:] ([600][D]), bz = b_ih0 + W_ih0[:, :300] b_ho.  4 gate rows per workgroup,
+// thread = column of [W_ho | its z part].
+constexpr int COMB_TPB = 320;
+__global__ __launch_bounds__(COMB_TPB) void coco_comb_kernel(const float* __restrict__ wih0, const float* __restrict__ bih0, const float* __restrict__ who,
+                                                             const float* __restrict__ bho, int D, const float* __restrict__ sos, bf16* comb, bf16* combT,
+                                                             float* sosv, float* wz, float* bz) {
     __shared__ float wr[4][E];
+    const int in0 = E + D, ino = H + D;
     const int c0 = blockIdx.x * 4, k = threadIdx.x;
-    for (int i = k; i < 4 * E; i += 256) {
+    for (int i = k; i < 4 * E; i += COMB_TPB) {
         const int r = i / E, e = i - r * E;
         wr[r][e] = c0 + r < G ? wih0[(size_t)(c0 + r) * in0 + e] : 0.f;
     }
     __syncthreads();
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    if (k < H) {
+    if (k < ino) {
 #pragma unroll 4
         for (int e = 0; e < E; ++e) {
             const float v = who[(size_t)e * ino + k];
@@ -813,22 +819,35 @@ __global__ __launch_bounds__(256) void coco_comb_kernel(const float* __restrict_
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int c = c0 + r;
+        if (k >= H) {                        // z side
+            if (c < G && k < ino) wz[(size_t)c * D + (k - H)] = wih0[(size_t)c * in0 + E + (k - H)] + acc[r];
+            continue;
+        }
         if (c < G) {
             const int g = c / H, n = c - g * H;
-            if (k < HP) comb[(size_t)g * 208 * HP + frag(n, k, HP)] = (bf16)(k < H ? acc[r] : 0.f);
+            comb[(size_t)g * 208 * HP + frag(n, k, HP)] = (bf16)acc[r];
         } else if (c < GP) {                 // rows 200..207 of the three gates: zero
             const int n = H + (c - G);
-            if (k < HP) for (int g = 0; g < 3; ++g) comb[(size_t)g * 208 * HP + frag(n, k, HP)] = (bf16)0.f;
+            for (int g = 0; g < 3; ++g) comb[(size_t)g * 208 * HP + frag(n, k, HP)] = (bf16)0.f;
         }
-        if (c < GP && k < 208) combT[frag(k, c, GP)] = (bf16)((c < G && k < H) ? acc[r] : 0.f);
+        if (c < GP) combT[frag(k, c, GP)] = (bf16)(c < G ? acc[r] : 0.f);
     }
-    const int w = k >> 6, lane = k & 63, c = c0 + w;
-    if (c < G) {
-        float t = 0.f;
-        for (int e = lane; e < E; e += 64) t += wr[w][e] * sos[e];
+    // pad columns / rows of the two packs (k = 200..223 of comb, unit rows 200..207 of combT): threads 0..23 / 0..7
+    if (k < HP - H)
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
-        if (lane == 0) sosv[c] = t;
+        for (int r = 0; r < 4; ++r) {
+            const int c = c0 + r;
+            if (c < G) { const int g = c / H, n = c - g * H; comb[(size_t)g * 208 * HP + frag(n, H + k, HP)] = (bf16)0.f; }
+            else if (c < GP) for (int g = 0; g < 3; ++g) comb[(size_t)g * 208 * HP + frag(H + (c - G), H + k, HP)] = (bf16)0.f;
+            if (k < 208 - H && c < GP) combT[frag(H + k, c, GP)] = (bf16)0.f;
+        }
+    const int w = k >> 6, lane = k & 63, c = c0 + w;
+    if (w < 4 && c < G) {
+        float t = 0.f, u = 0.f;
+        for (int e = lane; e < E; e += 64) { t += wr[w][e] * sos[e]; u += wr[w][e] * bho[e]; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { t += __shfl_xor(t, o); u += __shfl_xor(u, o); }
+        if (lane == 0) { sosv[c] = t; bz[c] = bih0[c] + u; }
     }
 }
 
@@ -2024,8 +2043,10 @@ int launch_coco_dw16(const float* dw, long long rows, bf16* dw16, hipStream_t s)
     return mmvae_check_launch("coco_dw16");
 }
 
-int launch_coco_comb(const float* wih0, int in0, const float* who, int ino, const float* sos, bf16* comb, bf16* combT, float* sosv, hipStream_t s) {
-    hipLaunchKernelGGL(coco_comb_kernel, dim3(GP / 4), dim3(256), 0, s, wih0, in0, who, ino, sos, comb, combT, sosv);
+int launch_coco_comb(const float* wih0, const float* bih0, const float* who, const float* bho, int D, const float* sos, bf16* comb, bf16* combT,
+                     float* sosv, float* wz, float* bz, hipStream_t s) {
+    MMVAE_REQUIRE(D >= 1 && H + D <= COMB_TPB, "coco_comb: n_latents = %d", D);
+    hipLaunchKernelGGL(coco_comb_kernel, dim3(GP / 4), dim3(COMB_TPB), 0, s, wih0, bih0, who, bho, D, sos, comb, combT, sosv, wz, bz);
     return mmvae_check_launch("coco_comb");
 }
 int launch_coco_dec_fwd(const CocoDecFwdArgs& a, hipStream_t s) {
