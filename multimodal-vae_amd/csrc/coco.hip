@@ -477,9 +477,9 @@ static int coco_step_body(CocoPlan* Pp, const CocoStepIO& io, int training, int 
         for (int k = 0; k < 3; ++k) mf.coef[k] = sk[k] ? 0.f : io.lambda_yx[k] / ((float)B * (float)T * (float)COCO_E);
         mf.target = io.text; mf.loss_sum = w.sums; mf.dw = do_backward ? w.td_dw : nullptr; mf.dw16 = P.text_bf16 ? w.tb_dw16 : nullptr;
         MMVAE_TRY(coco_text_dec_fwd(P, w.z_f32, 3, io.sos, gk, do_backward, sentence, Tx, true, &mf));
-        if (!P.mse_fused)
-            MMVAE_TRY(coco_mse3(sentence, io.text, 3, (long long)B * T * COCO_E, mf.coef, w.sums, mf.dw, Tx, mf.dw16));
-        P.dw16_fresh = do_backward && P.text_bf16;
+        if (!P.mse_fused)       // (no bf16 copy of the gradient here: only the composed BPTT kernel reads one, and converts it itself then)
+            MMVAE_TRY(coco_mse3(sentence, io.text, 3, (long long)B * T * COCO_E, mf.coef, w.sums, mf.dw, Tx));
+        P.dw16_fresh = do_backward && P.mse_fused;
     }
     if (do_backward) MMVAE_TRY(coco_text_dec_bwd(P, w.z_f32, 3, io.sos, gk, sentence, w.td_dw, w.dz_txt, Tx, serial ? Tx : P.st_wgrad2, true));
     ConvTLastFwdArgs last{};

@@ -105,7 +105,7 @@ struct CocoPlan : PlanBase {
     bool text_bf16 = true;
     const unsigned *cl_alarm_f = nullptr, *cl_alarm_b = nullptr;   // timeout words of this step's cluster launches (null: not used)
     const float* dec_wg_dw = nullptr;
-    bool dw16_fresh = false, dec_wg_composed = false;             // bf16 copy of dw made by this step's MSE kernel; dOut left to the wgrads
+    bool dw16_fresh = false, dec_wg_composed = false;             // bf16 copy of dw made by this step's decoder forward (fused MSE); dOut left to the wgrads
     int tb_ih0xT_rm = -1;                                          // row-major pack of W_ih0[:, :300]^T ([300][600]) for the batched dOut GEMM
     int pk_textdec_begin = 0;                                      // ... of the caption DECODER (the encoder's come first)
     int pk_text_begin = 0;                                         // first pack descriptor of the caption half (the table's tail)
@@ -169,6 +169,4 @@ int coco_text_dec_fwd(CocoPlan& P, const float* z, int groups, const float* sos,
 int coco_text_dec_bwd(CocoPlan& P, const float* z, int groups, const float* sos, const uint8_t* keep, const float* sentence, float* dw, float* dz, hipStream_t s, hipStream_t sw,
                       bool bf16_path = false);
 // recon [G*B][T][300] vs target [B][T][300]: loss_sum[slot][4+g] += sum sq err ; dw = coef[g] * 2 (recon - target) (or null)
-// dw16 (or null): bf16 copy of dw with rows of 320 (pad columns zero)
-int coco_mse3(const float* recon, const float* target, int G, long long per_group, const float* coef, float* loss_sum, float* dw, hipStream_t s,
-              bf16* dw16 = nullptr);
+int coco_mse3(const float* recon, const float* target, int G, long long per_group, const float* coef, float* loss_sum, float* dw, hipStream_t s);

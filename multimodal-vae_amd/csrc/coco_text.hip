@@ -250,10 +250,9 @@ int sum_mid(const float* in, long long outer, int T, long long inner, float* out
     return mmvae_check_launch("sum_mid");
 }
 
-// grid.y = group; recon rows of group g compare with the same target.  dw16 (or null): bf16 copy of dw with rows of 320
-// (the A operand of dw W_ho in the composed caption-decoder BPTT kernel), pad columns zero
+// grid.y = group; recon rows of group g compare with the same target
 __global__ __launch_bounds__(TPBT) void mse3_kernel(const float* recon, const float* target, long long per_group, float c0, float c1,
-                                                    float c2, float* loss_sum, float* dw, bf16* dw16) {
+                                                    float c2, float* loss_sum, float* dw) {
     const int g = blockIdx.y;
     const float coef = g == 0 ? c0 : (g == 1 ? c1 : c2);
     float acc = 0.f;
@@ -261,12 +260,6 @@ __global__ __launch_bounds__(TPBT) void mse3_kernel(const float* recon, const fl
         const float d = recon[g * per_group + i] - target[i];
         acc += d * d;
         if (dw) dw[g * per_group + i] = coef * 2.f * d;
-        if (dw16) {
-            const long long m = (g * per_group + i) / COCO_E;
-            const int e = (int)(g * per_group + i - m * COCO_E);
-            dw16[m * CTB_XP + e] = (bf16)(coef * 2.f * d);
-            if (e < CTB_XP - COCO_E) dw16[m * CTB_XP + COCO_E + e] = (bf16)0.f;
-        }
     }
     acc = wave_sum(acc);
     if (loss_sum && (threadIdx.x & 63) == 0) atomicAdd(loss_sum + (blockIdx.x % MMVAE_LOSS_SLOTS) * 16 + 4 + g, acc);
@@ -663,7 +656,7 @@ static int coco_text_dec_bwd_bf16(CocoPlan& P, const float* z, int groups, const
             MMVAE_TRY(launch_fill_zero(w.clb_xchg, w.clb_bytes, s));        // flags and the timeout word: zero before EVERY launch
             if (coco_dec_composed(Pc) && !getenv("MMVAE_COCO_NO_COMB_BWD")) {
                 MMVAE_TRY(coco_text_dec_prepare(P, sos, s));                // (no-op inside a step: the forward pass made W_comb)
-                if (!P.dw16_fresh) MMVAE_TRY(launch_coco_dw16(dw, (long long)R * T, w.tb_dw16, s));    // (the step's MSE kernel makes it)
+                if (!P.dw16_fresh) MMVAE_TRY(launch_coco_dw16(dw, (long long)R * T, w.tb_dw16, s));    // (normally made by the forward kernel with the fused MSE)
                 a.w_combT = w.tb_combT; a.dw16 = w.tb_dw16; a.dzi0 = w.td_dzi0; a.dzi1 = w.td_dzi1;
             }
         }
@@ -812,9 +805,9 @@ int coco_text_dec_bwd(CocoPlan& P, const float* z, int groups, const float* sos,
 }
 
 int coco_mse3(const float* recon, const float* target, int Gn, long long per_group, const float* coef, float* loss_sum, float* dw,
-              hipStream_t s, bf16* dw16) {
+              hipStream_t s) {
     MMVAE_REQUIRE(Gn >= 1 && Gn <= 3, "mse3: groups=%d", Gn);
     const unsigned nb = (unsigned)std::min<long long>((per_group + TPBT - 1) / TPBT, 4096);
-    hipLaunchKernelGGL(mse3_kernel, dim3(nb, Gn), dim3(TPBT), 0, s, recon, target, per_group, coef[0], coef[1], coef[2], loss_sum, dw, dw ? dw16 : nullptr);
+    hipLaunchKernelGGL(mse3_kernel, dim3(nb, Gn), dim3(TPBT), 0, s, recon, target, per_group, coef[0], coef[1], coef[2], loss_sum, dw);
     return mmvae_check_launch("mse3");
 }
