@@ -461,7 +461,7 @@ static int coco_step_body(CocoPlan* Pp, const CocoStepIO& io, int training, int 
     }
     MMVAE_TRY(coco_text_enc_fwd(P, io.text, do_backward, w.txtout, Tx, true, serial ? nullptr : &s));
     MMVAE_TRY(enc_fwd(P, io.image, 2, m1, m2, enc_drop, training, 2 - sk[0] - sk[1], w.encout, s));
-    MMVAE_TRY(coco_text_dec_prepare(P, io.sos, s));      // (main stream: idle here until the caption encoder is through)
+    if (coco_text_dec_composed(P, B3)) MMVAE_TRY(coco_text_dec_prepare(P, io.sos, s));     // (main stream: idle here until the caption encoder is through)
     MMVAE_TRY(edge(P, Tx, s));
     Latent3Args la{};
     la.B = B; la.D = D; la.img_out = w.encout; la.txt_out = w.txtout; la.eps = eps;

@@ -154,6 +154,7 @@ int coco_text_dec_wgrads(CocoPlan& P, hipStream_t sw);
 // composed decoder weights (W_comb, sosv) from the current parameters, once per step, on any stream the decoder's stream is
 // ordered behind; the decoder makes them itself (on its own stream) when nobody did
 int coco_text_dec_prepare(CocoPlan& P, const float* sos, hipStream_t s);
+bool coco_text_dec_composed(const CocoPlan& P, int R);      // will a decoder pass over R rows run the composed kernels?
 // side (or null): a stream ordered behind the step's prologue on which the reverse direction's single step runs
 int coco_text_enc_fwd(CocoPlan& P, const float* text, int save, float* out, hipStream_t s, bool bf16_path, const hipStream_t* side = nullptr);
 // d_out: [B][2D] (the h2p bias gradient is added here); accumulates every caption-encoder gradient into P.buf.grads

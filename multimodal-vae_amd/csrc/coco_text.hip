@@ -409,12 +409,13 @@ static int coco_dec_cluster(int R) {
 }
 
 // composed form of the cluster-of-8 decoder (two exchanges per step): MMVAE_COCO_NO_COMB=1 keeps the three-exchange kernels (A/B aid)
-static bool coco_dec_composed(int Pc) {
+static bool coco_dec_composed(const CocoPlan& P, int Pc) {
     const bool off = getenv("MMVAE_COCO_NO_COMB") != nullptr;   // (read per call)
-    return Pc == 8 && !off;
+    return Pc == 8 && !off && H + P.D <= 320;                   // (coco_comb_kernel: one thread per column of [W_ho | its z part])
 }
+bool coco_text_dec_composed(const CocoPlan& P, int R) { return P.text_bf16 && coco_dec_composed(P, coco_dec_cluster(R)); }
 int coco_text_dec_prepare(CocoPlan& P, const float* sos, hipStream_t s) {
-    if (!P.text_bf16 || P.comb_fresh) return MMVAE_OK;
+    if (!P.text_bf16 || P.comb_fresh || H + P.D > 320) return MMVAE_OK;
     const float* p = P.buf.params;
     MMVAE_TRY(launch_coco_comb(p + P.td0.wih, p + P.td0.bih, p + P.td_h2o_w, p + P.td_h2o_b, P.D, sos, P.w.tb_comb, P.w.tb_combT, P.w.td_sosv,
                                P.w.td_wz, P.w.td_bz, s));
@@ -565,7 +566,7 @@ int coco_text_dec_fwd(CocoPlan& P, const float* z, int groups, const float* sos,
     MMVAE_TRY(lin(z, D, R, p + P.td0.wih, G, D, in0, E, p + P.td0.bih, nullptr, 0, w.td_zi0, G, s));
     MMVAE_TRY(lin(z, D, R, p + P.td_h2o_w, E, D, ino, H, p + P.td_h2o_b, nullptr, 0, w.td_zo, E, s));
     MMVAE_TRY(lin(z, D, R, p + P.td_z2h_w, H, D, D, 0, p + P.td_z2h_b, nullptr, 0, w.td_h0, H, s));
-    const bool composed = bf16_path && P.text_bf16 && coco_dec_composed(coco_dec_cluster(R));
+    const bool composed = bf16_path && P.text_bf16 && coco_dec_composed(P, coco_dec_cluster(R));
     if (!composed) hipMemcpyAsync(w.td_h1, w.td_h0, RH * sizeof(float), hipMemcpyDeviceToDevice, s);   // (the composed kernel writes slice 0 of h1 itself)
     const float scale = 1.f / (1.f - DROP_P);
     if (bf16_path && P.text_bf16) {      // the whole recurrence in ONE persistent launch (coco_text_bf16.hip)
@@ -590,7 +591,7 @@ int coco_text_dec_fwd(CocoPlan& P, const float* z, int groups, const float* sos,
                 a.cl_timeout = reinterpret_cast<unsigned*>(w.cl_xchg + w.cl_bytes - 64);
                 P.cl_alarm_f = a.cl_timeout;
                 MMVAE_TRY(launch_fill_zero(w.cl_xchg, w.cl_bytes, s));      // flags and the timeout word: zero before EVERY launch
-                if (coco_dec_composed(Pc)) {
+                if (coco_dec_composed(P, Pc)) {
                     MMVAE_TRY(coco_text_dec_prepare(P, sos, s));            // (no-op when the step made W_comb already)
                     // zi0p = zi0 + zo W_ih0x^T, what the composed input projection adds to W_comb h1, straight from z through the
                     // composed z-weights the preparation left: W_ih0z + W_ih0x W_hoz and b_ih + W_ih0x b_ho
@@ -654,7 +655,7 @@ static int coco_text_dec_bwd_bf16(CocoPlan& P, const float* z, int groups, const
             a.cl_timeout = reinterpret_cast<unsigned*>(w.clb_xchg + w.clb_bytes - 64);
             P.cl_alarm_b = a.cl_timeout;
             MMVAE_TRY(launch_fill_zero(w.clb_xchg, w.clb_bytes, s));        // flags and the timeout word: zero before EVERY launch
-            if (coco_dec_composed(Pc) && !getenv("MMVAE_COCO_NO_COMB_BWD")) {
+            if (coco_dec_composed(P, Pc) && !getenv("MMVAE_COCO_NO_COMB_BWD")) {
                 MMVAE_TRY(coco_text_dec_prepare(P, sos, s));                // (no-op inside a step: the forward pass made W_comb)
                 if (!P.dw16_fresh) MMVAE_TRY(launch_coco_dw16(dw, (long long)R * T, w.tb_dw16, s));    // (normally made by the forward kernel with the fused MSE)
                 a.w_combT = w.tb_combT; a.dw16 = w.tb_dw16; a.dzi0 = w.td_dzi0; a.dzi1 = w.td_dzi1;
