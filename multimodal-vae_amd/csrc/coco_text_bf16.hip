@@ -681,14 +681,19 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_c8_kernel(const CocoDecFwdA
     __syncthreads();
     if (gact) rgemm(h0b, w_hh0, zero4, gb, LDC, wave);
     __syncthreads();
+    // Loads of the loop are requested right BEHIND a flag store and used a phase later: cl_signal drains the wave's memory
+    // queue (vmcnt is in order), so a load in flight across it delays the flag by its own latency, and a load used soon
+    // after a burst of saves waits for their acknowledgements.  The dropout keep flag of the own unit, read where it is used,
+    // sat with its L2 / HBM round trip in front of layer 0's gate math on every step (timed with s_memtime: 1,100-2,600 of a
+    // step's 12,000 clocks); now it is requested behind the flag of exchange B of the step before.
+    unsigned kp_next = 1;
+    if (KEEP && uok) kp_next = gok ? a.keep[gr * H + ju] : 0;
     for (int t = 0; t < T; ++t) {
         const unsigned ep = (unsigned)t + 1u;
         const bool last = t + 1 == T;
-        if (t > 0) get_target(t - 1);       // (for the output pass behind exchange A)
         // ---- layer 0
         {
-            unsigned kp = 1;
-            if (KEEP && uok) kp = gok ? a.keep[(size_t)t * RH + gr * H + ju] : 0;
+            const unsigned kp = kp_next;
             float sr = 0.f, sz = 0.f, sn = 0.f, sg = 0.f, sm = 0.f;
             if (uok) {
                 const float* pa = ga + grow * LDC; const float* pb = gb + grow * LDC;
@@ -702,6 +707,7 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_c8_kernel(const CocoDecFwdA
                 cl_store4(xA, (grow * H + ju) * 4, (bf16)h0f, (bf16)sm);       // (row, unit) = {h0, dropout(h0)}
             }
             cl_signal(xA, rank, ep, tid);
+            if (t > 0) get_target(t - 1);    // (for the output pass behind exchange A)
             if (SAVE && uok && gok) {        // (behind the flag: the exchange does not wait for these)
                 a.h0_all[(size_t)(t + 1) * RH + gr * H + ju] = h0f;
                 float* s = a.sav0 + ((size_t)t * R + gr) * 4 * H;
@@ -752,6 +758,7 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_c8_kernel(const CocoDecFwdA
                 __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, hb), xB.rs, (grow * H + ju) * 2, 0, 16);
             }
             cl_signal(xB, rank, ep, tid);
+            if (KEEP && uok && !last) kp_next = gok ? a.keep[(size_t)(t + 1) * RH + gr * H + ju] : 0;
             if (SAVE && uok && gok) {
                 a.h1_all[(size_t)(t + 1) * RH + gr * H + ju] = h1f;
                 float* s = a.sav1 + ((size_t)t * R + gr) * 4 * H;
