@@ -529,7 +529,7 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_cl_kernel(const CocoDecFwdA
 // window of exchange A of the NEXT step.  K of the composed product is 224 instead of 320, and with 8 ranks a wave owns ONE
 // tile of each of the five matrices: 5 x 7 k-steps x 4 VGPRs = 140 registers hold every weight the workgroup ever needs, so
 // nothing streams inside the loop.  Step: gates 0, publish A | hh1 h1 and ho h1 (step t-1's output) during A | ih1 mid |
-// gates 1, publish B | hh0 h0' during B | comb h1'.
+// gates 1, publish B | hh0 h0' and the output pass of step t-1 during B | comb h1'.
 template <bool KEEP, bool SAVE>
 __global__ __launch_bounds__(NTHR) void coco_dec_fwd_c8_kernel(const CocoDecFwdArgs a) {
     constexpr int P = 8, NUBMAX = 2, NOEMAX = 3, KS = HP / 32;
@@ -730,7 +730,6 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_c8_kernel(const CocoDecFwdA
             bf16x8 x[NPC];
 #pragma unroll
             for (int q = 0; q < NPC; ++q) { const int v = tid + q * NTHR; if (v < TR * H / 4) x[q] = cl_load16(xA, v * 16); }
-            if (t > 0) put_output(t - 1);
 #pragma unroll
             for (int q = 0; q < NPC; ++q) {
                 const int v = tid + q * NTHR;
@@ -766,8 +765,10 @@ __global__ __launch_bounds__(NTHR) void coco_dec_fwd_c8_kernel(const CocoDecFwdA
                 a.h1b_all[((size_t)(t + 1) * R + gr) * HP + ju] = (bf16)h1f;
             }
         }
-        // during exchange B: layer 0's hidden product of the NEXT step (reads the h0 of exchange A)
+        // during exchange B: layer 0's hidden product of the NEXT step (reads the h0 of exchange A), and the output pass of the
+        // step before (its projection ran during exchange A: barriers in between, and this window has the slack)
         if (!last && gact) rgemm(h0b, w_hh0, zero4, gb, LDC, wave);
+        if (t > 0) put_output(t - 1);
         cl_wait<P>(xB, ep, tmo, tid);
         if (tid < TR * H / 8) {     // 16 bytes = 8 units (400 pieces: one per thread)
             const bf16x8 x = cl_load16(xB, tid * 16);
