@@ -140,6 +140,8 @@ double mmvae_mm_layer_algo_flops(const mmvae_mm_t*, const char* layer);   /* alg
 double mmvae_mm_layer_algo_bytes(const mmvae_mm_t*, const char* layer);   /* algorithmic: each operand read once, the result written once (0: not a conv layer) */
 /* measurement aid: GEMM FLOPs enqueued by this process since the last reset (counted on the host by the launchers) */
 double mmvae_debug_flops(int reset);
+/* test / A-B aid: named integer switches read by the launchers ("convres" = 0 turns the image-resident conv kernels off) */
+int mmvae_debug_set(const char* key, int value);
 /* test aid: byte offset of a named intermediate inside the workspace (-1 if unknown) */
 long long mmvae_mm_debug_offset(mmvae_mm_t*, const char* name);
 

@@ -130,6 +130,7 @@ SIGNATURES = {
     "mmvae_mm_layer_algo_flops": (C.c_double, [_P, C.c_char_p]),
     "mmvae_mm_layer_algo_bytes": (C.c_double, [_P, C.c_char_p]),
     "mmvae_debug_flops": (C.c_double, [_I]),
+    "mmvae_debug_set": (_I, [C.c_char_p, _I]),
     "mmvae_mm_debug_offset": (_LL, [_P, C.c_char_p]),
     "mmvae_poe_fwd": (_I, [_P, _P, _I, _I, _P, _P, _P]),
     "mmvae_poe_bwd": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _P]),

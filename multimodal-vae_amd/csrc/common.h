@@ -25,6 +25,8 @@ void mmvae_count_flops(double flops);
 // side-stream priority policy (include/mmvae_hip.h: mmvae_set_stream_policy); -1 until somebody asked
 int mmvae_stream_policy();
 void mmvae_stream_policy_freeze();      // the side streams exist from here on
+// test / A-B knobs set through mmvae_debug_set (include/mmvae_hip.h); `dflt` when the key was never set
+int mmvae_knob(const char* key, int dflt);
 
 #define MMVAE_REQUIRE(cond, ...)                      \
     do {                                              \

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(TPB) void bn_act_kernel(const BnActArgs a) {
         float2 aff, mr;
         bn_channel_tables(f, i / a.C, i % a.C, aff, mr);
         aff_s[i] = aff;
-        if (blockIdx.x == 0) { f.affine[i] = aff; f.meanrstd[i] = mr; }
+        if (blockIdx.x == 0 && f.affine) { f.affine[i] = aff; f.meanrstd[i] = mr; }
     }
     if (blockIdx.x == 0) bn_running_update(f, threadIdx.x, TPB);
     __syncthreads();

@@ -5,6 +5,7 @@
 // row (n,oy,ox) and tap (ty,tx) is (n, oy*sy+offy+ty*dy, ox*sx+offx+tx*dx); K = TH*TW*C with c fastest.
 #pragma once
 #include "common.h"
+#include "elementwise.h"
 #include <vector>
 
 #define MMVAE_MAX_CLASSES 4
@@ -39,6 +40,23 @@ struct GatherCommon {
     int nclasses;
 };
 
+// Transform of the gathered tensor applied while it is staged (image-resident conv kernels only, convres.hip): the
+// elementwise kernel that used to materialise the operand leaves the chain.
+struct GatherTransform {
+    int kind;                   // 0 none
+                                // 1: the tensor is a RAW conv output; staged value = Swish(BatchNorm(x)), tables from `fin` (the launch
+                                //    also writes fin.affine / fin.meanrstd and updates the running statistics, like bn_act_kernel)
+                                // 2: the tensor is db (gradient w.r.t. a BatchNorm output); staged value = the BatchNorm-backward dr
+    BnFinalizeArgs fin;         // kind 1
+    const bf16* r;              // kind 2: raw tensor the BatchNorm normalised (geometry of the gathered tensor)
+    const float2* red;          //         [groups][SLOTS][C] (sum db, sum db*xhat)
+    const float2* mr;           //         [groups][C] (mean, rstd)
+    const float* gamma;
+    float* dgamma; float* dbeta;    //     += parameter gradients (may be null)
+    float inv_cnt;              //         1 / elements per channel per group
+    int groups;
+};
+
 struct GemmParams {
     GatherCommon c;
     GatherClass cls[MMVAE_MAX_CLASSES];
@@ -69,6 +87,7 @@ struct GemmParams {
     float2* d_red;             // [groups][MMVAE_STAT_SLOTS][N] += (sum v, sum v*xhat) or null
     float* d_colsum;           // [N] += sum v over all rows (bias gradient of the producer Linear) or null
     int npad;                  // rows of the packed weight matrices (gemm_small range-checks weight rows against it)
+    const GatherTransform* tr; // host-side only (read by the launcher): staging transform of the gathered tensor, or null
     int d_cmod;                // >0: the BatchNorm tables (d_affine/d_meanrstd/d_red) have d_cmod channels and output
                                // column n belongs to channel n % d_cmod (Linear over a flattened NHWC feature map)
 };

@@ -13,6 +13,7 @@
 //   split over row chunks with fp32 atomics into a packed gradient matrix.
 #include "gemm.h"
 #include "gemm_epi.h"
+#include "convres.h"
 #include <cstdlib>
 
 namespace {
@@ -826,6 +827,10 @@ int launch_gemm_gather(const GemmParams& p, hipStream_t stream) {
         MMVAE_REQUIRE(nimg_a * c.AH * c.AW * c.Ald * 2 < (1ll << 31), "gemm: gathered operand exceeds 2 GiB (32-bit buffer offsets)");
         for (int i = 0; i < c.nclasses; ++i)
             MMVAE_REQUIRE(p.cls[i].rows_per_group < (1 << 23), "gemm: more than 2^23 rows per group");
+    }
+    {   // conv layers with an image-resident kernel compiled for their geometry (convres.hip)
+        const int rc = try_launch_convres(p, stream);
+        if (rc != 0) return rc < 0 ? rc : MMVAE_OK;
     }
     {
         static const bool no_small = getenv("MMVAE_NO_SMALL") != nullptr;        // A/B aids

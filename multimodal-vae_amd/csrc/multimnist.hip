@@ -40,6 +40,7 @@ struct MMPlan : PlanBase {
         bf16 *patches4, *d3, *d2, *d1, *du;
         bf16 *d_encout; float* d_txtout; bf16* te_dout_bf; bf16 *te_dgi_f, *te_dgh_f, *te_dgi_r;
         bf16 *dy2, *dy1, *db4, *dr4, *d3e, *d2e, *d1e;
+        bf16 *d3r, *d2r, *d3er, *d2er;       // BatchNorm-backward outputs kept apart from db (fused staging: see dec_bwd / enc_bwd)
         float* tmp_f32;
         float* slab; size_t slab_floats;
     } w;
@@ -240,6 +241,8 @@ void carve(MMPlan& P, Workspace& ws) {
     w.dy2 = ws.take<bf16>(B2 * 200); w.dy1 = ws.take<bf16>(B2 * 400);
     w.db4 = ws.take<bf16>(B2 * 1024); w.dr4 = ws.take<bf16>(B * 1024);
     w.d3e = ws.take<bf16>(B * 36 * 128); w.d2e = ws.take<bf16>(B * 144 * 64); w.d1e = ws.take<bf16>(B * 625 * 32);
+    w.d3r = ws.take<bf16>(B3 * 625 * 32); w.d2r = ws.take<bf16>(B3 * 144 * 64);
+    w.d3er = ws.take<bf16>(B * 36 * 128); w.d2er = ws.take<bf16>(B * 144 * 64);
     w.tmp_f32 = ws.take<float>(B3 * NPIX);
     P.sk_floats = (size_t)256 * 128 * 128;                 // split-K partial slabs (fully overwritten, never zeroed)
     P.sk_buf = ws.take<float>(P.sk_floats);
@@ -252,8 +255,10 @@ void carve(MMPlan& P, Workspace& ws) {
 // convs once on B images; classifier on variants*B rows (different dropout masks): multimnist/model.py:183-188
 // Every layer output is kept twice: raw (r*, y*: backward needs the pre-activation) and activated (a*: the next
 // GEMM's operand, staged by pure copies).
+// `fuse`: the layers whose consumer is an image-resident kernel (convres.hip) hand it the RAW tensor and the BatchNorm
+// statistics (GatherTransform kind 1); the materialised activation is made later, off the main chain, for the weight gradient
 int enc_fwd(MMPlan& P, const float* image, int variants, const uint8_t* m1, const uint8_t* m2, int dropout, int training,
-            int bn_updates, float* out, hipStream_t s) {
+            int bn_updates, float* out, hipStream_t s, bool fuse = false) {
     MMPlan::W& w = P.w;
     const int B = P.B;
     MMVAE_TRY(launch_im2col_small(image, B, 1, IMG, IMG, 4, 4, 2, 1, 25, 25, w.patches1, 16, s));
@@ -271,8 +276,16 @@ int enc_fwd(MMPlan& P, const float* image, int variants, const uint8_t* m1, cons
         g.c.A = a[l - 1];
         g.out_bf = r[l]; g.ldo = L.g.Cout;
         g.colstats = training ? w.st_e[l - 1] : nullptr;
+        GatherTransform tr{};
+        if (fuse && l == 2) {          // conv3 stages Swish(BatchNorm(r2)) itself
+            const int prows = B * P.conv[1].g.OH * P.conv[1].g.OW;
+            tr.kind = 1;
+            tr.fin = bn_fin_args(P, P.bn[P.conv[1].bn], prows, 1, w.st_e[0], bn_updates, w.aff_e[0], w.mr_e[0], training);
+            g.c.A = r[1]; g.tr = &tr;
+        }
         MMVAE_TRY(launch_gemm_gather(g, s));
         const int rows = B * L.g.OH * L.g.OW;
+        if (fuse && l == 1) continue;  // a2 is made in front of conv3's weight gradient (enc_bwd)
         MMVAE_TRY(bn_act(P, P.bn[L.bn], r[l], a[l], rows, rows, 1, w.st_e[l - 1], bn_updates, w.aff_e[l - 1], w.mr_e[l - 1], training, s));
     }
     const int rows = variants * B;
@@ -314,7 +327,7 @@ int enc_fwd(MMPlan& P, const float* image, int variants, const uint8_t* m1, cons
 }
 
 // d_out: bf16 [variants*B][2D]; the bias gradient of classifier.6 must already be accumulated by the caller
-int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const uint8_t* m2, int dropout, hipStream_t s) {
+int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const uint8_t* m2, int dropout, hipStream_t s, bool fuse = false) {
     MMPlan::W& w = P.w;
     const int B = P.B, rows = variants * B, D2 = 2 * P.D;
     const float ms = 1.f / (1.f - DROP_P);
@@ -388,27 +401,45 @@ int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const
     bf16* r[4] = {w.r1, w.r2, w.r3, w.r4};
     bf16* a[4] = {w.a1, w.a2, w.a3, w.a4};
     bf16* dr[4] = {w.d1e, w.d2e, w.d3e, w.dr4};
+    bf16* drr[4] = {nullptr, w.d2er, w.d3er, nullptr};       // fused layers: BatchNorm-backward output apart from db
     for (int l = 3; l >= 1; --l) {
         const ConvL& L = P.conv[l];
         const BnL& b = P.bn[L.bn];
         const int pix = L.g.OH * L.g.OW;
+        // conv3 / conv2: the image-resident data-gradient kernel applies the BatchNorm backward to db while staging it
+        // (GatherTransform kind 2); the materialised dr is only the weight gradient's operand and is made in front of it,
+        // off the main chain, into a buffer of its own (db is still being read by the data gradient)
+        const bool fl = fuse && l < 3;
         BnBwdApplyArgs x{};
         x.db = (l == 3) ? w.db4 : dr[l];
         x.db2 = (l == 3 && variants == 2) ? w.db4 + (size_t)B * 1024 : nullptr;
-        x.r = r[l]; x.dr = dr[l]; x.rows = B * pix; x.C = L.g.Cout; x.ld = L.g.Cout; x.rows_per_group = B * pix; x.G = 1;
+        x.r = r[l]; x.dr = fl ? drr[l] : dr[l]; x.rows = B * pix; x.C = L.g.Cout; x.ld = L.g.Cout; x.rows_per_group = B * pix; x.G = 1;
         x.red = w.red_e[l - 1]; x.meanrstd = w.mr_e[l - 1]; x.gamma = P.buf.params + b.w_off;
         x.dgamma = P.buf.grads + b.w_off; x.dbeta = P.buf.grads + b.b_off;
-        MMVAE_TRY(launch_bn_bwd_apply(x, s));
+        if (!fl) MMVAE_TRY(launch_bn_bwd_apply(x, s));
         {   // wgrad: P = dr[l] (rows over the output grid), G = activated input gathered in forward form
             WgradParams g = wgrad_of(P, L.fwd, L.gk, 1, B);
-            g.c.A = a[l - 1]; g.P = dr[l]; g.ldp = L.g.Cout;
-            MMVAE_TRY(wgrad_async(P, g, s));
+            g.c.A = a[l - 1]; g.P = x.dr; g.ldp = L.g.Cout;
+            hipStream_t ws_;
+            MMVAE_TRY(wgrad_side_stream(P, s, &ws_));
+            if (fl) MMVAE_TRY(launch_bn_bwd_apply(x, ws_));
+            if (fuse && l == 2) {      // conv3's gathered operand a2 = Swish(BatchNorm(r2)) was never materialised
+                const int prows = B * P.conv[1].g.OH * P.conv[1].g.OW;
+                MMVAE_TRY(bn_act_side(P, P.bn[P.conv[1].bn], r[1], a[1], prows, prows, 1, w.st_e[0], 1, ws_));
+            }
+            MMVAE_TRY(wgrad_on(P, g, ws_));
         }
         {   // dgrad (class form) with the d-activation of the producer layer fused in the epilogue
             GemmParams d = gemm_of(P, L.dgrad, L.pk_dgrad, 1, B);
             d.c.A = dr[l]; d.out_bf = dr[l - 1]; d.ldo = L.g.Cin;
             d.d_r = r[l - 1]; d.d_ld = L.g.Cin; d.d_act = ACT_SWISH;
             if (l > 1) { d.d_affine = w.aff_e[l - 2]; d.d_meanrstd = w.mr_e[l - 2]; d.d_red = w.red_e[l - 2]; }
+            GatherTransform tr{};
+            if (fl) {
+                tr.kind = 2; tr.r = r[l]; tr.red = w.red_e[l - 1]; tr.mr = w.mr_e[l - 1]; tr.gamma = P.buf.params + b.w_off;
+                tr.inv_cnt = 1.f / (float)(B * pix); tr.groups = 1;
+                d.tr = &tr;
+            }
             MMVAE_TRY(launch_gemm_gather(d, s));
         }
     }
@@ -465,7 +496,8 @@ int fused_tail(MMPlan& P, int groups, int training, const ConvTLastFwdArgs* last
 // `fused_bwd_groups` >= 0: the fused tail (thin.h DecLastFusedArgs) replaces bn_act of the last BatchNorm + the thin last
 // layer, and for the first fused_bwd_groups groups also the last layer's data / weight gradients (step path only: the
 // granular modules get their upstream gradient from autograd and keep the separate kernels).
-int dec_fwd(MMPlan& P, int groups, int training, ConvTLastFwdArgs* last, hipStream_t s, int last_groups = -1, int fused_bwd_groups = -1) {
+int dec_fwd(MMPlan& P, int groups, int training, ConvTLastFwdArgs* last, hipStream_t s, int last_groups = -1, int fused_bwd_groups = -1,
+            bool fuse = false) {
     MMPlan::W& w = P.w;
     const int B = P.B, rows = groups * B;
     {
@@ -483,10 +515,19 @@ int dec_fwd(MMPlan& P, int groups, int training, ConvTLastFwdArgs* last, hipStre
             g.c.A = aq[l];
             g.out_bf = q[l + 1]; g.ldo = L.g.Cout;
             g.colstats = training ? w.st_d[l] : nullptr;
+            GatherTransform tr{};
+            if (fuse && l >= 1) {      // convT2 / convT3 stage Swish(BatchNorm(q[l])) themselves
+                const ConvL& Lp = P.convT[l - 1];
+                const int prpg = B * Lp.g.OH * Lp.g.OW;
+                tr.kind = 1;
+                tr.fin = bn_fin_args(P, P.bn[Lp.bn], prpg, groups, w.st_d[l - 1], 1, w.aff_d[l - 1], w.mr_d[l - 1], training);
+                g.c.A = q[l]; g.tr = &tr;
+            }
             MMVAE_TRY(launch_gemm_gather(g, s));
         }
         const int rpg = B * L.g.OH * L.g.OW;
         if (l == 2 && fused_bwd_groups >= 0) continue;
+        if (fuse && l <= 1) continue;  // aq[l+1] is made in front of the next layer's weight gradient (dec_bwd)
         MMVAE_TRY(bn_act(P, P.bn[L.bn], q[l + 1], aq[l + 1], groups * rpg, rpg, groups, w.st_d[l], 1, w.aff_d[l], w.mr_d[l], training, s));
     }
     if (fused_bwd_groups >= 0) return fused_tail(P, groups, training, last, last_groups, fused_bwd_groups, s);
@@ -496,12 +537,14 @@ int dec_fwd(MMPlan& P, int groups, int training, ConvTLastFwdArgs* last, hipStre
 }
 
 // dlogit: fp32 NCHW [groups*B][1][50][50] (grad wrt the pre-sigmoid logits). Writes dz (fp32 [groups*B][D]).
-int dec_bwd(MMPlan& P, const float* dlogit, int groups, float* dz, hipStream_t s, bool last_fused = false) {
+int dec_bwd(MMPlan& P, const float* dlogit, int groups, float* dz, hipStream_t s, bool last_fused = false, bool fuse = false,
+            int fwd_groups = 0, int training = 1) {
     MMPlan::W& w = P.w;
     const int B = P.B, rows = groups * B;
     bf16* q[4] = {w.u, w.q1, w.q2, w.q3};
     bf16* aq[4] = {w.au, w.aq1, w.aq2, w.aq3};
     bf16* dq[4] = {w.du, w.d1, w.d2, w.d3};
+    bf16* dqr[4] = {nullptr, nullptr, w.d2r, w.d3r};         // fused layers: BatchNorm-backward output apart from db
     if (last_fused) {
         // d3, the BatchNorm-backward sums and the weight-gradient partials of the last layer came out of the fused tail
         // (dec_fwd); only the sum of the partials is left, off the main chain
@@ -534,21 +577,39 @@ int dec_bwd(MMPlan& P, const float* dlogit, int groups, float* dz, hipStream_t s
         const ConvL& L = P.convT[l];
         const BnL& b = P.bn[L.bn];
         const int pix = L.g.OH * L.g.OW;
+        // convT3 / convT2: the image-resident data-gradient kernel applies the BatchNorm backward while it stages db
+        // (GatherTransform kind 2); dr and the activated layer input are only the weight gradient's operands and are made in
+        // front of it on the side stream (enc_bwd has the same arrangement)
+        const bool fl = fuse && l >= 1;
         BnBwdApplyArgs x{};
-        x.db = dq[l + 1]; x.r = q[l + 1]; x.dr = dq[l + 1]; x.rows = rows * pix; x.C = L.g.Cout; x.ld = L.g.Cout;
+        x.db = dq[l + 1]; x.r = q[l + 1]; x.dr = fl ? dqr[l + 1] : dq[l + 1]; x.rows = rows * pix; x.C = L.g.Cout; x.ld = L.g.Cout;
         x.rows_per_group = B * pix; x.G = groups;
         x.red = w.red_d[l]; x.meanrstd = w.mr_d[l]; x.gamma = P.buf.params + b.w_off;
         x.dgamma = P.buf.grads + b.w_off; x.dbeta = P.buf.grads + b.b_off;
-        MMVAE_TRY(launch_bn_bwd_apply(x, s));
+        if (!fl) MMVAE_TRY(launch_bn_bwd_apply(x, s));
         {
-            WgradParams g = convT_wgrad(P, L, groups, B, aq[l], dq[l + 1]);
-            MMVAE_TRY(wgrad_async(P, g, s));
+            WgradParams g = convT_wgrad(P, L, groups, B, aq[l], x.dr);
+            hipStream_t ws_;
+            MMVAE_TRY(wgrad_side_stream(P, s, &ws_));
+            if (fl) {
+                MMVAE_TRY(launch_bn_bwd_apply(x, ws_));
+                const ConvL& Lp = P.convT[l - 1];          // aq[l] = Swish(BatchNorm(q[l])) was never materialised
+                const int prpg = B * Lp.g.OH * Lp.g.OW;
+                MMVAE_TRY(bn_act_side(P, P.bn[Lp.bn], q[l], aq[l], groups * prpg, prpg, groups, w.st_d[l - 1], training, ws_));
+            }
+            MMVAE_TRY(wgrad_on(P, g, ws_));
         }
         {
             GemmParams d = gemm_of(P, L.dgrad, L.pk_dgrad, groups, B);
             d.c.A = dq[l + 1]; d.out_bf = dq[l]; d.ldo = L.g.Cin;
             d.d_r = q[l]; d.d_ld = L.g.Cin; d.d_act = ACT_SWISH;
             if (l > 0) { d.d_affine = w.aff_d[l - 1]; d.d_meanrstd = w.mr_d[l - 1]; d.d_red = w.red_d[l - 1]; }
+            GatherTransform tr{};
+            if (fl) {
+                tr.kind = 2; tr.r = q[l + 1]; tr.red = w.red_d[l]; tr.mr = w.mr_d[l]; tr.gamma = P.buf.params + b.w_off;
+                tr.inv_cnt = 1.f / (float)(B * pix); tr.groups = groups;
+                d.tr = &tr;
+            }
             MMVAE_TRY(launch_gemm_gather(d, s));
         }
     }
@@ -783,7 +844,8 @@ static int mm_step_body(MMPlan* Pp, const MMStepIO& io, int training, int do_bac
         TextEncArgs a = te_args(P, io.text, w.txtout, do_backward);
         MMVAE_TRY(launch_text_encoder_fwd(a, T));
     }
-    MMVAE_TRY(enc_fwd(P, io.image, 2, m1, m2, enc_drop, training, enc_updates, w.encout, s));
+    const bool fuse = mmvae_knob("mm_fuse_bn", 1) != 0 && mmvae_knob("convres", 1) != 0 && B % 4 == 0;
+    MMVAE_TRY(enc_fwd(P, io.image, 2, m1, m2, enc_drop, training, enc_updates, w.encout, s, fuse));
     MMVAE_TRY(edge(P, T, s));
     // ---- product of experts + reparametrisation + KL for the three passes
     Latent3Args la{};
@@ -817,7 +879,7 @@ static int mm_step_body(MMPlan* Pp, const MMStepIO& io, int training, int do_bac
     while (img_groups > 0 && (io.lambda_xy[img_groups - 1] == 0.f || sk[img_groups - 1])) --img_groups;
     static const bool no_fuse_tail = getenv("MMVAE_NO_FUSED_TAIL") != nullptr;        // A/B aid
     const bool fuse_tail = !no_fuse_tail && P.slab.pool != nullptr;
-    MMVAE_TRY(dec_fwd(P, 3, training, &last, s, last_groups, fuse_tail ? (do_backward ? std::min(img_groups, last_groups) : 0) : -1));
+    MMVAE_TRY(dec_fwd(P, 3, training, &last, s, last_groups, fuse_tail ? (do_backward ? std::min(img_groups, last_groups) : 0) : -1, fuse));
     if (!do_backward) {
         MMVAE_TRY(edge(P, T, s));
         hipLaunchKernelGGL(sum_slots_kernel, dim3(1), dim3(64), 0, s, w.sums, io.sums);
@@ -830,7 +892,7 @@ static int mm_step_body(MMPlan* Pp, const MMStepIO& io, int training, int do_bac
     static const bool defer = getenv("MMVAE_DEFER_WGRAD") != nullptr;
     P.deferred.clear();
     P.defer_wgrad = defer && !serial;
-    if (img_groups > 0) rc = dec_bwd(P, w.dlogit, img_groups, w.dz_img, s, fuse_tail);
+    if (img_groups > 0) rc = dec_bwd(P, w.dlogit, img_groups, w.dz_img, s, fuse_tail, fuse, 3, training);
     if (rc == MMVAE_OK) rc = edge(P, T, s);          // dz of the text decoder
     const bool dp_split = io.dp_split && !io.defer_unpack;
     if (dp_split && rc == MMVAE_OK) {
@@ -857,7 +919,7 @@ static int mm_step_body(MMPlan* Pp, const MMStepIO& io, int training, int do_bac
     if (rc == MMVAE_OK) rc = flush_wgrads(P, s);
     if (rc == MMVAE_OK) rc = edge(P, s, T);
     if (rc == MMVAE_OK) rc = txt_enc_bwd(P, io.text, w.d_txtout, T);
-    if (rc == MMVAE_OK) rc = enc_bwd(P, w.d_encout, 2, m1, m2, enc_drop, s);
+    if (rc == MMVAE_OK) rc = enc_bwd(P, w.d_encout, 2, m1, m2, enc_drop, s, fuse);
     P.wgrad_forked = false;
     MMVAE_TRY(rc);
     MMVAE_TRY(edge(P, T, s));
@@ -1210,6 +1272,10 @@ long long mm_debug_offset(MMPlan* P, const char* name) {
         {"aff_d0", w.aff_d[0]}, {"aff_d1", w.aff_d[1]}, {"aff_d2", w.aff_d[2]}, {"st_d0", w.st_d[0]}, {"patches4", w.patches4},
         {"tmp_f32", w.tmp_f32}, {"aff_e0", w.aff_e[0]}, {"aff_e1", w.aff_e[1]}, {"aff_e2", w.aff_e[2]},
         {"eps", w.eps}, {"m1", w.m1}, {"m2", w.m2}, {"gkeep", w.gkeep},
+        {"st_e0", w.st_e[0]}, {"st_e1", w.st_e[1]}, {"st_e2", w.st_e[2]}, {"st_d1", w.st_d[1]}, {"st_d2", w.st_d[2]},
+        {"red_e0", w.red_e[0]}, {"red_e1", w.red_e[1]}, {"red_e2", w.red_e[2]},
+        {"red_d0", w.red_d[0]}, {"red_d1", w.red_d[1]}, {"red_d2", w.red_d[2]},
+        {"a1", w.a1}, {"a2", w.a2}, {"a3", w.a3}, {"aq1", w.aq1}, {"aq2", w.aq2}, {"aq3", w.aq3},
     };
     auto it = m.find(name);
     if (it == m.end()) return -1;

@@ -95,6 +95,19 @@ inline int wgrad_async(PlanBase& P, const WgradParams& g, hipStream_t s) {
     return late ? MMVAE_OK : launch_wgrad_reduce(&P.slab, w, true);
 }
 
+// The side stream a weight gradient issued now would run on (after an edge from `s`), or `s` itself when the step is not forked:
+// lets the caller put the elementwise pass that prepares the gradient's operand in front of it, off the main chain.
+inline int wgrad_side_stream(PlanBase& P, hipStream_t s, hipStream_t* w) {
+    static const bool serial = getenv("MMVAE_SERIAL") != nullptr;
+    if (!P.wgrad_forked || serial) { *w = s; return MMVAE_OK; }
+    *w = (P.wgrad_rr++ & 1) ? P.st_wgrad2 : P.st_wgrad;
+    return edge(P, s, *w);
+}
+inline int wgrad_on(PlanBase& P, const WgradParams& g, hipStream_t w) {
+    MMVAE_TRY(launch_wgrad(g, w, &P.slab));
+    return launch_wgrad_reduce(&P.slab, w, true);
+}
+
 // issue the weight gradients collected while defer_wgrad was set (their operands are complete on `s` by now)
 inline int flush_wgrads(PlanBase& P, hipStream_t s) {
     P.defer_wgrad = false;
@@ -255,17 +268,33 @@ inline WgradParams convT_wgrad(const PlanBase& P, const ConvL& L, int groups, in
     return g;
 }
 
-inline int bn_act(PlanBase& P, const BnL& b, const bf16* r, bf16* a, int rows, int rows_per_group, int G, const float2* stats,
-           int updates, float2* aff, float2* mr, int training, hipStream_t s) {
-    BnActArgs x{};
-    x.r = r; x.a = a; x.rows = rows; x.C = b.C; x.ld = b.C; x.rows_per_group = rows_per_group; x.G = G; x.act = ACT_SWISH;
-    BnFinalizeArgs& f = x.fin;
+inline BnFinalizeArgs bn_fin_args(const PlanBase& P, const BnL& b, int rows_per_group, int G, const float2* stats, int updates,
+                                  float2* aff, float2* mr, int training) {
+    BnFinalizeArgs f{};
     f.stats = stats; f.G = G; f.C = b.C; f.count = (float)rows_per_group;
     f.gamma = P.buf.params + b.w_off; f.beta = P.buf.params + b.b_off;
     f.running_mean = P.buf.bn_stats + b.stat_off; f.running_var = P.buf.bn_stats + b.stat_off + b.C;
     f.num_batches_tracked = P.buf.bn_nbt + b.idx;
     f.updates_per_group = updates; f.affine = aff; f.meanrstd = mr; f.eps = BN_EPS; f.momentum = BN_MOM; f.training = training;
     f.skip_update_mask = G > 1 ? P.dec_skip_mask : 0u;
+    return f;
+}
+inline int bn_act(PlanBase& P, const BnL& b, const bf16* r, bf16* a, int rows, int rows_per_group, int G, const float2* stats,
+           int updates, float2* aff, float2* mr, int training, hipStream_t s) {
+    BnActArgs x{};
+    x.r = r; x.a = a; x.rows = rows; x.C = b.C; x.ld = b.C; x.rows_per_group = rows_per_group; x.G = G; x.act = ACT_SWISH;
+    x.fin = bn_fin_args(P, b, rows_per_group, G, stats, updates, aff, mr, training);
+    return launch_bn_act(x, s);
+}
+// The same normalise + activate pass for a layer whose CONSUMER staged the raw tensor itself (convres.hip, GatherTransform kind 1:
+// tables written, running statistics updated there): only the weight gradient still wants the materialised operand, so this
+// runs off the main chain, right in front of that weight gradient, and touches neither the tables nor the running buffers.
+inline int bn_act_side(PlanBase& P, const BnL& b, const bf16* r, bf16* a, int rows, int rows_per_group, int G, const float2* stats,
+                       int training, hipStream_t s) {
+    BnActArgs x{};
+    x.r = r; x.a = a; x.rows = rows; x.C = b.C; x.ld = b.C; x.rows_per_group = rows_per_group; x.G = G; x.act = ACT_SWISH;
+    x.fin = bn_fin_args(P, b, rows_per_group, G, stats, 0, nullptr, nullptr, training);
+    x.fin.running_mean = nullptr; x.fin.running_var = nullptr; x.fin.num_batches_tracked = nullptr;
     return launch_bn_act(x, s);
 }
 

@@ -1,0 +1,89 @@
+"""GPU check of the image-resident conv kernels (csrc/convres.hip) against the generic gather GEMM on the activations of a
+real B=256 step: same layer launched through mmvae_mm_bench_layer with the path off and on, outputs and column sums
+compared, both timed.  usage: python tools/convres_check.py [B]"""
+import os, sys, ctypes, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import multimodal_vae_amd
+from multimodal_vae_amd.core import MultimnistState, FusedELBOStep
+from multimodal_vae_amd.init import default_init_
+from multimodal_vae_amd._lib import call
+sys.path.insert(0, '.')
+from bench import synthetic_batch
+
+dev = torch.device('cuda:0')
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+st = MultimnistState(100, dev); default_init_(st, 1234)
+img, txt = synthetic_batch(B, 1234)
+eng = FusedELBOStep(st, B)
+call("mmvae_debug_set", b"convres", 0)
+eng(img.to(dev), txt.to(dev)); st.ensure_packed(); torch.cuda.synchronize()
+s = torch.cuda.current_stream(); sp = ctypes.c_void_p(s.cuda_stream)
+SLOTS = 16
+
+def view(name, nbytes, dtype):
+    off = call("mmvae_mm_debug_offset", eng.h, name.encode())
+    assert off >= 0, name
+    return eng.ws[off:off + nbytes].view(dtype)
+
+# layer -> (output buffer, images, pixels, channels, stats buffer, stat groups)
+G3 = 3
+layers = {
+    'enc_conv2': ('r2', B, 144, 64, 'st_e0', 1),
+    'enc_conv3': ('r3', B, 36, 128, 'st_e1', 1),
+    'dec_convT2': ('q2', 3 * B, 144, 64, 'st_d1', 3),
+    'dec_convT3': ('q3', 3 * B, 625, 32, 'st_d2', 3),
+    'enc_conv2_dgrad': ('d1e', B, 625, 32, None, 1),
+    'enc_conv3_dgrad': ('d2e', B, 144, 64, 'red_e0', 1),
+    'dec_convT2_dgrad': ('d1', 2 * B, 36, 128, 'red_d0', 2),
+    'dec_convT3_dgrad': ('d2', 2 * B, 144, 64, 'red_d1', 2),
+}
+sel = sys.argv[2:] or list(layers)
+
+def run(layer, on, iters):
+    call("mmvae_debug_set", b"convres", on)
+    call("mmvae_mm_bench_layer", eng.h, eng.ws.data_ptr(), eng.ws.numel(), layer.encode(), iters, sp)
+
+bad = 0
+for L in sel:
+    out_name, nimg, pix, ch, st_name, groups = layers[L]
+    out = view(out_name, nimg * pix * ch * 2, torch.bfloat16)
+    stats = view(st_name, G3 * SLOTS * ch * 8, torch.float32) if st_name else None
+    res = []
+    for on in (0, 1):
+        out.zero_()
+        if stats is not None: stats.zero_()
+        run(L, on, 1); torch.cuda.synchronize()
+        o = out.float().clone()
+        sres = stats.view(G3, SLOTS, ch, 2).sum(1).clone() if stats is not None else None
+        run(L, on, 3)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s); run(L, on, 20); e1.record(s); torch.cuda.synchronize()
+        res.append((o, sres, e0.elapsed_time(e1) * 1e3 / 20))
+    (o0, s0, t0), (o1, s1, t1) = res
+    fl = call("mmvae_mm_layer_flops", eng.h, L.encode())
+    den = o0.abs().max().item() + 1e-30
+    err = (o0 - o1).abs().max().item() / den
+    rel = ((o0 - o1).norm() / (o0.norm() + 1e-30)).item()
+    serr = 0.0
+    if s0 is not None:
+        serr = ((s0 - s1).abs().max() / (s0.abs().max() + 1e-30)).item()
+    ok = rel < 4e-3 and serr < 2e-3 and o1.abs().max().item() > 0
+    bad += 0 if ok else 1
+    print(f"{L:18s} old {t0:7.1f} us  new {t1:7.1f} us  ({fl / t1 / 1e6:6.1f} TFLOP/s)  out max-err {err:.2e} rel-l2 {rel:.2e}  "
+          f"stats err {serr:.2e}  {'ok' if ok else 'MISMATCH'}", flush=True)
+    if os.environ.get("CR_DBG"):
+        ts = []
+        for dbg in (1, 2, 4, 3, 7):
+            call("mmvae_debug_set", b"convres_dbg", dbg)
+            run(L, 1, 3)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s); run(L, 1, 20); e1.record(s); torch.cuda.synchronize()
+            ts.append(f"dbg{dbg}={e0.elapsed_time(e1) * 1e3 / 20:.1f}")
+        call("mmvae_debug_set", b"convres_dbg", 0)
+        print("      (1 no stores, 2 no MFMA loop, 4 no staging)  " + "  ".join(ts), flush=True)
+    if not ok:
+        d = (o0 - o1).abs().view(nimg, pix, ch)
+        print("   worst image/pixel/channel:", [int(x) for x in torch.nonzero(d == d.max())[0]],
+              " per-image max err of first 6:", [round(d[i].max().item() / den, 4) for i in range(min(6, nimg))])
+print("FAILED" if bad else "all layers agree")
+sys.exit(1 if bad else 0)
