@@ -64,6 +64,7 @@ struct ConvResArgs {
     float* t_dgamma; float* t_dbeta;    // += (may be null)
     float t_inv_cnt;            // 1 / elements per channel per group
     int t_groups;
+    unsigned long long* ts;     // measurement aid: per-wave s_memrealtime stamps (100 MHz) [wg][wave][16] or null
 };
 
 constexpr unsigned OOB_OFF = 0x40000000u;
@@ -82,6 +83,102 @@ __device__ __forceinline__ float dswish_fast(float x) {
     return s * (1.0f + x * (1.0f - s));
 }
 __device__ __forceinline__ float swish_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4c;
+
+// Epilogue of one 32x32 accumulator tile (lane = channel c = lane&31, register j = row (j&3) + 8*(j>>2) + 4*(lane>>5)).
+// The tile crosses a wave-private LDS scratch so that every global access is a 16-byte vector of 8 channels of one pixel
+// (2-byte accesses per lane cost one address per lane in the texture path: the first version, 16 short stores per tile,
+// spent as long storing as computing):
+//   * results leave as [channel][32 rows] (4 packed 8-byte writes per lane) and come back through ds_read_b64_tr_b16:
+//     lane (g = lane>>4, i = lane&15) gets channels 8g..8g+7 of rows i and 16+i -- its two 16-byte stores;
+//   * MODE 1: the saved tensor of the output geometry arrives the other way round: two 16-byte loads per lane in that same
+//     (row, channel octet) mapping, written as [row][32 channels], read back transposed into the accumulator layout.
+// `off0` / `off1`: byte offsets (row table + channel octet + image base) of this lane's two vectors; rows >= rows_valid
+// (PARTIAL tiles only) carry an out-of-range offset (dropped by the buffer range check) and are kept out of the sums.
+template <int MODE, bool PARTIAL>
+__device__ __forceinline__ void cr_epilogue_tile(const f32x16& acc, char* scr, int lane, int rows_valid, unsigned off0, unsigned off1,
+                                                 __amdgpu_buffer_rsrc_t orsrc, __amdgpu_buffer_rsrc_t rrsrc, float dsc, float dsh,
+                                                 float dmean, float drstd, float& s1, float& s2, bool store) {
+    constexpr int SP = 80;                                       // scratch row pitch: 32 x bf16 + 16
+    const int r = lane & 31, h = lane >> 5, g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = acc[j];
+    if constexpr (MODE == 1) {
+        const i32x4c r0 = __builtin_bit_cast(i32x4c, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, (int)off0, 0, 0));
+        const i32x4c r1 = __builtin_bit_cast(i32x4c, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, (int)off1, 0, 0));
+        *reinterpret_cast<i32x4c*>(scr + i * SP + g * 16) = r0;              // [row][channel]
+        *reinterpret_cast<i32x4c*>(scr + (16 + i) * SP + g * 16) = r1;
+        asm volatile("" ::: "memory");      // wave-private scratch: LDS order within a wave is issue order
+        // block of 4 rows x 16 channels per 16-lane group: lane 4q+p addresses row q, channels 4p..4p+3 and receives channel i
+        const char* rb = scr + (4 * h + q) * SP + (16 * ((lane >> 4) & 1) + 4 * p) * 2;
+        f32x2 t1 = {0.f, 0.f}, t2 = {0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            // (cast the WHOLE vector: __builtin_bit_cast on an element of an ext-vector returns element 0 for every index)
+            const bf16x4 rv = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4c*)(rb + 8 * k * SP)));
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                const f32x2 rr = {(float)rv[e], (float)rv[e + 1]};
+                const f32x2 x = rr * dsc + dsh;
+                f32x2 d = {dswish_fast(x[0]), dswish_fast(x[1])};
+                f32x2 o = {v[4 * k + e], v[4 * k + e + 1]};
+                o *= d;
+                if constexpr (PARTIAL) {
+                    const int row = 8 * k + 4 * h + e;
+                    o[0] = row < rows_valid ? o[0] : 0.f;
+                    o[1] = row + 1 < rows_valid ? o[1] : 0.f;
+                }
+                t1 += o;
+                t2 += o * ((rr - dmean) * drstd);
+                v[4 * k + e] = o[0]; v[4 * k + e + 1] = o[1];
+            }
+        }
+        s1 += t1[0] + t1[1];
+        s2 += t2[0] + t2[1];
+        asm volatile("" ::: "memory");
+    } else {
+        f32x2 t1 = {0.f, 0.f}, t2 = {0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) {
+            f32x2 o = {v[j], v[j + 1]};
+            if constexpr (PARTIAL) {
+                const int row = (j & 3) + 8 * (j >> 2) + 4 * h;
+                o[0] = row < rows_valid ? o[0] : 0.f;
+                o[1] = row + 1 < rows_valid ? o[1] : 0.f;
+                v[j] = o[0]; v[j + 1] = o[1];
+            }
+            t1 += o;
+            t2 += o * o;
+        }
+        s1 += t1[0] + t1[1];
+        s2 += t2[0] + t2[1];
+    }
+    // results -> [channel][32 rows] bf16: this lane's 4 runs of 4 rows
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (bf16)v[4 * k + e];
+        *reinterpret_cast<bf16x4*>(scr + r * SP + (8 * k + 4 * h) * 2) = o;
+    }
+    asm volatile("" ::: "memory");
+    if (store) {
+        // block of 4 channels x 16 rows: lane 4q+p addresses channel c0+q, rows 4p..4p+3 (+16 for the second vector) and
+        // receives row i
+        const char* ob = scr + (8 * g + q) * SP + (4 * p) * 2;
+        union { struct { s16x4 a, b; } s; i32x4c v; } u0, u1;
+        u0.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4c*)(ob));
+        u0.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4c*)(ob + 4 * SP));
+        u1.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4c*)(ob + 32));
+        u1.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4c*)(ob + 4 * SP + 32));
+        __builtin_amdgcn_raw_buffer_store_b128(u0.v, orsrc, (int)off0, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u1.v, orsrc, (int)off1, 0, 0);
+    }
+    asm volatile("" ::: "memory");
+}
 
 template <class G, int NI, int CH, int WAVES, int NG, bool SCR_OWN>
 struct CrLayout {
@@ -117,6 +214,10 @@ __global__ __launch_bounds__(WAVES * 64) void convres_kernel(const ConvResArgs a
     const int ng = wave % NG, mg = wave / NG;
     const int img0 = blockIdx.x * NI;
     const int grp = img0 / a.group_n;
+    auto stamp = [&](int idx) {
+        if (a.ts && lane == 0) a.ts[((size_t)blockIdx.x * WAVES + wave) * 16 + idx] = __builtin_amdgcn_s_memrealtime();
+    };
+    stamp(0);
 
     // ---- weight chunks: global -> registers (issued a phase ahead of their use) -> LDS
     constexpr int WV = crgeo::cdiv(G::N * CH * 2, NTHR);        // 16-byte vectors per thread of a full chunk
@@ -252,7 +353,9 @@ __global__ __launch_bounds__(WAVES * 64) void convres_kernel(const ConvResArgs a
             }
         }
     }
+    stamp(1);
     __syncthreads();
+    stamp(2);
     if constexpr (TR != 0) {
         const int cv0 = (tid % VPP) * 8;
 #pragma unroll
@@ -267,7 +370,9 @@ __global__ __launch_bounds__(WAVES * 64) void convres_kernel(const ConvResArgs a
         for (int b = 1; b < NB; ++b) { i_fetch(b); i_store(b); }
     }
     w_store(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    stamp(3);
     __syncthreads();
+    stamp(4);
 
     // ---- epilogue constants of this lane's channels
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -284,8 +389,6 @@ __global__ __launch_bounds__(WAVES * 64) void convres_kernel(const ConvResArgs a
         if (MODE == 1 && a.d_meanrstd) { const float2 t = a.d_meanrstd[grp * G::N + co]; dmean[nt] = t.x; drstd[nt] = t.y; }
     }
     char* const scr = (SCR_OWN ? smem + L::OFF_SCR : w_s) + wave * L::SCR_BYTES;
-    const int sc_w = r * 2 + 4 * h * SCR_PITCH;                 // this lane's element of row (j&3) + 8*(j>>2)
-    const int vrow = lane >> 2, vcq = lane & 3;                  // 16-byte vector `lane` / `lane + 64` of a tile
 
     // ---- classes.  At the top of a chunk its weights are in LDS and a barrier has been passed.
     static_for<0, G::NCLS>([&](auto ci) {
@@ -353,59 +456,30 @@ __global__ __launch_bounds__(WAVES * 64) void convres_kernel(const ConvResArgs a
                 });
             }
             if constexpr (last_chunk) {
-                // ---- epilogue: lane = channel, register j = row (j&3) + 8*(j>>2) + 4*h of the tile.  The tile crosses a
-                //      per-wave LDS scratch ([32 rows][64 B + 16]) so that every global access is a 16-byte vector of 8
-                //      channels of one pixel (2-byte accesses cost one address per lane in the texture path: the first
-                //      version, 16 short stores per tile, spent as long storing as computing)
+                stamp(5 + 2 * c);
+                // ---- epilogue (cr_epilogue_tile): accumulator layout lane = channel, register j = row (j&3) + 8*(j>>2) + 4*h
                 if constexpr (!SCR_OWN) __syncthreads();            // the scratch is the weight buffer: everybody is done reading it
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     const int t = mg + m * MG;
                     if (t < T) {
                         const unsigned* trow = tab + tab_base<G, NI>(c) + t * 32;
-                        const unsigned off0 = trow[vrow], off1 = trow[vrow + 16];
-                        const int rlim = ROWS - t * 32 - 4 * h;              // rows (j&3) + 8*(j>>2) below it exist
+                        const unsigned off0 = trow[lane & 15], off1 = trow[16 + (lane & 15)];
+                        const int rows_left = ROWS - t * 32;                  // < 32: the class's last, partial tile
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) {
-                            const unsigned cob = (unsigned)(((ng * NT + nt) * 32 + vcq * 8) * 2) + wg_out;
-                            if constexpr (MODE == 1) {
-                                const i32x4c r0 = __builtin_bit_cast(i32x4c, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, (int)(off0 + cob), 0, 0));
-                                const i32x4c r1 = __builtin_bit_cast(i32x4c, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, (int)(off1 + cob), 0, 0));
-                                *reinterpret_cast<i32x4c*>(scr + vrow * SCR_PITCH + vcq * 16) = r0;
-                                *reinterpret_cast<i32x4c*>(scr + (vrow + 16) * SCR_PITCH + vcq * 16) = r1;
-                            }
-                            asm volatile("" ::: "memory");      // the scratch is wave-private: LDS order within a wave is issue order
-#pragma unroll
-                            for (int j = 0; j < 16; ++j) {
-                                const int row = (j & 3) + 8 * (j >> 2);
-                                const bool valid = row < rlim;
-                                float v = acc[m][nt][j];
-                                bf16* cell = reinterpret_cast<bf16*>(scr + sc_w + row * SCR_PITCH);
-                                if constexpr (MODE == 1) {
-                                    const float rr = (float)*cell;
-                                    v *= dswish_fast(rr * dsc[nt] + dsh[nt]);
-                                    v = valid ? v : 0.f;
-                                    s1[nt] += v;
-                                    s2[nt] += v * (rr - dmean[nt]) * drstd[nt];
-                                } else {
-                                    v = valid ? v : 0.f;
-                                    s1[nt] += v;
-                                    s2[nt] += v * v;
-                                }
-                                *cell = (bf16)v;
-                            }
-                            asm volatile("" ::: "memory");
-                            if (!(a.dbg & 1)) {
-                                const i32x4c o0 = *reinterpret_cast<const i32x4c*>(scr + vrow * SCR_PITCH + vcq * 16);
-                                const i32x4c o1 = *reinterpret_cast<const i32x4c*>(scr + (vrow + 16) * SCR_PITCH + vcq * 16);
-                                __builtin_amdgcn_raw_buffer_store_b128(o0, orsrc, (int)(off0 + cob), 0, 0);
-                                __builtin_amdgcn_raw_buffer_store_b128(o1, orsrc, (int)(off1 + cob), 0, 0);
-                            }
-                            asm volatile("" ::: "memory");
+                            const unsigned cob = (unsigned)(((ng * NT + nt) * 32 + (lane >> 4) * 8) * 2) + wg_out;
+                            if (rows_left >= 32)
+                                cr_epilogue_tile<MODE, false>(acc[m][nt], scr, lane, 32, off0 + cob, off1 + cob, orsrc, rrsrc,
+                                                              dsc[nt], dsh[nt], dmean[nt], drstd[nt], s1[nt], s2[nt], !(a.dbg & 1));
+                            else
+                                cr_epilogue_tile<MODE, true>(acc[m][nt], scr, lane, rows_left, off0 + cob, off1 + cob, orsrc, rrsrc,
+                                                             dsc[nt], dsh[nt], dmean[nt], drstd[nt], s1[nt], s2[nt], !(a.dbg & 1));
                         }
                     }
                 }
             }
+            if constexpr (last_chunk) stamp(6 + 2 * c);
             if constexpr (has_next) {
                 __syncthreads();                                        // every wave is done with this chunk (and the scratch)
                 w_store(std::integral_constant<int, cn>{}, std::integral_constant<int, chn>{});
@@ -414,6 +488,7 @@ __global__ __launch_bounds__(WAVES * 64) void convres_kernel(const ConvResArgs a
         });
     });
 
+    stamp(13);
     // ---- column sums: one atomic pair per channel per wave
     float2* red = MODE == 1 ? a.d_red : a.colstats;
     if (red) {
@@ -428,6 +503,7 @@ __global__ __launch_bounds__(WAVES * 64) void convres_kernel(const ConvResArgs a
             }
         }
     }
+    stamp(14);
 }
 
 }  // namespace
@@ -476,6 +552,8 @@ int launch_cr(const GemmParams& p, hipStream_t stream) {
     for (int i = 0; i < G::NCLS; ++i) { a.Wp[i] = p.cls[i].Wp; a.Kpad[i] = p.cls[i].Kpad; }
     a.out = p.out_bf; a.ldo = p.ldo; a.colstats = p.colstats;
     a.dbg = mmvae_knob("convres_dbg", 0);
+    a.ts = reinterpret_cast<unsigned long long*>(((unsigned long long)(unsigned)mmvae_knob("convres_ts_hi", 0) << 32) |
+                                                 (unsigned)mmvae_knob("convres_ts_lo", 0));
     a.d_r = p.d_r; a.d_affine = p.d_affine; a.d_meanrstd = p.d_meanrstd; a.d_red = p.d_red;
     const int kind = p.tr ? p.tr->kind : 0;
     if (kind == 1) {
@@ -533,12 +611,16 @@ int try_launch_convres(const GemmParams& p, hipStream_t stream) {
         return 0;
     }
     int rc;
+    const int nimg = p.c.groups * p.c.group_n;
+    const int alt = mmvae_knob("convres_alt", 0);       // measurement aid: alternative tile configurations
     //                          NI  CH  WAVES NG SCR_OWN
     if ((rc = try_cr<G_mm_conv2, 1, 16, 8, 2, true>(p, stream)) != 0) return rc;
     if ((rc = try_cr<G_mm_conv3, 2, 8, 8, 4, true>(p, stream)) != 0) return rc;
+    if (nimg <= 256) { if ((rc = try_cr<G_mm_convT2, 2, 8, 4, 1, true>(p, stream)) != 0) return rc; }
     if ((rc = try_cr<G_mm_convT2, 4, 16, 8, 2, true>(p, stream)) != 0) return rc;
+    if (alt == 1) { if ((rc = try_cr<G_mm_convT3, 4, 20, 8, 1, false>(p, stream)) != 0) return rc; }
     if ((rc = try_cr<G_mm_convT3, 2, 16, 4, 1, false>(p, stream)) != 0) return rc;
-    if ((rc = try_cr<G_mm_conv2d, 1, 16, 4, 1, true>(p, stream)) != 0) return rc;
+    if ((rc = try_cr<G_mm_conv2d, 1, 16, 8, 1, true>(p, stream)) != 0) return rc;
     if ((rc = try_cr<G_mm_convT3d, 2, 10, 8, 2, false>(p, stream)) != 0) return rc;
     MMVAE_REQUIRE(!forced, "convres: no kernel is compiled for the geometry of a launch with a staging transform");
     return 0;

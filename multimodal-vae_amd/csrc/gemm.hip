@@ -884,6 +884,7 @@ static int wgrad_validate(const WgradParams& p) {
 }
 
 int launch_wgrad(const WgradParams& pin, hipStream_t stream, WgradSlabCtx* ctx) {
+    if (mmvae_knob("dbg_skip_wgrad", 0)) return MMVAE_OK;       // measurement aid: the step without its weight gradients
     MMVAE_TRY(wgrad_validate(pin));
     WgradParams p = pin;
     dim3 grid; size_t lds;
@@ -898,6 +899,7 @@ int launch_wgrad(const WgradParams& pin, hipStream_t stream, WgradSlabCtx* ctx) 
 // Several problems of the 128 x 128 tile class in one launch; anything that does not fit the grouped kernel (another tile
 // shape, more than WGRAD_MULTI_MAX problems) is launched on its own.
 int launch_wgrad_group(const WgradParams* list, int n, hipStream_t stream, WgradSlabCtx* ctx) {
+    if (mmvae_knob("dbg_skip_wgrad", 0)) return MMVAE_OK;
     static const bool no_group = getenv("MMVAE_NO_WGRAD_GROUP") != nullptr;
     int i = 0;
     while (i < n) {

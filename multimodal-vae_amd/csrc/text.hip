@@ -548,6 +548,7 @@ void set_lds_attr(K kernel) {
 }  // namespace
 
 int launch_text_encoder_fwd(const TextEncArgs& a, hipStream_t s) {
+    if (mmvae_knob("dbg_skip_text", 0)) return MMVAE_OK;          // measurement aid: the step without its text kernels
     MMVAE_REQUIRE(a.B >= 1 && 2 * a.D <= 256 && a.nh2p % 16 == 0, "text encoder: B=%d D=%d", a.B, a.D);
     size_t lds = (size_t)(2 * TR * GL + 2 * TR * H + 2400) * 4 + (size_t)3 * TR * (HP + 8) * 2;
     static std::atomic<unsigned> once{0};
@@ -556,6 +557,7 @@ int launch_text_encoder_fwd(const TextEncArgs& a, hipStream_t s) {
     return mmvae_check_launch("text_encoder_fwd");
 }
 int launch_text_encoder_bwd(const TextEncBwdArgs& a, hipStream_t s) {
+    if (mmvae_knob("dbg_skip_text", 0)) return MMVAE_OK;          // measurement aid: the step without its text kernels
     const int K2 = round_up(2 * a.f.D, 32);
     size_t lds = (size_t)(TR * HP + 2 * TR * H + TXT_V * H) * 4 + (size_t)(2 * TR * (GK + 8) + TR * (K2 + 8)) * 2;
     static std::atomic<unsigned> once{0};
@@ -564,6 +566,7 @@ int launch_text_encoder_bwd(const TextEncBwdArgs& a, hipStream_t s) {
     return mmvae_check_launch("text_encoder_bwd");
 }
 int launch_text_decoder_fwd(const TextDecArgs& a, hipStream_t s) {
+    if (mmvae_knob("dbg_skip_text", 0)) return MMVAE_OK;          // measurement aid: the step without its text kernels
     MMVAE_REQUIRE(a.R >= 1 && a.D >= 1 && a.D <= 128 && a.kx == round_up(H + a.D, 32) && a.kz == round_up(a.D, 32) && a.kx <= 256,
                   "text decoder: R=%d D=%d kx=%d kz=%d", a.R, a.D, a.kx, a.kz);
     static std::atomic<unsigned> once{0};
@@ -572,6 +575,7 @@ int launch_text_decoder_fwd(const TextDecArgs& a, hipStream_t s) {
     return mmvae_check_launch("text_decoder_fwd");
 }
 int launch_text_decoder_bwd(const TextDecBwdArgs& a, hipStream_t s) {
+    if (mmvae_knob("dbg_skip_text", 0)) return MMVAE_OK;          // measurement aid: the step without its text kernels
     MMVAE_REQUIRE(a.f.tokens_out != nullptr || a.f.force_tokens != nullptr, "text decoder bwd needs the token path");
     size_t lds = (size_t)(TR * 256 + 3 * TR * H + TR * 128 + TXT_V * H) * 4 + (size_t)(2 * TR * (GK + 8) + TR * 40 + TR * 136) * 2;
     static std::atomic<unsigned> once{0};

@@ -71,6 +71,41 @@ for L in sel:
     bad += 0 if ok else 1
     print(f"{L:18s} old {t0:7.1f} us  new {t1:7.1f} us  ({fl / t1 / 1e6:6.1f} TFLOP/s)  out max-err {err:.2e} rel-l2 {rel:.2e}  "
           f"stats err {serr:.2e}  {'ok' if ok else 'MISMATCH'}", flush=True)
+    if os.environ.get("CR_ALT"):
+        ts = []
+        for alt in (1, 2):
+            call("mmvae_debug_set", b"convres_alt", alt)
+            out.zero_()
+            run(L, 1, 3); torch.cuda.synchronize()
+            rel2 = ((o0 - out.float()).norm() / (o0.norm() + 1e-30)).item()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s); run(L, 1, 20); e1.record(s); torch.cuda.synchronize()
+            ts.append(f"alt{alt}={e0.elapsed_time(e1) * 1e3 / 20:.1f} (rel {rel2:.1e})")
+        call("mmvae_debug_set", b"convres_alt", 0)
+        print("      " + "  ".join(ts), flush=True)
+    if os.environ.get("CR_TS"):
+        tsb = torch.zeros(4096 * 8 * 16, dtype=torch.int64, device=dev)
+        call("mmvae_debug_set", b"convres_ts_lo", ctypes.c_int(tsb.data_ptr() & 0xffffffff).value)
+        call("mmvae_debug_set", b"convres_ts_hi", ctypes.c_int(tsb.data_ptr() >> 32).value)
+        run(L, 1, 1); torch.cuda.synchronize()
+        call("mmvae_debug_set", b"convres_ts_lo", 0); call("mmvae_debug_set", b"convres_ts_hi", 0)
+        t = tsb.view(-1, 16).cpu()
+        t = t[t[:, 0] > 0].double()
+        names = ["start", "zero+tab+issue", "barrier", "stage+w0", "barrier", "c0 mfma", "c0 epi", "c1 mfma", "c1 epi", "c2 mfma", "c2 epi",
+                 "c3 mfma", "c3 epi", "to end of classes", "atomics"]
+        base = t[:, 0].min()
+        print(f"      stamps of {t.shape[0]} waves; kernel span {(t[:, 14].max() - base) / 100:.1f} us; last wave start +{(t[:, 0].max() - base) / 100:.1f} us; "
+              f"wave lifetime mean {((t[:, 14] - t[:, 0]) / 100).mean():.1f} max {((t[:, 14] - t[:, 0]) / 100).max():.1f} us")
+        prev = t[:, 0]
+        line = []
+        for i in range(1, 15):
+            cur = t[:, i]
+            okm = cur > 0
+            if okm.any():
+                d = (cur[okm] - prev[okm]) / 100
+                line.append(f"{names[i]} {d.mean():.2f}")
+                prev = torch.where(okm, cur, prev)
+        print("      mean us per phase: " + " | ".join(line), flush=True)
     if os.environ.get("CR_DBG"):
         ts = []
         for dbg in (1, 2, 4, 3, 7):
