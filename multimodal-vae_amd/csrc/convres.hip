@@ -21,13 +21,12 @@
 #include "convres_geo.h"
 #include "convres.h"
 #include "bn_dev.h"
+#include "convres_epi.h"
 #include <type_traits>
 #include <cstdlib>
 
 namespace {
 
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) int i32x4c;
 
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -40,8 +39,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 struct ConvResArgs {
     const bf16* A;              // gathered tensor [nimg][AH][AW][C]
     int nimg, group_n;          // images in all / per BatchNorm group
-    const bf16* Wp[4];          // packed weights per class [N][Kpad]
+    const bf16* Wp[4];          // packed weights per class [N][Kpad] (BDIR kernels: the fragment-major copy, PackDesc::frag)
     int Kpad[4];
+    int Npad;
     bf16* out;                  // [nimg][OH][OW][ldo]
     int ldo;
     float2* colstats;           // [groups][SLOTS][N] += (sum v, sum v^2) or null
@@ -77,114 +77,18 @@ constexpr int tab_base(int c) {
     return r;
 }
 
-// derivative of Swish at pre-activation x (hardware exp / rcp: the result multiplies a bf16-rounded gradient)
-__device__ __forceinline__ float dswish_fast(float x) {
-    const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-x));
-    return s * (1.0f + x * (1.0f - s));
-}
-__device__ __forceinline__ float swish_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-typedef __attribute__((address_space(3))) s16x4 lds_s16x4c;
-
-// Epilogue of one 32x32 accumulator tile (lane = channel c = lane&31, register j = row (j&3) + 8*(j>>2) + 4*(lane>>5)).
-// The tile crosses a wave-private LDS scratch so that every global access is a 16-byte vector of 8 channels of one pixel
-// (2-byte accesses per lane cost one address per lane in the texture path: the first version, 16 short stores per tile,
-// spent as long storing as computing):
-//   * results leave as [channel][32 rows] (4 packed 8-byte writes per lane) and come back through ds_read_b64_tr_b16:
-//     lane (g = lane>>4, i = lane&15) gets channels 8g..8g+7 of rows i and 16+i -- its two 16-byte stores;
-//   * MODE 1: the saved tensor of the output geometry arrives the other way round: two 16-byte loads per lane in that same
-//     (row, channel octet) mapping, written as [row][32 channels], read back transposed into the accumulator layout.
-// `off0` / `off1`: byte offsets (row table + channel octet + image base) of this lane's two vectors; rows >= rows_valid
-// (PARTIAL tiles only) carry an out-of-range offset (dropped by the buffer range check) and are kept out of the sums.
-template <int MODE, bool PARTIAL>
-__device__ __forceinline__ void cr_epilogue_tile(const f32x16& acc, char* scr, int lane, int rows_valid, unsigned off0, unsigned off1,
-                                                 __amdgpu_buffer_rsrc_t orsrc, __amdgpu_buffer_rsrc_t rrsrc, float dsc, float dsh,
-                                                 float dmean, float drstd, float& s1, float& s2, bool store) {
-    constexpr int SP = 80;                                       // scratch row pitch: 32 x bf16 + 16
-    const int r = lane & 31, h = lane >> 5, g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-    float v[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = acc[j];
-    if constexpr (MODE == 1) {
-        const i32x4c r0 = __builtin_bit_cast(i32x4c, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, (int)off0, 0, 0));
-        const i32x4c r1 = __builtin_bit_cast(i32x4c, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, (int)off1, 0, 0));
-        *reinterpret_cast<i32x4c*>(scr + i * SP + g * 16) = r0;              // [row][channel]
-        *reinterpret_cast<i32x4c*>(scr + (16 + i) * SP + g * 16) = r1;
-        asm volatile("" ::: "memory");      // wave-private scratch: LDS order within a wave is issue order
-        // block of 4 rows x 16 channels per 16-lane group: lane 4q+p addresses row q, channels 4p..4p+3 and receives channel i
-        const char* rb = scr + (4 * h + q) * SP + (16 * ((lane >> 4) & 1) + 4 * p) * 2;
-        f32x2 t1 = {0.f, 0.f}, t2 = {0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            // (cast the WHOLE vector: __builtin_bit_cast on an element of an ext-vector returns element 0 for every index)
-            const bf16x4 rv = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4c*)(rb + 8 * k * SP)));
-#pragma unroll
-            for (int e = 0; e < 4; e += 2) {
-                const f32x2 rr = {(float)rv[e], (float)rv[e + 1]};
-                const f32x2 x = rr * dsc + dsh;
-                f32x2 d = {dswish_fast(x[0]), dswish_fast(x[1])};
-                f32x2 o = {v[4 * k + e], v[4 * k + e + 1]};
-                o *= d;
-                if constexpr (PARTIAL) {
-                    const int row = 8 * k + 4 * h + e;
-                    o[0] = row < rows_valid ? o[0] : 0.f;
-                    o[1] = row + 1 < rows_valid ? o[1] : 0.f;
-                }
-                t1 += o;
-                t2 += o * ((rr - dmean) * drstd);
-                v[4 * k + e] = o[0]; v[4 * k + e + 1] = o[1];
-            }
-        }
-        s1 += t1[0] + t1[1];
-        s2 += t2[0] + t2[1];
-        asm volatile("" ::: "memory");
-    } else {
-        f32x2 t1 = {0.f, 0.f}, t2 = {0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < 16; j += 2) {
-            f32x2 o = {v[j], v[j + 1]};
-            if constexpr (PARTIAL) {
-                const int row = (j & 3) + 8 * (j >> 2) + 4 * h;
-                o[0] = row < rows_valid ? o[0] : 0.f;
-                o[1] = row + 1 < rows_valid ? o[1] : 0.f;
-                v[j] = o[0]; v[j + 1] = o[1];
-            }
-            t1 += o;
-            t2 += o * o;
-        }
-        s1 += t1[0] + t1[1];
-        s2 += t2[0] + t2[1];
-    }
-    // results -> [channel][32 rows] bf16: this lane's 4 runs of 4 rows
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        bf16x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (bf16)v[4 * k + e];
-        *reinterpret_cast<bf16x4*>(scr + r * SP + (8 * k + 4 * h) * 2) = o;
-    }
-    asm volatile("" ::: "memory");
-    if (store) {
-        // block of 4 channels x 16 rows: lane 4q+p addresses channel c0+q, rows 4p..4p+3 (+16 for the second vector) and
-        // receives row i
-        const char* ob = scr + (8 * g + q) * SP + (4 * p) * 2;
-        union { struct { s16x4 a, b; } s; i32x4c v; } u0, u1;
-        u0.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4c*)(ob));
-        u0.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4c*)(ob + 4 * SP));
-        u1.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4c*)(ob + 32));
-        u1.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4c*)(ob + 4 * SP + 32));
-        __builtin_amdgcn_raw_buffer_store_b128(u0.v, orsrc, (int)off0, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(u1.v, orsrc, (int)off1, 0, 0);
-    }
-    asm volatile("" ::: "memory");
-}
-
+// CH > 0: the packed weights of a class come through LDS in chunks of CH k-steps shared by all waves.
+// CH == 0 ("direct B"): every wave streams the weight fragments of its own column tiles straight from L2 into registers, PD
+// k-steps ahead (fragment-major packed weights: a fragment is two contiguous 512-byte runs).  No weight buffer, no barrier
+// after the staging one: for the layers whose weights dwarf their activations (N >= 64, K >= 512 at 6x6 / 12x12 pixels) a
+// chunk of weights was 0.25 us of MFMA work behind two barriers and an exposed L2 round trip.
 template <class G, int NI, int CH, int WAVES, int NG, bool SCR_OWN>
 struct CrLayout {
     static constexpr int NTHR = WAVES * 64;
+    static constexpr bool BDIR = CH == 0;
     static constexpr int BP = (CH * 16 + 8) * 2;            // weight row pitch in LDS (bytes): odd multiple of 16
-    static constexpr int W_BYTES = G::N * BP;
+    static constexpr int W_BYTES = BDIR ? 0 : G::N * BP;
+    static_assert(!BDIR || SCR_OWN, "direct-B kernels have no weight buffer to lend to the epilogue");
     static constexpr int IMG_ALL = NI * G::IMG_BYTES;
     static constexpr int TAB_BYTES = tab_base<G, NI>(G::NCLS) * 4;
     static constexpr int SCR_PITCH = 80, SCR_BYTES = 32 * SCR_PITCH;   // per-wave epilogue scratch [32 rows][64 B + 16]
@@ -220,11 +124,12 @@ __global__ __launch_bounds__(WAVES * 64) void convres_kernel(const ConvResArgs a
     stamp(0);
 
     // ---- weight chunks: global -> registers (issued a phase ahead of their use) -> LDS
-    constexpr int WV = crgeo::cdiv(G::N * CH * 2, NTHR);        // 16-byte vectors per thread of a full chunk
+    constexpr bool BDIR = L::BDIR;
+    constexpr int WV = BDIR ? 1 : crgeo::cdiv(G::N * CH * 2, NTHR);        // 16-byte vectors per thread of a full chunk
     i32x4c wreg[WV];
     auto w_fetch = [&](auto ci, auto chi) {
         constexpr int c = decltype(ci)::value, ch = decltype(chi)::value;
-        constexpr int CHK = crgeo::cmin(CH, G::KSTEPS(c) - ch * CH), VPR = CHK * 2, NV = G::N * VPR;
+        constexpr int CHK = crgeo::cmin(CH, G::KSTEPS(c) - ch * CH), VPR = CHK * 2 + (BDIR ? 1 : 0), NV = G::N * VPR;
         const bf16* wsrc = a.Wp[c] + ch * CH * 16;
         const int kpad = a.Kpad[c];
 #pragma unroll
@@ -236,7 +141,7 @@ __global__ __launch_bounds__(WAVES * 64) void convres_kernel(const ConvResArgs a
     };
     auto w_store = [&](auto ci, auto chi) {
         constexpr int c = decltype(ci)::value, ch = decltype(chi)::value;
-        constexpr int CHK = crgeo::cmin(CH, G::KSTEPS(c) - ch * CH), VPR = CHK * 2, NV = G::N * VPR;
+        constexpr int CHK = crgeo::cmin(CH, G::KSTEPS(c) - ch * CH), VPR = CHK * 2 + (BDIR ? 1 : 0), NV = G::N * VPR;
 #pragma unroll
         for (int it = 0; it < crgeo::cdiv(NV, NTHR); ++it) {
             const int v = tid + it * NTHR;
@@ -244,7 +149,7 @@ __global__ __launch_bounds__(WAVES * 64) void convres_kernel(const ConvResArgs a
             if (v < NV) *reinterpret_cast<i32x4c*>(w_s + n * BP + kv * 16) = wreg[it];
         }
     };
-    w_fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    if constexpr (!BDIR) w_fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
 
     // ---- image staging: batches of SB vectors per thread (loads of a batch in flight together)
     constexpr int VPP = G::C / 8;                               // 16-byte vectors per pixel
@@ -369,7 +274,7 @@ __global__ __launch_bounds__(WAVES * 64) void convres_kernel(const ConvResArgs a
         i_store(0);
         for (int b = 1; b < NB; ++b) { i_fetch(b); i_store(b); }
     }
-    w_store(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    if constexpr (!BDIR) w_store(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
     stamp(3);
     __syncthreads();
     stamp(4);
@@ -389,12 +294,18 @@ __global__ __launch_bounds__(WAVES * 64) void convres_kernel(const ConvResArgs a
         if (MODE == 1 && a.d_meanrstd) { const float2 t = a.d_meanrstd[grp * G::N + co]; dmean[nt] = t.x; drstd[nt] = t.y; }
     }
     char* const scr = (SCR_OWN ? smem + L::OFF_SCR : w_s) + wave * L::SCR_BYTES;
+    __amdgpu_buffer_rsrc_t wrsrc[BDIR ? G::NCLS : 1];
+    if constexpr (BDIR) {
+#pragma unroll
+        for (int i = 0; i < G::NCLS; ++i)
+            wrsrc[i] = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.Wp[i]), 0, a.Npad * a.Kpad[i] * 2, 0x00020000);
+    }
 
     // ---- classes.  At the top of a chunk its weights are in LDS and a barrier has been passed.
     static_for<0, G::NCLS>([&](auto ci) {
         constexpr int c = decltype(ci)::value;
         constexpr int ROWS = NI * G::OYX(c), T = crgeo::cdiv(ROWS, 32), MT = crgeo::cdiv(T, MG);
-        constexpr int KS = G::KSTEPS(c), NCH = crgeo::cdiv(KS, CH);
+        constexpr int KS = G::KSTEPS(c), CHE = BDIR ? KS : CH, NCH = crgeo::cdiv(KS, CHE);
         // this wave's row tiles: mg, mg + MG, ...
         int abase[MT];
 #pragma unroll
@@ -415,19 +326,64 @@ __global__ __launch_bounds__(WAVES * 64) void convres_kernel(const ConvResArgs a
                 for (int j = 0; j < 16; ++j) acc[m][nt][j] = 0.f;
         const int wrow = ((ng * NT) * 32 + r) * BP + h * 16;
 
+        if constexpr (BDIR) {
+            // weight fragments straight from L2, PD k-steps ahead; activation fragments from LDS one step ahead
+            constexpr int PD = KS < 8 ? KS : 8;
+            unsigned voff[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                voff[nt] = (unsigned)(((2 * (ng * NT + nt) + (r >> 4)) * (a.Kpad[c] >> 5) * 64 + h * 16 + (r & 15)) * 16);
+            auto bload = [&](auto ki, bf16x8 (&fb)[NT]) {
+                constexpr int kk = decltype(ki)::value;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    fb[nt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc[c], (int)voff[nt], (kk >> 1) * 1024 + (kk & 1) * 512, 0));
+            };
+            auto aload = [&](auto ki, bf16x8 (&fa)[MT]) {
+                constexpr int kk = decltype(ki)::value;
+                constexpr int aoff = G::step_off(c, kk);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) fa[m] = *reinterpret_cast<const bf16x8*>(img_s + abase[m] + aoff);
+            };
+            bf16x8 bq[PD][NT], af[MT];
+            static_for<0, PD>([&](auto pi) { bload(pi, bq[decltype(pi)::value]); });
+            aload(std::integral_constant<int, 0>{}, af);
+            __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);
+            if (!(a.dbg & 2))
+            static_for<0, KS>([&](auto ki) {
+                constexpr int kk = decltype(ki)::value;
+                bf16x8 bcur[NT], an[MT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bcur[nt] = bq[kk % PD][nt];
+                if constexpr (kk + PD < KS) bload(std::integral_constant<int, kk + PD>{}, bq[kk % PD]);
+                if constexpr (kk + 1 < KS) aload(std::integral_constant<int, kk + 1>{}, an);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bcur[nt], acc[m][nt], 0, 0, 0);
+                if constexpr (kk + PD < KS) __builtin_amdgcn_sched_group_barrier(0x020, NT, 0);
+                if constexpr (kk + 1 < KS) __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);
+                if constexpr (kk + 1 < KS) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) af[m] = an[m];
+                }
+            });
+        }
         static_for<0, NCH>([&](auto chi) {
             constexpr int ch = decltype(chi)::value;
-            constexpr int CHK = crgeo::cmin(CH, KS - ch * CH);           // k-steps in this chunk
+            constexpr int CHK = crgeo::cmin(CHE, KS - ch * CHE);         // k-steps in this chunk
             constexpr bool last_chunk = ch + 1 == NCH;
-            constexpr bool has_next = !last_chunk || c + 1 < G::NCLS;
+            constexpr bool has_next = !BDIR && (!last_chunk || c + 1 < G::NCLS);
             constexpr int cn = last_chunk ? c + 1 : c, chn = last_chunk ? 0 : ch + 1;
             if constexpr (has_next) w_fetch(std::integral_constant<int, cn>{}, std::integral_constant<int, chn>{});
-            if (!(a.dbg & 2)) {
+            if (!BDIR && !(a.dbg & 2)) {
                 // fragments of step kk+1 are requested before the MFMAs of step kk
                 bf16x8 af[MT], bfr[NT];
                 auto frag = [&](auto ki, bf16x8 (&fa)[MT], bf16x8 (&fb)[NT]) {
                     constexpr int kk = decltype(ki)::value;
-                    constexpr int aoff = G::step_off(c, ch * CH + kk);
+                    constexpr int aoff = G::step_off(c, ch * CHE + kk);
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
                         fb[nt] = *reinterpret_cast<const bf16x8*>(w_s + wrow + nt * 32 * BP + kk * 32);
@@ -538,7 +494,7 @@ int launch_cr_mode(const ConvResArgs& a, hipStream_t stream) {
     if (mmvae_first_use_on_device(attr_set))
         hipFuncSetAttribute(reinterpret_cast<const void*>(&convres_kernel<G, NI, CH, WAVES, NG, SCR_OWN, MODE, TR>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL((convres_kernel<G, NI, CH, WAVES, NG, SCR_OWN, MODE, TR>), dim3(a.nimg / NI), dim3(WAVES * 64), L::TOTAL, stream, a);
+    MMVAE_LAUNCH((convres_kernel<G, NI, CH, WAVES, NG, SCR_OWN, MODE, TR>), dim3(a.nimg / NI), dim3(WAVES * 64), L::TOTAL, stream, a);
     MMVAE_TRY(mmvae_check_launch("convres"));
     return 1;
 }
@@ -549,7 +505,12 @@ int launch_cr(const GemmParams& p, hipStream_t stream) {
     const int nimg = c.groups * c.group_n;
     ConvResArgs a{};
     a.A = c.A; a.nimg = nimg; a.group_n = c.group_n;
-    for (int i = 0; i < G::NCLS; ++i) { a.Wp[i] = p.cls[i].Wp; a.Kpad[i] = p.cls[i].Kpad; }
+    constexpr bool BDIR = CH == 0;
+    for (int i = 0; i < G::NCLS; ++i) {
+        a.Wp[i] = BDIR ? p.cls[i].Wf : p.cls[i].Wp; a.Kpad[i] = p.cls[i].Kpad;
+        if (BDIR && (!a.Wp[i] || a.Kpad[i] % 32 != 0)) return 0;      // no fragment-major copy of these weights: not this kernel
+    }
+    a.Npad = p.npad;
     a.out = p.out_bf; a.ldo = p.ldo; a.colstats = p.colstats;
     a.dbg = mmvae_knob("convres_dbg", 0);
     a.ts = reinterpret_cast<unsigned long long*>(((unsigned long long)(unsigned)mmvae_knob("convres_ts_hi", 0) << 32) |
@@ -615,6 +576,11 @@ int try_launch_convres(const GemmParams& p, hipStream_t stream) {
     const int alt = mmvae_knob("convres_alt", 0);       // measurement aid: alternative tile configurations
     //                          NI  CH  WAVES NG SCR_OWN
     if ((rc = try_cr<G_mm_conv2, 1, 16, 8, 2, true>(p, stream)) != 0) return rc;
+    if (alt != 3) {       // CH = 0: direct-B kernels (need the fragment-major weight copy; else the LDS-chunk form below)
+        if ((rc = try_cr<G_mm_conv3, 2, 0, 8, 4, true>(p, stream)) != 0) return rc;
+        if (nimg <= 256) { if ((rc = try_cr<G_mm_convT2, 2, 0, 8, 2, true>(p, stream)) != 0) return rc; }
+        if ((rc = try_cr<G_mm_convT2, 4, 0, 8, 2, true>(p, stream)) != 0) return rc;
+    }
     if ((rc = try_cr<G_mm_conv3, 2, 8, 8, 4, true>(p, stream)) != 0) return rc;
     if (nimg <= 256) { if ((rc = try_cr<G_mm_convT2, 2, 8, 4, 1, true>(p, stream)) != 0) return rc; }
     if ((rc = try_cr<G_mm_convT2, 4, 16, 8, 2, true>(p, stream)) != 0) return rc;

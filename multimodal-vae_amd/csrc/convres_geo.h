@@ -21,11 +21,13 @@ constexpr int fdiv(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 constexpr int cmin(int a, int b) { return a < b ? a : b; }
 
-template <int FORM_, int C_, int N_, int AH_, int AW_, int OH_, int OW_, int KH_, int KW_, int S_, int PAD_>
+// PIXPAD_: bytes added to a pixel's C*2 (16: conflict-free 16-byte row reads of the forward / data-gradient kernels; 0 for the
+// weight-gradient kernel, whose transposed 8-byte reads do not need it and whose two resident tensors need the room)
+template <int FORM_, int C_, int N_, int AH_, int AW_, int OH_, int OW_, int KH_, int KW_, int S_, int PAD_, int PIXPAD_ = 16>
 struct Geo {
     static constexpr int FORM = FORM_, C = C_, N = N_, AH = AH_, AW = AW_, OH = OH_, OW = OW_, KH = KH_, KW = KW_, S = S_, PAD = PAD_;
     static constexpr int NCLS = FORM == 0 ? 1 : S * S;
-    static constexpr int PIX = C * 2 + 16;                 // LDS bytes per pixel
+    static constexpr int PIX = C * 2 + PIXPAD_;            // LDS bytes per pixel
     static constexpr int KSTEP_PER_TAP = C / 16;           // 32x32x16 MFMA k-steps per tap
     static_assert(C % 16 == 0 && N % 32 == 0, "channel counts");
 

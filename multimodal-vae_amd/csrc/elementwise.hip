@@ -942,7 +942,7 @@ int launch_bn_act(const BnActArgs& a, hipStream_t s) {
 }
 int launch_bn_bwd_apply(const BnBwdApplyArgs& a, hipStream_t s) {
     MMVAE_REQUIRE(a.ld % 8 == 0 && a.ld >= round_up(a.C, 8), "bn_bwd_apply: C=%d ld=%d", a.C, a.ld);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblocks((long long)a.rows * ((a.C + 7) / 8), TPB, 2048)), dim3(TPB),
+    MMVAE_LAUNCH(bn_bwd_apply_kernel, dim3(nblocks((long long)a.rows * ((a.C + 7) / 8), TPB, 2048)), dim3(TPB),
                        (size_t)a.G * a.C * sizeof(float4), s, a);
     return mmvae_check_launch("bn_bwd_apply");
 }
@@ -986,12 +986,12 @@ int launch_keep_mask(uint8_t* out, long long n, float p, unsigned long long seed
 }
 int launch_latent3_fwd(const Latent3Args& a, hipStream_t s) {
     MMVAE_REQUIRE(a.ldz >= a.D && a.ldz % 8 == 0, "latent3: ldz=%d", a.ldz);
-    hipLaunchKernelGGL(latent3_fwd_kernel, dim3(nblocks((long long)a.B * a.ldz, TPB, 256)), dim3(TPB), 0, s, a);
+    MMVAE_LAUNCH(latent3_fwd_kernel, dim3(nblocks((long long)a.B * a.ldz, TPB, 256)), dim3(TPB), 0, s, a);
     return mmvae_check_launch("latent3_fwd");
 }
 int launch_latent3_bwd(const Latent3BwdArgs& a, hipStream_t s) {
     MMVAE_REQUIRE((a.loss_slots == nullptr) == (a.loss_out == nullptr), "latent3_bwd: loss_slots / loss_out go together");
-    hipLaunchKernelGGL(latent3_bwd_kernel, dim3(ceil_div(a.f.D, 64), ceil_div(a.f.B, L3B_ROWS)), dim3(TPB), 0, s, a);
+    MMVAE_LAUNCH(latent3_bwd_kernel, dim3(ceil_div(a.f.D, 64), ceil_div(a.f.B, L3B_ROWS)), dim3(TPB), 0, s, a);
     return mmvae_check_launch("latent3_bwd");
 }
 int launch_adam(const AdamArgs& a, hipStream_t s) {
@@ -1029,7 +1029,7 @@ int launch_nll_bwd(const long long* tg, int rows, int classes, float coef, const
 int launch_step_begin(const StepBeginArgs& a, hipStream_t s) {
     for (int r = 0; r < 4; ++r)
         MMVAE_REQUIRE(a.zero_ptr[r] == nullptr || (a.zero_bytes[r] % 16 == 0 && ((uintptr_t)a.zero_ptr[r] & 15) == 0), "step_begin: zero range %d is not 16-byte aligned", r);
-    hipLaunchKernelGGL(step_begin_kernel, dim3(2048 + (a.pack_blocks > 0 ? a.pack_blocks : 0)), dim3(TPB), 0, s, a);
+    MMVAE_LAUNCH(step_begin_kernel, dim3(2048 + (a.pack_blocks > 0 ? a.pack_blocks : 0)), dim3(TPB), 0, s, a);
     return mmvae_check_launch("step_begin");
 }
 // fills the pack part of a step prologue (StepBeginArgs::pack_*) from a descriptor table

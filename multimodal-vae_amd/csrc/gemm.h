@@ -19,6 +19,7 @@ struct GatherClass {        // one stride-parity class (conv fwd and Linear have
     int K;                  // TH*TW*C
     int Kpad;               // packed weight row stride (multiple of 64)
     const bf16* Wp;         // gemm: packed weights [Npad][Kpad]
+    const bf16* Wf;         // gemm: optional fragment-major copy of Wp (PackDesc::frag = 1) for the direct-B convres kernels
     float* dWp;             // wgrad: packed fp32 gradient [Npad][Kpad]
 };
 
@@ -100,6 +101,9 @@ struct WgradParams {
     const float2* p_affine; // optional transform of the plain operand [groups][N]
     int p_act;
     int rows_per_block;     // multiple of 64
+    // staging transforms of the two operands (image-resident weight-gradient kernel only, convres_wgrad.hip), or null
+    const GatherTransform* trA;     // gathered operand (c.A)
+    const GatherTransform* trP;     // plain operand (P)
     // slab form (filled by the launcher): partial tiles go to slab + chunk*slab_chunk_stride + slab_cls_off[class] as
     // [rows][Kpad] with plain stores and wgrad_reduce_kernel sums the chunk copies into dWp; null: fp32 atomics into dWp
     float* slab;

@@ -887,6 +887,10 @@ int launch_wgrad(const WgradParams& pin, hipStream_t stream, WgradSlabCtx* ctx) 
     if (mmvae_knob("dbg_skip_wgrad", 0)) return MMVAE_OK;       // measurement aid: the step without its weight gradients
     MMVAE_TRY(wgrad_validate(pin));
     WgradParams p = pin;
+    {   // conv layers with an image-resident kernel compiled for their geometry (convres_wgrad.hip)
+        const int rc = try_launch_convres_wgrad(p, stream, ctx);
+        if (rc != 0) return rc < 0 ? rc : MMVAE_OK;
+    }
     dim3 grid; size_t lds;
     MMVAE_TRY(wgrad_setup(p, ctx, grid, lds, stream));
     const WgradCfg cfg = wgrad_cfg(p);

@@ -288,7 +288,7 @@ int launch_small(const GemmParams& p, hipStream_t stream) {
     for (int i = 0; i < c.nclasses; ++i) max_tiles = max(max_tiles, ceil_div(p.cls[i].rows_per_group, MT * 16));
     dim3 grid(max_tiles * c.groups, ceil_div(c.N, NT * 16), c.nclasses);
     const size_t lds = KS > 1 ? (size_t)(KS - 1) * MT * NT * 4 * 64 * sizeof(float) : 0;
-    hipLaunchKernelGGL((gemm_small_kernel<MT, NT, KS, DGRAD>), grid, dim3(KS * 64), lds, stream, p);
+    MMVAE_LAUNCH((gemm_small_kernel<MT, NT, KS, DGRAD>), grid, dim3(KS * 64), lds, stream, p);
     return mmvae_check_launch("gemm_small");
 }
 

@@ -166,12 +166,12 @@ __global__ __launch_bounds__(NTHR) void mlp2_bwd_kernel(const Mlp2BwdArgs a) {
 int launch_mlp2_fwd(const Mlp2FwdArgs& a, hipStream_t s) {
     MMVAE_REQUIRE(a.rows > 0 && a.x && a.w2 && a.w3 && a.b2 && a.b3 && a.y2 && a.ay2 && a.out, "mlp2_fwd: null argument");
     const size_t lds = (size_t)TR * LDO * sizeof(float) + (size_t)TR * (LDX1 + LDX2) * sizeof(bf16);
-    hipLaunchKernelGGL(mlp2_fwd_kernel, dim3(ceil_div(a.rows, TR)), dim3(NTHR), lds, s, a);
+    MMVAE_LAUNCH(mlp2_fwd_kernel, dim3(ceil_div(a.rows, TR)), dim3(NTHR), lds, s, a);
     return mmvae_check_launch("mlp2_fwd");
 }
 int launch_mlp2_bwd(const Mlp2BwdArgs& a, hipStream_t s) {
     MMVAE_REQUIRE(a.rows > 0 && a.d_out && a.w3t && a.w2t && a.y2 && a.y1 && a.dy2 && a.dy1 && a.db2 && a.db1, "mlp2_bwd: null argument");
     const size_t lds = (size_t)(TR * LDO + NQ1 * TR * 32) * sizeof(float) + (size_t)TR * LDX2 * sizeof(bf16);
-    hipLaunchKernelGGL(mlp2_bwd_kernel, dim3(ceil_div(a.rows, TR)), dim3(NTHR), lds, s, a);
+    MMVAE_LAUNCH(mlp2_bwd_kernel, dim3(ceil_div(a.rows, TR)), dim3(NTHR), lds, s, a);
     return mmvae_check_launch("mlp2_bwd");
 }

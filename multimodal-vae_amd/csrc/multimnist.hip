@@ -99,6 +99,8 @@ void build_plan(MMPlan& P) {
     build_conv(P, P.convT[1], "image_decoder.hallucinate.3.weight", ConvGeom{128, 64, 4, 4, 2, 1, 6, 6, 12, 12, true}, 4, true, false, false);
     build_conv(P, P.convT[2], "image_decoder.hallucinate.6.weight", ConvGeom{64, 32, 5, 5, 2, 1, 12, 12, 25, 25, true}, 5, true, false, false);
     build_conv(P, P.convT[3], "image_decoder.hallucinate.9.weight", ConvGeom{32, 1, 4, 4, 2, 1, 25, 25, 50, 50, true}, -1, true, false, true);
+    add_frag_packs(P, P.conv[2]);      // 6x6 / 12x12 layers with 64-256 KB of weights per class: direct-B kernels (convres.hip)
+    add_frag_packs(P, P.convT[1]);
 
     // classifier (multimnist/model.py:173-179). fc1 consumes the NCHW flatten c*4+y*2+x of a (256,2,2) map that
     // lives here as NHWC [2][2][256]: a 2x2-tap gather with k = (y*2+x)*256 + c.
@@ -272,7 +274,7 @@ int enc_fwd(MMPlan& P, const float* image, int variants, const uint8_t* m1, cons
     bf16* a[4] = {w.a1, w.a2, w.a3, w.a4};
     for (int l = 1; l < 4; ++l) {
         const ConvL& L = P.conv[l];
-        GemmParams g = gemm_of(P, L.fwd, L.pk_fwd, 1, B);
+        GemmParams g = gemm_of(P, L.fwd, L.pk_fwd, 1, B, L.pk_fwd_f);
         g.c.A = a[l - 1];
         g.out_bf = r[l]; g.ldo = L.g.Cout;
         g.colstats = training ? w.st_e[l - 1] : nullptr;
@@ -336,7 +338,8 @@ int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const
             GatherPlan pl = dense_plan(rows, 200, 200, D2);
             WgradParams g = wgrad_of(P, pl, &P.fc[2].gk, 1, rows);
             g.c.A = w.ay2; g.P = d_out; g.ldp = D2;
-            MMVAE_TRY(wgrad_async(P, g, s));
+            if (fuse) { MMPlan* pp = &P; side_later(P, [pp, g](hipStream_t ws_) { return wgrad_on(*pp, g, ws_); }); }   // behind conv4's data gradient
+            else MMVAE_TRY(wgrad_async(P, g, s));
         }
         Mlp2BwdArgs a{};
         a.rows = rows; a.d_out = d_out;
@@ -349,7 +352,8 @@ int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const
         GatherPlan pl = dense_plan(rows, 400, 400, 200);
         WgradParams g = wgrad_of(P, pl, &P.fc[1].gk, 1, rows);
         g.c.A = w.ay1; g.P = w.dy2; g.ldp = 200;
-        MMVAE_TRY(wgrad_async(P, g, s));
+        if (fuse) { MMPlan* pp = &P; side_later(P, [pp, g](hipStream_t ws_) { return wgrad_on(*pp, g, ws_); }); }
+        else MMVAE_TRY(wgrad_async(P, g, s));
     } else {
     {   // fc3
         GatherPlan pl = dense_plan(rows, 200, 200, D2);
@@ -381,7 +385,12 @@ int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const
         WgradParams g = wgrad_of(P, pl, &P.fc[0].gk, 1, rows);
         g.c.A = w.a4; g.c.a_bcast_n = B;
         g.P = w.dy1; g.ldp = 400;
-        MMVAE_TRY(wgrad_async(P, g, s));
+        if (P.mlp_tail && fuse) {
+            MMPlan* pp = &P;
+            side_later(P, [pp, g](hipStream_t ws_) { return wgrad_on(*pp, g, ws_); });
+        } else {
+            MMVAE_TRY(wgrad_async(P, g, s));
+        }
         // dgrad: 4 classes = the 4 pixels of the 2x2 map, each with its own [256][400] matrix
         GatherPlan pd{};
         pd.c.AH = 1; pd.c.AW = 1; pd.c.Ald = 400; pd.c.C = 400; pd.c.sy = pd.c.sx = 1; pd.c.dy = pd.c.dx = 1;
@@ -417,20 +426,51 @@ int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const
         x.red = w.red_e[l - 1]; x.meanrstd = w.mr_e[l - 1]; x.gamma = P.buf.params + b.w_off;
         x.dgamma = P.buf.grads + b.w_off; x.dbeta = P.buf.grads + b.b_off;
         if (!fl) MMVAE_TRY(launch_bn_bwd_apply(x, s));
-        {   // wgrad: P = dr[l] (rows over the output grid), G = activated input gathered in forward form
-            WgradParams g = wgrad_of(P, L.fwd, L.gk, 1, B);
-            g.c.A = a[l - 1]; g.P = x.dr; g.ldp = L.g.Cout;
-            hipStream_t ws_;
-            MMVAE_TRY(wgrad_side_stream(P, s, &ws_));
-            if (fl) MMVAE_TRY(launch_bn_bwd_apply(x, ws_));
-            if (fuse && l == 2) {      // conv3's gathered operand a2 = Swish(BatchNorm(r2)) was never materialised
-                const int prows = B * P.conv[1].g.OH * P.conv[1].g.OW;
-                MMVAE_TRY(bn_act_side(P, P.bn[P.conv[1].bn], r[1], a[1], prows, prows, 1, w.st_e[0], 1, ws_));
+        // wgrad: P = dr[l] (rows over the output grid), G = activated input gathered in forward form.  Forks are bound to a
+        // producer kernel's completion: a fused layer's operands came out of the previous data gradient (the current event);
+        // the unfused conv4 issues its weight gradient behind its own data gradient, on the event conv3's needs anyway
+        WgradParams gw = wgrad_of(P, L.fwd, L.gk, 1, B);
+        gw.c.A = a[l - 1]; gw.P = x.dr; gw.ldp = L.g.Cout;
+        if (fuse) {
+            // fused layers (conv3, conv2): the image-resident weight-gradient kernel stages db through the BatchNorm backward
+            // itself (and adds the BatchNorm parameter gradients); conv3's gathered operand a2 = Swish(BatchNorm(r2)) comes
+            // out of the raw tensor the same way.  conv4 keeps the streamed kernel on its materialised operands
+            MMPlan* pp = &P;
+            GatherTransform tp{}, ta{};
+            if (fl) {
+                tp.kind = 2; tp.r = r[l]; tp.red = w.red_e[l - 1]; tp.mr = w.mr_e[l - 1]; tp.gamma = P.buf.params + b.w_off;
+                tp.dgamma = P.buf.grads + b.w_off; tp.dbeta = P.buf.grads + b.b_off;
+                tp.inv_cnt = 1.f / (float)(B * pix); tp.groups = 1;
+                gw.P = dr[l];
+                if (l == 2) {
+                    const int prows = B * P.conv[1].g.OH * P.conv[1].g.OW;
+                    ta.kind = 1;
+                    ta.fin = bn_fin_args(P, P.bn[P.conv[1].bn], prows, 1, w.st_e[0], 0, nullptr, nullptr, 1);
+                    gw.c.A = r[1];
+                }
             }
-            MMVAE_TRY(wgrad_on(P, g, ws_));
+            if (mmvae_knob("mm_wkernel", 0) || !fl) {
+                side_later(P, [pp, gw, tp, ta](hipStream_t ws_) mutable {
+                    gw.trA = ta.kind ? &ta : nullptr; gw.trP = tp.kind ? &tp : nullptr;
+                    return wgrad_on(*pp, gw, ws_);
+                });
+            } else {        // A/B aid: materialise the operands in front of the streamed weight-gradient kernel
+                const bool act2 = l == 2;
+                const int prows = B * P.conv[1].g.OH * P.conv[1].g.OW;
+                const BnL bp = P.bn[P.conv[1].bn];
+                const bf16* rin = r[1]; bf16* ao = a[1]; const float2* st = w.st_e[0];
+                WgradParams g0 = wgrad_of(P, L.fwd, L.gk, 1, B);
+                g0.c.A = a[l - 1]; g0.P = x.dr; g0.ldp = L.g.Cout;
+                side_later(P, [pp, x, g0, act2, bp, rin, ao, st, prows](hipStream_t ws_) {
+                    MMVAE_TRY(launch_bn_bwd_apply(x, ws_));
+                    if (act2) MMVAE_TRY(bn_act_side(*pp, bp, rin, ao, prows, prows, 1, st, 1, ws_));
+                    return wgrad_on(*pp, g0, ws_);
+                });
+            }
+            if (fuse && l == 1) MMVAE_TRY(side_flush(P, s));    // conv2's: its operands came out of conv3's data gradient (current event)
         }
         {   // dgrad (class form) with the d-activation of the producer layer fused in the epilogue
-            GemmParams d = gemm_of(P, L.dgrad, L.pk_dgrad, 1, B);
+            GemmParams d = gemm_of(P, L.dgrad, L.pk_dgrad, 1, B, L.pk_dgrad_f);
             d.c.A = dr[l]; d.out_bf = dr[l - 1]; d.ldo = L.g.Cin;
             d.d_r = r[l - 1]; d.d_ld = L.g.Cin; d.d_act = ACT_SWISH;
             if (l > 1) { d.d_affine = w.aff_e[l - 2]; d.d_meanrstd = w.mr_e[l - 2]; d.d_red = w.red_e[l - 2]; }
@@ -440,9 +480,15 @@ int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const
                 tr.inv_cnt = 1.f / (float)(B * pix); tr.groups = 1;
                 d.tr = &tr;
             }
+            // forks: behind conv4's data gradient (classifier + conv4 + conv3 weight gradients) and behind conv3's (conv2's)
+            const bool flush = fuse && P.wgrad_forked && l >= 2;
+            if (flush) arm_fork(P);
             MMVAE_TRY(launch_gemm_gather(d, s));
+            if (flush) { MMVAE_TRY(commit_fork(P, s)); MMVAE_TRY(side_flush(P, s)); }
         }
+        if (!fuse) MMVAE_TRY(wgrad_async(P, gw, s));
     }
+    if (fuse && !P.wgrad_forked) MMVAE_TRY(side_flush(P, s));     // unforked (serial) use: nothing to wait for
     {   // conv1 wgrad over the im2col patches: the LAST kernel of the backward chain -- it stays on the main stream (a hop
         // to a side stream and back would put two event latencies on the critical path)
         GatherPlan pl = dense_plan(B * 625, 16, 16, 32);
@@ -480,7 +526,7 @@ int fused_tail(MMPlan& P, int groups, int training, const ConvTLastFwdArgs* last
     for (int k = 0; k < 4; ++k) x.coef[k] = last->coef[k];
     x.loss_sum = last->loss_sum;
     if (x.bwd_groups > 0) {
-        const int chunks = x.bwd_groups * B * dec_last_fused_strips(25);
+        const int chunks = x.bwd_groups * B * (dec_last_mfma_applies(x) ? 1 : dec_last_fused_strips(25));
         x.wslab = P.slab.take((size_t)chunks * 32 * 16);
         MMVAE_REQUIRE(x.wslab != nullptr, "fused decoder tail: the weight-gradient slab pool is exhausted");
         x.db = w.d3; x.red = w.red_d[2];
@@ -511,7 +557,7 @@ int dec_fwd(MMPlan& P, int groups, int training, ConvTLastFwdArgs* last, hipStre
     for (int l = 0; l < 3; ++l) {
         const ConvL& L = P.convT[l];
         {
-            GemmParams g = gemm_of(P, L.fwd, L.pk_fwd, groups, B);
+            GemmParams g = gemm_of(P, L.fwd, L.pk_fwd, groups, B, L.pk_fwd_f);
             g.c.A = aq[l];
             g.out_bf = q[l + 1]; g.ldo = L.g.Cout;
             g.colstats = training ? w.st_d[l] : nullptr;
@@ -549,10 +595,11 @@ int dec_bwd(MMPlan& P, const float* dlogit, int groups, float* dz, hipStream_t s
         // d3, the BatchNorm-backward sums and the weight-gradient partials of the last layer came out of the fused tail
         // (dec_fwd); only the sum of the partials is left, off the main chain
         if (P.wgrad_forked) {
-            hipStream_t wst = P.st_wgrad;
-            MMVAE_TRY(edge(P, s, wst));
-            for (WgradSlabJob& j : P.slab.jobs) if (j.stream == s && j.src_ld == 16) j.stream = wst;
-            MMVAE_TRY(launch_wgrad_reduce(&P.slab, wst, true));
+            PlanBase* pb = &P;
+            side_later(P, [pb, s](hipStream_t wst) {
+                for (WgradSlabJob& j : pb->slab.jobs) if (j.stream == s && j.src_ld == 16) j.stream = wst;
+                return launch_wgrad_reduce(&pb->slab, wst, true);
+            });
         }
     } else {   // last transposed conv (32 -> 1): both gradients go through the im2col patches of dlogit (K = 16 taps):
         // input gradient = dense GEMM patches x W (d-Swish + BatchNorm-backward sums in the epilogue), weight
@@ -565,7 +612,9 @@ int dec_bwd(MMPlan& P, const float* dlogit, int groups, float* dz, hipStream_t s
             GemmParams d = gemm_of(P, pd, L.pk_dgrad, groups, B * 625);
             d.c.A = w.patches4; d.out_bf = w.d3; d.ldo = 32;
             d.d_r = w.q3; d.d_ld = 32; d.d_act = ACT_SWISH; d.d_affine = w.aff_d[2]; d.d_meanrstd = w.mr_d[2]; d.d_red = w.red_d[2];
+            arm_fork(P);
             MMVAE_TRY(launch_gemm_gather(d, s));
+            MMVAE_TRY(commit_fork(P, s));
         }
         GatherPlan pl = plan_fwdform(1, 1, 25, 25, 16, 1, 1, 1, 0, 32, groups, B);   // rows (n, iy, ix), dense K=16
         WgradParams g = wgrad_of(P, pl, L.gk, groups, B);
@@ -587,20 +636,45 @@ int dec_bwd(MMPlan& P, const float* dlogit, int groups, float* dz, hipStream_t s
         x.red = w.red_d[l]; x.meanrstd = w.mr_d[l]; x.gamma = P.buf.params + b.w_off;
         x.dgamma = P.buf.grads + b.w_off; x.dbeta = P.buf.grads + b.b_off;
         if (!fl) MMVAE_TRY(launch_bn_bwd_apply(x, s));
-        {
-            WgradParams g = convT_wgrad(P, L, groups, B, aq[l], x.dr);
-            hipStream_t ws_;
-            MMVAE_TRY(wgrad_side_stream(P, s, &ws_));
-            if (fl) {
-                MMVAE_TRY(launch_bn_bwd_apply(x, ws_));
-                const ConvL& Lp = P.convT[l - 1];          // aq[l] = Swish(BatchNorm(q[l])) was never materialised
-                const int prpg = B * Lp.g.OH * Lp.g.OW;
-                MMVAE_TRY(bn_act_side(P, P.bn[Lp.bn], q[l], aq[l], groups * prpg, prpg, groups, w.st_d[l - 1], training, ws_));
+        // Forks are bound to a producer kernel's completion (arm_fork / commit_fork).  Fused layers: the operands of the
+        // weight gradient came out of the previous data gradient (or the fused tail), whose event is the current one.  The
+        // unfused first layer: its weight gradient is issued behind the layer's own data gradient, on the event the upsample
+        // weight gradient needs anyway (one bound event less on the main chain)
+        WgradParams gw = convT_wgrad(P, L, groups, B, aq[l], x.dr);
+        if (fl) {
+            // The image-resident weight-gradient kernel (convres_wgrad.hip) stages both operands itself: the layer input
+            // aq[l] = Swish(BatchNorm(q[l])) out of the raw tensor, the output gradient's BatchNorm backward out of db -- neither
+            // is materialised any more, and the BatchNorm parameter gradients are added there
+            const ConvL& Lp = P.convT[l - 1];
+            const int prpg = B * Lp.g.OH * Lp.g.OW;
+            GatherTransform tp{}, ta{};
+            tp.kind = 1;
+            tp.fin = bn_fin_args(P, P.bn[Lp.bn], prpg, groups, w.st_d[l - 1], 0, nullptr, nullptr, training);
+            ta.kind = 2; ta.r = q[l + 1]; ta.red = w.red_d[l]; ta.mr = w.mr_d[l]; ta.gamma = P.buf.params + b.w_off;
+            ta.dgamma = P.buf.grads + b.w_off; ta.dbeta = P.buf.grads + b.b_off;
+            ta.inv_cnt = 1.f / (float)(B * pix); ta.groups = groups;
+            MMPlan* pp = &P;
+            if (mmvae_knob("mm_wkernel", 0)) {
+                gw.c.A = dq[l + 1]; gw.P = q[l];
+                side_later(P, [pp, gw, tp, ta](hipStream_t ws_) mutable {
+                    gw.trA = &ta; gw.trP = &tp;
+                    return wgrad_on(*pp, gw, ws_);
+                });
+            } else {        // A/B aid: materialise both operands in front of the streamed weight-gradient kernel
+                const BnL bp = P.bn[Lp.bn];
+                const bf16* qin = q[l]; bf16* aqo = aq[l]; const float2* st = w.st_d[l - 1];
+                side_later(P, [pp, x, gw, bp, qin, aqo, st, groups, prpg, training](hipStream_t ws_) {
+                    MMVAE_TRY(launch_bn_bwd_apply(x, ws_));
+                    MMVAE_TRY(bn_act_side(*pp, bp, qin, aqo, groups * prpg, prpg, groups, st, training, ws_));
+                    return wgrad_on(*pp, gw, ws_);
+                });
             }
-            MMVAE_TRY(wgrad_on(P, g, ws_));
+        } else if (fuse || l == 0) {
+            MMPlan* pp = &P;
+            side_later(P, [pp, gw](hipStream_t ws_) { return wgrad_on(*pp, gw, ws_); });
         }
         {
-            GemmParams d = gemm_of(P, L.dgrad, L.pk_dgrad, groups, B);
+            GemmParams d = gemm_of(P, L.dgrad, L.pk_dgrad, groups, B, L.pk_dgrad_f);
             d.c.A = dq[l + 1]; d.out_bf = dq[l]; d.ldo = L.g.Cin;
             d.d_r = q[l]; d.d_ld = L.g.Cin; d.d_act = ACT_SWISH;
             if (l > 0) { d.d_affine = w.aff_d[l - 1]; d.d_meanrstd = w.mr_d[l - 1]; d.d_red = w.red_d[l - 1]; }
@@ -610,14 +684,21 @@ int dec_bwd(MMPlan& P, const float* dlogit, int groups, float* dz, hipStream_t s
                 tr.inv_cnt = 1.f / (float)(B * pix); tr.groups = groups;
                 d.tr = &tr;
             }
+            // the side work collected so far forks off the completion of the first and of the last data gradient
+            const bool flush = P.wgrad_forked && (l == 2 || l == 0);
+            if (flush) arm_fork(P);
             MMVAE_TRY(launch_gemm_gather(d, s));
+            if (flush) { MMVAE_TRY(commit_fork(P, s)); if (l == 2) MMVAE_TRY(side_flush(P, s)); }
         }
+        if (!fl && !(fuse || l == 0)) MMVAE_TRY(wgrad_async(P, gw, s));
     }
     {   // upsample Linear: weight (+ folded bias) gradient and dz
         GatherPlan pl = dense_plan(rows, P.ldz, P.ldz, 1024);
         WgradParams g = wgrad_of(P, pl, &P.up.gk, 1, rows);
         g.c.A = w.z_bf; g.P = w.du; g.ldp = 1024;
-        MMVAE_TRY(wgrad_async(P, g, s));
+        MMPlan* pp = &P;
+        side_later(P, [pp, g](hipStream_t ws_) { return wgrad_on(*pp, g, ws_); });
+        MMVAE_TRY(side_flush(P, s));                // forks off the last data gradient above (du is its output)
         GatherPlan pd = dense_plan(rows, 1024, 1024, P.D);
         GemmParams d = gemm_of(P, pd, &P.up.pk_dgrad, 1, rows);
         d.c.A = w.du; d.out_f = dz; d.ldo = P.D;
@@ -733,7 +814,7 @@ MMPlan* mm_create(int D, int B) {
     if (D < 1 || D > 127 || B < 1) { mmvae_set_error("mm_create: need 1 <= n_latents <= 127 and batch >= 1"); return nullptr; }
     MMPlan* P = new MMPlan();
     P->D = D; P->B = B;
-    P->single_wgrad_stream = true;
+    P->single_wgrad_stream = false;     // round 3: the weight-gradient chain is the step's tail; two streams side by side: 758 -> 718 us
     build_plan(*P);
     Workspace ws(nullptr, 0);
     carve(*P, ws);
@@ -826,7 +907,11 @@ static int mm_step_body(MMPlan* Pp, const MMStepIO& io, int training, int do_bac
     if (training && io.gru_dropout && !gk) { sb.mask[2] = w.gkeep; sb.n_mask[2] = (long long)4 * B3 * 100; gk = w.gkeep; }
     if (io.pack_first)
         MMVAE_TRY(step_begin_with_pack(sb, P.buf.desc_dev, P.pk.d.data(), (int)P.pk.d.size(), P.buf.params, P.buf.packed, P.buf.packed_vec));
+    MMVAE_TRY(ensure_streams(P));
+    P.in_step = true;
+    arm_fork(P);                    // the text path forks off the prologue kernel's completion
     MMVAE_TRY(launch_step_begin(sb, s));
+    MMVAE_TRY(commit_fork(P, s));
     if (do_backward && P.nparams % 4 != 0)
         MMVAE_TRY(launch_fill_zero(P.buf.grads + (P.nparams / 4) * 4, (size_t)(P.nparams % 4) * sizeof(float), s));
     const int enc_drop = training && io.enc_dropout;
@@ -835,11 +920,10 @@ static int mm_step_body(MMPlan* Pp, const MMStepIO& io, int training, int do_bac
     const int sk[3] = {io.pass_skip[0] != 0, io.pass_skip[1] != 0, io.pass_skip[2] != 0};
     P.dec_skip_mask = (unsigned)(sk[0] | (sk[1] << 1) | (sk[2] << 2));
     const int enc_updates = 2 - sk[0] - sk[1];
-    MMVAE_TRY(ensure_streams(P));
     static const bool serial = getenv("MMVAE_SERIAL") != nullptr;      // profiling aid: one stream, no overlap
     hipStream_t T = serial ? s : P.st_text;
     // ---- encoders: image features once for passes 1 and 2 (main), text encoder once for passes 1 and 3 (side)
-    MMVAE_TRY(edge(P, s, T));
+    if (T != s) MMVAE_TRY(fork_to(P, T));
     {
         TextEncArgs a = te_args(P, io.text, w.txtout, do_backward);
         MMVAE_TRY(launch_text_encoder_fwd(a, T));
@@ -852,9 +936,11 @@ static int mm_step_body(MMPlan* Pp, const MMStepIO& io, int training, int do_bac
     la.B = B; la.D = D; la.img_out = w.encout; la.txt_out = w.txtout; la.eps = eps;
     la.mu = io.mu ? io.mu : w.mu; la.logvar = io.logvar ? io.logvar : w.logvar;
     la.z_f32 = w.z_f32; la.z_bf = w.z_bf; la.ldz = P.ldz; la.kl_sum = w.sums + 8; la.training = training;
+    arm_fork(P);
     MMVAE_TRY(launch_latent3_fwd(la, s));
+    MMVAE_TRY(commit_fork(P, s));
     // ---- text decoder (forward, backward and its weight gradients) on the side stream, image decoder on main
-    MMVAE_TRY(edge(P, s, T));
+    if (T != s) MMVAE_TRY(fork_to(P, T));
     TextDecArgs td = td_args(P, w.z_f32, 3, do_backward);
     td.keep = (training && io.gru_dropout) ? gk : nullptr; td.keep_scale = 1.f / (1.f - DROP_P);
     td.force_tokens = io.force_tokens;
@@ -882,6 +968,7 @@ static int mm_step_body(MMPlan* Pp, const MMStepIO& io, int training, int do_bac
     MMVAE_TRY(dec_fwd(P, 3, training, &last, s, last_groups, fuse_tail ? (do_backward ? std::min(img_groups, last_groups) : 0) : -1, fuse));
     if (!do_backward) {
         MMVAE_TRY(edge(P, T, s));
+        P.in_step = false;
         hipLaunchKernelGGL(sum_slots_kernel, dim3(1), dim3(64), 0, s, w.sums, io.sums);
         return mmvae_check_launch("sum_slots");
     }
@@ -915,12 +1002,17 @@ static int mm_step_body(MMPlan* Pp, const MMStepIO& io, int training, int do_bac
     for (int k = 0; k < 3; ++k) lb.kl_coef[k] = sk[k] ? 0.f : io.kl_lambda / (float)B;
     lb.d_img_out_bf = w.d_encout; lb.d_img_bias = P.buf.grads + P.fc[2].b_off; lb.d_txt_out = w.d_txtout;
     lb.loss_slots = w.sums; lb.loss_out = io.sums;      // every loss term is final here (text-decoder NLL joined above)
-    if (rc == MMVAE_OK) rc = launch_latent3_bwd(lb, s);
+    if (rc == MMVAE_OK) {
+        arm_fork(P);                // the text encoder's backward and classifier.6's weight gradient fork off this kernel
+        rc = launch_latent3_bwd(lb, s);
+        if (rc == MMVAE_OK) rc = commit_fork(P, s);
+    }
     if (rc == MMVAE_OK) rc = flush_wgrads(P, s);
-    if (rc == MMVAE_OK) rc = edge(P, s, T);
+    if (rc == MMVAE_OK && T != s) rc = fork_to(P, T);
     if (rc == MMVAE_OK) rc = txt_enc_bwd(P, io.text, w.d_txtout, T);
     if (rc == MMVAE_OK) rc = enc_bwd(P, w.d_encout, 2, m1, m2, enc_drop, s, fuse);
     P.wgrad_forked = false;
+    P.in_step = false;
     MMVAE_TRY(rc);
     MMVAE_TRY(edge(P, T, s));
     MMVAE_TRY(edge(P, P.st_wgrad, s));
@@ -1031,13 +1123,13 @@ static bool layer_gemm(MMPlan& P, const std::string& name, GemmParams& g) {
     for (int l = 1; l < 4; ++l) {
         const ConvL& L = P.conv[l];
         if (name == "enc_conv" + std::to_string(l + 1)) {
-            g = gemm_of(P, L.fwd, L.pk_fwd, 1, B);
+            g = gemm_of(P, L.fwd, L.pk_fwd, 1, B, L.pk_fwd_f);
             g.c.A = a[l - 1];
             g.out_bf = r[l]; g.ldo = L.g.Cout; g.colstats = w.st_e[l - 1];
             return true;
         }
         if (name == "enc_conv" + std::to_string(l + 1) + "_dgrad") {
-            g = gemm_of(P, L.dgrad, L.pk_dgrad, 1, B);
+            g = gemm_of(P, L.dgrad, L.pk_dgrad, 1, B, L.pk_dgrad_f);
             g.c.A = dre[l]; g.out_bf = dre[l - 1]; g.ldo = L.g.Cin;
             g.d_r = r[l - 1]; g.d_ld = L.g.Cin; g.d_act = ACT_SWISH;
             if (l > 1) { g.d_affine = w.aff_e[l - 2]; g.d_meanrstd = w.mr_e[l - 2]; g.d_red = w.red_e[l - 2]; }
@@ -1107,13 +1199,13 @@ static bool layer_gemm(MMPlan& P, const std::string& name, GemmParams& g) {
     for (int l = 0; l < 3; ++l) {
         const ConvL& L = P.convT[l];
         if (name == "dec_convT" + std::to_string(l + 1)) {
-            g = gemm_of(P, L.fwd, L.pk_fwd, 3, B);
+            g = gemm_of(P, L.fwd, L.pk_fwd, 3, B, L.pk_fwd_f);
             g.c.A = aq[l];
             g.out_bf = q[l + 1]; g.ldo = L.g.Cout; g.colstats = w.st_d[l];
             return true;
         }
         if (name == "dec_convT" + std::to_string(l + 1) + "_dgrad") {
-            g = gemm_of(P, L.dgrad, L.pk_dgrad, 2, B);
+            g = gemm_of(P, L.dgrad, L.pk_dgrad, 2, B, L.pk_dgrad_f);
             g.c.A = dq[l + 1]; g.out_bf = dq[l]; g.ldo = L.g.Cin;
             g.d_r = q[l]; g.d_ld = L.g.Cin; g.d_act = ACT_SWISH;
             if (l > 0) { g.d_affine = w.aff_d[l - 1]; g.d_meanrstd = w.mr_d[l - 1]; g.d_red = w.red_d[l - 1]; }

@@ -6,6 +6,7 @@
 #include "layers.h"
 #include <map>
 #include <mutex>
+#include <functional>
 #include <cstdlib>
 
 constexpr float BN_EPS = 1e-5f, BN_MOM = 0.1f, DROP_P = 0.1f;
@@ -29,6 +30,7 @@ struct ConvL {
     int bn;                       // index into bn tables or -1
     GatherPlan fwd, dgrad;        // geometry templates (groups/pointers filled per call)
     int pk_fwd[4], pk_dgrad[4], gk[4];
+    int pk_fwd_f[4] = {-1, -1, -1, -1}, pk_dgrad_f[4] = {-1, -1, -1, -1};   // fragment-major copies (add_frag_packs) or -1
     bool wgrad_fwdform = false;   // transposed conv: weight gradient in the data-gradient geometry (gk[0] only)
 };
 struct LinL {
@@ -56,6 +58,9 @@ struct PlanBase {
     std::vector<WgradParams> deferred;
     std::vector<hipEvent_t> events;
     size_t next_event = 0;
+    hipEvent_t fork_ev = nullptr;   // the event of the last arm_fork / commit_fork pair
+    std::vector<std::function<int(hipStream_t)>> side_pending;   // side-stream work waiting for the next fork (side_later / side_flush)
+    bool in_step = false;           // a fused multi-stream step is being enqueued (arm_fork / commit_fork are no-ops otherwise)
     hipEvent_t ev_early = nullptr;  // data-parallel step: the early gradient part is complete in the flat buffer
     bool wgrad_forked = false;
     unsigned dec_skip_mask = 0;     // bit k: pass k is absent from this step (weak-supervision variants): its decoder BatchNorm
@@ -80,6 +85,7 @@ struct PlanBase {
 
 
 inline int edge(PlanBase& P, hipStream_t from, hipStream_t to);
+inline hipEvent_t next_ev(PlanBase& P);
 
 // weight gradients only feed the optimizer: when the step runs multi-stream they go to the side stream
 inline int wgrad_async(PlanBase& P, const WgradParams& g, hipStream_t s) {
@@ -93,6 +99,70 @@ inline int wgrad_async(PlanBase& P, const WgradParams& g, hipStream_t s) {
     // at the end of the step would read every slab of the step on the critical tail)
     static const bool late = getenv("MMVAE_WGRAD_REDUCE_LATE") != nullptr;
     return late ? MMVAE_OK : launch_wgrad_reduce(&P.slab, w, true);
+}
+
+// ---- forks bound to a kernel's completion (common.h: MMVAE_LAUNCH)
+//   arm_fork(P);  <launch ONE main-chain kernel>;  commit_fork(P, s);  then fork_to(P, stream) any number of times
+// A launcher that does not go through MMVAE_LAUNCH leaves the event unclaimed: commit_fork records it the old way.
+inline void arm_fork(PlanBase& P) {
+    if (!P.in_step) return;
+    P.fork_ev = next_ev(P);
+    if (!mmvae_knob("no_stop_events", 0)) mmvae_arm_stop_event(P.fork_ev);
+}
+inline int commit_fork(PlanBase& P, hipStream_t s) {
+    if (!P.in_step) return MMVAE_OK;
+    const bool unclaimed = mmvae_take_stop_event() != nullptr || mmvae_knob("no_stop_events", 0);
+    if (unclaimed && hipEventRecord(P.fork_ev, s) != hipSuccess) {
+        mmvae_set_error("stream fork failed: %s", hipGetErrorString(hipGetLastError()));
+        return MMVAE_EHIP;
+    }
+    return MMVAE_OK;
+}
+inline int fork_to(PlanBase& P, hipStream_t to) {
+    {
+        const int k = mmvae_knob("dbg_skip_edges", 0);
+        if (k == 1 || k == 2) return MMVAE_OK;
+    }
+    if (hipStreamWaitEvent(to, P.fork_ev, 0) != hipSuccess) {
+        mmvae_set_error("stream fork failed: %s", hipGetErrorString(hipGetLastError()));
+        return MMVAE_EHIP;
+    }
+    return MMVAE_OK;
+}
+// the weight-gradient side stream (alternating when the plan has two), or `s` when the step is not forked; the caller has
+// committed a fork event for the kernel that produced the operands
+inline int wgrad_fork(PlanBase& P, hipStream_t s, hipStream_t* w) {
+    static const bool serial = getenv("MMVAE_SERIAL") != nullptr;
+    if (!P.wgrad_forked || serial) { *w = s; return MMVAE_OK; }
+    *w = (P.wgrad_rr++ & 1) ? P.st_wgrad2 : P.st_wgrad;
+    return fork_to(P, *w);
+}
+
+// Side-stream work (weight gradients and the elementwise passes in front of them) is collected and issued behind the NEXT
+// fork the main chain makes anyway: every fork costs the main chain ~5-6 us, and the one weight-gradient stream carries a
+// backlog through most of the backward pass, so a fork per layer bought nothing.
+inline void side_later(PlanBase& P, std::function<int(hipStream_t)> fn) { P.side_pending.push_back(std::move(fn)); }
+inline int side_flush(PlanBase& P, hipStream_t s) {
+    if (P.side_pending.empty()) return MMVAE_OK;
+    static const bool serial = getenv("MMVAE_SERIAL") != nullptr;
+    int rc = MMVAE_OK;
+    if (!P.wgrad_forked || serial) {
+        for (auto& fn : P.side_pending)
+            if (rc == MMVAE_OK) rc = fn(s);
+        P.side_pending.clear();
+        return rc;
+    }
+    // the pieces are independent of each other: they alternate between the weight-gradient streams (each of these kernels is a
+    // latency chain on a fraction of the chip; two of them side by side finish sooner than one after the other)
+    hipStream_t w[2] = {P.st_wgrad, P.st_wgrad2};
+    bool forked[2] = {false, false};
+    for (auto& fn : P.side_pending) {
+        const int i = (w[0] == w[1]) ? 0 : (P.wgrad_rr++ & 1);
+        if (!forked[i]) { forked[i] = true; if (rc == MMVAE_OK) rc = fork_to(P, w[i]); }
+        if (rc == MMVAE_OK) rc = fn(w[i]);
+    }
+    P.side_pending.clear();
+    return rc;
 }
 
 // The side stream a weight gradient issued now would run on (after an edge from `s`), or `s` itself when the step is not forked:
@@ -211,8 +281,18 @@ inline void build_conv(PlanBase& P, ConvL& L, const std::string& wname, ConvGeom
     }
 }
 
+// Fragment-major copies (PackDesc::frag) of a conv layer's forward / data-gradient weight packs: what the direct-B
+// image-resident kernels stream (convres.hip).  Call after build_conv for the layers whose weights dwarf their activations.
+inline void add_frag_packs(PlanBase& P, ConvL& L) {
+    for (int i = 0; i < 4; ++i) {
+        if (L.pk_fwd[i] >= 0) { PackDesc d = P.pk.d[L.pk_fwd[i]]; d.frag = 1; L.pk_fwd_f[i] = P.pk.add(d); }
+        if (L.pk_dgrad[i] >= 0) { PackDesc d = P.pk.d[L.pk_dgrad[i]]; d.frag = 1; L.pk_dgrad_f[i] = P.pk.add(d); }
+    }
+}
+
 // ------------------------------------------------------------------ launch helpers
-inline GemmParams gemm_of(const PlanBase& P, const GatherPlan& pl, const int* pk, int groups, int group_n) {
+// pkf: optional fragment-major copies of the same matrices (GatherClass::Wf)
+inline GemmParams gemm_of(const PlanBase& P, const GatherPlan& pl, const int* pk, int groups, int group_n, const int* pkf = nullptr) {
     GemmParams g{};
     g.c = pl.c; g.c.groups = groups; g.c.group_n = group_n;
     g.npad = P.pk.d[pk[0]].Npad;
@@ -221,6 +301,7 @@ inline GemmParams gemm_of(const PlanBase& P, const GatherPlan& pl, const int* pk
         g.cls[i] = pl.cls[i];
         g.cls[i].rows_per_group = group_n * pl.cls[i].OY * pl.cls[i].OX;
         g.cls[i].Wp = P.buf.packed + P.pk.d[pk[i]].dst_off;
+        g.cls[i].Wf = (pkf && pkf[i] >= 0) ? P.buf.packed + P.pk.d[pkf[i]].dst_off : nullptr;
         max_tiles = max(max_tiles, ceil_div(g.cls[i].rows_per_group, 128));
         min_nk = min(min_nk, ceil_div(g.cls[i].K, 64));
     }
@@ -377,6 +458,11 @@ inline hipEvent_t next_ev(PlanBase& P) {
 }
 // `to` waits for everything enqueued on `from` so far
 inline int edge(PlanBase& P, hipStream_t from, hipStream_t to) {
+    {   // measurement aid (only meaningful with the side work switched off): 1 all edges, 2 forks (main -> side), 3 joins
+        const int k = mmvae_knob("dbg_skip_edges", 0);
+        const bool to_side = to == P.st_text || to == P.st_wgrad || to == P.st_wgrad2;
+        if (k == 1 || (k == 2 && to_side) || (k == 3 && !to_side)) return MMVAE_OK;
+    }
     hipEvent_t e = next_ev(P);
     if (hipEventRecord(e, from) != hipSuccess || hipStreamWaitEvent(to, e, 0) != hipSuccess) {
         mmvae_set_error("stream fork/join failed: %s", hipGetErrorString(hipGetLastError()));
@@ -442,7 +528,9 @@ inline void join_after_error(PlanBase& P, hipStream_t s) {
     }
     P.deferred.clear();
     P.slab.jobs.clear();
-    P.defer_wgrad = false; P.wgrad_forked = false; P.no_splitk = false;
+    P.defer_wgrad = false; P.wgrad_forked = false; P.no_splitk = false; P.in_step = false;
+    (void)mmvae_take_stop_event();
+    P.side_pending.clear();
 }
 
 inline int check_bound(const PlanBase* P) {

@@ -50,4 +50,7 @@ struct DecLastFusedArgs {
     float* wslab;            // [bwd_groups*B*strips][Cin][16]: per-workgroup weight-gradient partials (plain stores)
 };
 int dec_last_fused_strips(int IH);
+// matrix-core form (dec_last.hip): one workgroup per image, i.e. ONE weight-gradient partial per image (strips = 1)
+bool dec_last_mfma_applies(const DecLastFusedArgs& a);
+int launch_dec_last_mfma(const DecLastFusedArgs& a, hipStream_t s);
 int launch_dec_last_fused(const DecLastFusedArgs& a, hipStream_t s);

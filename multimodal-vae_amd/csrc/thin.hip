@@ -468,6 +468,7 @@ int launch_dec_last_fused(const DecLastFusedArgs& a, hipStream_t s) {
                   "dec last fused: Cin=%d G=%d bwd_groups=%d", a.Cin, a.G, a.bwd_groups);
     MMVAE_REQUIRE(a.bwd_groups == 0 || (a.target && a.db && a.red && a.wslab), "dec last fused: backward outputs missing");
     MMVAE_REQUIRE(!a.fin.training || a.fin.count > 1.f, "Expected more than 1 value per channel when training");
+    if (dec_last_mfma_applies(a)) return launch_dec_last_mfma(a, s);
     const int strips = dec_last_fused_strips(a.IH);
     const int TW = a.IW + 2, DLW = 2 * a.IW + 2;
     const size_t lds = (size_t)16 * 32 * sizeof(bf16) + (size_t)32 * 16 * sizeof(float) + 2 * 32 * sizeof(float2) +
@@ -475,6 +476,6 @@ int launch_dec_last_fused(const DecLastFusedArgs& a, hipStream_t s) {
                        (size_t)(2 * FR + 2) * 2 * a.IW * sizeof(float) + (size_t)2 * (FR + 2) * TW * 32 * sizeof(bf16);
     MMVAE_REQUIRE((FR + 2) * TW * 4 <= 1024 && (size_t)(FR + 2) * TW * 32 * sizeof(bf16) >= (size_t)4 * 32 * 16 * sizeof(float),
                   "dec last fused: IW=%d out of range", a.IW);
-    hipLaunchKernelGGL(dec_last_fused_kernel<32>, dim3(a.B * strips, a.G), dim3(TPB), lds, s, a);
+    MMVAE_LAUNCH(dec_last_fused_kernel<32>, dim3(a.B * strips, a.G), dim3(TPB), lds, s, a);
     return mmvae_check_launch("dec_last_fused");
 }

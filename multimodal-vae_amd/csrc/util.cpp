@@ -76,3 +76,12 @@ extern "C" int mmvae_debug_set(const char* key, int value) {
     g_knobs[g_nknobs++].value = value;
     return MMVAE_OK;
 }
+
+// ---- completion event of the next launch (common.h: MMVAE_LAUNCH)
+static thread_local hipEvent_t g_stop_event = nullptr;
+void mmvae_arm_stop_event(hipEvent_t e) { g_stop_event = e; }
+hipEvent_t mmvae_take_stop_event() {
+    hipEvent_t e = g_stop_event;
+    g_stop_event = nullptr;
+    return e;
+}

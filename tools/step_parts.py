@@ -23,9 +23,12 @@ def timeit(n=300):
     return (time.perf_counter() - t0) / n * 1e6
 
 cases = [("full step", {}), ("no weight gradients", {"dbg_skip_wgrad": 1}), ("no text kernels", {"dbg_skip_text": 1}),
-         ("neither (main chain alone)", {"dbg_skip_wgrad": 1, "dbg_skip_text": 1})]
+         ("neither (main chain alone)", {"dbg_skip_wgrad": 1, "dbg_skip_text": 1}),
+         ("main chain alone, no event edges", {"dbg_skip_wgrad": 1, "dbg_skip_text": 1, "dbg_skip_edges": 1}),
+         ("main chain alone, no forks (records on main)", {"dbg_skip_wgrad": 1, "dbg_skip_text": 1, "dbg_skip_edges": 2}),
+         ("main chain alone, no joins (waits on main)", {"dbg_skip_wgrad": 1, "dbg_skip_text": 1, "dbg_skip_edges": 3})]
 extra = [a.split("=") for a in sys.argv[1:]]
 for name, knobs in cases:
-    for k in ("dbg_skip_wgrad", "dbg_skip_text"): call("mmvae_debug_set", k.encode(), knobs.get(k, 0))
+    for k in ("dbg_skip_wgrad", "dbg_skip_text", "dbg_skip_edges"): call("mmvae_debug_set", k.encode(), knobs.get(k, 0))
     for k, v in extra: call("mmvae_debug_set", k.encode(), int(v))
     print(f"{name:32s} {timeit():8.1f} us/step", flush=True)
