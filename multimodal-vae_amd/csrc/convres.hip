@@ -82,9 +82,15 @@ constexpr int tab_base(int c) {
 // k-steps ahead (fragment-major packed weights: a fragment is two contiguous 512-byte runs).  No weight buffer, no barrier
 // after the staging one: for the layers whose weights dwarf their activations (N >= 64, K >= 512 at 6x6 / 12x12 pixels) a
 // chunk of weights was 0.25 us of MFMA work behind two barriers and an exposed L2 round trip.
-template <class G, int NI, int CH, int WAVES, int NG, bool SCR_OWN>
+// NSPLIT: the output channels are split over gridDim.y workgroups (direct-B only: each streams its own weight columns).
+// KSPL: the k range of a tile is split over KSPL waves by tap ROW (partial tiles meet in LDS); for the layers with a handful of
+// pixels per image and K = 1024..2048, where a workgroup's images give one or two row tiles.
+template <class G, int NI, int CH, int WAVES, int NG, bool SCR_OWN, int NSPLIT = 1, int KSPL = 1>
 struct CrLayout {
     static constexpr int NTHR = WAVES * 64;
+    static constexpr int MG = WAVES / (NG * KSPL), NT = G::N / 32 / NSPLIT / NG;
+    static constexpr int max_mt() { int m = 0; for (int c = 0; c < G::NCLS; ++c) m = crgeo::cmax(m, crgeo::cdiv(crgeo::cdiv(NI * G::OYX(c), 32), MG)); return m; }
+    static constexpr int RED_BYTES = KSPL > 1 ? WAVES * max_mt() * NT * 4096 : 0;
     static constexpr bool BDIR = CH == 0;
     static constexpr int BP = (CH * 16 + 8) * 2;            // weight row pitch in LDS (bytes): odd multiple of 16
     static constexpr int W_BYTES = BDIR ? 0 : G::N * BP;
@@ -94,17 +100,18 @@ struct CrLayout {
     static constexpr int SCR_PITCH = 80, SCR_BYTES = 32 * SCR_PITCH;   // per-wave epilogue scratch [32 rows][64 B + 16]
     static constexpr int TRT_BYTES = G::C * 16;             // per-channel staging-transform coefficients
     static constexpr int OFF_W = IMG_ALL, OFF_TAB = OFF_W + W_BYTES, OFF_TRT = OFF_TAB + TAB_BYTES,
-                         OFF_SCR = OFF_TRT + TRT_BYTES, TOTAL = OFF_SCR + (SCR_OWN ? WAVES * SCR_BYTES : 0);
+                         OFF_SCR = OFF_TRT + TRT_BYTES, OFF_RED = OFF_SCR + (SCR_OWN ? WAVES * SCR_BYTES : 0), TOTAL = OFF_RED + RED_BYTES;
+    static_assert((NSPLIT == 1 && KSPL == 1) || BDIR, "column / k splits exist for the direct-B kernels only");
+    static_assert(G::N % (32 * NSPLIT * NG) == 0 && WAVES % (NG * KSPL) == 0, "wave decomposition");
     static_assert(SCR_OWN || W_BYTES >= WAVES * SCR_BYTES, "the weight buffer doubles as the epilogue scratch");
     static_assert(TOTAL <= 160 * 1024, "LDS budget");
 };
 
 // MODE 0: forward (raw bf16 store + column statistics); MODE 1: data gradient (d-Swish of the saved tensor + BatchNorm-backward sums)
-template <class G, int NI, int CH, int WAVES, int NG, bool SCR_OWN, int MODE, int TR>
+template <class G, int NI, int CH, int WAVES, int NG, bool SCR_OWN, int MODE, int TR, int NSPLIT = 1, int KSPL = 1>
 __global__ __launch_bounds__(WAVES * 64) void convres_kernel(const ConvResArgs a) {
-    using L = CrLayout<G, NI, CH, WAVES, NG, SCR_OWN>;
-    constexpr int NTOT = G::N / 32, NT = NTOT / NG, MG = WAVES / NG, NTHR = WAVES * 64;
-    static_assert(NTOT % NG == 0 && WAVES % NG == 0, "column groups");
+    using L = CrLayout<G, NI, CH, WAVES, NG, SCR_OWN, NSPLIT, KSPL>;
+    constexpr int NT = L::NT, MG = L::MG, NTHR = WAVES * 64;
     constexpr int BP = L::BP, SCR_PITCH = L::SCR_PITCH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const img_s = smem;
@@ -115,7 +122,8 @@ __global__ __launch_bounds__(WAVES * 64) void convres_kernel(const ConvResArgs a
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int ng = wave % NG, mg = wave / NG;
+    const int kg = wave % KSPL, ng = (wave / KSPL) % NG, mg = wave / (KSPL * NG);
+    const int ntb = blockIdx.y * (G::N / 32 / NSPLIT) + ng * NT;        // first 32-channel tile of this wave
     const int img0 = blockIdx.x * NI;
     const int grp = img0 / a.group_n;
     auto stamp = [&](int idx) {
@@ -223,7 +231,7 @@ __global__ __launch_bounds__(WAVES * 64) void convres_kernel(const ConvResArgs a
                 bn_channel_tables(a.fin, grp, ch, aff, mr);
                 trt[ch] = make_float4(aff.x, aff.y, 0.f, 0.f);
             }
-            if (blockIdx.x == 0) {       // the tables backward reads, the running statistics: once per layer
+            if (blockIdx.x == 0 && blockIdx.y == 0) {       // the tables backward reads, the running statistics: once per layer
                 for (int i = tid; i < a.fin.G * G::C; i += NTHR) {
                     float2 aff, mr;
                     bn_channel_tables(a.fin, i / G::C, i % G::C, aff, mr);
@@ -244,7 +252,7 @@ __global__ __launch_bounds__(WAVES * 64) void convres_kernel(const ConvResArgs a
                 const float cb = -g * m2 * mr.y;
                 trt[ch] = make_float4(g, cb, -cb * mr.x - g * m1, 0.f);
             }
-            if (blockIdx.x == 0 && (a.t_dgamma || a.t_dbeta)) {
+            if (blockIdx.x == 0 && blockIdx.y == 0 && (a.t_dgamma || a.t_dbeta)) {
                 for (int ch = tid; ch < G::C; ch += NTHR) {
                     float tg = 0.f, tb = 0.f;
                     for (int gg = 0; gg < a.t_groups; ++gg)
@@ -288,7 +296,7 @@ __global__ __launch_bounds__(WAVES * 64) void convres_kernel(const ConvResArgs a
     float dsc[NT], dsh[NT], dmean[NT], drstd[NT], s1[NT], s2[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int co = (ng * NT + nt) * 32 + r;
+        const int co = (ntb + nt) * 32 + r;
         dsc[nt] = 1.f; dsh[nt] = 0.f; dmean[nt] = 0.f; drstd[nt] = 0.f; s1[nt] = 0.f; s2[nt] = 0.f;
         if (MODE == 1 && a.d_affine) { const float2 t = a.d_affine[grp * G::N + co]; dsc[nt] = t.x; dsh[nt] = t.y; }
         if (MODE == 1 && a.d_meanrstd) { const float2 t = a.d_meanrstd[grp * G::N + co]; dmean[nt] = t.x; drstd[nt] = t.y; }
@@ -306,6 +314,7 @@ __global__ __launch_bounds__(WAVES * 64) void convres_kernel(const ConvResArgs a
         constexpr int c = decltype(ci)::value;
         constexpr int ROWS = NI * G::OYX(c), T = crgeo::cdiv(ROWS, 32), MT = crgeo::cdiv(T, MG);
         constexpr int KS = G::KSTEPS(c), CHE = BDIR ? KS : CH, NCH = crgeo::cdiv(KS, CHE);
+        constexpr int KSL = KS / KSPL;                       // k-steps of this wave
         // this wave's row tiles: mg, mg + MG, ...
         int abase[MT];
 #pragma unroll
@@ -316,6 +325,11 @@ __global__ __launch_bounds__(WAVES * 64) void convres_kernel(const ConvResArgs a
             const int img = R / G::OYX(c), q = R - img * G::OYX(c);
             const int jy = q / G::OX(c), jx = q - jy * G::OX(c);
             abase[m] = img * G::IMG_BYTES + G::base0(c) + jy * G::row_stride(c) + jx * G::col_stride(c) + h * 16;
+            if constexpr (KSPL > 1) {                        // this wave's tap rows: a constant offset (both forms are linear in ty)
+                static_assert(G::TH(c) % KSPL == 0, "the k split is by tap row");
+                constexpr int KSL_ = KS / KSPL;
+                abase[m] += kg * (G::step_off(c, KSL_) - G::step_off(c, 0));
+            }
         }
         f32x16 acc[MT][NT];
 #pragma unroll
@@ -328,11 +342,13 @@ __global__ __launch_bounds__(WAVES * 64) void convres_kernel(const ConvResArgs a
 
         if constexpr (BDIR) {
             // weight fragments straight from L2, PD k-steps ahead; activation fragments from LDS one step ahead
-            constexpr int PD = KS < 8 ? KS : 8;
+            constexpr int PD = KSL < 8 ? KSL : 8;
+            static_assert(KSPL == 1 || KSL % 2 == 0, "a wave's k range starts on a 32-column block of the packed weights");
             unsigned voff[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                voff[nt] = (unsigned)(((2 * (ng * NT + nt) + (r >> 4)) * (a.Kpad[c] >> 5) * 64 + h * 16 + (r & 15)) * 16);
+                voff[nt] = (unsigned)(((2 * (ntb + nt) + (r >> 4)) * (a.Kpad[c] >> 5) * 64 + h * 16 + (r & 15)) * 16) +
+                           (unsigned)(kg * (KSL / 2) * 1024);
             auto bload = [&](auto ki, bf16x8 (&fb)[NT]) {
                 constexpr int kk = decltype(ki)::value;
 #pragma unroll
@@ -350,8 +366,9 @@ __global__ __launch_bounds__(WAVES * 64) void convres_kernel(const ConvResArgs a
             aload(std::integral_constant<int, 0>{}, af);
             __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);
             if (!(a.dbg & 2))
-            static_for<0, KS>([&](auto ki) {
+            static_for<0, KSL>([&](auto ki) {
                 constexpr int kk = decltype(ki)::value;
+                constexpr int KS = KSL;                      // (the loop below runs over this wave's steps)
                 bf16x8 bcur[NT], an[MT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) bcur[nt] = bq[kk % PD][nt];
@@ -370,6 +387,35 @@ __global__ __launch_bounds__(WAVES * 64) void convres_kernel(const ConvResArgs a
                     for (int m = 0; m < MT; ++m) af[m] = an[m];
                 }
             });
+            if constexpr (KSPL > 1) {
+                // partial tiles of the KSPL waves of a tile meet in LDS; wave kg == 0 carries on with the sum
+                float* const red = reinterpret_cast<float*>(smem + L::OFF_RED);
+                constexpr int WSTR = L::max_mt() * NT * 1024;            // floats per wave
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int v4 = 0; v4 < 4; ++v4)
+                            *reinterpret_cast<f32x4*>(red + wave * WSTR + ((m * NT + nt) * 64 + lane) * 16 + v4 * 4) =
+                                f32x4{acc[m][nt][4 * v4], acc[m][nt][4 * v4 + 1], acc[m][nt][4 * v4 + 2], acc[m][nt][4 * v4 + 3]};
+                __syncthreads();
+                if (kg == 0) {
+#pragma unroll
+                    for (int k2 = 1; k2 < KSPL; ++k2)
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                                for (int v4 = 0; v4 < 4; ++v4) {
+                                    const f32x4 t = *reinterpret_cast<const f32x4*>(red + (wave + k2) * WSTR + ((m * NT + nt) * 64 + lane) * 16 + v4 * 4);
+                                    acc[m][nt][4 * v4] += t[0]; acc[m][nt][4 * v4 + 1] += t[1];
+                                    acc[m][nt][4 * v4 + 2] += t[2]; acc[m][nt][4 * v4 + 3] += t[3];
+                                }
+                }
+                __syncthreads();
+            }
         }
         static_for<0, NCH>([&](auto chi) {
             constexpr int ch = decltype(chi)::value;
@@ -418,13 +464,13 @@ __global__ __launch_bounds__(WAVES * 64) void convres_kernel(const ConvResArgs a
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     const int t = mg + m * MG;
-                    if (t < T) {
+                    if (t < T && kg == 0) {
                         const unsigned* trow = tab + tab_base<G, NI>(c) + t * 32;
                         const unsigned off0 = trow[lane & 15], off1 = trow[16 + (lane & 15)];
                         const int rows_left = ROWS - t * 32;                  // < 32: the class's last, partial tile
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) {
-                            const unsigned cob = (unsigned)(((ng * NT + nt) * 32 + (lane >> 4) * 8) * 2) + wg_out;
+                            const unsigned cob = (unsigned)(((ntb + nt) * 32 + (lane >> 4) * 8) * 2) + wg_out;
                             if (rows_left >= 32)
                                 cr_epilogue_tile<MODE, false>(acc[m][nt], scr, lane, 32, off0 + cob, off1 + cob, orsrc, rrsrc,
                                                               dsc[nt], dsh[nt], dmean[nt], drstd[nt], s1[nt], s2[nt], !(a.dbg & 1));
@@ -447,13 +493,13 @@ __global__ __launch_bounds__(WAVES * 64) void convres_kernel(const ConvResArgs a
     stamp(13);
     // ---- column sums: one atomic pair per channel per wave
     float2* red = MODE == 1 ? a.d_red : a.colstats;
-    if (red) {
+    if (red && kg == 0) {
         const int slot = (int)(blockIdx.x + wave) % MMVAE_STAT_SLOTS;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const float t1 = s1[nt] + __shfl_xor(s1[nt], 32, 64), t2 = s2[nt] + __shfl_xor(s2[nt], 32, 64);
             if (h == 0) {
-                float2* d = red + ((size_t)grp * MMVAE_STAT_SLOTS + slot) * G::N + (ng * NT + nt) * 32 + r;
+                float2* d = red + ((size_t)grp * MMVAE_STAT_SLOTS + slot) * G::N + (ntb + nt) * 32 + r;
                 atomicAdd(&d->x, t1);
                 atomicAdd(&d->y, t2);
             }
@@ -487,19 +533,19 @@ bool geo_matches(const GemmParams& p) {
     return true;
 }
 
-template <class G, int NI, int CH, int WAVES, int NG, bool SCR_OWN, int MODE, int TR>
+template <class G, int NI, int CH, int WAVES, int NG, bool SCR_OWN, int MODE, int TR, int NSPLIT, int KSPL>
 int launch_cr_mode(const ConvResArgs& a, hipStream_t stream) {
-    using L = CrLayout<G, NI, CH, WAVES, NG, SCR_OWN>;
+    using L = CrLayout<G, NI, CH, WAVES, NG, SCR_OWN, NSPLIT, KSPL>;
     static std::atomic<unsigned> attr_set{0};
     if (mmvae_first_use_on_device(attr_set))
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&convres_kernel<G, NI, CH, WAVES, NG, SCR_OWN, MODE, TR>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&convres_kernel<G, NI, CH, WAVES, NG, SCR_OWN, MODE, TR, NSPLIT, KSPL>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    MMVAE_LAUNCH((convres_kernel<G, NI, CH, WAVES, NG, SCR_OWN, MODE, TR>), dim3(a.nimg / NI), dim3(WAVES * 64), L::TOTAL, stream, a);
+    MMVAE_LAUNCH((convres_kernel<G, NI, CH, WAVES, NG, SCR_OWN, MODE, TR, NSPLIT, KSPL>), dim3(a.nimg / NI, NSPLIT), dim3(WAVES * 64), L::TOTAL, stream, a);
     MMVAE_TRY(mmvae_check_launch("convres"));
     return 1;
 }
 
-template <class G, int NI, int CH, int WAVES, int NG, bool SCR_OWN>
+template <class G, int NI, int CH, int WAVES, int NG, bool SCR_OWN, int NSPLIT = 1, int KSPL = 1>
 int launch_cr(const GemmParams& p, hipStream_t stream) {
     const GatherCommon& c = p.c;
     const int nimg = c.groups * c.group_n;
@@ -522,17 +568,17 @@ int launch_cr(const GemmParams& p, hipStream_t stream) {
         MMVAE_REQUIRE(a.fin.C == G::C && a.fin.G == c.groups && a.fin.affine && a.fin.meanrstd && a.fin.gamma && a.fin.beta,
                       "convres: BatchNorm tables of the staged operand do not match the layer");
         MMVAE_REQUIRE(!p.d_r, "convres: forward-type staging transform on a data-gradient launch");
-        return launch_cr_mode<G, NI, CH, WAVES, NG, SCR_OWN, 0, 1>(a, stream);
+        return launch_cr_mode<G, NI, CH, WAVES, NG, SCR_OWN, 0, 1, NSPLIT, KSPL>(a, stream);
     }
     if (kind == 2) {
         const GatherTransform& t = *p.tr;
         MMVAE_REQUIRE(p.d_r && t.r && t.red && t.mr && t.gamma && t.groups == c.groups, "convres: BatchNorm-backward staging needs r / sums / tables");
         a.t_r = t.r; a.t_red = t.red; a.t_mr = t.mr; a.t_gamma = t.gamma; a.t_dgamma = t.dgamma; a.t_dbeta = t.dbeta;
         a.t_inv_cnt = t.inv_cnt; a.t_groups = t.groups;
-        return launch_cr_mode<G, NI, CH, WAVES, NG, SCR_OWN, 1, 2>(a, stream);
+        return launch_cr_mode<G, NI, CH, WAVES, NG, SCR_OWN, 1, 2, NSPLIT, KSPL>(a, stream);
     }
-    return p.d_r ? launch_cr_mode<G, NI, CH, WAVES, NG, SCR_OWN, 1, 0>(a, stream)
-                 : launch_cr_mode<G, NI, CH, WAVES, NG, SCR_OWN, 0, 0>(a, stream);
+    return p.d_r ? launch_cr_mode<G, NI, CH, WAVES, NG, SCR_OWN, 1, 0, NSPLIT, KSPL>(a, stream)
+                 : launch_cr_mode<G, NI, CH, WAVES, NG, SCR_OWN, 0, 0, NSPLIT, KSPL>(a, stream);
 }
 
 // the features of GemmParams this path implements
@@ -547,11 +593,11 @@ bool features_ok(const GemmParams& p) {
     return true;
 }
 
-template <class G, int NI, int CH, int WAVES, int NG, bool SCR_OWN>
+template <class G, int NI, int CH, int WAVES, int NG, bool SCR_OWN, int NSPLIT = 1, int KSPL = 1>
 int try_cr(const GemmParams& p, hipStream_t stream) {
     if (!geo_matches<G>(p)) return 0;
     if (p.c.group_n % NI != 0) return 0;
-    return launch_cr<G, NI, CH, WAVES, NG, SCR_OWN>(p, stream);
+    return launch_cr<G, NI, CH, WAVES, NG, SCR_OWN, NSPLIT, KSPL>(p, stream);
 }
 
 using crgeo::Geo;
@@ -562,6 +608,8 @@ typedef Geo<1, 128, 64, 6, 6, 12, 12, 4, 4, 2, 1> G_mm_convT2;         // halluc
 typedef Geo<1, 64, 32, 12, 12, 25, 25, 5, 5, 2, 1> G_mm_convT3;        // hallucinate.6 forward
 typedef Geo<1, 64, 32, 12, 12, 25, 25, 4, 4, 2, 1> G_mm_conv2d;        // features.2 data gradient
 typedef Geo<0, 32, 64, 25, 25, 12, 12, 5, 5, 2, 1> G_mm_convT3d;       // hallucinate.6 data gradient
+typedef Geo<1, 256, 128, 2, 2, 6, 6, 4, 4, 2, 0> G_mm_convT1;          // hallucinate.0 forward == features.8 data gradient
+typedef Geo<0, 128, 256, 6, 6, 2, 2, 4, 4, 2, 0> G_mm_conv4;           // features.8 forward == hallucinate.0 data gradient
 
 }  // namespace
 
@@ -587,6 +635,12 @@ int try_launch_convres(const GemmParams& p, hipStream_t stream) {
     if (alt == 1) { if ((rc = try_cr<G_mm_convT3, 4, 20, 8, 1, false>(p, stream)) != 0) return rc; }
     if ((rc = try_cr<G_mm_convT3, 2, 16, 4, 1, false>(p, stream)) != 0) return rc;
     if ((rc = try_cr<G_mm_conv2d, 1, 16, 8, 1, true>(p, stream)) != 0) return rc;
+    if (alt != 4) {       // the 2x2 <-> 6x6 bottleneck layers (1 MB of weights): output channels over 4 workgroups, k over the waves
+        //                          NI CH WAVES NG SCR_OWN NSPLIT KSPL
+        if (nimg > 256 && alt != 5) { if ((rc = try_cr<G_mm_convT1, 16, 0, 5, 1, true, 4, 1>(p, stream)) != 0) return rc; }   // one round of 192 workgroups
+        if ((rc = try_cr<G_mm_convT1, 8, 0, 6, 1, true, 4, 2>(p, stream)) != 0) return rc;
+        if ((rc = try_cr<G_mm_conv4, 8, 0, 8, 2, true, 4, 4>(p, stream)) != 0) return rc;
+    }
     if ((rc = try_cr<G_mm_convT3d, 2, 10, 8, 2, false>(p, stream)) != 0) return rc;
     MMVAE_REQUIRE(!forced, "convres: no kernel is compiled for the geometry of a launch with a staging transform");
     return 0;

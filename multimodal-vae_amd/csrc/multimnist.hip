@@ -40,7 +40,7 @@ struct MMPlan : PlanBase {
         bf16 *patches4, *d3, *d2, *d1, *du;
         bf16 *d_encout; float* d_txtout; bf16* te_dout_bf; bf16 *te_dgi_f, *te_dgh_f, *te_dgi_r;
         bf16 *dy2, *dy1, *db4, *dr4, *d3e, *d2e, *d1e;
-        bf16 *d3r, *d2r, *d3er, *d2er;       // BatchNorm-backward outputs kept apart from db (fused staging: see dec_bwd / enc_bwd)
+        bf16 *d3r, *d2r, *d1r, *d3er, *d2er;       // BatchNorm-backward outputs kept apart from db (fused staging: see dec_bwd / enc_bwd)
         float* tmp_f32;
         float* slab; size_t slab_floats;
     } w;
@@ -101,6 +101,8 @@ void build_plan(MMPlan& P) {
     build_conv(P, P.convT[3], "image_decoder.hallucinate.9.weight", ConvGeom{32, 1, 4, 4, 2, 1, 25, 25, 50, 50, true}, -1, true, false, true);
     add_frag_packs(P, P.conv[2]);      // 6x6 / 12x12 layers with 64-256 KB of weights per class: direct-B kernels (convres.hip)
     add_frag_packs(P, P.convT[1]);
+    add_frag_packs(P, P.conv[3]);      // the 2x2 <-> 6x6 bottleneck layers (1 MB of weights each)
+    add_frag_packs(P, P.convT[0]);
 
     // classifier (multimnist/model.py:173-179). fc1 consumes the NCHW flatten c*4+y*2+x of a (256,2,2) map that
     // lives here as NHWC [2][2][256]: a 2x2-tap gather with k = (y*2+x)*256 + c.
@@ -243,7 +245,7 @@ void carve(MMPlan& P, Workspace& ws) {
     w.dy2 = ws.take<bf16>(B2 * 200); w.dy1 = ws.take<bf16>(B2 * 400);
     w.db4 = ws.take<bf16>(B2 * 1024); w.dr4 = ws.take<bf16>(B * 1024);
     w.d3e = ws.take<bf16>(B * 36 * 128); w.d2e = ws.take<bf16>(B * 144 * 64); w.d1e = ws.take<bf16>(B * 625 * 32);
-    w.d3r = ws.take<bf16>(B3 * 625 * 32); w.d2r = ws.take<bf16>(B3 * 144 * 64);
+    w.d3r = ws.take<bf16>(B3 * 625 * 32); w.d2r = ws.take<bf16>(B3 * 144 * 64); w.d1r = ws.take<bf16>(B3 * 36 * 128);
     w.d3er = ws.take<bf16>(B * 36 * 128); w.d2er = ws.take<bf16>(B * 144 * 64);
     w.tmp_f32 = ws.take<float>(B3 * NPIX);
     P.sk_floats = (size_t)256 * 128 * 128;                 // split-K partial slabs (fully overwritten, never zeroed)
@@ -279,15 +281,15 @@ int enc_fwd(MMPlan& P, const float* image, int variants, const uint8_t* m1, cons
         g.out_bf = r[l]; g.ldo = L.g.Cout;
         g.colstats = training ? w.st_e[l - 1] : nullptr;
         GatherTransform tr{};
-        if (fuse && l == 2) {          // conv3 stages Swish(BatchNorm(r2)) itself
-            const int prows = B * P.conv[1].g.OH * P.conv[1].g.OW;
+        if (fuse && l >= 2) {          // conv3 / conv4 stage Swish(BatchNorm(raw output of the layer below)) themselves
+            const int prows = B * P.conv[l - 1].g.OH * P.conv[l - 1].g.OW;
             tr.kind = 1;
-            tr.fin = bn_fin_args(P, P.bn[P.conv[1].bn], prows, 1, w.st_e[0], bn_updates, w.aff_e[0], w.mr_e[0], training);
-            g.c.A = r[1]; g.tr = &tr;
+            tr.fin = bn_fin_args(P, P.bn[P.conv[l - 1].bn], prows, 1, w.st_e[l - 2], bn_updates, w.aff_e[l - 2], w.mr_e[l - 2], training);
+            g.c.A = r[l - 1]; g.tr = &tr;
         }
         MMVAE_TRY(launch_gemm_gather(g, s));
         const int rows = B * L.g.OH * L.g.OW;
-        if (fuse && l == 1) continue;  // a2 is made in front of conv3's weight gradient (enc_bwd)
+        if (fuse && l <= 2) continue;  // a2 / a3 are made in front of the next layer's weight gradient (enc_bwd)
         MMVAE_TRY(bn_act(P, P.bn[L.bn], r[l], a[l], rows, rows, 1, w.st_e[l - 1], bn_updates, w.aff_e[l - 1], w.mr_e[l - 1], training, s));
     }
     const int rows = variants * B;
@@ -449,21 +451,21 @@ int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const
                     gw.c.A = r[1];
                 }
             }
-            if (mmvae_knob("mm_wkernel", 0) || !fl) {
+            if (mmvae_knob("mm_wkernel", 0) && fl) {
                 side_later(P, [pp, gw, tp, ta](hipStream_t ws_) mutable {
                     gw.trA = ta.kind ? &ta : nullptr; gw.trP = tp.kind ? &tp : nullptr;
                     return wgrad_on(*pp, gw, ws_);
                 });
-            } else {        // A/B aid: materialise the operands in front of the streamed weight-gradient kernel
-                const bool act2 = l == 2;
-                const int prows = B * P.conv[1].g.OH * P.conv[1].g.OW;
-                const BnL bp = P.bn[P.conv[1].bn];
-                const bf16* rin = r[1]; bf16* ao = a[1]; const float2* st = w.st_e[0];
+            } else {        // the streamed weight-gradient kernel on operands materialised right in front of it (side stream)
+                const bool actp = l >= 2;              // a[l-1] = Swish(BatchNorm(r[l-1])) was never materialised (conv3, conv4)
+                const int prows = B * P.conv[l >= 2 ? l - 1 : 1].g.OH * P.conv[l >= 2 ? l - 1 : 1].g.OW;
+                const BnL bp = P.bn[P.conv[l >= 2 ? l - 1 : 1].bn];
+                const bf16* rin = r[l >= 2 ? l - 1 : 1]; bf16* ao = a[l >= 2 ? l - 1 : 1]; const float2* st = w.st_e[l >= 2 ? l - 2 : 0];
                 WgradParams g0 = wgrad_of(P, L.fwd, L.gk, 1, B);
                 g0.c.A = a[l - 1]; g0.P = x.dr; g0.ldp = L.g.Cout;
-                side_later(P, [pp, x, g0, act2, bp, rin, ao, st, prows](hipStream_t ws_) {
-                    MMVAE_TRY(launch_bn_bwd_apply(x, ws_));
-                    if (act2) MMVAE_TRY(bn_act_side(*pp, bp, rin, ao, prows, prows, 1, st, 1, ws_));
+                side_later(P, [pp, x, g0, fl, actp, bp, rin, ao, st, prows](hipStream_t ws_) {
+                    if (fl) MMVAE_TRY(launch_bn_bwd_apply(x, ws_));
+                    if (actp) MMVAE_TRY(bn_act_side(*pp, bp, rin, ao, prows, prows, 1, st, 1, ws_));
                     return wgrad_on(*pp, g0, ws_);
                 });
             }
@@ -590,7 +592,7 @@ int dec_bwd(MMPlan& P, const float* dlogit, int groups, float* dz, hipStream_t s
     bf16* q[4] = {w.u, w.q1, w.q2, w.q3};
     bf16* aq[4] = {w.au, w.aq1, w.aq2, w.aq3};
     bf16* dq[4] = {w.du, w.d1, w.d2, w.d3};
-    bf16* dqr[4] = {nullptr, nullptr, w.d2r, w.d3r};         // fused layers: BatchNorm-backward output apart from db
+    bf16* dqr[4] = {nullptr, w.d1r, w.d2r, w.d3r};         // fused layers: BatchNorm-backward output apart from db
     if (last_fused) {
         // d3, the BatchNorm-backward sums and the weight-gradient partials of the last layer came out of the fused tail
         // (dec_fwd); only the sum of the partials is left, off the main chain
@@ -629,7 +631,7 @@ int dec_bwd(MMPlan& P, const float* dlogit, int groups, float* dz, hipStream_t s
         // convT3 / convT2: the image-resident data-gradient kernel applies the BatchNorm backward while it stages db
         // (GatherTransform kind 2); dr and the activated layer input are only the weight gradient's operands and are made in
         // front of it on the side stream (enc_bwd has the same arrangement)
-        const bool fl = fuse && l >= 1;
+        const bool fl = fuse;          // (hallucinate.0 too: its input is the upsample Linear's activation, no BatchNorm below it)
         BnBwdApplyArgs x{};
         x.db = dq[l + 1]; x.r = q[l + 1]; x.dr = fl ? dqr[l + 1] : dq[l + 1]; x.rows = rows * pix; x.C = L.g.Cout; x.ld = L.g.Cout;
         x.rows_per_group = B * pix; x.G = groups;
@@ -642,30 +644,33 @@ int dec_bwd(MMPlan& P, const float* dlogit, int groups, float* dz, hipStream_t s
         // weight gradient needs anyway (one bound event less on the main chain)
         WgradParams gw = convT_wgrad(P, L, groups, B, aq[l], x.dr);
         if (fl) {
-            // The image-resident weight-gradient kernel (convres_wgrad.hip) stages both operands itself: the layer input
-            // aq[l] = Swish(BatchNorm(q[l])) out of the raw tensor, the output gradient's BatchNorm backward out of db -- neither
-            // is materialised any more, and the BatchNorm parameter gradients are added there
-            const ConvL& Lp = P.convT[l - 1];
-            const int prpg = B * Lp.g.OH * Lp.g.OW;
-            GatherTransform tp{}, ta{};
-            tp.kind = 1;
-            tp.fin = bn_fin_args(P, P.bn[Lp.bn], prpg, groups, w.st_d[l - 1], 0, nullptr, nullptr, training);
-            ta.kind = 2; ta.r = q[l + 1]; ta.red = w.red_d[l]; ta.mr = w.mr_d[l]; ta.gamma = P.buf.params + b.w_off;
-            ta.dgamma = P.buf.grads + b.w_off; ta.dbeta = P.buf.grads + b.b_off;
-            ta.inv_cnt = 1.f / (float)(B * pix); ta.groups = groups;
             MMPlan* pp = &P;
-            if (mmvae_knob("mm_wkernel", 0)) {
+            const ConvL& Lp = P.convT[l >= 1 ? l - 1 : 0];
+            const int prpg = B * Lp.g.OH * Lp.g.OW;
+            if (l >= 1 && mmvae_knob("mm_wkernel", 0)) {
+                // opt-in: the image-resident weight-gradient kernel (convres_wgrad.hip) stages both operands itself -- the layer
+                // input aq[l] = Swish(BatchNorm(q[l])) out of the raw tensor, the output gradient's BatchNorm backward out of db
+                GatherTransform tp{}, ta{};
+                tp.kind = 1;
+                tp.fin = bn_fin_args(P, P.bn[Lp.bn], prpg, groups, w.st_d[l - 1], 0, nullptr, nullptr, training);
+                ta.kind = 2; ta.r = q[l + 1]; ta.red = w.red_d[l]; ta.mr = w.mr_d[l]; ta.gamma = P.buf.params + b.w_off;
+                ta.dgamma = P.buf.grads + b.w_off; ta.dbeta = P.buf.grads + b.b_off;
+                ta.inv_cnt = 1.f / (float)(B * pix); ta.groups = groups;
                 gw.c.A = dq[l + 1]; gw.P = q[l];
                 side_later(P, [pp, gw, tp, ta](hipStream_t ws_) mutable {
                     gw.trA = &ta; gw.trP = &tp;
                     return wgrad_on(*pp, gw, ws_);
                 });
-            } else {        // A/B aid: materialise both operands in front of the streamed weight-gradient kernel
+            } else {
+                // the streamed weight-gradient kernel on operands materialised right in front of it, on the side stream: the
+                // BatchNorm backward of db (its own buffer: the data gradient on the main chain still reads db) and, above the
+                // first layer, the layer input aq[l] = Swish(BatchNorm(q[l])) that the forward never wrote
+                const bool actp = l >= 1;
                 const BnL bp = P.bn[Lp.bn];
-                const bf16* qin = q[l]; bf16* aqo = aq[l]; const float2* st = w.st_d[l - 1];
-                side_later(P, [pp, x, gw, bp, qin, aqo, st, groups, prpg, training](hipStream_t ws_) {
+                const bf16* qin = q[l]; bf16* aqo = aq[l]; const float2* st = w.st_d[l >= 1 ? l - 1 : 0];
+                side_later(P, [pp, x, gw, actp, bp, qin, aqo, st, groups, prpg, training](hipStream_t ws_) {
                     MMVAE_TRY(launch_bn_bwd_apply(x, ws_));
-                    MMVAE_TRY(bn_act_side(*pp, bp, qin, aqo, groups * prpg, prpg, groups, st, training, ws_));
+                    if (actp) MMVAE_TRY(bn_act_side(*pp, bp, qin, aqo, groups * prpg, prpg, groups, st, training, ws_));
                     return wgrad_on(*pp, gw, ws_);
                 });
             }

@@ -36,6 +36,10 @@ layers = {
     'enc_conv3_dgrad': ('d2e', B, 144, 64, 'red_e0', 1),
     'dec_convT2_dgrad': ('d1', 2 * B, 36, 128, 'red_d0', 2),
     'dec_convT3_dgrad': ('d2', 2 * B, 144, 64, 'red_d1', 2),
+    'enc_conv4': ('r4', B, 4, 256, 'st_e2', 1),
+    'dec_convT1': ('q1', 3 * B, 36, 128, 'st_d0', 3),
+    'enc_conv4_dgrad': ('d3e', B, 36, 128, 'red_e1', 1),
+    'dec_convT1_dgrad': ('du', 2 * B, 4, 256, None, 2),
 }
 sel = sys.argv[2:] or list(layers)
 
@@ -73,7 +77,7 @@ for L in sel:
           f"stats err {serr:.2e}  {'ok' if ok else 'MISMATCH'}", flush=True)
     if os.environ.get("CR_ALT"):
         ts = []
-        for alt in (1, 2):
+        for alt in (1, 5):
             call("mmvae_debug_set", b"convres_alt", alt)
             out.zero_()
             run(L, 1, 3); torch.cuda.synchronize()
