@@ -18,6 +18,7 @@ struct MMPlan : PlanBase {
     BnL bn[6];
     // text packs
     struct GruIdx { int wih, whh, wihT, whhT, g_wih, g_whh; long long bih, bhh; } te_f, te_r, td0, td1;
+    const float* step_image = nullptr;      // the image batch of the running fused step (conv1's weight gradient rebuilds its patches)
     int te_h2p, te_h2pT, g_te_h2p, td_z2h, td_z2hT, g_td_z2h, td_h2o, td_h2oT, g_td_h2o;
     // fused classifier tail (mlp_tail.hip; n_latents = 100 only): fragment-major copies of classifier.3 / classifier.6
     bool mlp_tail = false;
@@ -265,12 +266,17 @@ int enc_fwd(MMPlan& P, const float* image, int variants, const uint8_t* m1, cons
             int bn_updates, float* out, hipStream_t s, bool fuse = false) {
     MMPlan::W& w = P.w;
     const int B = P.B;
+    if (fuse && mmvae_knob("mm_conv1_mfma", 1)) {      // one workgroup per image on the matrix cores (conv1.hip)
+        const PackDesc& d = P.pk.d[P.conv[0].pk_fwd[0]];
+        MMVAE_TRY(launch_conv1_fwd_mfma(image, B, P.buf.packed + d.dst_off, d.Kpad, w.r1, w.a1, s));
+    } else {
     MMVAE_TRY(launch_im2col_small(image, B, 1, IMG, IMG, 4, 4, 2, 1, 25, 25, w.patches1, 16, s));
     {   // conv1 + Swish (no BatchNorm): the epilogue emits raw and activated
         GatherPlan pl = dense_plan(B * 625, 16, 16, 32);
         GemmParams g = gemm_of(P, pl, P.conv[0].pk_fwd, 1, B * 625);
         g.c.A = w.patches1; g.out_bf = w.r1; g.ldo = 32; g.out_act_bf = w.a1; g.e_act = ACT_SWISH;
         MMVAE_TRY(launch_gemm_gather(g, s));
+    }
     }
     bf16* r[4] = {w.r1, w.r2, w.r3, w.r4};
     bf16* a[4] = {w.a1, w.a2, w.a3, w.a4};
@@ -491,7 +497,10 @@ int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const
         if (!fuse) MMVAE_TRY(wgrad_async(P, gw, s));
     }
     if (fuse && !P.wgrad_forked) MMVAE_TRY(side_flush(P, s));     // unforked (serial) use: nothing to wait for
-    {   // conv1 wgrad over the im2col patches: the LAST kernel of the backward chain -- it stays on the main stream (a hop
+    if (fuse && mmvae_knob("mm_conv1_mfma", 1) && P.step_image) {       // the LAST kernel of the backward chain: conv1.hip
+        const PackDesc& gd = P.gk.d[P.conv[0].gk[0]];
+        MMVAE_TRY(launch_conv1_wgrad_mfma(P.step_image, B, w.d1e, P.buf.gpk + gd.dst_off, gd.Kpad, s));
+    } else {   // conv1 wgrad over the im2col patches: the LAST kernel of the backward chain -- it stays on the main stream (a hop
         // to a side stream and back would put two event latencies on the critical path)
         GatherPlan pl = dense_plan(B * 625, 16, 16, 32);
         WgradParams g = wgrad_of(P, pl, P.conv[0].gk, 1, B * 625);
@@ -933,6 +942,7 @@ static int mm_step_body(MMPlan* Pp, const MMStepIO& io, int training, int do_bac
         TextEncArgs a = te_args(P, io.text, w.txtout, do_backward);
         MMVAE_TRY(launch_text_encoder_fwd(a, T));
     }
+    P.step_image = io.image;
     const bool fuse = mmvae_knob("mm_fuse_bn", 1) != 0 && mmvae_knob("convres", 1) != 0 && B % 4 == 0;
     MMVAE_TRY(enc_fwd(P, io.image, 2, m1, m2, enc_drop, training, enc_updates, w.encout, s, fuse));
     MMVAE_TRY(edge(P, T, s));

@@ -54,3 +54,8 @@ int dec_last_fused_strips(int IH);
 bool dec_last_mfma_applies(const DecLastFusedArgs& a);
 int launch_dec_last_mfma(const DecLastFusedArgs& a, hipStream_t s);
 int launch_dec_last_fused(const DecLastFusedArgs& a, hipStream_t s);
+
+// First encoder layer of MultiMNIST on the matrix cores (conv1.hip): Conv2d(1, 32, 4, 2, 1) on 50x50 images, raw + Swish
+// copies [B][25][25][32] bf16; and its weight gradient added (float atomics) into the packed gradient [32][Kpad].
+int launch_conv1_fwd_mfma(const float* image, int B, const bf16* Wp, int Kpad, bf16* r1, bf16* a1, hipStream_t s);
+int launch_conv1_wgrad_mfma(const float* image, int B, const bf16* d1, float* dWp, int Kpad, hipStream_t s);
