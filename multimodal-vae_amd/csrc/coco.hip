@@ -65,6 +65,8 @@ void build(CocoPlan& P) {
     build_conv(P, P.convT[1], "image_decoder.hallucinate.3.weight", ConvGeom{256, 128, 4, 4, 2, 1, 4, 4, 8, 8, true}, 4, true, false, false);
     build_conv(P, P.convT[2], "image_decoder.hallucinate.6.weight", ConvGeom{128, 64, 4, 4, 2, 1, 8, 8, 16, 16, true}, 5, true, false, false);
     build_conv(P, P.convT[3], "image_decoder.hallucinate.9.weight", ConvGeom{64, 3, 4, 4, 2, 1, 16, 16, 32, 32, true}, -1, true, false, true);
+    add_frag_packs(P, P.conv[1]);      // 8x8 / 16x16 layers: direct-B image-resident kernels (convres.hip)
+    add_frag_packs(P, P.convT[2]);
     {   // classifier.0 consumes the NCHW flatten c*4 + y*2 + x of the (512,2,2) map held here as NHWC [2][2][512]
         LinL& f = P.fc[0];
         f.w_off = off(P, "image_encoder.classifier.0.weight"); f.b_off = off(P, "image_encoder.classifier.0.bias");
@@ -164,7 +166,7 @@ int enc_fwd(CocoPlan& P, const float* image, int variants, const uint8_t* m1, co
     bf16* a[4] = {w.a1, w.a2, w.a3, w.a4};
     for (int l = 1; l < 4; ++l) {
         const ConvL& L = P.conv[l];
-        GemmParams g = gemm_of(P, L.fwd, L.pk_fwd, 1, B);
+        GemmParams g = gemm_of(P, L.fwd, L.pk_fwd, 1, B, L.pk_fwd_f);
         g.c.A = a[l - 1];
         g.out_bf = r[l]; g.ldo = L.g.Cout;
         g.colstats = training ? w.st_e[l - 1] : nullptr;
@@ -263,7 +265,7 @@ int enc_bwd(CocoPlan& P, const bf16* d_out, int variants, const uint8_t* m1, con
             MMVAE_TRY(wgrad_async(P, g, s));
         }
         {
-            GemmParams d = gemm_of(P, L.dgrad, L.pk_dgrad, 1, B);
+            GemmParams d = gemm_of(P, L.dgrad, L.pk_dgrad, 1, B, L.pk_dgrad_f);
             d.c.A = dr[l]; d.out_bf = dr[l - 1]; d.ldo = L.g.Cin;
             d.d_r = r[l - 1]; d.d_ld = L.g.Cin; d.d_act = ACT_SWISH;
             if (l > 1) { d.d_affine = w.aff_e[l - 2]; d.d_meanrstd = w.mr_e[l - 2]; d.d_red = w.red_e[l - 2]; }
@@ -293,7 +295,7 @@ int dec_fwd(CocoPlan& P, int groups, int training, ConvTLastFwdArgs* last, hipSt
     bf16* aq[4] = {w.au, w.aq1, w.aq2, w.aq3};
     for (int l = 0; l < 3; ++l) {
         const ConvL& L = P.convT[l];
-        GemmParams g = gemm_of(P, L.fwd, L.pk_fwd, groups, B);
+        GemmParams g = gemm_of(P, L.fwd, L.pk_fwd, groups, B, L.pk_fwd_f);
         g.c.A = aq[l];
         g.out_bf = q[l + 1]; g.ldo = L.g.Cout;
         g.colstats = training ? w.st_d[l] : nullptr;
@@ -344,7 +346,7 @@ int dec_bwd(CocoPlan& P, const float* dlogit, int groups, float* dz, hipStream_t
             MMVAE_TRY(wgrad_async(P, g, s));
         }
         {
-            GemmParams d = gemm_of(P, L.dgrad, L.pk_dgrad, groups, B);
+            GemmParams d = gemm_of(P, L.dgrad, L.pk_dgrad, groups, B, L.pk_dgrad_f);
             d.c.A = dq[l + 1]; d.out_bf = dq[l]; d.ldo = L.g.Cin;
             d.d_r = q[l]; d.d_ld = L.g.Cin; d.d_act = ACT_SWISH;
             if (l > 0) { d.d_affine = w.aff_d[l - 1]; d.d_meanrstd = w.mr_d[l - 1]; d.d_red = w.red_d[l - 1]; }

@@ -610,6 +610,11 @@ typedef Geo<1, 64, 32, 12, 12, 25, 25, 4, 4, 2, 1> G_mm_conv2d;        // featur
 typedef Geo<0, 32, 64, 25, 25, 12, 12, 5, 5, 2, 1> G_mm_convT3d;       // hallucinate.6 data gradient
 typedef Geo<1, 256, 128, 2, 2, 6, 6, 4, 4, 2, 0> G_mm_convT1;          // hallucinate.0 forward == features.8 data gradient
 typedef Geo<0, 128, 256, 6, 6, 2, 2, 4, 4, 2, 0> G_mm_conv4;           // features.8 forward == hallucinate.0 data gradient
+// CelebA (64x64 images; celeba/model.py:101-150) -- the 16x16 / 8x8 pairs are also COCO's features.2 / hallucinate.6
+typedef Geo<0, 32, 64, 32, 32, 16, 16, 4, 4, 2, 1> G_ca_conv2;         // features.2 forward == hallucinate.6 data gradient
+typedef Geo<0, 64, 128, 16, 16, 8, 8, 4, 4, 2, 1> G_ca_conv3;          // features.5 forward == hallucinate.3 data gradient
+typedef Geo<1, 128, 64, 8, 8, 16, 16, 4, 4, 2, 1> G_ca_convT2;         // hallucinate.3 forward == features.5 data gradient
+typedef Geo<1, 64, 32, 16, 16, 32, 32, 4, 4, 2, 1> G_ca_convT3;        // hallucinate.6 forward == features.2 data gradient
 
 }  // namespace
 
@@ -642,6 +647,12 @@ int try_launch_convres(const GemmParams& p, hipStream_t stream) {
         if ((rc = try_cr<G_mm_conv4, 8, 0, 8, 2, true, 4, 4>(p, stream)) != 0) return rc;
     }
     if ((rc = try_cr<G_mm_convT3d, 2, 10, 8, 2, false>(p, stream)) != 0) return rc;
+    if (mmvae_knob("convres_celeba", 1)) {
+        if ((rc = try_cr<G_ca_conv2, 1, 16, 8, 2, true>(p, stream)) != 0) return rc;
+        if ((rc = try_cr<G_ca_conv3, 2, 0, 8, 4, true>(p, stream)) != 0) return rc;
+        if ((rc = try_cr<G_ca_convT2, 4, 0, 8, 2, true>(p, stream)) != 0) return rc;
+        if ((rc = try_cr<G_ca_convT3, 2, 16, 4, 1, false>(p, stream)) != 0) return rc;
+    }
     MMVAE_REQUIRE(!forced, "convres: no kernel is compiled for the geometry of a launch with a staging transform");
     return 0;
 }
