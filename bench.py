@@ -14,10 +14,14 @@ The JSON line carries, next to the contract fields:
                    included; counted by the launchers), and step_mfma_frac_executed on that count
   step_hbm_frac    algorithmic bytes per step (0.59 GB at B=256) x steps/s / 8 TB/s
   roofline         the kernel family with the largest GPU-time share of the step (rocprofv3 --kernel-trace --stats of this
-                   command: profiles/r02_multimnist_kernel_stats.csv) -- the gather GEMM -- on its longest launch, the forward
-                   of dec_convT3: ALGORITHMIC FLOPs / average launch time measured live with HIP events; executed FLOPs,
-                   algorithmic bytes and the PMC-measured HBM-side traffic of the same launch (profiles/r02_traffic.json) beside it
-  roofline_wgrad / roofline_dgrad   the weight- and data-gradient launches of the same layer, same definition
+                   command: profiles/r03_<workload>_kernel_stats.csv) -- the image-resident conv kernel `convres_kernel` --
+                   measured IN THE STEP: every launch of 20 extra steps carries its own HIP start/stop events
+                   (mmvae_debug_probe), achieved = sum of the launches' ALGORITHMIC FLOPs / sum of their durations, with the
+                   other streams' kernels running beside them.  `frac_isolated`: the same launches replayed alone
+                   (mmvae_mm_bench_layer).  `launches`: the per-launch numbers.  `traffic`: PMC-measured HBM-side bytes of the
+                   family's longest launch (profiles/r03_traffic.json) next to its algorithmic bytes
+  kernels_in_step  every probed kernel of the step (all workloads): launches per step, in-step microseconds, TFLOP/s
+  roofline_wgrad / roofline_dgrad   weight- and data-gradient launches of the last 64->32 layer replayed alone (as in round 2)
 """
 import argparse
 import json
@@ -76,10 +80,10 @@ def synthetic_sos():
 
 def measured_traffic(kernel_key):
     """HBM-side bytes per launch of a roofline kernel from rocprofv3 PMC passes (one pass per counter, no trace domains;
-    FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH "HBM"): profiles/r02_traffic.json, written from the
+    FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH "HBM"): profiles/r03_traffic.json, written from the
     raw counter rows committed next to it.  None when the kernel has not been measured."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03_traffic.json")) as f:
             t = json.load(f)
         e = t.get(kernel_key)
         return (e["bytes"], e["source"]) if e else (None, None)
@@ -169,6 +173,68 @@ def time_layer(eng, call, layer, iters=50):
     return e0.elapsed_time(e1) * 1e3 / iters
 
 
+def probe_steps(call, run, steps):
+    """In-step kernel timing: `steps` steps with a HIP start/stop event pair on every launch that goes through the library's
+    tagged launcher (include/mmvae_hip.h mmvae_debug_probe).  -> [{tag, kernel, family, launches_per_step, us, flops}] per
+    distinct (tag, kernel), `us` the mean duration of one launch inside the running step."""
+    import ctypes
+    run()
+    torch.cuda.synchronize()
+    call("mmvae_debug_probe", 1)
+    for _ in range(steps):
+        run()
+    call("mmvae_debug_probe", 0)
+    torch.cuda.synchronize()
+    cap = 1 << 22
+    buf = ctypes.create_string_buffer(cap)
+    call("mmvae_debug_probe_read", buf, cap)
+    acc = {}
+    for line in buf.value.decode().splitlines():
+        tag, kernel, us, flops = line.split("\t")
+        kernel = kernel.strip("() ")
+        e = acc.setdefault((tag, kernel), {"tag": tag, "kernel": kernel, "family": kernel.split("<")[0].strip(), "n": 0, "us": 0.0, "flops": float(flops)})
+        e["n"] += 1
+        e["us"] += float(us)
+    out = []
+    for e in acc.values():
+        out.append({"tag": e["tag"], "kernel": e["kernel"], "family": e["family"], "launches_per_step": e["n"] / steps,
+                    "us": e["us"] / e["n"], "flops": e["flops"]})
+    return out
+
+
+def family_roofline(rows, family):
+    """Sum of algorithmic FLOPs / sum of in-step launch time over one step's launches of `family`."""
+    sel = [r for r in rows if r["family"] == family and r["flops"] > 0]
+    us = sum(r["us"] * r["launches_per_step"] for r in sel)
+    fl = sum(r["flops"] * r["launches_per_step"] for r in sel)
+    n = sum(r["launches_per_step"] for r in sel)
+    ach = fl / (us * 1e-6) / 1e12 if us > 0 else 0.0
+    return {"kernel": "%s: %d launches per step, timed inside the step" % (family, round(n)), "bound": "mfma", "achieved": ach,
+            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "us_per_launch": us / max(n, 1),
+            "flops_per_launch": fl / max(n, 1), "us_per_step": us,
+            "launches": [{"tag": r["tag"], "us": round(r["us"], 2), "tflops": round(r["flops"] / (r["us"] * 1e-6) / 1e12, 1)}
+                         for r in sorted(sel, key=lambda r: -r["us"])]}
+
+
+def kernels_in_step(rows, top=16):
+    tot = {}
+    for r in rows:
+        e = tot.setdefault(r["kernel"] if r["family"] != "convres_kernel" else r["family"], {"launches_per_step": 0.0, "us_per_step": 0.0, "flops": 0.0})
+        e["launches_per_step"] += r["launches_per_step"]
+        e["us_per_step"] += r["us"] * r["launches_per_step"]
+        e["flops"] += r["flops"] * r["launches_per_step"]
+    out = []
+    for k, e in sorted(tot.items(), key=lambda kv: -kv[1]["us_per_step"])[:top]:
+        out.append({"kernel": k, "launches_per_step": round(e["launches_per_step"], 2), "us_per_step": round(e["us_per_step"], 1),
+                    "tflops": round(e["flops"] / (e["us_per_step"] * 1e-6) / 1e12, 1) if e["flops"] > 0 else None})
+    return out
+
+
+# MultiMNIST layers that run on convres_kernel (multimodal-vae_amd/csrc/convres.hip), by their mmvae_mm_bench_layer names
+MM_CONVRES_LAYERS = ["enc_conv2", "enc_conv3", "enc_conv4", "dec_convT1", "dec_convT2", "dec_convT3",
+                     "enc_conv2_dgrad", "enc_conv3_dgrad", "enc_conv4_dgrad", "dec_convT1_dgrad", "dec_convT2_dgrad", "dec_convT3_dgrad"]
+
+
 def roofline_entry(eng, call, layer, kernel, B, D):
     lb = layer.encode()
     us = time_layer(eng, call, lb)
@@ -196,6 +262,8 @@ def main():
     ap.add_argument("--n_latents", type=int, default=100)
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (1 GPU only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dp-overlap", action="store_true", help="N>1, MultiMNIST: all-reduce the decoders' gradients while the encoders' backward runs")
+    ap.add_argument("--no-probe", action="store_true", help="skip the in-step kernel timing (roofline falls back to the whole step)")
     args = ap.parse_args()
     wl = args.workload
 
@@ -216,12 +284,12 @@ def main():
     all_reduce = None
     if world > 1:
         dp.init_distributed("nccl", dev)                   # backend "nccl" IS RCCL on ROCm
-        # SUM all-reduce of the flat gradient, 1/world folded into Adam.  MMVAE_DP_OVERLAP=1 (MultiMNIST): the decoders'
+        # SUM all-reduce of the flat gradient, 1/world folded into Adam.  --dp-overlap (MultiMNIST): the decoders'
         # gradient ranges go out while the encoders' backward still runs (core.FusedELBOStep._call_dp_overlap).  Not the
         # default: measured on one GPU with a world-1 RCCL group the extra communication stream (parked on the early-gradient
         # event) lands on a hardware queue shared with the step's streams and stalls them (0.91 -> 2.2 ms per step), and even
         # without that the split costs 0.05 ms against the ~0.06 ms of a 9.4 MB exchange it can hide
-        all_reduce = dp.GradAllReduce(overlap=os.environ.get("MMVAE_DP_OVERLAP") == "1")
+        all_reduce = dp.GradAllReduce(overlap=args.dp_overlap)
 
     B, D = args.batch or DEFAULT_BATCH[wl], args.n_latents
     seed = dp.rank_seed(1234, rank)
@@ -319,15 +387,35 @@ def main():
     result["ms_per_step_p10_p50_p90"] = [per[int(0.1 * (n_ev - 1))], per[(n_ev - 1) // 2], per[int(0.9 * (n_ev - 1))]]
 
     if rank == 0:
+        rows = [] if (args.no_probe or use_graph) else probe_steps(call, run, 20)
+        if rows:
+            result["kernels_in_step"] = kernels_in_step(rows)
+        fam_us = {}
+        for r in rows:
+            if r["flops"] > 0:
+                fam_us[r["family"]] = fam_us.get(r["family"], 0.0) + r["us"] * r["launches_per_step"]
+        if fam_us:
+            # ---- roofline: the GEMM kernel family with the most GPU time in the step, all of its launches, timed in the step
+            fam = max(fam_us, key=fam_us.get)
+            result["roofline"] = family_roofline(rows, fam)
+            result["roofline"]["traffic"] = None
+            if wl == "multimnist" and fam == "convres_kernel":
+                iso_us = sum(time_layer(eng, call, l.encode()) for l in MM_CONVRES_LAYERS)
+                iso_fl = sum(call("mmvae_mm_layer_algo_flops", eng.h, l.encode()) for l in MM_CONVRES_LAYERS)
+                result["roofline"]["frac_isolated"] = iso_fl / (iso_us * 1e-6) / 1e12 / PEAK_BF16_TFLOPS
+                result["roofline"]["us_per_step_isolated"] = iso_us
+                # HBM-side traffic of the family's longest launch (the forward of the last 64->32 ConvTranspose2d)
+                traffic, src = measured_traffic("dec_convT3:%d:%d" % (B, D))
+                result["roofline"]["traffic"] = traffic
+                result["roofline"]["traffic_source"] = src
+                result["roofline"]["traffic_launch"] = "dec_convT3"
+                result["roofline"]["algorithmic_bytes_of_that_launch"] = call("mmvae_mm_layer_algo_bytes", eng.h, b"dec_convT3")
         if wl == "multimnist":
-            # ---- roofline: the gather-GEMM family holds the most GPU time of the step (profiles/r02_*kernel_stats.csv), its
-            # longest launch is the forward of the last 64->32 ConvTranspose2d; next to it the weight gradient of that layer
-            # (round 1's dominant kernel) and its data gradient
-            result["roofline"] = roofline_entry(eng, call, "dec_convT3", "gemm_gather_kernel<2>", B, D)
+            result["roofline_fwd_isolated"] = roofline_entry(eng, call, "dec_convT3", "convres_kernel", B, D)
             result["roofline_wgrad"] = roofline_entry(eng, call, "dec_convT3_wgrad", "wgrad_kernel + wgrad_reduce_kernel", B, D)
-            result["roofline_dgrad"] = roofline_entry(eng, call, "dec_convT3_dgrad", "gemm_gather_kernel<4>", B, D)
-        else:
-            # no per-layer replay hook for this family: the whole step against the MFMA roof on the executed GEMM FLOPs
+            result["roofline_dgrad"] = roofline_entry(eng, call, "dec_convT3_dgrad", "convres_kernel", B, D)
+        if "roofline" not in result:
+            # no probe: the whole step against the MFMA roof on the executed GEMM FLOPs
             ms = result["ms_per_step"]
             ach = executed / (ms * 1e-3) / 1e12
             result["roofline"] = {"kernel": "whole 3-pass step (all GEMM launches)", "bound": "mfma", "achieved": ach,

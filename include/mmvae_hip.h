@@ -23,6 +23,7 @@ extern "C" {
 #define MMVAE_EHIP (-2)
 #define MMVAE_ENOSPC (-3)
 #define MMVAE_ESTATE (-4)
+#define MMVAE_ETIMEOUT (-5)               /* a device-side exchange of the step gave up: the step is void (mmvae_step_status) */
 
 int mmvae_init(int device);                 /* checks the device is gfx950, makes it current */
 const char* mmvae_last_error(void);
@@ -329,6 +330,12 @@ typedef struct {
     int defer_unpack;                       /* 1: the optimizer consumes the packed gradients itself (see the MultiMNIST step) */
     int pack_first;                         /* 1: the step refreshes the packed bf16 weights itself (the caller skipped mmvae_coco_pack_weights
                                                after the optimizer step): caption half on the text stream, image half on the main one */
+    long long* optimizer_state;             /* the 16-byte state block this step's mmvae_adam_step* call will get, or NULL.  The caption
+                                               decoder's workgroups exchange hidden-state slices through memory and give up after a
+                                               bounded spin (a device that cannot keep them co-resident); such a step is void: its `sums`
+                                               are NaN, its gradient is marked (element 0 = NaN, which survives a SUM all-reduce) and
+                                               the skip word of this block is set -- mmvae_adam_step* then leaves parameters, moments
+                                               and step count untouched.  mmvae_step_status reports it to the host */
 } mmvae_coco_step_io;
 int mmvae_coco_step(mmvae_coco_t*, const mmvae_coco_step_io*, int training, int do_backward, void* stream);
 /* Granular modules (forward + autograd backward), workspace rules as for mmvae_mm_*_fwd/bwd */
@@ -379,6 +386,21 @@ int mmvae_mse_bwd(const float* a, const float* b, long long n, float coef, const
 int mmvae_u8_to_f32(const uint8_t* src, long long n, float denom, float* dst, void* stream);
 /* torch.optim.Adam defaults (multimnist/train.py:129,173) on flat buffers; state = device int64[2] {step, ticket},
  * zero-initialised by the caller; grad_scale multiplies g first (1/world_size after a sum all-reduce). */
+/* The three losses of train()'s closure from a step's `sums` block (multimnist/train.py:33-62: the weighted sum each
+ * loss_function call ends with): losses[k] = w_bce[k]*sums[k] + w_nll[k]*sums[4+k] + w_kl[k]*sums[8+k].  The weights are HOST
+ * arrays of 3 floats (lambda / divisor per pass, 0 for an absent pass); `sums` and `losses` are device pointers. */
+int mmvae_step_losses(const float* sums, const float* w_bce, const float* w_nll, const float* w_kl, float* losses, void* stream);
+/* Measurement aids (not part of the reference's interface).  mmvae_debug_set: named integer A/B switches of the library
+ * (DESIGN.md lists them).  mmvae_debug_probe(1): every kernel the library launches through its tagged launcher carries a start
+ * and a stop event of its own until mmvae_debug_probe(0); mmvae_debug_probe_read waits for them and writes one line per launch
+ * "tag\tkernel\tmicroseconds\talgorithmic FLOPs\n" into buf (returns the number of lines) -- bench.py's in-step roofline. */
+/* Waits for `stream`, then MMVAE_OK, or MMVAE_ETIMEOUT when the step that wrote `sums` (device, [16]) declared itself void. */
+int mmvae_step_status(const float* sums, void* stream);
+int mmvae_debug_probe(int on);
+int mmvae_debug_probe_read(char* buf, long long cap);
+/* torch.optim.Adam (multimnist/train.py:129,173) on flat fp32 buffers.  `state`: 16 zero-initialised device bytes the caller keeps
+ * next to the moments -- int64 step count, then two words of the kernel's own (block ticket, skip flag).  The update is dropped
+ * (and the step count kept) when the skip flag is set or g[0] is NaN: see mmvae_coco_step_io.optimizer_state. */
 int mmvae_adam_step(float* p, const float* g, float* m, float* v, long long n, long long* state, float lr, float beta1,
                     float beta2, float eps, float grad_scale, void* stream);
 /* The same update with the unpack of the packed weight gradients fused in (mmvae_mm_step_io.defer_unpack = 1):

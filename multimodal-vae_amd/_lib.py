@@ -63,6 +63,7 @@ class CocoStepIO(C.Structure):
         ("pass_skip", C.c_int * 3),
         ("defer_unpack", C.c_int),
         ("pack_first", C.c_int),
+        ("optimizer_state", C.c_void_p),
     ]
 
 
@@ -147,6 +148,10 @@ SIGNATURES = {
     "mmvae_mse_fwd": (_I, [_P, _P, _LL, _P, _P]),
     "mmvae_mse_bwd": (_I, [_P, _P, _LL, _F, _P, _P, _P]),
     "mmvae_u8_to_f32": (_I, [_P, _LL, _F, _P, _P]),
+    "mmvae_step_status": (_I, [_P, _P]),
+    "mmvae_step_losses": (_I, [_P, _P, _P, _P, _P, _P]),
+    "mmvae_debug_probe": (_I, [_I]),
+    "mmvae_debug_probe_read": (_I, [_P, _LL]),
     "mmvae_adam_step": (_I, [_P, _P, _P, _P, _LL, _P, _F, _F, _F, _F, _F, _P]),
     "mmvae_adam_step_packed": (_I, [_P, _P, _P, _P, _LL, _P, _F, _F, _F, _F, _F, _P, _P, _P, _P]),
 }
@@ -209,7 +214,7 @@ SIGNATURES["mmvae_coco_text_encoder_fwd"] = (_I, [_P, _P, _SZ, _P, _P, _P])
 SIGNATURES["mmvae_coco_text_encoder_bwd"] = (_I, [_P, _P, _SZ, _P, _P, _P])
 SIGNATURES["mmvae_coco_text_decoder_fwd"] = (_I, [_P, _P, _SZ, _P, _P, _P, _I, _P, _P])
 SIGNATURES["mmvae_coco_text_decoder_bwd"] = (_I, [_P, _P, _SZ, _P, _P, _P, _P, _P, _P, _P])
-_STATUS = {n for n, (r, _) in SIGNATURES.items() if r is _I and not n.endswith(("_num_params", "_num_bn", "_precision", "_coco_steps", "_comm_world"))}
+_STATUS = {n for n, (r, _) in SIGNATURES.items() if r is _I and not n.endswith(("_num_params", "_num_bn", "_precision", "_coco_steps", "_comm_world", "_probe_read"))}
 
 _lib = None
 _inited = set()

@@ -6,7 +6,6 @@ PyTorch is used for plumbing only: it owns the device allocations (``torch.empty
 from __future__ import annotations
 
 import ctypes as C
-import os as _os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -189,26 +188,25 @@ class StepOutputs:
         self.lxy, self.lyx = tuple(float(x) for x in lambda_xy), tuple(float(x) for x in lambda_yx)
         self.passes = tuple(bool(x) for x in passes)
 
-    _W: Dict[tuple, torch.Tensor] = {}      # (device, weights...) -> [3][16] device matrix, uploaded once per configuration
-
     def losses(self) -> torch.Tensor:
-        """loss_1, loss_2, loss_3 of the reference's train() closure as a device tensor [3].  Pure device arithmetic: the
-        loss weights live in a cached device matrix (a fresh ``torch.tensor(..., device=cuda)`` per call would be a blocking
-        pageable H2D copy, i.e. one host synchronisation per training step)."""
+        """loss_1, loss_2, loss_3 of the reference's train() closure as a device tensor [3]: the weighted sums that end each
+        loss_function call (multimnist/train.py:33-62), evaluated by the library (mmvae_step_losses) on the step's stream --
+        the weights travel as kernel arguments, nothing is synchronised."""
         s = self.sums
-        key = (s.device, self.lxy, self.lyx, self.passes, self.bce_div, self.nll_div, self.kl_scale)
-        m = StepOutputs._W.get(key)
-        if m is None:
-            h = torch.zeros(3, 16, dtype=torch.float32)
-            for k in range(3):
-                on = 1.0 if self.passes[k] else 0.0               # absent passes (weak supervision) report 0
-                h[k, k] = on * self.lxy[k] / self.bce_div
-                h[k, 4 + k] = on * self.lyx[k] / self.nll_div
-                h[k, 8 + k] = on * self.kl_scale
-            if len(StepOutputs._W) > 256:
-                StepOutputs._W.clear()
-            m = StepOutputs._W[key] = h.to(s.device)
-        return m @ s
+        w = [(C.c_float * 3)() for _ in range(3)]
+        for k in range(3):
+            on = 1.0 if self.passes[k] else 0.0                   # absent passes (weak supervision) report 0
+            w[0][k] = on * self.lxy[k] / self.bce_div
+            w[1][k] = on * self.lyx[k] / self.nll_div
+            w[2][k] = on * self.kl_scale
+        out = torch.empty(3, dtype=torch.float32, device=s.device)
+        call("mmvae_step_losses", ptr(s), w[0], w[1], w[2], ptr(out), _stream())
+        return out
+
+    def check(self) -> None:
+        """Synchronises, then raises MMVAEError if the step declared itself void (mmvae_step_status: a device-side exchange of
+        the COCO caption decoder gave up; the optimizer update of that step was skipped on every rank)."""
+        call("mmvae_step_status", ptr(self.sums), _stream())
 
     def parts(self):
         """(mean BCE, mean NLL, KL sum) per pass"""
@@ -263,9 +261,10 @@ class _FusedStepBase:
         self._after_update()
 
     _DEFER_PACK = False         # the family's step prologue can refresh the packed weights itself (pack_first)
+    separate_unpack = False     # tests: unpack the gradient + plain Adam instead of the packed-gradient Adam (same numbers)
 
     def _after_update(self) -> None:
-        if self._DEFER_PACK and not _os.environ.get("MMVAE_EAGER_PACK"):
+        if self._DEFER_PACK:
             self.state.pack_pending = True
         else:
             self.state.pack_weights()
@@ -284,7 +283,7 @@ class _FusedStepBase:
         """backward + optimizer.step() (multimnist/train.py:168,173) in one pass over the parameters: the GEMM-weight
         gradients stay in their packed layout and the Adam kernel gathers them (and completes ``grads``) itself.  The
         data-parallel path needs the complete flat gradient BEFORE Adam (all-reduce), so it keeps the separate unpack."""
-        if self._dp_active() or _os.environ.get("MMVAE_SEPARATE_UNPACK"):
+        if self._dp_active() or self.separate_unpack:
             return _FusedStepBase.__call__(self, a, b, **kw)
         st = self.state
         out = self.forward_backward(a, b, True, True, _defer_unpack=True, **kw)
@@ -420,7 +419,7 @@ class FusedELBOStep(_FusedStepBase):
         return out
 
     def __call__(self, image, text, **kw) -> StepOutputs:
-        if self._dp_active() and getattr(self.all_reduce, "overlap", False) and not _os.environ.get("MMVAE_DP_NO_OVERLAP"):
+        if self._dp_active() and getattr(self.all_reduce, "overlap", False):
             return self._call_dp_overlap(image, text, **kw)
         return self._call_packed(image, text, **kw)
 
@@ -535,6 +534,7 @@ class FusedCocoStep(_FusedStepBase):
         io = _lib.CocoStepIO()
         io.ws, io.ws_bytes = self.ws.data_ptr(), self.ws.numel()
         io.step_counter = self.adam_state.data_ptr()
+        io.optimizer_state = self.adam_state.data_ptr() if backward else None     # a void step (exchange time-out) skips its Adam update
         io.image, io.text, io.sos = image.data_ptr(), text.data_ptr(), self.sos.data_ptr()
         for k, t in (("eps", eps), ("enc_mask1", enc_mask1), ("enc_mask2", enc_mask2), ("gru_keep", gru_keep),
                      ("recon_image", recon_image), ("recon_text", recon_text), ("mu", mu), ("logvar", logvar)):

@@ -390,7 +390,7 @@ int mmvae_coco_step(mmvae_coco_t* p, const mmvae_coco_step_io* io, int training,
     s.seed = io->seed; s.sums = io->sums; s.recon_image = io->recon_image; s.recon_text = io->recon_text;
     s.mu = io->mu; s.logvar = io->logvar;
     for (int k = 0; k < 3; ++k) s.pass_skip[k] = io->pass_skip[k];
-    s.defer_unpack = io->defer_unpack; s.pack_first = io->pack_first;
+    s.defer_unpack = io->defer_unpack; s.pack_first = io->pack_first; s.optimizer_state = io->optimizer_state;
     return coco_step(p, s, training, do_backward, S(stream));
     API_GUARD_END
 }
@@ -462,6 +462,26 @@ int mmvae_adam_step(float* p, const float* g, float* m, float* v, long long n, l
     AdamArgs a{};
     a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.step = state; a.lr = lr; a.b1 = b1; a.b2 = b2; a.eps = eps; a.grad_scale = grad_scale;
     return launch_adam(a, S(s));
+}
+int mmvae_step_status(const float* sums, void* s) {
+    MMVAE_REQUIRE(sums, "step_status: null sums");
+    float h[16];
+    if (hipMemcpyAsync(h, sums, sizeof(h), hipMemcpyDeviceToHost, S(s)) != hipSuccess || hipStreamSynchronize(S(s)) != hipSuccess) {
+        mmvae_set_error("step_status: %s", hipGetErrorString(hipGetLastError()));
+        return MMVAE_EHIP;
+    }
+    if (h[15] != h[15]) {        // only a void step writes NaN there (no loss term accumulates into word 15)
+        mmvae_set_error("the step gave up on a device-side exchange (caption decoder cluster): losses are NaN, the optimizer update was skipped");
+        return MMVAE_ETIMEOUT;
+    }
+    return MMVAE_OK;
+}
+int mmvae_step_losses(const float* sums, const float* w_bce, const float* w_nll, const float* w_kl, float* losses, void* s) {
+    MMVAE_REQUIRE(w_bce && w_nll && w_kl, "step_losses: null weights");
+    StepLossArgs a{};
+    a.sums = sums; a.out = losses;
+    for (int k = 0; k < 3; ++k) { a.w_bce[k] = w_bce[k]; a.w_nll[k] = w_nll[k]; a.w_kl[k] = w_kl[k]; }
+    return launch_step_losses(a, S(s));
 }
 int mmvae_adam_step_packed(float* p, float* g, float* m, float* v, long long n, long long* state, float lr, float b1, float b2,
                            float eps, float grad_scale, const int* gmap, const float* gpk, const float* gpk_vec, void* s) {

@@ -471,7 +471,7 @@ static int celeba_step_body(CelebaPlan* Pp, const CelebaStepIO& io, int training
     const int sk[3] = {io.pass_skip[0] != 0, io.pass_skip[1] != 0, io.pass_skip[2] != 0};
     P.dec_skip_mask = (unsigned)(sk[0] | (sk[1] << 1) | (sk[2] << 2));
     MMVAE_TRY(ensure_streams(P));
-    static const bool serial = getenv("MMVAE_SERIAL") != nullptr;
+    const bool serial = mmvae_serial();
     hipStream_t T = serial ? s : P.st_text;
     // ---- encoders: attribute MLP on the side stream, image encoder on main
     MMVAE_TRY(edge(P, s, T));

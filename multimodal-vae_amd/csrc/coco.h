@@ -29,6 +29,7 @@ struct CocoStepIO {
     int pack_first = 0;                 // 1: the step refreshes the packed bf16 weights itself (after an optimizer step): the caption
                                         //    GRUs' part on the text stream, the image half's on the main stream, side by side
     int defer_unpack = 0;               // 1: leave the GEMM-weight gradients packed (mmvae_adam_step_packed gathers them)
+    long long* optimizer_state = nullptr;   // Adam's 16-byte state block: skip word set by a step that timed out (plan_base.h sum_slots_kernel)
 };
 
 struct CocoPlan;

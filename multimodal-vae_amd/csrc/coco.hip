@@ -445,7 +445,7 @@ static int coco_step_body(CocoPlan* Pp, const CocoStepIO& io, int training, int 
     const int sk[3] = {io.pass_skip[0] != 0, io.pass_skip[1] != 0, io.pass_skip[2] != 0};
     P.dec_skip_mask = (unsigned)(sk[0] | (sk[1] << 1) | (sk[2] << 2));
     MMVAE_TRY(ensure_streams(P));
-    static const bool serial = getenv("MMVAE_SERIAL") != nullptr;
+    const bool serial = mmvae_serial();
     hipStream_t Tx = serial ? s : P.st_text;
     // ---- encoders: caption GRU on the side stream, image encoder on main
     MMVAE_TRY(edge(P, s, Tx));
@@ -515,11 +515,12 @@ static int coco_step_body(CocoPlan* Pp, const CocoStepIO& io, int training, int 
     MMVAE_TRY(edge(P, Tx, s));
     MMVAE_TRY(edge(P, P.st_wgrad, s));
     if (P.st_wgrad2 != P.st_wgrad) MMVAE_TRY(edge(P, P.st_wgrad2, s));
-    // (timeout words of the decoder's cluster launches of THIS step: zeroed before each of them, set only when an exchange gave up)
-    hipLaunchKernelGGL(sum_slots_kernel, dim3(1), dim3(64), 0, s, w.sums, io.sums, P.cl_alarm_f, P.cl_alarm_b);
-    MMVAE_TRY(mmvae_check_launch("sum_slots"));
-    if (io.defer_unpack) return launch_wgrad_reduce(&P.slab, s);      // the packed gradients are complete; Adam gathers them
-    return unpack(P, s);
+    if (io.defer_unpack) MMVAE_TRY(launch_wgrad_reduce(&P.slab, s));  // the packed gradients are complete; Adam gathers them
+    else MMVAE_TRY(unpack(P, s));
+    // (timeout words of the decoder's cluster launches of THIS step: zeroed before each of them, set only when an exchange gave up;
+    //  last kernel of the step, so that the mark in the gradient is not overwritten)
+    hipLaunchKernelGGL(sum_slots_kernel, dim3(1), dim3(64), 0, s, w.sums, io.sums, P.cl_alarm_f, P.cl_alarm_b, io.optimizer_state, P.buf.grads);
+    return mmvae_check_launch("sum_slots");
 }
 
 // ---------------------------------------------------------------- granular module entry points (drop-in modules)

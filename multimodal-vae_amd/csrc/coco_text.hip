@@ -401,16 +401,18 @@ void coco_text_carve(CocoPlan& P, Workspace& ws) {
 
 // ranks per 16-row block of the caption decoder's persistent launches (cluster form), 0 / 1: one workgroup per block
 static int coco_dec_cluster(int R) {
-    const char* cl_env = getenv("MMVAE_COCO_CLUSTER");          // (read per call: tools/coco_cluster_check.py toggles it)
-    int Pc = cl_env ? atoi(cl_env) : 8;
+    int Pc = mmvae_knob("coco_cluster", 8);                     // (A/B aid, mmvae_debug_set: tools/coco_cluster_check.py)
     const int nblk_pad = ((R + 15) / 16 + 7) / 8 * 8;
-    while (Pc > 1 && nblk_pad * Pc > 224) Pc /= 2;
+    // every rank of every row block must be resident at once (they spin on each other), next to the image half and the weight
+    // gradients on the other streams: 7/8 of the device's CUs at most, else fewer ranks per block, else the one-workgroup kernels
+    const int limit = mmvae_cu_count() * 7 / 8;
+    while (Pc > 1 && nblk_pad * Pc > limit) Pc /= 2;
     return (Pc == 4 || Pc == 8) ? Pc : 0;
 }
 
-// composed form of the cluster-of-8 decoder (two exchanges per step): MMVAE_COCO_NO_COMB=1 keeps the three-exchange kernels (A/B aid)
+// composed form of the cluster-of-8 decoder (two exchanges per step): knob coco_no_comb keeps the three-exchange kernels (A/B aid)
 static bool coco_dec_composed(const CocoPlan& P, int Pc) {
-    const bool off = getenv("MMVAE_COCO_NO_COMB") != nullptr;   // (read per call)
+    const bool off = mmvae_knob("coco_no_comb", 0) != 0;
     return Pc == 8 && !off && H + P.D <= 320;                   // (coco_comb_kernel: one thread per column of [W_ho | its z part])
 }
 bool coco_text_dec_composed(const CocoPlan& P, int R) { return P.text_bf16 && coco_dec_composed(P, coco_dec_cluster(R)); }
@@ -425,7 +427,7 @@ int coco_text_dec_prepare(CocoPlan& P, const float* sos, hipStream_t s) {
 
 // the weight-resident encoder kernels (coco_text_bf16.hip) need 4-row vectors of the batch
 static bool coco_enc_resident(const CocoPlan& P) {
-    const bool streamed = getenv("MMVAE_COCO_ENC_STREAMED") != nullptr;     // A/B aid: the weight-streaming kernels (read per call)
+    const bool streamed = mmvae_knob("coco_enc_streamed", 0) != 0;          // A/B aid: the weight-streaming kernels
     return P.text_bf16 && !streamed && P.B % 4 == 0;
 }
 
@@ -597,7 +599,7 @@ int coco_text_dec_fwd(CocoPlan& P, const float* z, int groups, const float* sos,
                     // composed z-weights the preparation left: W_ih0z + W_ih0x W_hoz and b_ih + W_ih0x b_ho
                     MMVAE_TRY(lin(z, D, R, w.td_wz, G, D, D, 0, w.td_bz, nullptr, 0, w.td_zi0p, G, s));
                     a.wg_comb = w.tb_comb; a.zi0p = w.td_zi0p; a.sosv = w.td_sosv;
-                    if (mse && !getenv("MMVAE_COCO_NO_MSE_FUSE")) {         // (A/B aid, read per call)
+                    if (mse && !mmvae_knob("coco_no_mse_fuse", 0)) {        // (A/B aid)
                         a.mse_target = mse->target; a.mse_B = P.B; a.mse_loss = mse->loss_sum; a.mse_dw = mse->dw; a.mse_dw16 = mse->dw16;
                         for (int g3 = 0; g3 < 3; ++g3) a.mse_coef[g3] = g3 < groups ? mse->coef[g3] : 0.f;
                         P.mse_fused = true;
@@ -655,7 +657,7 @@ static int coco_text_dec_bwd_bf16(CocoPlan& P, const float* z, int groups, const
             a.cl_timeout = reinterpret_cast<unsigned*>(w.clb_xchg + w.clb_bytes - 64);
             P.cl_alarm_b = a.cl_timeout;
             MMVAE_TRY(launch_fill_zero(w.clb_xchg, w.clb_bytes, s));        // flags and the timeout word: zero before EVERY launch
-            if (coco_dec_composed(P, Pc) && !getenv("MMVAE_COCO_NO_COMB_BWD")) {
+            if (coco_dec_composed(P, Pc) && !mmvae_knob("coco_no_comb_bwd", 0)) {
                 MMVAE_TRY(coco_text_dec_prepare(P, sos, s));                // (no-op inside a step: the forward pass made W_comb)
                 if (!P.dw16_fresh) MMVAE_TRY(launch_coco_dw16(dw, (long long)R * T, w.tb_dw16, s));    // (normally made by the forward kernel with the fused MSE)
                 a.w_combT = w.tb_combT; a.dw16 = w.tb_dw16; a.dzi0 = w.td_dzi0; a.dzi1 = w.td_dzi1;

@@ -2077,12 +2077,20 @@ int launch_coco_dec_fwd(const CocoDecFwdArgs& a, hipStream_t s) {
         };
         // every rank of a cluster must be resident for the exchange to complete: one workgroup per CU (LDS > 80 KB is not
         // needed for that: the grid never exceeds the CU count)
-        MMVAE_REQUIRE(nblk_pad * a.cluster <= 256, "coco_dec_fwd: %d x %d workgroups do not fit the chip", nblk_pad, a.cluster);
-        auto gc = [&](auto kern, int P) { hipLaunchKernelGGL(kern, dim3(nblk_pad * P), dim3(NTHR), lds_of(P), s, a); };
+        MMVAE_REQUIRE(nblk_pad * a.cluster <= mmvae_cu_count(), "coco_dec_fwd: %d x %d workgroups do not fit the chip", nblk_pad, a.cluster);
+        // (the dynamic-LDS limit is raised per kernel to what the launch asks for: a few microseconds of host time per step,
+        //  and no silent dependence on the 64 KB default when the tile constants change)
+        auto gc = [&](auto kern, int P) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(P));
+            hipLaunchKernelGGL(kern, dim3(nblk_pad * P), dim3(NTHR), lds_of(P), s, a);
+        };
         if (a.cluster == 8 && a.wg_comb) {      // composed form: two exchanges per step, weights resident
             MMVAE_REQUIRE(a.zi0p && a.sosv, "coco_dec_fwd: composed-form arguments");
             const size_t lds8 = (size_t)(2 * TR * (3 * 2 * 16 + 4) + TR * (3 * 16 + 4) + 3 * G) * sizeof(float) + (size_t)(3 * TR * LDH) * sizeof(bf16);
-            auto g8 = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(nblk_pad * 8), dim3(NTHR), lds8, s, a); };
+            auto g8 = [&](auto kern) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
+                hipLaunchKernelGGL(kern, dim3(nblk_pad * 8), dim3(NTHR), lds8, s, a);
+            };
             if (a.keep) { if (save) g8(&coco_dec_fwd_c8_kernel<true, true>); else g8(&coco_dec_fwd_c8_kernel<true, false>); }
             else { if (save) g8(&coco_dec_fwd_c8_kernel<false, true>); else g8(&coco_dec_fwd_c8_kernel<false, false>); }
             return mmvae_check_launch("coco_dec_fwd_c8");
@@ -2112,13 +2120,16 @@ int launch_coco_dec_bwd(const CocoDecBwdArgs& a, hipStream_t s) {
     if (a.cluster > 1) {        // P ranks per row block (coco_dec_bwd_cl_kernel); the caller zeroed cl_xchg / cl_timeout
         MMVAE_REQUIRE((a.cluster == 4 || a.cluster == 8) && a.cl_xchg && a.cl_timeout, "coco_dec_bwd: cluster arguments");
         const int nblk = ceil_div(a.R, TR), nblk_pad = (nblk + 7) / 8 * 8;
-        MMVAE_REQUIRE(nblk_pad * a.cluster <= 256, "coco_dec_bwd: %d x %d workgroups do not fit the chip", nblk_pad, a.cluster);
+        MMVAE_REQUIRE(nblk_pad * a.cluster <= mmvae_cu_count(), "coco_dec_bwd: %d x %d workgroups do not fit the chip", nblk_pad, a.cluster);
         auto lds_of = [](int P) {
             const int nubmax = (13 + P - 1) / P, noemax = (19 + P - 1) / P, kh = NW / nubmax;
             return (size_t)(3 * kh * TR * (nubmax * 16 + 4) + kh * TR * (noemax * 16 + 4)) * sizeof(float) +
                    (size_t)(TR * LDX + 2 * TR * LDGK) * sizeof(bf16);
         };
-        auto gc = [&](auto kern, int P) { hipLaunchKernelGGL(kern, dim3(nblk_pad * P), dim3(NTHR), lds_of(P), s, a); };
+        auto gc = [&](auto kern, int P) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(P));
+            hipLaunchKernelGGL(kern, dim3(nblk_pad * P), dim3(NTHR), lds_of(P), s, a);
+        };
         if (a.cluster == 8 && a.w_combT) {      // composed form: two exchanges per step, weights resident
             MMVAE_REQUIRE(a.dw16 && a.dzi0 && a.dzi1, "coco_dec_bwd: the composed form needs the bf16 copy of the loss gradient and the sum buffers");
             const size_t lds8 = (size_t)(4 * 4 * TR * (2 * 16 + 4)) * sizeof(float) + (size_t)(2 * TR * LDGK) * sizeof(bf16);

@@ -16,6 +16,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 #define MMVAE_EHIP (-2)
 #define MMVAE_ENOSPC (-3)
 #define MMVAE_ESTATE (-4)
+#define MMVAE_ETIMEOUT (-5)
 
 // thread-local last error (include/mmvae_hip.h: mmvae_last_error)
 void mmvae_set_error(const char* fmt, ...);
@@ -52,11 +53,22 @@ int mmvae_knob(const char* key, int dflt);
 #include <hip/hip_ext.h>
 void mmvae_arm_stop_event(hipEvent_t e);
 hipEvent_t mmvae_take_stop_event();
+// In-step kernel timing (mmvae_debug_probe, include/mmvae_hip.h): while the probe is on every MMVAE_LAUNCH carries a start and a
+// stop event of its own, labelled with the tag (and algorithmic FLOP count) the launcher set just before with mmvae_probe_tag.
+// MMVAE_SERIAL=1 (read once per process): every step on one stream, no overlap -- the profiling aid of tools/prof_serial.sh
+bool mmvae_serial();
+// compute units of the current device (cached per device): co-residency limits of the cluster kernels derive from it
+int mmvae_cu_count();
+bool mmvae_probe_on();
+void mmvae_probe_tag(const char* tag, double algo_flops);
+void mmvae_probe_events(const char* kernel, hipEvent_t* start, hipEvent_t* stop);
 #define MMVAE_LAUNCH(kernel, grid, block, lds, stream, ...)                                              \
     do {                                                                                                 \
-        hipEvent_t _se = mmvae_take_stop_event();                                                        \
-        if (_se) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, nullptr, _se, 0, __VA_ARGS__);  \
+        hipEvent_t _se = mmvae_take_stop_event(), _st = nullptr, _fork = nullptr;                        \
+        if (mmvae_probe_on()) { _fork = _se; _se = nullptr; mmvae_probe_events(#kernel, &_st, &_se); }   \
+        if (_se) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, _st, _se, 0, __VA_ARGS__);      \
         else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                          \
+        if (_fork) (void)hipEventRecord(_fork, stream);                                                  \
     } while (0)
 
 enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2 };

@@ -64,6 +64,7 @@ struct ConvResArgs {
     float* t_dgamma; float* t_dbeta;    // += (may be null)
     float t_inv_cnt;            // 1 / elements per channel per group
     int t_groups;
+    bf16* stage_out;            // the staged tensor of a TR 1 / TR 2 launch is also written here (null: not)
     unsigned long long* ts;     // measurement aid: per-wave s_memrealtime stamps (100 MHz) [wg][wave][16] or null
 };
 
@@ -166,6 +167,7 @@ __global__ __launch_bounds__(WAVES * 64) void convres_kernel(const ConvResArgs a
     static_assert(NTHR % VPP == 0, "a thread keeps its channel vector across staging iterations");
     const bf16* const src = a.A + (size_t)img0 * (G::AH * G::AW * G::C);
     const bf16* const src_r = TR == 2 ? a.t_r + (size_t)img0 * (G::AH * G::AW * G::C) : nullptr;
+    bf16* const stage_dst = (TR != 0 && a.stage_out && blockIdx.y == 0) ? a.stage_out + (size_t)img0 * (G::AH * G::AW * G::C) : nullptr;
     i32x4c ireg[SB], rreg[TR == 2 ? SB : 1];
     auto i_fetch = [&](int b) {
 #pragma unroll
@@ -202,6 +204,8 @@ __global__ __launch_bounds__(WAVES * 64) void convres_kernel(const ConvResArgs a
                     val = __builtin_bit_cast(i32x4c, o);
                 }
                 if (cell >= 0) *reinterpret_cast<i32x4c*>(img_s + img * G::IMG_BYTES + cell + cv * 16) = val;
+                if constexpr (TR != 0)
+                    if (stage_dst) *reinterpret_cast<i32x4c*>(stage_dst + (size_t)v * 8) = val;
             }
         }
     };
@@ -563,8 +567,14 @@ int launch_cr(const GemmParams& p, hipStream_t stream) {
                                                  (unsigned)mmvae_knob("convres_ts_lo", 0));
     a.d_r = p.d_r; a.d_affine = p.d_affine; a.d_meanrstd = p.d_meanrstd; a.d_red = p.d_red;
     const int kind = p.tr ? p.tr->kind : 0;
+    if (mmvae_probe_on()) {      // FLOPs the way the reference's FlopCounterMode counts the layer: cropped taps not subtracted
+        char tag[96];
+        snprintf(tag, sizeof(tag), "convres form%d %d>%d %dx%d>%dx%d k%d s%d %s tr%d img%d", G::FORM, G::C, G::N, G::AH, G::AW, G::OH, G::OW,
+                 G::KH, G::S, p.d_r ? "dgrad" : "fwd", kind, nimg);
+        mmvae_probe_tag(tag, 2.0 * (G::FORM == 0 ? G::OH * G::OW : G::AH * G::AW) * G::KH * G::KW * G::C * G::N * (double)nimg);
+    }
     if (kind == 1) {
-        a.fin = p.tr->fin;
+        a.fin = p.tr->fin; a.stage_out = p.tr->out;
         MMVAE_REQUIRE(a.fin.C == G::C && a.fin.G == c.groups && a.fin.affine && a.fin.meanrstd && a.fin.gamma && a.fin.beta,
                       "convres: BatchNorm tables of the staged operand do not match the layer");
         MMVAE_REQUIRE(!p.d_r, "convres: forward-type staging transform on a data-gradient launch");
@@ -574,7 +584,7 @@ int launch_cr(const GemmParams& p, hipStream_t stream) {
         const GatherTransform& t = *p.tr;
         MMVAE_REQUIRE(p.d_r && t.r && t.red && t.mr && t.gamma && t.groups == c.groups, "convres: BatchNorm-backward staging needs r / sums / tables");
         a.t_r = t.r; a.t_red = t.red; a.t_mr = t.mr; a.t_gamma = t.gamma; a.t_dgamma = t.dgamma; a.t_dbeta = t.dbeta;
-        a.t_inv_cnt = t.inv_cnt; a.t_groups = t.groups;
+        a.t_inv_cnt = t.inv_cnt; a.t_groups = t.groups; a.stage_out = t.out;
         return launch_cr_mode<G, NI, CH, WAVES, NG, SCR_OWN, 1, 2, NSPLIT, KSPL>(a, stream);
     }
     return p.d_r ? launch_cr_mode<G, NI, CH, WAVES, NG, SCR_OWN, 1, 0, NSPLIT, KSPL>(a, stream)

@@ -145,6 +145,9 @@ struct AdamArgs {
     const int* gmap; const float* gpk; const float* gpk_vec; float* g_out;
 };
 int launch_adam(const AdamArgs& a, hipStream_t s);
+// loss_k = w_bce[k] * sums[k] + w_nll[k] * sums[4+k] + w_kl[k] * sums[8+k]   (the closing arithmetic of loss_function, train.py:33-62)
+struct StepLossArgs { const float* sums; float* out; float w_bce[3], w_nll[3], w_kl[3]; };
+int launch_step_losses(const StepLossArgs& a, hipStream_t s);
 // map[flat parameter index] = location of its packed gradient (see AdamArgs), -1 where there is none
 int launch_unpack_map(const PackDesc* table_dev, const PackDesc* table_host, int nd, long long nparams, long long gmat_elems, int* map, hipStream_t s);
 int launch_fill_zero(void* p, size_t bytes, hipStream_t s);

@@ -647,11 +647,13 @@ __global__ __launch_bounds__(TPB) void latent3_bwd_kernel(const Latent3BwdArgs a
 // ------------------------------------------------------------------ Adam (torch.optim.Adam defaults)
 __global__ __launch_bounds__(TPB) void adam_kernel(const AdamArgs a, unsigned* done) {
     const long long t = *a.step + 1;
+    // a step that gave up on a device-side exchange marked itself (plan_base.h sum_slots_kernel): no update, no step count
+    const bool skip = done[1] != 0u || a.g[0] != a.g[0];
     const float bc1 = 1.0f - powf(a.b1, (float)t);
     const float bc2 = 1.0f - powf(a.b2, (float)t);
     const float step_size = a.lr / bc1;
     const float inv_sqrt_bc2 = rsqrtf(bc2);
-    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i * 4 < a.n; i += (long long)gridDim.x * TPB) {
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i * 4 < a.n && !skip; i += (long long)gridDim.x * TPB) {
         const long long e = i * 4;
         if (e + 4 <= a.n) {
             f32x4 g = *reinterpret_cast<const f32x4*>(a.g + e);
@@ -698,8 +700,9 @@ __global__ __launch_bounds__(TPB) void adam_kernel(const AdamArgs a, unsigned* d
     if (threadIdx.x == 0) {
         unsigned ticket = atomicAdd(done, 1u);
         if (ticket == gridDim.x - 1) {
-            *done = 0u;
-            *a.step = t;
+            done[0] = 0u;
+            done[1] = 0u;
+            if (!skip) *a.step = t;
             __threadfence();
         }
     }
@@ -1000,6 +1003,15 @@ int launch_adam(const AdamArgs& a, hipStream_t s) {
     unsigned* done = reinterpret_cast<unsigned*>(a.step + 1);
     hipLaunchKernelGGL(adam_kernel, dim3(nblocks((a.n + 3) / 4, TPB, 512)), dim3(TPB), 0, s, a, done);   // few blocks: one ticket atomic each
     return mmvae_check_launch("adam");
+}
+static __global__ void step_losses_kernel(StepLossArgs a) {
+    const int k = threadIdx.x;
+    if (k < 3) a.out[k] = a.w_bce[k] * a.sums[k] + a.w_nll[k] * a.sums[4 + k] + a.w_kl[k] * a.sums[8 + k];
+}
+int launch_step_losses(const StepLossArgs& a, hipStream_t s) {
+    MMVAE_REQUIRE(a.sums && a.out, "step_losses: null buffer");
+    hipLaunchKernelGGL(step_losses_kernel, dim3(1), dim3(64), 0, s, a);
+    return mmvae_check_launch("step_losses");
 }
 int launch_fill_zero(void* p, size_t bytes, hipStream_t s) {
     if (hipMemsetAsync(p, 0, bytes, s) != hipSuccess) {

@@ -56,6 +56,8 @@ struct GatherTransform {
     float* dgamma; float* dbeta;    //     += parameter gradients (may be null)
     float inv_cnt;              //         1 / elements per channel per group
     int groups;
+    bf16* out;                  // kind 1 / 2, optional: the staged (transformed) tensor is also written here, same layout as the gathered
+                                // tensor -- the operand the layer's weight gradient reads, as a by-product instead of a kernel of its own
 };
 
 struct GemmParams {

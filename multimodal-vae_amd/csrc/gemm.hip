@@ -483,10 +483,7 @@ int wgrad_setup(WgradParams& p, WgradSlabCtx* ctx, dim3& grid, size_t& lds, hipS
         max_k = max(max_k, p.cls[i].K);
     }
     const int tiles = ceil_div(c.N, TN) * ceil_div(max_k, TK) * c.nclasses;
-    static const int env_it = getenv("MMVAE_WGRAD_MINIT") ? atoi(getenv("MMVAE_WGRAD_MINIT")) : 0;
-    static const int blk_target = getenv("MMVAE_WGRAD_BLOCKS") ? atoi(getenv("MMVAE_WGRAD_BLOCKS")) : 384;
-    static const int slab_target = getenv("MMVAE_WGRAD_SLAB_BLOCKS") ? atoi(getenv("MMVAE_WGRAD_SLAB_BLOCKS")) : 1024;
-    static const int slab_it = getenv("MMVAE_WGRAD_SLAB_MINIT") ? atoi(getenv("MMVAE_WGRAD_SLAB_MINIT")) : 2;
+    constexpr int env_it = 0, blk_target = 384, slab_target = 1024, slab_it = 2;      // tuned on MultiMNIST / CelebA
     p.slab = nullptr;
     int chunks;
     // slab form: ~4 workgroups per CU, each at least 2 iterations long (a slab copy costs one plain-store pass and one
@@ -496,7 +493,7 @@ int wgrad_setup(WgradParams& p, WgradSlabCtx* ctx, dim3& grid, size_t& lds, hipS
     if (ctx && ctx->pool) {
         // (a grouped launch fills the chip with its problems together; every slab copy is written once and read once,
         //  so a launch's copies are capped at SLAB_CAP floats: the big-weight layers have few rows per output anyway)
-        static const long long slab_cap = getenv("MMVAE_WGRAD_SLAB_CAP") ? atoll(getenv("MMVAE_WGRAD_SLAB_CAP")) : (3ll << 20);
+        constexpr long long slab_cap = 3ll << 20;
         chunks = max(1, min(ceil_div(max_rows, slab_it * WM), ceil_div(max(64, slab_target / group_size), tiles)));
         chunks = (int)min((long long)chunks, max(1ll, slab_cap / slab_elems));
         while (chunks > 1 && ctx->used + (size_t)chunks * slab_elems > ctx->cap) chunks = (chunks + 1) / 2;
@@ -543,7 +540,7 @@ int launch_wgrad_v(const WgradParams& p, dim3 grid, size_t lds, hipStream_t stre
         hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<NWT, KWT, WN, WK>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     }
-    hipLaunchKernelGGL((wgrad_kernel<NWT, KWT, WN, WK>), grid, dim3(256), lds, stream, p);
+    MMVAE_LAUNCH((wgrad_kernel<NWT, KWT, WN, WK>), grid, dim3(256), lds, stream, p);
     return mmvae_check_launch("wgrad");
 }
 
@@ -770,7 +767,7 @@ int launch_rowtile(const GemmParams& p, hipStream_t stream) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rowtile_kernel<NTW>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
     }
     dim3 grid(max_tiles * p.c.groups, 1, p.c.nclasses);
-    hipLaunchKernelGGL(gemm_rowtile_kernel<NTW>, grid, dim3(256), lds, stream, p);
+    MMVAE_LAUNCH(gemm_rowtile_kernel<NTW>, grid, dim3(256), lds, stream, p);
     return mmvae_check_launch("gemm_rowtile");
 }
 
@@ -789,12 +786,14 @@ int launch_gemm_nt(const GemmParams& p, hipStream_t stream) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&splitk_finish_kernel<NT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     }
-    hipLaunchKernelGGL(gemm_gather_kernel<NT>, grid, dim3(256), lds, stream, p);
+    hipEvent_t held = ksplit > 1 ? mmvae_take_stop_event() : nullptr;    // a completion event belongs to the LAST kernel of the launch
+    MMVAE_LAUNCH(gemm_gather_kernel<NT>, grid, dim3(256), lds, stream, p);
     MMVAE_TRY(mmvae_check_launch("gemm_gather"));
     if (ksplit > 1) {
+        if (held) mmvae_arm_stop_event(held);
         constexpr int SLICES = BM / (256 / (BN / 8));
         dim3 fgrid(max_tiles * p.c.groups * SLICES, ceil_div(p.c.N, BN), p.c.nclasses);
-        hipLaunchKernelGGL(splitk_finish_kernel<NT>, fgrid, dim3(256), (size_t)32 * 1024, stream, p);
+        MMVAE_LAUNCH(splitk_finish_kernel<NT>, fgrid, dim3(256), (size_t)32 * 1024, stream, p);
         return mmvae_check_launch("splitk_finish");
     }
     return MMVAE_OK;
@@ -832,12 +831,17 @@ int launch_gemm_gather(const GemmParams& p, hipStream_t stream) {
         const int rc = try_launch_convres(p, stream);
         if (rc != 0) return rc < 0 ? rc : MMVAE_OK;
     }
+    if (mmvae_probe_on()) {
+        char tag[96];
+        double f = 0;
+        for (int i = 0; i < c.nclasses; ++i) f += 2.0 * c.groups * p.cls[i].rows_per_group * (double)c.N * p.cls[i].K;
+        snprintf(tag, sizeof(tag), "gemm %d>%d %dx%d>%dx%d taps%dx%d %s img%d", c.C, c.N, c.AH, c.AW, c.OH, c.OW, p.cls[0].TH, p.cls[0].TW,
+                 p.d_r ? "dgrad" : "fwd", c.groups * c.group_n);
+        mmvae_probe_tag(tag, f);
+    }
     {
-        static const bool no_small = getenv("MMVAE_NO_SMALL") != nullptr;        // A/B aids
-        if (!no_small) {
-            const int rc = try_launch_gemm_small(p, stream);
-            if (rc != 0) return rc < 0 ? rc : MMVAE_OK;
-        }
+        const int rc = try_launch_gemm_small(p, stream);
+        if (rc != 0) return rc < 0 ? rc : MMVAE_OK;
     }
     {
         // few 128-row tiles and a long K loop: use the 16-row weight-streaming kernel (rows/16 workgroups)
@@ -868,6 +872,12 @@ static int wgrad_validate(const WgradParams& p) {
         double f = 0;
         for (int i = 0; i < c.nclasses; ++i) f += 2.0 * c.groups * p.cls[i].rows_per_group * (double)c.N * p.cls[i].K;
         mmvae_count_flops(f);
+        if (mmvae_probe_on()) {
+            char tag[96];
+            snprintf(tag, sizeof(tag), "wgrad %d>%d %dx%d>%dx%d taps%dx%d img%d", c.C, c.N, c.AH, c.AW, c.OH, c.OW, p.cls[0].TH, p.cls[0].TW,
+                     c.groups * c.group_n);
+            mmvae_probe_tag(tag, f);
+        }
     }
     MMVAE_REQUIRE(c.nclasses >= 1 && c.nclasses <= MMVAE_MAX_CLASSES, "wgrad: bad class count %d", c.nclasses);
     MMVAE_REQUIRE(c.C % 8 == 0 && c.Ald % 8 == 0 && p.ldp % 8 == 0 && p.ldp >= round_up(c.N, 8),
@@ -904,7 +914,7 @@ int launch_wgrad(const WgradParams& pin, hipStream_t stream, WgradSlabCtx* ctx) 
 // shape, more than WGRAD_MULTI_MAX problems) is launched on its own.
 int launch_wgrad_group(const WgradParams* list, int n, hipStream_t stream, WgradSlabCtx* ctx) {
     if (mmvae_knob("dbg_skip_wgrad", 0)) return MMVAE_OK;
-    static const bool no_group = getenv("MMVAE_NO_WGRAD_GROUP") != nullptr;
+    constexpr bool no_group = false;
     int i = 0;
     while (i < n) {
         WgradMulti m{};
@@ -931,7 +941,7 @@ int launch_wgrad_group(const WgradParams* list, int n, hipStream_t stream, Wgrad
         if (mmvae_first_use_on_device(attr_set))
             hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_multi_kernel<4, 4, 2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         const size_t lds = (size_t)WM * (128 + 16 + 128 + 16) * sizeof(bf16);
-        hipLaunchKernelGGL((wgrad_multi_kernel<4, 4, 2, 2>), dim3(gxm, gym, m.zoff[m.n]), dim3(256), lds, stream, m);
+        MMVAE_LAUNCH((wgrad_multi_kernel<4, 4, 2, 2>), dim3(gxm, gym, m.zoff[m.n]), dim3(256), lds, stream, m);
         MMVAE_TRY(mmvae_check_launch("wgrad_multi"));
     }
     return MMVAE_OK;
@@ -955,7 +965,7 @@ int launch_wgrad_reduce(WgradSlabCtx* ctx, hipStream_t stream, bool only_own) {
             q.groups = ceil_div(j.chunks, REDUCE_CG);
             blocks += (int)(((long long)j.N * (j.Kpad / 4) * q.groups + 255) / 256);
         }
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a);
+        MMVAE_LAUNCH(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a);
         MMVAE_TRY(mmvae_check_launch("wgrad_reduce"));
     }
     return MMVAE_OK;

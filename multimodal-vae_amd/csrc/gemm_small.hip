@@ -320,7 +320,7 @@ int try_launch_gemm_small(const GemmParams& pin, hipStream_t stream) {
     const long long tiles128 = (long long)max_tiles128 * c.groups * c.nclasses * ceil_div(c.N, 128);
     if (tiles128 > 128) return 0;
     {   // ... and not the long-K giants: one wave per 32x32 tile re-reads both operands from L2 with no reuse
-        static const double cap = getenv("MMVAE_SMALL_MAX_GFLOP") ? atof(getenv("MMVAE_SMALL_MAX_GFLOP")) : 8.0;   // CelebA classifier.0 (13.4 GFLOP): 107 us here, ~35 us tiled + split-K
+        constexpr double cap = 8.0;   // CelebA classifier.0 (13.4 GFLOP): 107 us here, ~35 us tiled + split-K
         double fl = 0.0;
         for (int i = 0; i < c.nclasses; ++i) fl += 2.0 * pin.cls[i].rows_per_group * c.groups * c.N * pin.cls[i].K;
         if (cap > 0.0 && fl > cap * 1e9) return 0;
@@ -335,7 +335,7 @@ int try_launch_gemm_small(const GemmParams& pin, hipStream_t stream) {
     (void)tiles44;
     if (tiles22 > 1536) return 0;                                                  // enough work for the tile kernels
     if (p.d_r == nullptr && (p.d_mask || p.d_red || p.d_colsum)) return 0;
-    static const long long wave_target = getenv("MMVAE_SMALL_WAVES") ? atoll(getenv("MMVAE_SMALL_WAVES")) : 1024;
+    constexpr long long wave_target = 1024;
     const int ks = (int)min((long long)min(4, max(1, min_nch / 2)), max(1ll, wave_target / max(tiles22, 1ll)));
     const int rc = p.d_r ? launch_small_ks<2, 2, true>(p, ks, stream) : launch_small_ks<2, 2, false>(p, ks, stream);
     return rc == MMVAE_OK ? 1 : rc;

@@ -194,7 +194,7 @@ int mnist_step(MnistPlan* Pp, const MnistStepIO& io, int training, int do_backwa
     // =============================== backward ===============================
     // every kernel of this model is launch-latency sized (~50 launches of a few us): forking the weight gradients to
     // side streams costs more in event edges than it overlaps (measured 0.405 ms forked vs 0.387 ms in-order at B=128)
-    P.wgrad_forked = getenv("MMVAE_MNIST_FORK") != nullptr;
+    P.wgrad_forked = false;
     int rc = MMVAE_OK;
     auto TRY = [&](int r) { if (rc == MMVAE_OK) rc = r; };
     float* G = P.buf.grads;

@@ -129,8 +129,7 @@ void build_plan(MMPlan& P) {
     lin(P.fc[1], "image_encoder.classifier.3", 200, 400);
     lin(P.fc[2], "image_encoder.classifier.6", 2 * D, 200);
     if (D == 100) {      // the widths mlp_tail.hip is compiled for
-        static const bool off_ = getenv("MMVAE_NO_MLP_TAIL") != nullptr;     // A/B aid
-        P.mlp_tail = !off_;
+        P.mlp_tail = true;
         auto fragd = [&](PackDesc d) { d.frag = 1; return P.pk.add(d); };
         P.mt_w2 = fragd(pack_dense(P.fc[1].w_off, 200, 400, 208, 416, 400, 1));
         P.mt_w3 = fragd(pack_dense(P.fc[2].w_off, 200, 200, 208, 224, 200, 1));
@@ -292,6 +291,7 @@ int enc_fwd(MMPlan& P, const float* image, int variants, const uint8_t* m1, cons
             tr.kind = 1;
             tr.fin = bn_fin_args(P, P.bn[P.conv[l - 1].bn], prows, 1, w.st_e[l - 2], bn_updates, w.aff_e[l - 2], w.mr_e[l - 2], training);
             g.c.A = r[l - 1]; g.tr = &tr;
+            if (mmvae_knob("mm_stage_out", 1)) tr.out = a[l - 1];      // a2 / a3: operands of the weight gradients, a by-product of the staging
         }
         MMVAE_TRY(launch_gemm_gather(g, s));
         const int rows = B * L.g.OH * L.g.OW;
@@ -463,14 +463,18 @@ int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const
                     return wgrad_on(*pp, gw, ws_);
                 });
             } else {        // the streamed weight-gradient kernel on operands materialised right in front of it (side stream)
-                const bool actp = l >= 2;              // a[l-1] = Swish(BatchNorm(r[l-1])) was never materialised (conv3, conv4)
+                // With staging by-products (GatherTransform::out) the forward of conv3 / conv4 left a2 / a3 behind and conv3's
+                // data gradient below leaves its BatchNorm-backward dr behind: nothing to materialise in front of the kernel
+                const bool byp = mmvae_knob("mm_stage_out", 1) != 0;
+                const bool actp = l >= 2 && !byp;      // a[l-1] = Swish(BatchNorm(r[l-1])) was never materialised (conv3, conv4)
+                const bool bnb = fl && !(byp && l == 2);
                 const int prows = B * P.conv[l >= 2 ? l - 1 : 1].g.OH * P.conv[l >= 2 ? l - 1 : 1].g.OW;
                 const BnL bp = P.bn[P.conv[l >= 2 ? l - 1 : 1].bn];
                 const bf16* rin = r[l >= 2 ? l - 1 : 1]; bf16* ao = a[l >= 2 ? l - 1 : 1]; const float2* st = w.st_e[l >= 2 ? l - 2 : 0];
                 WgradParams g0 = wgrad_of(P, L.fwd, L.gk, 1, B);
                 g0.c.A = a[l - 1]; g0.P = x.dr; g0.ldp = L.g.Cout;
-                side_later(P, [pp, x, g0, fl, actp, bp, rin, ao, st, prows](hipStream_t ws_) {
-                    if (fl) MMVAE_TRY(launch_bn_bwd_apply(x, ws_));
+                side_later(P, [pp, x, g0, bnb, actp, bp, rin, ao, st, prows](hipStream_t ws_) {
+                    if (bnb) MMVAE_TRY(launch_bn_bwd_apply(x, ws_));
                     if (actp) MMVAE_TRY(bn_act_side(*pp, bp, rin, ao, prows, prows, 1, st, 1, ws_));
                     return wgrad_on(*pp, g0, ws_);
                 });
@@ -486,6 +490,9 @@ int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const
             if (fl) {
                 tr.kind = 2; tr.r = r[l]; tr.red = w.red_e[l - 1]; tr.mr = w.mr_e[l - 1]; tr.gamma = P.buf.params + b.w_off;
                 tr.inv_cnt = 1.f / (float)(B * pix); tr.groups = 1;
+                if (l == 2 && mmvae_knob("mm_stage_out", 1)) {      // conv3: dr for its weight gradient + the BatchNorm parameter gradients
+                    tr.out = drr[l]; tr.dgamma = P.buf.grads + b.w_off; tr.dbeta = P.buf.grads + b.b_off;
+                }
                 d.tr = &tr;
             }
             // forks: behind conv4's data gradient (classifier + conv4 + conv3 weight gradients) and behind conv3's (conv2's)
@@ -507,8 +514,7 @@ int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const
         g.c.A = w.patches1; g.P = w.d1e; g.ldp = 32;
         // fp32 atomics into the (zeroed) packed gradient instead of slab copies + a reduce launch: this is the last kernel in
         // front of the optimizer, a second launch here is pure tail latency (the tile is 32 x 16)
-        static const bool slab_last = getenv("MMVAE_CONV1_WGRAD_SLAB") != nullptr;      // A/B aid
-        MMVAE_TRY(launch_wgrad(g, s, slab_last ? &P.slab : nullptr));
+        MMVAE_TRY(launch_wgrad(g, s, nullptr));
     }
     return MMVAE_OK;
 }
@@ -579,6 +585,7 @@ int dec_fwd(MMPlan& P, int groups, int training, ConvTLastFwdArgs* last, hipStre
                 tr.kind = 1;
                 tr.fin = bn_fin_args(P, P.bn[Lp.bn], prpg, groups, w.st_d[l - 1], 1, w.aff_d[l - 1], w.mr_d[l - 1], training);
                 g.c.A = q[l]; g.tr = &tr;
+                if (mmvae_knob("mm_stage_out", 1)) tr.out = aq[l];     // operand of this layer's weight gradient, a by-product of the staging
             }
             MMVAE_TRY(launch_gemm_gather(g, s));
         }
@@ -674,11 +681,14 @@ int dec_bwd(MMPlan& P, const float* dlogit, int groups, float* dz, hipStream_t s
                 // the streamed weight-gradient kernel on operands materialised right in front of it, on the side stream: the
                 // BatchNorm backward of db (its own buffer: the data gradient on the main chain still reads db) and, above the
                 // first layer, the layer input aq[l] = Swish(BatchNorm(q[l])) that the forward never wrote
-                const bool actp = l >= 1;
+                // (with staging by-products, GatherTransform::out, both come out of kernels of the main chain instead: aq[l]
+                //  out of this layer's forward, dr out of this layer's data gradient below -- the side work is the GEMM alone)
+                const bool byp = mmvae_knob("mm_stage_out", 1) != 0;
+                const bool actp = l >= 1 && !byp;
                 const BnL bp = P.bn[Lp.bn];
                 const bf16* qin = q[l]; bf16* aqo = aq[l]; const float2* st = w.st_d[l >= 1 ? l - 1 : 0];
-                side_later(P, [pp, x, gw, actp, bp, qin, aqo, st, groups, prpg, training](hipStream_t ws_) {
-                    MMVAE_TRY(launch_bn_bwd_apply(x, ws_));
+                side_later(P, [pp, x, gw, byp, actp, bp, qin, aqo, st, groups, prpg, training](hipStream_t ws_) {
+                    if (!byp) MMVAE_TRY(launch_bn_bwd_apply(x, ws_));
                     if (actp) MMVAE_TRY(bn_act_side(*pp, bp, qin, aqo, groups * prpg, prpg, groups, st, training, ws_));
                     return wgrad_on(*pp, gw, ws_);
                 });
@@ -696,6 +706,7 @@ int dec_bwd(MMPlan& P, const float* dlogit, int groups, float* dz, hipStream_t s
             if (fl) {
                 tr.kind = 2; tr.r = q[l + 1]; tr.red = w.red_d[l]; tr.mr = w.mr_d[l]; tr.gamma = P.buf.params + b.w_off;
                 tr.inv_cnt = 1.f / (float)(B * pix); tr.groups = groups;
+                if (mmvae_knob("mm_stage_out", 1)) { tr.out = dqr[l + 1]; tr.dgamma = P.buf.grads + b.w_off; tr.dbeta = P.buf.grads + b.b_off; }
                 d.tr = &tr;
             }
             // the side work collected so far forks off the completion of the first and of the last data gradient
@@ -934,7 +945,7 @@ static int mm_step_body(MMPlan* Pp, const MMStepIO& io, int training, int do_bac
     const int sk[3] = {io.pass_skip[0] != 0, io.pass_skip[1] != 0, io.pass_skip[2] != 0};
     P.dec_skip_mask = (unsigned)(sk[0] | (sk[1] << 1) | (sk[2] << 2));
     const int enc_updates = 2 - sk[0] - sk[1];
-    static const bool serial = getenv("MMVAE_SERIAL") != nullptr;      // profiling aid: one stream, no overlap
+    const bool serial = mmvae_serial();      // profiling aid: one stream, no overlap
     hipStream_t T = serial ? s : P.st_text;
     // ---- encoders: image features once for passes 1 and 2 (main), text encoder once for passes 1 and 3 (side)
     if (T != s) MMVAE_TRY(fork_to(P, T));
@@ -978,8 +989,7 @@ static int mm_step_body(MMPlan* Pp, const MMStepIO& io, int training, int do_bac
     // zero gradient); the fused tail needs to know it already in the forward
     int img_groups = 3;
     while (img_groups > 0 && (io.lambda_xy[img_groups - 1] == 0.f || sk[img_groups - 1])) --img_groups;
-    static const bool no_fuse_tail = getenv("MMVAE_NO_FUSED_TAIL") != nullptr;        // A/B aid
-    const bool fuse_tail = !no_fuse_tail && P.slab.pool != nullptr;
+    const bool fuse_tail = P.slab.pool != nullptr;
     MMVAE_TRY(dec_fwd(P, 3, training, &last, s, last_groups, fuse_tail ? (do_backward ? std::min(img_groups, last_groups) : 0) : -1, fuse));
     if (!do_backward) {
         MMVAE_TRY(edge(P, T, s));
@@ -991,9 +1001,8 @@ static int mm_step_body(MMPlan* Pp, const MMStepIO& io, int training, int do_bac
     // =============================== backward ===============================
     P.wgrad_forked = true;
     int rc = MMVAE_OK;
-    static const bool defer = getenv("MMVAE_DEFER_WGRAD") != nullptr;
     P.deferred.clear();
-    P.defer_wgrad = defer && !serial;
+    P.defer_wgrad = false;
     if (img_groups > 0) rc = dec_bwd(P, w.dlogit, img_groups, w.dz_img, s, fuse_tail, fuse, 3, training);
     if (rc == MMVAE_OK) rc = edge(P, T, s);          // dz of the text decoder
     const bool dp_split = io.dp_split && !io.defer_unpack;

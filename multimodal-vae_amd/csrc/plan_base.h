@@ -89,7 +89,7 @@ inline hipEvent_t next_ev(PlanBase& P);
 
 // weight gradients only feed the optimizer: when the step runs multi-stream they go to the side stream
 inline int wgrad_async(PlanBase& P, const WgradParams& g, hipStream_t s) {
-    static const bool serial = getenv("MMVAE_SERIAL") != nullptr;
+    const bool serial = mmvae_serial();
     if (!P.wgrad_forked || serial) return launch_wgrad(g, s, &P.slab);
     if (P.defer_wgrad) { P.deferred.push_back(g); return MMVAE_OK; }
     hipStream_t w = (P.wgrad_rr++ & 1) ? P.st_wgrad2 : P.st_wgrad;
@@ -97,8 +97,7 @@ inline int wgrad_async(PlanBase& P, const WgradParams& g, hipStream_t s) {
     MMVAE_TRY(launch_wgrad(g, w, &P.slab));
     // the slab copies are summed right behind the kernel on the SAME side stream: off the main chain (one reduce launch
     // at the end of the step would read every slab of the step on the critical tail)
-    static const bool late = getenv("MMVAE_WGRAD_REDUCE_LATE") != nullptr;
-    return late ? MMVAE_OK : launch_wgrad_reduce(&P.slab, w, true);
+    return launch_wgrad_reduce(&P.slab, w, true);
 }
 
 // ---- forks bound to a kernel's completion (common.h: MMVAE_LAUNCH)
@@ -132,7 +131,7 @@ inline int fork_to(PlanBase& P, hipStream_t to) {
 // the weight-gradient side stream (alternating when the plan has two), or `s` when the step is not forked; the caller has
 // committed a fork event for the kernel that produced the operands
 inline int wgrad_fork(PlanBase& P, hipStream_t s, hipStream_t* w) {
-    static const bool serial = getenv("MMVAE_SERIAL") != nullptr;
+    const bool serial = mmvae_serial();
     if (!P.wgrad_forked || serial) { *w = s; return MMVAE_OK; }
     *w = (P.wgrad_rr++ & 1) ? P.st_wgrad2 : P.st_wgrad;
     return fork_to(P, *w);
@@ -144,7 +143,7 @@ inline int wgrad_fork(PlanBase& P, hipStream_t s, hipStream_t* w) {
 inline void side_later(PlanBase& P, std::function<int(hipStream_t)> fn) { P.side_pending.push_back(std::move(fn)); }
 inline int side_flush(PlanBase& P, hipStream_t s) {
     if (P.side_pending.empty()) return MMVAE_OK;
-    static const bool serial = getenv("MMVAE_SERIAL") != nullptr;
+    const bool serial = mmvae_serial();
     int rc = MMVAE_OK;
     if (!P.wgrad_forked || serial) {
         for (auto& fn : P.side_pending)
@@ -168,12 +167,13 @@ inline int side_flush(PlanBase& P, hipStream_t s) {
 // The side stream a weight gradient issued now would run on (after an edge from `s`), or `s` itself when the step is not forked:
 // lets the caller put the elementwise pass that prepares the gradient's operand in front of it, off the main chain.
 inline int wgrad_side_stream(PlanBase& P, hipStream_t s, hipStream_t* w) {
-    static const bool serial = getenv("MMVAE_SERIAL") != nullptr;
+    const bool serial = mmvae_serial();
     if (!P.wgrad_forked || serial) { *w = s; return MMVAE_OK; }
     *w = (P.wgrad_rr++ & 1) ? P.st_wgrad2 : P.st_wgrad;
     return edge(P, s, *w);
 }
 inline int wgrad_on(PlanBase& P, const WgradParams& g, hipStream_t w) {
+    if (mmvae_knob("wgrad_atomic", 0)) return launch_wgrad(g, w, nullptr);      // A/B: fp32 atomics into the packed gradient, no slab / reduce
     MMVAE_TRY(launch_wgrad(g, w, &P.slab));
     return launch_wgrad_reduce(&P.slab, w, true);
 }
@@ -491,7 +491,7 @@ inline int ensure_streams(PlanBase& P) {
             // measured on MI355X / ROCm 7, as soon as ANOTHER default-priority stream carries work next to the main one
             // (an H2D copy stream, a collective library's internal stream) they make every kernel of the process run
             // several times slower (0.98 -> 2.63 ms per step).
-            const bool low = (getenv("MMVAE_LOW_PRIORITY") != nullptr || mmvae_stream_policy() == 0) && getenv("MMVAE_FLAT_PRIORITY") == nullptr;
+            const bool low = mmvae_stream_policy() == 0;
             const bool flat = !low;
             mmvae_stream_policy_freeze();
             const int prio = flat ? 0 : least;
@@ -504,11 +504,7 @@ inline int ensure_streams(PlanBase& P) {
         }
         P.st_text = shared[0]; P.st_wgrad = shared[1]; P.st_wgrad2 = shared[2];
     }
-    static const bool one_side = getenv("MMVAE_ONE_SIDE") != nullptr;   // experiment: text path and wgrads share a stream
-    static const bool one_wgrad = getenv("MMVAE_ONE_WGRAD") != nullptr; // experiment: a single weight-gradient stream
-    if (one_side) P.st_wgrad = P.st_wgrad2 = P.st_text;
-    static const bool two_wgrad = getenv("MMVAE_TWO_WGRAD") != nullptr; // A/B aid: overrides single_wgrad_stream
-    if (one_wgrad || (P.single_wgrad_stream && !two_wgrad)) P.st_wgrad2 = P.st_wgrad;
+    if (P.single_wgrad_stream) P.st_wgrad2 = P.st_wgrad;
     P.next_event = 0; P.wgrad_rr = 0;
     return MMVAE_OK;
 }
@@ -542,13 +538,22 @@ inline int check_bound(const PlanBase* P) {
 // out[16] = sum over the MMVAE_LOSS_SLOTS replicated rows of the loss accumulators.  alarm0 / alarm1 (optional): words a
 // kernel of the step sets when it gave up waiting for a peer (the cluster exchange of the COCO caption decoder): the
 // step's numbers are then garbage, and the loss sums say so (NaN) instead of looking plausible.
-static __global__ void sum_slots_kernel(const float* slots, float* out, const unsigned* alarm0 = nullptr, const unsigned* alarm1 = nullptr) {
+// A failed step must also never reach the parameters: `adam_state` (the caller's 16-byte optimizer state block, elementwise.h
+// AdamArgs::step) gets its skip word set, and element 0 of the flat gradient becomes NaN -- a mark that survives the SUM
+// all-reduce of a data-parallel job, so that EVERY rank's Adam kernel drops the update (adam_kernel).
+static __global__ void sum_slots_kernel(const float* slots, float* out, const unsigned* alarm0 = nullptr, const unsigned* alarm1 = nullptr,
+                                        long long* adam_state = nullptr, float* grads = nullptr) {
     const int j = threadIdx.x;
     if (j >= 16) return;
     float s = 0.f;
     for (int q = 0; q < MMVAE_LOSS_SLOTS; ++q) s += slots[q * 16 + j];
-    if ((alarm0 && *alarm0) || (alarm1 && *alarm1)) s = __builtin_nanf("");
+    const bool alarm = (alarm0 && *alarm0) || (alarm1 && *alarm1);
+    if (alarm) s = __builtin_nanf("");
     out[j] = s;
+    if (alarm && j == 0) {
+        if (adam_state) reinterpret_cast<unsigned*>(adam_state + 1)[1] = 1u;
+        if (grads) grads[0] = __builtin_nanf("");
+    }
 }
 static __global__ void cast_z_kernel(const float* z, int rows, int D, bf16* out, int ldz) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -2,6 +2,7 @@
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 static thread_local char g_err[512] = "";
 
@@ -77,6 +78,22 @@ extern "C" int mmvae_debug_set(const char* key, int value) {
     return MMVAE_OK;
 }
 
+int mmvae_cu_count() {
+    static std::atomic<int> cached[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    int n = cached[dev].load();
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 1;
+        cached[dev].store(n);
+    }
+    return n;
+}
+bool mmvae_serial() {
+    static const bool serial = getenv("MMVAE_SERIAL") != nullptr;
+    return serial;
+}
+
 // ---- completion event of the next launch (common.h: MMVAE_LAUNCH)
 static thread_local hipEvent_t g_stop_event = nullptr;
 void mmvae_arm_stop_event(hipEvent_t e) { g_stop_event = e; }
@@ -84,4 +101,64 @@ hipEvent_t mmvae_take_stop_event() {
     hipEvent_t e = g_stop_event;
     g_stop_event = nullptr;
     return e;
+}
+
+// ---- in-step kernel timing (common.h: MMVAE_LAUNCH; include/mmvae_hip.h: mmvae_debug_probe / mmvae_debug_probe_read)
+#include <string>
+#include <vector>
+namespace {
+struct ProbeRec { std::string tag, kernel; double flops; hipEvent_t start, stop; };
+std::atomic<bool> g_probe{false};
+std::mutex g_probe_mu;
+std::vector<ProbeRec> g_probe_recs;
+std::vector<hipEvent_t> g_probe_pool;
+thread_local char g_probe_tag[96] = "";
+thread_local double g_probe_flops = 0.0;
+}
+bool mmvae_probe_on() { return g_probe.load(std::memory_order_relaxed); }
+void mmvae_probe_tag(const char* tag, double algo_flops) {
+    if (!mmvae_probe_on()) return;
+    snprintf(g_probe_tag, sizeof(g_probe_tag), "%s", tag);
+    g_probe_flops = algo_flops;
+}
+void mmvae_probe_events(const char* kernel, hipEvent_t* start, hipEvent_t* stop) {
+    std::lock_guard<std::mutex> g(g_probe_mu);
+    hipEvent_t e[2];
+    for (int i = 0; i < 2; ++i) {
+        if (!g_probe_pool.empty()) { e[i] = g_probe_pool.back(); g_probe_pool.pop_back(); }
+        else if (hipEventCreate(&e[i]) != hipSuccess) { *start = nullptr; *stop = nullptr; return; }
+    }
+    g_probe_recs.push_back(ProbeRec{g_probe_tag, kernel, g_probe_flops, e[0], e[1]});
+    g_probe_tag[0] = 0;
+    g_probe_flops = 0.0;
+    *start = e[0];
+    *stop = e[1];
+}
+extern "C" int mmvae_debug_probe(int on) {
+    g_probe.store(on != 0);
+    return MMVAE_OK;
+}
+// Waits for the probed launches, writes one line per launch "tag\tkernel\tmicroseconds\tflops\n" into buf (truncated at a line
+// boundary when cap is too small) and forgets them.  Returns the number of launches written, or a negative error.
+extern "C" int mmvae_debug_probe_read(char* buf, long long cap) {
+    std::lock_guard<std::mutex> g(g_probe_mu);
+    long long used = 0;
+    int n = 0;
+    int rc = MMVAE_OK;
+    for (ProbeRec& r : g_probe_recs) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.stop) != hipSuccess || hipEventElapsedTime(&ms, r.start, r.stop) != hipSuccess) {
+            mmvae_set_error("probe_read: %s", hipGetErrorString(hipGetLastError()));
+            rc = MMVAE_EHIP;
+        } else if (buf) {
+            char line[512];
+            const int len = snprintf(line, sizeof(line), "%s\t%.200s\t%.3f\t%.6g\n", r.tag.c_str(), r.kernel.c_str(), ms * 1e3, r.flops);
+            if (used + len < cap) { memcpy(buf + used, line, len); used += len; ++n; }
+        }
+        g_probe_pool.push_back(r.start);
+        g_probe_pool.push_back(r.stop);
+    }
+    g_probe_recs.clear();
+    if (buf && cap > 0) buf[used] = 0;
+    return rc != MMVAE_OK ? rc : n;
 }

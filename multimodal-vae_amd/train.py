@@ -131,9 +131,15 @@ def main(argv=None) -> dict:
         te_x, te_t = D.load_multimnist(args.data, train=False)
     if world > 1:                        # rank r trains / tests on samples r, r + world, ... (equal shard sizes)
         n_tr, n_te = len(tr_x) // world * world, len(te_x) // world * world
-        tr_x, tr_t, te_x, te_t = tr_x[rank:n_tr:world], tr_t[rank:n_tr:world], te_x[rank:n_te:world], te_t[rank:n_te:world]
+        tr_x, tr_t, te_x, te_t = (t.contiguous() for t in (tr_x[rank:n_tr:world], tr_t[rank:n_tr:world],
+                                                           te_x[rank:n_te:world], te_t[rank:n_te:world]))
     train_loader = D.DeviceBatcher(tr_x, tr_t, args.batch_size, dev, shuffle=True, seed=dp.rank_seed(args.seed, rank))
     test_loader = D.DeviceBatcher(te_x, te_t, args.batch_size, dev, shuffle=True, seed=dp.rank_seed(args.seed + 7, rank))
+
+    if len(train_loader) == 0 or len(test_loader) == 0:
+        import warnings
+        warnings.warn("rank %d: %d training / %d test samples give no full batch of %d: nothing to do in that phase"
+                      % (rank, len(tr_x), len(te_x), args.batch_size))
 
     vae = MultimodalVAE(args.n_latents, use_cuda=True).cuda()
     trainer = FusedTrainer(vae, args.batch_size, lr=args.lr, kl_lambda=1e-3, seed=dp.rank_seed(args.seed, rank), world_size=world,

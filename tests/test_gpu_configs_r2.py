@@ -106,7 +106,8 @@ def test_single_rank_rccl_group_runs_the_data_parallel_step():
     from multimodal_vae_amd.core import FusedELBOStep, MultimnistState
     from multimodal_vae_amd.init import default_init_
     dev = _dev()
-    assert os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"          # exported by the image / gpurun; dp asserts it too
+    if os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") != "0":             # exported by the image / gpurun; dp refuses without it
+        pytest.skip("HSA_ENABLE_IPC_MODE_LEGACY=0 is not exported: RCCL cannot share device memory across processes here")
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     created = not dist.is_initialized()
@@ -207,21 +208,16 @@ def test_coco_caption_kernel_forms_agree():
     keep = (torch.rand(T, 3 * B, 200, generator=g) > 0.1).to(torch.uint8).to(dev)
     st = CocoState(D, dev, steps=T); default_init_(st, 21)
     eng = FusedCocoStep(st, B, 0.4 * torch.randn(300, generator=g), seed=3)
-    switches = ("MMVAE_COCO_CLUSTER", "MMVAE_COCO_ENC_STREAMED", "MMVAE_COCO_NO_COMB", "MMVAE_COCO_NO_COMB_BWD", "MMVAE_COCO_NO_MSE_FUSE")
-    old = {k: os.environ.get(k) for k in switches}
+    from multimodal_vae_amd._lib import call
+    switches = ("coco_no_comb", "coco_no_comb_bwd", "coco_no_mse_fuse")       # A/B knobs (include/mmvae_hip.h: mmvae_debug_set)
 
     def run(cluster, streamed, *off):
-        """off: switches that take parts of the composed cluster-of-8 form out (W_comb = W_ih0x W_ho, two exchanges per step,
+        """off: knobs that take parts of the composed cluster-of-8 form out (W_comb = W_ih0x W_ho, two exchanges per step,
         the MSE fused into the forward kernel's output pass); the default at cluster == 8 has all of them in."""
-        for k in switches[2:]:
-            os.environ.pop(k, None)
-        for k in off:
-            os.environ[k] = "1"
-        os.environ["MMVAE_COCO_CLUSTER"] = str(cluster)
-        if streamed:
-            os.environ["MMVAE_COCO_ENC_STREAMED"] = "1"
-        else:
-            os.environ.pop("MMVAE_COCO_ENC_STREAMED", None)
+        for k in switches:
+            call("mmvae_debug_set", k.encode(), 1 if k in off else 0)
+        call("mmvae_debug_set", b"coco_cluster", cluster)
+        call("mmvae_debug_set", b"coco_enc_streamed", 1 if streamed else 0)
         rt = torch.zeros(3, B, T, 300, device=dev)
         out = eng.forward_backward(image, text, True, True, eps=eps, gru_keep=keep, recon_text=rt)
         torch.cuda.synchronize()
@@ -229,19 +225,18 @@ def test_coco_caption_kernel_forms_agree():
 
     try:
         r0, g0, l0 = run(0, True)
-        for cluster, streamed, *off in ((0, False), (4, False), (8, False), (8, True), (8, False, "MMVAE_COCO_NO_COMB"),
-                                        (8, False, "MMVAE_COCO_NO_COMB_BWD"), (8, False, "MMVAE_COCO_NO_MSE_FUSE")):
+        for cluster, streamed, *off in ((0, False), (4, False), (8, False), (8, True), (8, False, "coco_no_comb"),
+                                        (8, False, "coco_no_comb_bwd"), (8, False, "coco_no_mse_fuse")):
             r, gg, l = run(cluster, streamed, *off)
             np.testing.assert_allclose(l, l0, rtol=2e-4)
             assert float((r - r0).abs().max()) < 1e-2, (cluster, streamed, off)
             assert float((gg - g0).norm() / g0.norm()) < 1e-2, (cluster, streamed, off)
-            for n, shape, off in st.table:        # every tensor, so that a slice of units left out cannot hide in the norm
+            for n, shape, o in st.table:        # every tensor, so that a slice of units left out cannot hide in the norm
                 k = int(np.prod(shape))
-                a, b = gg[off:off + k], g0[off:off + k]
+                a, b = gg[o:o + k], g0[o:o + k]
                 assert float((a - b).norm()) <= 5e-2 * float(b.norm()) + 1e-7, (cluster, streamed, off, n)
     finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        for k in switches:
+            call("mmvae_debug_set", k.encode(), 0)
+        call("mmvae_debug_set", b"coco_cluster", 8)
+        call("mmvae_debug_set", b"coco_enc_streamed", 0)

@@ -1,11 +1,12 @@
 """Composed (two-exchange) caption decoder kernels against the three-exchange cluster kernels in ONE process: per-tensor
-gradient differences (the environment switches are read per call)."""
+gradient differences (the knobs are read per call)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 import multimodal_vae_amd  # noqa
 from multimodal_vae_amd import core
 from multimodal_vae_amd.init import default_init_
+from multimodal_vae_amd._lib import call
 from bench import synthetic_batch_for, synthetic_sos
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dev = torch.device("cuda:0")
@@ -18,16 +19,15 @@ eps = torch.randn(3, B, 100, generator=g).to(dev)
 keep = (torch.rand(102, 3 * B, 200, generator=g) > 0.1).to(torch.uint8).to(dev)
 
 def run(env):
-    for k in ("MMVAE_COCO_NO_COMB", "MMVAE_COCO_NO_COMB_BWD"):
-        os.environ.pop(k, None)
-    os.environ.update(env)
+    for k in ("coco_no_comb", "coco_no_comb_bwd"):
+        call("mmvae_debug_set", k.encode(), 1 if k in env else 0)
     rt = torch.zeros(3, B, 102, 300, device=dev)
     out = eng.forward_backward(a, b, True, True, eps=eps, gru_keep=keep, recon_text=rt)
     torch.cuda.synchronize()
     return rt.clone(), st.grads.clone(), out.losses().cpu().numpy()
 
-r0, g0, l0 = run({"MMVAE_COCO_NO_COMB": "1"})
-for name, env in (("fwd composed", {"MMVAE_COCO_NO_COMB_BWD": "1"}), ("fwd+bwd composed", {})):
+r0, g0, l0 = run({"coco_no_comb"})
+for name, env in (("fwd composed", {"coco_no_comb_bwd"}), ("fwd+bwd composed", set())):
     r, gg, l = run(env)
     print(name, ": recon max diff", float((r - r0).abs().max()), "grads rel", float((gg - g0).norm() / g0.norm()), l - l0)
     for n, shape, off in st.table:

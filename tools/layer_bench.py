@@ -11,7 +11,9 @@ st = MultimnistState(100, dev); default_init_(st, 1234)
 img, txt = synthetic_batch(B, 1234)
 eng = FusedELBOStep(st, B)
 eng(img.to(dev), txt.to(dev)); st.ensure_packed(); torch.cuda.synchronize()
-layers = sys.argv[1:] or ['enc_conv1', 'enc_conv2', 'enc_conv3', 'enc_conv4', 'enc_conv2_dgrad', 'enc_conv3_dgrad', 'enc_conv4_dgrad', 'dec_convT1', 'dec_convT2', 'dec_convT3', 'dec_convT1_dgrad', 'dec_convT2_dgrad', 'dec_convT3_dgrad', 'enc_fc1', 'enc_fc2', 'enc_fc3', 'enc_fc3_dgrad', 'enc_fc2_dgrad', 'dec_up', 'dec_up_dgrad', 'dec_convT1_wgrad', 'dec_convT2_wgrad', 'dec_convT3_wgrad', 'dec_last_wgrad', 'enc_conv1_wgrad', 'enc_conv2_wgrad', 'enc_conv3_wgrad', 'enc_conv4_wgrad']
+for kv in [a for a in sys.argv[1:] if "=" in a]:          # knob=value arguments (mmvae_debug_set)
+    k, v = kv.split("="); call("mmvae_debug_set", k.encode(), int(v))
+layers = [a for a in sys.argv[1:] if "=" not in a] or ['enc_conv1', 'enc_conv2', 'enc_conv3', 'enc_conv4', 'enc_conv2_dgrad', 'enc_conv3_dgrad', 'enc_conv4_dgrad', 'dec_convT1', 'dec_convT2', 'dec_convT3', 'dec_convT1_dgrad', 'dec_convT2_dgrad', 'dec_convT3_dgrad', 'enc_fc1', 'enc_fc2', 'enc_fc3', 'enc_fc3_dgrad', 'enc_fc2_dgrad', 'dec_up', 'dec_up_dgrad', 'dec_convT1_wgrad', 'dec_convT2_wgrad', 'dec_convT3_wgrad', 'dec_last_wgrad', 'enc_conv1_wgrad', 'enc_conv2_wgrad', 'enc_conv3_wgrad', 'enc_conv4_wgrad']
 s = torch.cuda.current_stream(); sp = ctypes.c_void_p(s.cuda_stream)
 for L in layers:
     fl = call("mmvae_mm_layer_flops", eng.h, L.encode())
