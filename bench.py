@@ -263,6 +263,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph (1 GPU only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dp-overlap", action="store_true", help="N>1, MultiMNIST: all-reduce the decoders' gradients while the encoders' backward runs")
+    ap.add_argument("--knob", action="append", default=[], help="name=value: an A/B switch of the library (mmvae_debug_set), measurement aid")
     ap.add_argument("--no-probe", action="store_true", help="skip the in-step kernel timing (roofline falls back to the whole step)")
     args = ap.parse_args()
     wl = args.workload
@@ -279,6 +280,10 @@ def main():
     from multimodal_vae_amd import core
     from multimodal_vae_amd.init import default_init_
     from multimodal_vae_amd._lib import call
+
+    for kv in args.knob:
+        k, v = kv.split("=")
+        call("mmvae_debug_set", k.encode(), int(v))
 
     from multimodal_vae_amd import dp
     all_reduce = None

@@ -179,8 +179,11 @@ int cast_pad(const float* x, int rows, int cols, bf16* out, int ld, hipStream_t 
 }
 
 // ================================================================== image encoder (celeba/model.py:124-128)
+// fuse (the fused step, B % 4 == 0): the layers that run on the image-resident kernels (convres.hip) stage BatchNorm + Swish /
+// the BatchNorm backward of their gathered operand themselves (GatherTransform) and leave the staged tensor behind for the
+// weight gradients (GatherTransform::out) -- no bn_act / bn_bwd_apply launch in front of them
 int enc_fwd(CelebaPlan& P, const float* image, int variants, const uint8_t* m1, int dropout, int training, int bn_updates,
-            float* out, hipStream_t s) {
+            float* out, hipStream_t s, bool fuse = false) {
     CelebaPlan::W& w = P.w;
     const int B = P.B;
     MMVAE_TRY(launch_im2col_small(image, B, 3, IMG, IMG, 4, 4, 2, 1, 32, 32, w.patches1, 48, s));
@@ -198,8 +201,17 @@ int enc_fwd(CelebaPlan& P, const float* image, int variants, const uint8_t* m1, 
         g.c.A = a[l - 1];
         g.out_bf = r[l]; g.ldo = L.g.Cout;
         g.colstats = training ? w.st_e[l - 1] : nullptr;
+        GatherTransform tr{};
+        if (fuse && l == 2) {          // features.5 stages a2 = Swish(BatchNorm(r2)) itself
+            const int prows = B * P.conv[1].g.OH * P.conv[1].g.OW;
+            tr.kind = 1;
+            tr.fin = bn_fin_args(P, P.bn[P.conv[1].bn], prows, 1, w.st_e[0], bn_updates, w.aff_e[0], w.mr_e[0], training);
+            tr.out = a[1];
+            g.c.A = r[1]; g.tr = &tr;
+        }
         MMVAE_TRY(launch_gemm_gather(g, s));
         const int rows = B * L.g.OH * L.g.OW;
+        if (fuse && l == 1) continue;
         MMVAE_TRY(bn_act(P, P.bn[L.bn], r[l], a[l], rows, rows, 1, w.st_e[l - 1], bn_updates, w.aff_e[l - 1], w.mr_e[l - 1], training, s));
     }
     const int rows = variants * B;
@@ -216,7 +228,7 @@ int enc_fwd(CelebaPlan& P, const float* image, int variants, const uint8_t* m1, 
 }
 
 // d_out: bf16 [variants*B][2D]; the bias gradient of classifier.3 must already be accumulated by the caller
-int enc_bwd(CelebaPlan& P, const bf16* d_out, int variants, const uint8_t* m1, int dropout, hipStream_t s) {
+int enc_bwd(CelebaPlan& P, const bf16* d_out, int variants, const uint8_t* m1, int dropout, hipStream_t s, bool fuse = false) {
     CelebaPlan::W& w = P.w;
     const int B = P.B, rows = variants * B;
     {   // classifier.3
@@ -254,19 +266,29 @@ int enc_bwd(CelebaPlan& P, const bf16* d_out, int variants, const uint8_t* m1, i
         x.r = r[l]; x.dr = dr[l]; x.rows = B * pix; x.C = L.g.Cout; x.ld = L.g.Cout; x.rows_per_group = B * pix; x.G = 1;
         x.red = w.red_e[l - 1]; x.meanrstd = w.mr_e[l - 1]; x.gamma = P.buf.params + b.w_off;
         x.dgamma = P.buf.grads + b.w_off; x.dbeta = P.buf.grads + b.b_off;
-        MMVAE_TRY(launch_bn_bwd_apply(x, s));
-        {
-            WgradParams g = wgrad_of(P, L.fwd, L.gk, 1, B);
-            g.c.A = a[l - 1]; g.P = dr[l]; g.ldp = L.g.Cout;
-            MMVAE_TRY(wgrad_async(P, g, s));
-        }
+        // features.5 / features.2 (fused): their data gradient applies the BatchNorm backward to db while staging it and writes
+        // dr back IN PLACE (a workgroup owns its images: each vector is read, then overwritten, by the same thread) -- the weight
+        // gradient follows it
+        const bool fl = fuse && l <= 2;
+        if (!fl) MMVAE_TRY(launch_bn_bwd_apply(x, s));
+        WgradParams gw = wgrad_of(P, L.fwd, L.gk, 1, B);
+        gw.c.A = a[l - 1]; gw.P = dr[l]; gw.ldp = L.g.Cout;
+        if (!fl) MMVAE_TRY(wgrad_async(P, gw, s));
         {
             GemmParams d = gemm_of(P, L.dgrad, L.pk_dgrad, 1, B, L.pk_dgrad_f);
             d.c.A = dr[l]; d.out_bf = dr[l - 1]; d.ldo = L.g.Cin;
             d.d_r = r[l - 1]; d.d_ld = L.g.Cin; d.d_act = ACT_SWISH;
             if (l > 1) { d.d_affine = w.aff_e[l - 2]; d.d_meanrstd = w.mr_e[l - 2]; d.d_red = w.red_e[l - 2]; }
+            GatherTransform tr{};
+            if (fl) {
+                tr.kind = 2; tr.r = r[l]; tr.red = w.red_e[l - 1]; tr.mr = w.mr_e[l - 1]; tr.gamma = P.buf.params + b.w_off;
+                tr.dgamma = P.buf.grads + b.w_off; tr.dbeta = P.buf.grads + b.b_off;
+                tr.inv_cnt = 1.f / (float)(B * pix); tr.groups = 1; tr.out = dr[l];
+                d.tr = &tr;
+            }
             MMVAE_TRY(launch_gemm_gather(d, s));
         }
+        if (fl) MMVAE_TRY(wgrad_async(P, gw, s));
     }
     {   // conv1 wgrad over the im2col patches
         GatherPlan pl = dense_plan(B * 1024, 48, 48, 32);
@@ -278,7 +300,11 @@ int enc_bwd(CelebaPlan& P, const bf16* d_out, int variants, const uint8_t* m1, i
 }
 
 // ================================================================== image decoder (celeba/model.py:157-161)
-int dec_fwd(CelebaPlan& P, int groups, int training, ConvTLastFwdArgs* last, hipStream_t s) {
+// fused_bwd_groups >= 0 (the fused step): BatchNorm + Swish of hallucinate.7, the last ConvTranspose2d, sigmoid + BCE and -- for
+// the first fused_bwd_groups passes -- its input / weight gradients in ONE kernel per image (dec_last.hip dec_last_ca_kernel);
+// last_groups: passes whose last layer is computed at all
+int dec_fwd(CelebaPlan& P, int groups, int training, ConvTLastFwdArgs* last, hipStream_t s, int last_groups = -1, int fused_bwd_groups = -1,
+            bool fuse = false) {
     CelebaPlan::W& w = P.w;
     const int B = P.B, rows = groups * B;
     {
@@ -295,9 +321,44 @@ int dec_fwd(CelebaPlan& P, int groups, int training, ConvTLastFwdArgs* last, hip
         g.c.A = aq[l];
         g.out_bf = q[l + 1]; g.ldo = L.g.Cout;
         g.colstats = training ? w.st_d[l] : nullptr;
+        GatherTransform tr{};
+        if (fuse && l >= 1) {          // hallucinate.3 / .6 stage Swish(BatchNorm(q[l])) themselves and leave aq[l] behind
+            const ConvL& Lp = P.convT[l - 1];
+            tr.kind = 1;
+            tr.fin = bn_fin_args(P, P.bn[Lp.bn], B * Lp.g.OH * Lp.g.OW, groups, w.st_d[l - 1], 1, w.aff_d[l - 1], w.mr_d[l - 1], training);
+            tr.out = aq[l];
+            g.c.A = q[l]; g.tr = &tr;
+        }
         MMVAE_TRY(launch_gemm_gather(g, s));
         const int rpg = B * L.g.OH * L.g.OW;
+        if (l == 2 && fused_bwd_groups >= 0) continue;
+        if (fuse && l <= 1) continue;
         MMVAE_TRY(bn_act(P, P.bn[L.bn], q[l + 1], aq[l + 1], groups * rpg, rpg, groups, w.st_d[l], 1, w.aff_d[l], w.mr_d[l], training, s));
+    }
+    if (fused_bwd_groups >= 0) {
+        const ConvL& L = P.convT[2];
+        const BnL& b = P.bn[L.bn];
+        DecLastFusedArgs x{};
+        x.r = w.q3; x.act = ACT_SWISH; x.w = P.buf.params + P.convT[3].w_off;
+        x.G = last_groups > 0 ? last_groups : groups; x.B = B; x.IH = 32; x.IW = 32; x.Cin = 32; x.Cout = 3;
+        x.bwd_groups = std::min(fused_bwd_groups, x.G);
+        x.fin = bn_fin_args(P, b, B * L.g.OH * L.g.OW, groups, w.st_d[2], 1, w.aff_d[2], w.mr_d[2], training);
+        x.target = last->target; x.logits = last->logits; x.recon = last->recon; x.dlogit = nullptr;
+        for (int k = 0; k < 4; ++k) x.coef[k] = last->coef[k];
+        x.loss_sum = last->loss_sum;
+        if (x.bwd_groups > 0) {
+            const int chunks = x.bwd_groups * B;
+            x.wslab = P.slab.take((size_t)chunks * 32 * 48);
+            MMVAE_REQUIRE(x.wslab != nullptr, "fused decoder tail: the weight-gradient slab pool is exhausted");
+            x.db = w.d3; x.red = w.red_d[2];
+            WgradSlabJob j{};
+            const PackDesc& gd = P.gk.d[P.convT[3].gk[0]];
+            j.dst = P.buf.gpk + gd.dst_off; j.slab = x.wslab; j.N = 32; j.K = 48; j.Kpad = gd.Kpad; j.chunks = chunks;
+            j.chunk_stride = 32 * 48; j.src_ld = 48;
+            j.stream = s;            // (dec_bwd moves the sum behind its first weight gradient, off the main chain)
+            P.slab.jobs.push_back(j);
+        }
+        return launch_dec_last_ca(x, s);
     }
     ConvTLastFwdArgs x = *last;
     x.act = w.aq3; x.w = P.buf.params + P.convT[3].w_off; x.G = groups; x.B = B; x.IH = 32; x.IW = 32; x.Cin = 32; x.Cout = 3;
@@ -305,13 +366,19 @@ int dec_fwd(CelebaPlan& P, int groups, int training, ConvTLastFwdArgs* last, hip
 }
 
 // dlogit: fp32 NCHW [groups*B][3][64][64] (grad wrt the pre-sigmoid logits). Writes dz (fp32 [groups*B][D]).
-int dec_bwd(CelebaPlan& P, const float* dlogit, int groups, float* dz, hipStream_t s) {
+int dec_bwd(CelebaPlan& P, const float* dlogit, int groups, float* dz, hipStream_t s, bool last_fused = false, bool fuse = false) {
     CelebaPlan::W& w = P.w;
     const int B = P.B, rows = groups * B;
     bf16* q[4] = {w.u, w.q1, w.q2, w.q3};
     bf16* aq[4] = {w.au, w.aq1, w.aq2, w.aq3};
     bf16* dq[4] = {w.du, w.d1, w.d2, w.d3};
-    {   // last transposed conv (32 -> 3): both gradients go through the im2col patches of dlogit (K = 16 taps x 3):
+    if (last_fused && P.wgrad_forked && !mmvae_serial()) {
+        // d3, the BatchNorm-backward sums and the per-image weight-gradient partials of the last layer came out of the fused tail
+        // (dec_fwd); the sum of the partials goes behind the first weight gradient below, on its side stream (wgrad_async)
+        hipStream_t wst = (P.wgrad_rr & 1) ? P.st_wgrad2 : P.st_wgrad;
+        for (WgradSlabJob& j : P.slab.jobs) if (j.stream == s && j.src_ld == 48) j.stream = wst;
+    }
+    if (!last_fused) {   // last transposed conv (32 -> 3): both gradients go through the im2col patches of dlogit (K = 16 taps x 3):
         // input gradient = dense GEMM patches x W with d-Swish + BatchNorm-backward sums in the epilogue
         const ConvL& L = P.convT[3];
         MMVAE_TRY(launch_im2col_small(dlogit, rows, 3, IMG, IMG, 4, 4, 2, 1, 32, 32, w.patches4, 48, s));
@@ -337,18 +404,25 @@ int dec_bwd(CelebaPlan& P, const float* dlogit, int groups, float* dz, hipStream
         x.rows_per_group = B * pix; x.G = groups;
         x.red = w.red_d[l]; x.meanrstd = w.mr_d[l]; x.gamma = P.buf.params + b.w_off;
         x.dgamma = P.buf.grads + b.w_off; x.dbeta = P.buf.grads + b.b_off;
-        MMVAE_TRY(launch_bn_bwd_apply(x, s));
-        {
-            WgradParams g = convT_wgrad(P, L, groups, B, aq[l], dq[l + 1]);
-            MMVAE_TRY(wgrad_async(P, g, s));
-        }
+        const bool fl = fuse && l >= 1;       // hallucinate.6 / .3: BatchNorm backward inside the data gradient's staging, dr in place (enc_bwd)
+        if (!fl) MMVAE_TRY(launch_bn_bwd_apply(x, s));
+        WgradParams gw = convT_wgrad(P, L, groups, B, aq[l], dq[l + 1]);
+        if (!fl) MMVAE_TRY(wgrad_async(P, gw, s));
         {
             GemmParams d = gemm_of(P, L.dgrad, L.pk_dgrad, groups, B, L.pk_dgrad_f);
             d.c.A = dq[l + 1]; d.out_bf = dq[l]; d.ldo = L.g.Cin;
             d.d_r = q[l]; d.d_ld = L.g.Cin; d.d_act = ACT_SWISH;
             if (l > 0) { d.d_affine = w.aff_d[l - 1]; d.d_meanrstd = w.mr_d[l - 1]; d.d_red = w.red_d[l - 1]; }
+            GatherTransform tr{};
+            if (fl) {
+                tr.kind = 2; tr.r = q[l + 1]; tr.red = w.red_d[l]; tr.mr = w.mr_d[l]; tr.gamma = P.buf.params + b.w_off;
+                tr.dgamma = P.buf.grads + b.w_off; tr.dbeta = P.buf.grads + b.b_off;
+                tr.inv_cnt = 1.f / (float)(B * pix); tr.groups = groups; tr.out = dq[l + 1];
+                d.tr = &tr;
+            }
             MMVAE_TRY(launch_gemm_gather(d, s));
         }
+        if (fl) MMVAE_TRY(wgrad_async(P, gw, s));
     }
     {   // upsample Linear: weight (+ folded bias) gradient and dz
         GatherPlan pl = dense_plan(rows, P.ldz, P.ldz, FEAT);
@@ -478,7 +552,9 @@ static int celeba_step_body(CelebaPlan* Pp, const CelebaStepIO& io, int training
     P.no_splitk = !serial;
     MMVAE_TRY(att_enc_fwd(P, io.attrs, training, 2 - sk[0] - sk[2], w.attout, T));
     P.no_splitk = false;
-    MMVAE_TRY(enc_fwd(P, io.image, 2, m1, enc_drop, training, 2 - sk[0] - sk[1], w.encout, s));
+    // BatchNorm passes folded into the staging of the image-resident conv kernels (convres.hip; their tiles hold 4 / 2 images)
+    const bool fuse = mmvae_knob("ca_fuse_bn", 1) && mmvae_knob("convres", 1) && mmvae_knob("convres_celeba", 1) && B % 4 == 0;
+    MMVAE_TRY(enc_fwd(P, io.image, 2, m1, enc_drop, training, 2 - sk[0] - sk[1], w.encout, s, fuse));
     MMVAE_TRY(edge(P, T, s));
     Latent3Args la{};
     la.B = B; la.D = D; la.img_out = w.encout; la.txt_out = w.attout; la.eps = eps;
@@ -505,7 +581,13 @@ static int celeba_step_body(CelebaPlan* Pp, const CelebaStepIO& io, int training
     ConvTLastFwdArgs last{};
     last.target = io.image; last.recon = io.recon_image; last.dlogit = do_backward ? w.dlogit : nullptr; last.loss_sum = w.sums;
     for (int k = 0; k < 3; ++k) last.coef[k] = sk[k] ? 0.f : io.lambda_x[k] / (float)(B * NPIX);
-    MMVAE_TRY(dec_fwd(P, 3, training, &last, s));
+    int img_groups = 3;         // passes whose image term has a gradient (a pass with lambda_x = 0 has exactly none)
+    while (img_groups > 0 && (io.lambda_x[img_groups - 1] == 0.f || sk[img_groups - 1])) --img_groups;
+    int last_groups = 3;        // passes whose reconstruction is looked at by anyone
+    if (!io.recon_image)
+        while (last_groups > 1 && last.coef[last_groups - 1] == 0.f) --last_groups;
+    const bool fuse_tail = P.slab.pool != nullptr && mmvae_knob("dec_last_ca", 1) != 0;
+    MMVAE_TRY(dec_fwd(P, 3, training, &last, s, last_groups, fuse_tail ? (do_backward ? std::min(img_groups, last_groups) : 0) : -1, fuse));
     if (!do_backward) {
         MMVAE_TRY(edge(P, T, s));
         hipLaunchKernelGGL(sum_slots_kernel, dim3(1), dim3(64), 0, s, w.sums, io.sums);
@@ -513,10 +595,8 @@ static int celeba_step_body(CelebaPlan* Pp, const CelebaStepIO& io, int training
     }
     // =============================== backward ===============================
     P.wgrad_forked = true;
-    int img_groups = 3;
-    while (img_groups > 0 && (io.lambda_x[img_groups - 1] == 0.f || sk[img_groups - 1])) --img_groups;
     int rc = MMVAE_OK;
-    if (img_groups > 0) rc = dec_bwd(P, w.dlogit, img_groups, w.dz_img, s);
+    if (img_groups > 0) rc = dec_bwd(P, w.dlogit, img_groups, w.dz_img, s, fuse_tail, fuse);
     if (rc == MMVAE_OK) rc = edge(P, T, s);          // dz of the attribute decoder
     Latent3BwdArgs lb{};
     lb.f = la; lb.dz_a = w.dz_img; lb.dz_b = w.dz_att;
@@ -528,7 +608,7 @@ static int celeba_step_body(CelebaPlan* Pp, const CelebaStepIO& io, int training
     P.wgrad_forked = false; P.no_splitk = !serial;
     if (rc == MMVAE_OK) rc = att_enc_bwd(P, w.d_attout_bf, T);
     P.wgrad_forked = true; P.no_splitk = false;
-    if (rc == MMVAE_OK) rc = enc_bwd(P, w.d_encout, 2, m1, enc_drop, s);
+    if (rc == MMVAE_OK) rc = enc_bwd(P, w.d_encout, 2, m1, enc_drop, s, fuse);
     P.wgrad_forked = false;
     MMVAE_TRY(rc);
     MMVAE_TRY(edge(P, T, s));

@@ -567,6 +567,7 @@ int launch_cr(const GemmParams& p, hipStream_t stream) {
                                                  (unsigned)mmvae_knob("convres_ts_lo", 0));
     a.d_r = p.d_r; a.d_affine = p.d_affine; a.d_meanrstd = p.d_meanrstd; a.d_red = p.d_red;
     const int kind = p.tr ? p.tr->kind : 0;
+    MMVAE_REQUIRE(!(p.tr && p.tr->out == c.A) || NSPLIT == 1, "convres: an in-place staging by-product needs one workgroup per image tile");
     if (mmvae_probe_on()) {      // FLOPs the way the reference's FlopCounterMode counts the layer: cropped taps not subtracted
         char tag[96];
         snprintf(tag, sizeof(tag), "convres form%d %d>%d %dx%d>%dx%d k%d s%d %s tr%d img%d", G::FORM, G::C, G::N, G::AH, G::AW, G::OH, G::OW,

@@ -254,11 +254,339 @@ __global__ __launch_bounds__(DL_NTHR) void dec_last_mfma_kernel(const DecLastFus
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// CelebA tail (celeba/model.py:146-150): ConvTranspose2d(32, 3, 4, 2, 1) on 32x32 maps -> 64x64x3 + sigmoid + BCE, its input
+// and weight gradients.  Same three products as above with j = tap*3 + co (48 of 64 columns) as the narrow dimension; one
+// workgroup owns one image and walks it in 4 strips of 8 input rows so that P (fp32) fits LDS: a strip stages input rows
+// y0-1 .. y0+8 (BatchNorm + Swish on the way), makes P for those 10 rows, the logits of output rows 2y0-1 .. 2y0+16 (the
+// outer two only for the gradient windows of the strip's own pixels; loss / outputs for the 16 owned rows), the patches and
+// the input gradient of its 8 rows; the weight-gradient accumulators stay in registers across the strips.
+constexpr int CL_IH = 32, CL_IW = 32, CL_OH = 64, CL_OW = 64, CL_C = 32, CL_CO = 3, CL_J = 48, CL_SR = 8, CL_NS = CL_IH / CL_SR;
+constexpr int CL_NPIX = CL_IH * CL_IW;
+constexpr int CL_AROWS = CL_SR + 2, CL_APX = CL_AROWS * CL_IW, CL_ATILES = CL_APX / 32;       // staged rows / pixels / 32-pixel tiles
+constexpr int CL_OPX = CL_SR * CL_IW, CL_OTILES = CL_OPX / 32;                                  // owned pixels of a strip
+constexpr int CL_AP = 80;              // A: bytes per pixel (32 bf16 + 16)
+constexpr int CL_PF = 49;              // P: floats per pixel (48 + 1: the overlap-add reads a column across pixels)
+constexpr int CL_PP = 144;             // patches: bytes per pixel (64 bf16 columns, 48 used, + 16)
+constexpr int CL_DLR = 2 * CL_SR + 2, CL_DLW = CL_OW + 2;                                        // dlogit rows of a strip, width with halo
+constexpr int CL_WAVES = 8, CL_NTHR = CL_WAVES * 64;
+constexpr int CL_OFF_A = 0;
+constexpr int CL_OFF_P = CL_OFF_A + CL_APX * CL_AP;                       // P fp32 [320][49]; then patches [256][144]; at the end dW partials
+constexpr int CL_P_BYTES = CL_APX * CL_PF * 4;
+constexpr int CL_OFF_DL = CL_OFF_P + (CL_P_BYTES + 15) / 16 * 16;         // dlogit fp32 [3][18][66]
+constexpr int CL_OFF_SCR = CL_OFF_DL + (CL_CO * CL_DLR * CL_DLW * 4 + 15) / 16 * 16;    // per-wave epilogue scratch [8][2560]
+constexpr int CL_OFF_TAB = CL_OFF_SCR + CL_WAVES * 2560;
+constexpr int CL_LDS = CL_OFF_TAB + 2 * CL_C * 8;
+static_assert(CL_OPX * CL_PP <= CL_P_BYTES && CL_WAVES * CL_C * CL_J * 4 <= CL_P_BYTES, "patches / dW partials reuse the P buffer");
+static_assert(CL_LDS <= 160 * 1024 - 64, "LDS budget");
+static_assert(CL_OTILES == CL_WAVES, "one owned 32-pixel tile per wave");
+
+__global__ __launch_bounds__(CL_NTHR) void dec_last_ca_kernel(const DecLastFusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const A_s = smem + CL_OFF_A;
+    float* const P_s = reinterpret_cast<float*>(smem + CL_OFF_P);
+    char* const pat_s = smem + CL_OFF_P;
+    float* const dl_s = reinterpret_cast<float*>(smem + CL_OFF_DL);
+    char* const scr_s = smem + CL_OFF_SCR;
+    float2* const aff_s = reinterpret_cast<float2*>(smem + CL_OFF_TAB);
+    float2* const mr_s = aff_s + CL_C;
+    __shared__ float part[CL_WAVES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int n_in_g = blockIdx.x, g = blockIdx.y;
+    const long long n = (long long)g * a.B + n_in_g;
+    const BnFinalizeArgs& f = a.fin;
+    const bool bwd = g < a.bwd_groups;
+
+    if (tid < CL_C) {
+        float2 aff, mr;
+        bn_channel_tables(f, g, tid, aff, mr);
+        aff_s[tid] = aff; mr_s[tid] = mr;
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0) {                // the tables backward reads + running statistics: once
+        for (int i = tid; i < f.G * CL_C; i += CL_NTHR) {
+            float2 aff, mr;
+            bn_channel_tables(f, i / CL_C, i % CL_C, aff, mr);
+            f.affine[i] = aff; f.meanrstd[i] = mr;
+        }
+        bn_running_update(f, tid, CL_NTHR);
+    }
+    // weight fragments, fp32 (32, 3, 4, 4) -> bf16, column j = tap*3 + co:
+    //   forward B[k = ch][j] for the two k-steps and the two column tiles; input gradient B[k = j][ch] for the three k-steps
+    bf16x8 wf[2][2], wd[3];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int j = nt * 32 + r, tap = j / CL_CO, co = j - tap * CL_CO;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) wf[ks][nt][e] = j < CL_J ? (bf16)a.w[((ks * 16 + 8 * h + e) * CL_CO + co) * 16 + tap] : (bf16)0.f;
+        }
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int j = ks * 16 + 8 * h + e, tap = j / CL_CO, co = j - tap * CL_CO;
+            wd[ks][e] = (bf16)a.w[(r * CL_CO + co) * 16 + tap];
+        }
+    __syncthreads();
+    const int cv = tid & 3;                                  // CL_NTHR % 4 == 0: a thread keeps its channel octet
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float2 t = aff_s[cv * 8 + e]; sc[e] = t.x; sh[e] = t.y; }
+    const float2 af = aff_s[r], mr = mr_s[r];
+
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+        a.db, 0, (int)((size_t)a.bwd_groups * a.B * CL_NPIX * CL_C * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16*>(a.r), 0, (int)((size_t)a.bwd_groups * a.B * CL_NPIX * CL_C * 2), 0x00020000);
+    f32x16 accw[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accw[nt][e] = 0.f;
+    float s1 = 0.f, s2 = 0.f, loss = 0.f;
+    const bf16* const rimg = a.r + (size_t)n * CL_NPIX * CL_C;
+    constexpr int NV = CL_APX * 4, IT = (NV + CL_NTHR - 1) / CL_NTHR;
+
+    constexpr int NO = CL_CO * CL_DLR * CL_OW;               // logits of a strip
+    constexpr int ND = CL_CO * CL_DLR * CL_DLW, DT = (ND + CL_NTHR - 1) / CL_NTHR;     // dlogit buffer elements / per thread
+    i32x4c rv[IT];
+    auto fetch_rows = [&](int y0) {                          // raw rows y0-1 .. y0+8 of the image (outside: zero)
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int v = tid + it * CL_NTHR, px = v >> 2, iy = y0 - 1 + px / CL_IW;
+            rv[it] = i32x4c{0, 0, 0, 0};
+            if (v < NV && (unsigned)iy < (unsigned)CL_IH)
+                rv[it] = *reinterpret_cast<const i32x4c*>(rimg + ((size_t)(iy * CL_IW + (px & (CL_IW - 1))) * CL_C + cv * 8));
+        }
+    };
+    fetch_rows(0);
+    const float* const timg = a.target ? a.target + (size_t)n_in_g * CL_CO * CL_OH * CL_OW : nullptr;
+    // targets of a strip's 18 output rows: fetched one strip ahead, parked in the dlogit buffer (halo columns / rows outside the
+    // image: zero) where the logits pass picks them up and leaves the gradient -- no global load inside that loop
+    float tv[DT];
+    auto fetch_targets = [&](int y0) {
+#pragma unroll
+        for (int k = 0; k < DT; ++k) {
+            const int i = tid + k * CL_NTHR;
+            const int co = i / (CL_DLR * CL_DLW), rem = i - co * (CL_DLR * CL_DLW);
+            const int lo = rem / CL_DLW, c = rem - lo * CL_DLW, oy = 2 * y0 - 1 + lo;
+            tv[k] = 0.f;
+            if (timg && i < ND && c >= 1 && c <= CL_OW && (unsigned)oy < (unsigned)CL_OH) tv[k] = timg[(co * CL_OH + oy) * CL_OW + c - 1];
+        }
+    };
+    fetch_targets(0);
+
+    for (int strip = 0; strip < CL_NS; ++strip) {
+        const int y0 = strip * CL_SR;
+        // ---- stage rows y0-1 .. y0+8 (fetched during the previous strip): BatchNorm + Swish -> A (rows outside the image: zero)
+        __syncthreads();                                     // the previous strip's readers of A / patches / dlogit are done
+#pragma unroll
+        for (int k = 0; k < DT; ++k) {
+            const int i = tid + k * CL_NTHR;
+            if (i < ND) dl_s[i] = tv[k];
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int v = tid + it * CL_NTHR, px = v >> 2, iy = y0 - 1 + px / CL_IW;
+            if (v < NV) {
+                bf16x8 o;
+                if ((unsigned)iy < (unsigned)CL_IH) {
+                    const bf16x8 x = __builtin_bit_cast(bf16x8, rv[it]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16)swish_fast((float)x[e] * sc[e] + sh[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16)0.f;
+                }
+                *reinterpret_cast<bf16x8*>(A_s + px * CL_AP + cv * 16) = o;
+            }
+        }
+        if (strip + 1 < CL_NS) { fetch_rows(y0 + CL_SR); fetch_targets(y0 + CL_SR); }   // next strip's: in flight through the rest of this one
+        __syncthreads();
+        // ---- forward: P[pixel][j] for the 10 staged rows
+        if (!(a.dbg & 16))
+        for (int t = wave; t < CL_ATILES; t += CL_WAVES) {
+            const char* ap = A_s + (t * 32 + r) * CL_AP + h * 16;
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ap), a1 = *reinterpret_cast<const bf16x8*>(ap + 32);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                f32x16 acc;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wf[0][nt], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, wf[1][nt], acc, 0, 0, 0);
+                const int j = nt * 32 + r;
+                if (j < CL_J) {                              // lane = column j, register e = pixel (e&3) + 8*(e>>2) + 4h of the tile
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) P_s[(t * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * CL_PF + j] = acc[e];
+                }
+            }
+        }
+        __syncthreads();
+        // ---- logits of output rows 2y0-1 .. 2y0+16 by overlap-add, sigmoid, BCE and its gradient
+#pragma unroll 2
+        for (int o = (a.dbg & 1) ? NO : tid; o < NO; o += CL_NTHR) {
+            const int co = o / (CL_DLR * CL_OW), rem = o - co * (CL_DLR * CL_OW);
+            const int lo = rem / CL_OW, ox = rem - lo * CL_OW, oy = 2 * y0 - 1 + lo;
+            if ((unsigned)oy >= (unsigned)CL_OH) continue;
+            const int kh0 = (oy + 1) & 1, kw0 = (ox + 1) & 1;
+            const int iy0 = (oy + 1 - kh0) >> 1, ix0 = (ox + 1 - kw0) >> 1;
+            float acc = 0.f;
+#pragma unroll
+            for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+                for (int tx = 0; tx < 2; ++tx) {
+                    // (rows outside the image are staged as zeros, i.e. P = 0 there; a column outside is masked, not branched on)
+                    const int iy = iy0 - ty, ix = ix0 - tx, ixc = min(max(ix, 0), CL_IW - 1);
+                    const float pv = P_s[((iy - y0 + 1) * CL_IW + ixc) * CL_PF + ((kh0 + 2 * ty) * 4 + kw0 + 2 * tx) * CL_CO + co];
+                    acc += ix == ixc ? pv : 0.f;
+                }
+            const bool owned = lo >= 1 && lo <= 2 * CL_SR;
+            const long long oidx = ((n * CL_CO + co) * CL_OH + oy) * CL_OW + ox;       // NCHW
+            const float p = __builtin_amdgcn_rcpf(1.0f + __expf(-acc));
+            if (owned) {
+                if (a.logits) a.logits[oidx] = acc;
+                if (a.recon) a.recon[oidx] = p;
+            }
+            if (a.target) {
+                const float t = dl_s[(co * CL_DLR + lo) * CL_DLW + ox + 1];
+                const float pq = p * (1.0f - p);
+                const float dl = a.coef[g] * (p - t) / fmaxf(pq, 1e-12f) * pq;
+                if (owned) {
+                    const float lp = fmaxf(__logf(p), -100.f), lq = fmaxf(__logf(1.0f - p), -100.f);   // BCE log clamp
+                    loss += -(t * lp + (1.0f - t) * lq);
+                    if (a.dlogit) a.dlogit[oidx] = dl;
+                }
+                dl_s[(co * CL_DLR + lo) * CL_DLW + ox + 1] = dl;
+            }
+        }
+        if (!bwd) continue;                                  // (uniform over the workgroup)
+        __syncthreads();
+        // ---- patches[pixel][j] = dlogit(co, 2iy-1+kh, 2ix-1+kw) as bf16 for the 8 owned rows (P is dead: same buffer);
+        //      two threads per pixel (kernel rows 0-1 / 2-3), the second also zeroes the 16 unused columns
+        if (!(a.dbg & 2)) {
+            const int px = tid >> 1, half = tid & 1;
+            const int iyl = px / CL_IW, ix = px - iyl * CL_IW;
+            bf16 v[24];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int kw = 0; kw < 4; ++kw)
+#pragma unroll
+                    for (int co = 0; co < CL_CO; ++co)
+                        v[(kk * 4 + kw) * CL_CO + co] = (bf16)dl_s[(co * CL_DLR + 2 * iyl + 2 * half + kk) * CL_DLW + 2 * ix + kw];
+            char* dst = pat_s + px * CL_PP + half * 48;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = v[q * 8 + e];
+                *reinterpret_cast<bf16x8*>(dst + q * 16) = o;
+            }
+            if (half) {
+                const i32x4c z = {0, 0, 0, 0};
+                *reinterpret_cast<i32x4c*>(pat_s + px * CL_PP + 96) = z;
+                *reinterpret_cast<i32x4c*>(pat_s + px * CL_PP + 112) = z;
+            }
+        }
+        __syncthreads();
+        // ---- input gradient of the wave's 32 owned pixels: three MFMAs, then the conv kernels' accumulator epilogue
+        if (!(a.dbg & 4)) {
+            const int t = wave;
+            f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                const bf16x8 pa = *reinterpret_cast<const bf16x8*>(pat_s + (t * 32 + r) * CL_PP + ks * 32 + h * 16);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, wd[ks], acc, 0, 0, 0);
+            }
+            const unsigned base = (unsigned)((n * CL_NPIX + y0 * CL_IW + t * 32) * (CL_C * 2)) + (unsigned)((lane >> 4) * 16);
+            const unsigned off0 = base + (unsigned)((lane & 15) * (CL_C * 2)), off1 = base + (unsigned)((16 + (lane & 15)) * (CL_C * 2));
+            cr_epilogue_tile<1, false>(acc, scr_s + wave * 2560, lane, 32, off0, off1, orsrc, rrsrc, af.x, af.y, mr.x, mr.y, s1, s2, true);
+        }
+        // ---- weight gradient dW[ch][j] += A^T . patches over the 256 owned pixels: 16 k-steps of 16 rows, two per wave
+        if (!(a.dbg & 8)) {
+            const int g4 = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+            for (int ks = wave; ks < CL_OPX / 16; ks += CL_WAVES) {
+                const int row = ks * 16 + 8 * h + q;
+                const char* a0 = A_s + (row + CL_IW) * CL_AP + (16 * (g4 & 1) + 4 * p) * 2;       // owned pixels start at staged row 1
+                const bf16x8 af2 = tr_pair_d(a0, a0 + 4 * CL_AP);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const char* b0 = pat_s + row * CL_PP + (nt * 32 + 16 * (g4 & 1) + 4 * p) * 2;
+                    const bf16x8 bf2 = tr_pair_d(b0, b0 + 4 * CL_PP);
+                    accw[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af2, bf2, accw[nt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- loss, BatchNorm-backward sums, weight-gradient partial of the image
+    if (a.loss_sum) {
+        loss = wave_sum(loss);
+        if (lane == 0) part[wave] = loss;
+    }
+    __syncthreads();
+    if (a.loss_sum && tid == 0) {
+        float s = 0.f;
+        for (int w = 0; w < CL_WAVES; ++w) s += part[w];
+        atomicAdd(a.loss_sum + (blockIdx.x % MMVAE_LOSS_SLOTS) * 16 + g, s);
+    }
+    if (!bwd) return;
+    {
+        const float t1 = s1 + __shfl_xor(s1, 32, 64), t2 = s2 + __shfl_xor(s2, 32, 64);
+        if (h == 0) {
+            const int slot = (int)(blockIdx.x + wave) % MMVAE_STAT_SLOTS;
+            float2* d = a.red + ((size_t)g * MMVAE_STAT_SLOTS + slot) * CL_C + r;
+            atomicAdd(&d->x, t1);
+            atomicAdd(&d->y, t2);
+        }
+    }
+    float* const wred = P_s;                                 // [8 waves][32 ch][48]  (every reader of the patches passed the barrier above)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int j = nt * 32 + r;
+        if (j < CL_J) {                                      // lane = column j, register e = channel (e&3) + 8*(e>>2) + 4h
+#pragma unroll
+            for (int e = 0; e < 16; ++e) wred[(wave * CL_C + (e & 3) + 8 * (e >> 2) + 4 * h) * CL_J + j] = accw[nt][e];
+        }
+    }
+    __syncthreads();
+    float* dst = a.wslab + ((size_t)g * gridDim.x + blockIdx.x) * CL_C * CL_J;
+    for (int i = tid; i < CL_C * CL_J; i += CL_NTHR) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < CL_WAVES; ++w) s += wred[w * CL_C * CL_J + i];
+        dst[i] = s;
+    }
+}
+
 }  // namespace
+
+bool dec_last_ca_applies(const DecLastFusedArgs& a) {
+    return a.Cin == CL_C && a.Cout == CL_CO && a.IH == CL_IH && a.IW == CL_IW && a.act == ACT_SWISH && mmvae_knob("dec_last_ca", 1) != 0 &&
+           (size_t)a.G * a.B * CL_NPIX * CL_C * 2 < 0x40000000ull;
+}
+int launch_dec_last_ca(const DecLastFusedArgs& a, hipStream_t s) {
+    MMVAE_REQUIRE(dec_last_ca_applies(a), "dec_last_ca: not the 32x32x32 -> 64x64x3 tail");
+    MMVAE_REQUIRE(a.r && a.w && a.G >= 1 && a.B >= 1 && a.bwd_groups >= 0 && a.bwd_groups <= a.G, "dec_last_ca: arguments");
+    MMVAE_REQUIRE(a.bwd_groups == 0 || (a.target && a.db && a.red && a.wslab), "dec_last_ca: backward outputs missing");
+    static std::atomic<unsigned> attr_set{0};
+    if (mmvae_first_use_on_device(attr_set))
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_last_ca_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CL_LDS);
+    DecLastFusedArgs b = a;
+    b.dbg = mmvae_knob("dec_last_ca_dbg", 0);      // measurement aid: bit 0 no logits, 1 no patches, 2 no input gradient, 3 no weight gradient, 4 no P
+    MMVAE_LAUNCH(dec_last_ca_kernel, dim3(a.B, a.G), dim3(CL_NTHR), CL_LDS, s, b);
+    return mmvae_check_launch("dec_last_ca");
+}
 
 // strips = 1: one workgroup per image
 bool dec_last_mfma_applies(const DecLastFusedArgs& a) {
-    return a.Cin == 32 && a.IH == DL_IH && a.IW == DL_IW && a.act == ACT_SWISH && mmvae_knob("dec_last_mfma", 1) != 0 &&
+    return a.Cin == 32 && a.Cout == 1 && a.IH == DL_IH && a.IW == DL_IW && a.act == ACT_SWISH && mmvae_knob("dec_last_mfma", 1) != 0 &&
            (size_t)a.G * a.B * DL_NPIX * DL_C * 2 < 0x40000000ull;
 }
 int launch_dec_last_mfma(const DecLastFusedArgs& a, hipStream_t s) {

@@ -40,6 +40,8 @@ struct DecLastFusedArgs {
     int act;
     const float* w;          // fp32 (Cin, 1, 4, 4)
     int G, B, IH, IW, Cin;   // G = groups (passes) whose last layer is computed
+    int dbg = 0;             // measurement aid (dec_last_ca_kernel): phases switched off
+    int Cout = 1;            // output channels (weights (Cin, Cout, 4, 4); targets / dumps NCHW [..][Cout][2IH][2IW])
     int bwd_groups;          // groups [0, bwd_groups) also produce db / red / weight-gradient partials (0: forward only)
     const float* target;     // NCHW [B][1][2IH][2IW] or null
     float* logits; float* recon; float* dlogit;      // optional dumps, NCHW [G*B][1][2IH][2IW]
@@ -54,6 +56,10 @@ int dec_last_fused_strips(int IH);
 bool dec_last_mfma_applies(const DecLastFusedArgs& a);
 int launch_dec_last_mfma(const DecLastFusedArgs& a, hipStream_t s);
 int launch_dec_last_fused(const DecLastFusedArgs& a, hipStream_t s);
+// CelebA tail (dec_last.hip): 32x32x32 -> 64x64x3, one workgroup per image in 4 strips; wslab [bwd_groups*B][32][48], column
+// j = tap*3 + co (the packed layout of the layer's gradient, plan_base.h build_conv thin_out)
+bool dec_last_ca_applies(const DecLastFusedArgs& a);
+int launch_dec_last_ca(const DecLastFusedArgs& a, hipStream_t s);
 
 // First encoder layer of MultiMNIST on the matrix cores (conv1.hip): Conv2d(1, 32, 4, 2, 1) on 50x50 images, raw + Swish
 // copies [B][25][25][32] bf16; and its weight gradient added (float atomics) into the packed gradient [32][Kpad].
