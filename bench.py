@@ -264,6 +264,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dp-overlap", action="store_true", help="N>1, MultiMNIST: all-reduce the decoders' gradients while the encoders' backward runs")
     ap.add_argument("--knob", action="append", default=[], help="name=value: an A/B switch of the library (mmvae_debug_set), measurement aid")
+    ap.add_argument("--loader", action="store_true",
+                    help="also time the step fed by data.DeviceBatcher (pinned uint8 pixels + second modality, double-buffered async H2D, "
+                         "u8->f32 on the device) inside the timed loop: reported as `with_loader` next to the resident-input `value`")
     ap.add_argument("--no-probe", action="store_true", help="skip the in-step kernel timing (roofline falls back to the whole step)")
     args = ap.parse_args()
     wl = args.workload
@@ -379,6 +382,43 @@ def main():
     if wl in ALGO_BYTES_PER_SAMPLE:
         result["algorithmic_bytes_per_step"] = B * ALGO_BYTES_PER_SAMPLE[wl]
         result["step_hbm_frac"] = steps_per_s * B * ALGO_BYTES_PER_SAMPLE[wl] / (PEAK_HBM_GBS * 1e9)
+
+    # ---- the same steps fed by the asynchronous loader ("async H2D image + caption pipeline"): a synthetic
+    # dataset of 8 batches on the host, gathered / copied / converted batch by batch while the previous step runs
+    if args.loader:
+        from multimodal_vae_amd.data import DeviceBatcher
+        nb_ds = 8
+        rng = np.random.default_rng(seed + 99)
+        a_h, b_h = synthetic_batch_for(wl, nb_ds * B, seed + 99)
+        img_u8 = (a_h * 255.0).round().clamp(0, 255).to(torch.uint8)
+        if wl == "multimnist":
+            img_u8 = img_u8[:, 0]
+        loader = DeviceBatcher(img_u8, b_h, B, dev, shuffle=True, seed=seed)
+
+        def loader_steps(n):
+            done = 0
+            while done < n:
+                for im, tx in loader:
+                    eng(im, tx)
+                    done += 1
+                    if done == n:
+                        break
+        loader_steps(max(10, args.warmup // 4))
+        barrier()
+        t0 = time.perf_counter()
+        loader_steps(args.steps)
+        barrier()
+        dtl = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([dtl], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtl = float(t.item())
+        result["with_loader"] = {"value": args.steps / dtl, "unit": "ELBO-steps/s", "ms_per_step": 1e3 * dtl / args.steps,
+                                 "vs_resident": (args.steps / dtl) / steps_per_s,
+                                 "h2d_bytes_per_step": int(img_u8[0].numel() * B + b_h[0].numel() * b_h.element_size() * B),
+                                 "loader": "data.DeviceBatcher: %d-batch host dataset, numpy gather into pinned staging, async H2D on a copy stream, "
+                                           "u8->f32 on the device, two slots" % nb_ds}
 
     # ---- per-step distribution: HIP events around single steps, outside the timed region
     n_ev = min(100, args.steps)

@@ -29,7 +29,7 @@ struct Geo {
     static constexpr int NCLS = FORM == 0 ? 1 : S * S;
     static constexpr int PIX = C * 2 + PIXPAD_;            // LDS bytes per pixel
     static constexpr int KSTEP_PER_TAP = C / 16;           // 32x32x16 MFMA k-steps per tap
-    static_assert(C % 16 == 0 && N % 32 == 0, "channel counts");
+    static_assert(C % 8 == 0 && N % 32 == 0, "channel counts");      // (C % 16 == 0 for the MFMA k-steps; 8-channel slices: wgrad)
 
     // ---- per-class row grid / taps (identical to layers.h plan_fwdform / plan_classform)
     static constexpr int ph(int c) { return FORM == 0 ? 0 : c / S; }

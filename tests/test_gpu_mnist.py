@@ -186,6 +186,24 @@ def test_full_size_b128_scalars(golden_dir):
     np.testing.assert_allclose(g.double().norm().item(), tot_c, rtol=3e-2)
     check_gradients(((n, g[off:off + P[n].numel()], P[n].grad) for n, shape, off in st.table if n not in PRE_BN_BIAS), 5e-2, None,
                     "mnist b128 bf16 contract")
+    # (3) the reference's own gradient ELEMENTS (64 samples per tensor, oracle/make_golden.py grad_samples) and BatchNorm running
+    # buffers at the full batch, on the default fp32 plan -- the plan whose arithmetic is the reference's
+    st32, _ = _state(dev, "fp32")
+    eng32 = FusedMnistStep(st32, B)
+    out32 = eng32.forward_backward(image.reshape(B, 784).to(dev).contiguous(), label.to(dev), True, True,
+                                   eps=torch.stack(eps).to(dev).contiguous())
+    np.testing.assert_allclose(out32.losses().cpu().numpy(), fx["loss"], rtol=2e-5)
+    g32 = st32.grads.cpu().double()
+    for i, (n, shape, off) in enumerate(st32.table):
+        if n in PRE_BN_BIAS:
+            continue
+        numel = int(np.prod(shape))
+        idx = R.sample_idx(numel, 64)
+        ref = torch.from_numpy(fx["grad_samples"][i, :len(idx)]).double()
+        assert (g32[off:off + numel][idx] - ref).norm().item() <= 1e-3 * ref.norm().item() + 1e-6 * tot, n
+    for pre, c, off in st32.bn_table:
+        np.testing.assert_allclose(st32.bn_stats[off:off + c].cpu().numpy(), fx["buf:" + pre + ".running_mean"], atol=1e-5)
+        np.testing.assert_allclose(st32.bn_stats[off + c:off + 2 * c].cpu().numpy(), fx["buf:" + pre + ".running_var"], rtol=1e-4, atol=1e-6)
 
 
 def test_training_reduces_loss_and_eval_mode():
