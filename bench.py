@@ -417,8 +417,8 @@ def main():
         result["with_loader"] = {"value": args.steps / dtl, "unit": "ELBO-steps/s", "ms_per_step": 1e3 * dtl / args.steps,
                                  "vs_resident": (args.steps / dtl) / steps_per_s,
                                  "h2d_bytes_per_step": int(img_u8[0].numel() * B + b_h[0].numel() * b_h.element_size() * B),
-                                 "loader": "data.DeviceBatcher: %d-batch host dataset, numpy gather into pinned staging, async H2D on a copy stream, "
-                                           "u8->f32 on the device, two slots" % nb_ds}
+                                 "loader": "data.DeviceBatcher: %d-batch host dataset, gather into pinned staging on a worker thread, async H2D on a "
+                                           "copy stream, u8->f32 on the device, three slots" % nb_ds}
 
     # ---- per-step distribution: HIP events around single steps, outside the timed region
     n_ev = min(100, args.steps)

@@ -394,6 +394,16 @@ int mmvae_step_losses(const float* sums, const float* w_bce, const float* w_nll,
  * (DESIGN.md lists them).  mmvae_debug_probe(1): every kernel the library launches through its tagged launcher carries a start
  * and a stop event of its own until mmvae_debug_probe(0); mmvae_debug_probe_read waits for them and writes one line per launch
  * "tag\tkernel\tmicroseconds\talgorithmic FLOPs\n" into buf (returns the number of lines) -- bench.py's in-step roofline. */
+/* ONE more HIP stream (non-blocking, default priority) for host code that needs a copy / communication stream next to the
+ * step's: a PyTorch host must not take it from torch's pool -- the first torch.cuda.Stream() creates the pool's 32 streams, past
+ * the hardware queues the runtime maps streams to (GPU_MAX_HW_QUEUES) every stream of the process is then time-sliced and each
+ * step runs ~2x slower (measured 0.67 -> 1.26 ms, tools/loader_probe.py).  Wrap it with torch.cuda.ExternalStream. */
+int mmvae_stream_create(void** out);
+int mmvae_stream_destroy(void* stream);
+/* Batch assembly for the input pipeline (coco/train.py:117-128's DataLoader role): dst[i] = src[idx[i]], rows of row_bytes (a
+ * multiple of 16).  `idx` and `dst` are device memory; `src` may be PINNED HOST memory -- the kernel then pulls the rows over the
+ * host link itself, and the host never copies a sample (data.DeviceBatcher). */
+int mmvae_gather_rows(const void* src, const long long* idx, long long rows, long long row_bytes, void* dst, void* stream);
 /* Waits for `stream`, then MMVAE_OK, or MMVAE_ETIMEOUT when the step that wrote `sums` (device, [16]) declared itself void. */
 int mmvae_step_status(const float* sums, void* stream);
 int mmvae_debug_probe(int on);

@@ -148,6 +148,9 @@ SIGNATURES = {
     "mmvae_mse_fwd": (_I, [_P, _P, _LL, _P, _P]),
     "mmvae_mse_bwd": (_I, [_P, _P, _LL, _F, _P, _P, _P]),
     "mmvae_u8_to_f32": (_I, [_P, _LL, _F, _P, _P]),
+    "mmvae_stream_create": (_I, [_P]),
+    "mmvae_stream_destroy": (_I, [_P]),
+    "mmvae_gather_rows": (_I, [_P, _P, _LL, _LL, _P, _P]),
     "mmvae_step_status": (_I, [_P, _P]),
     "mmvae_step_losses": (_I, [_P, _P, _P, _P, _P, _P]),
     "mmvae_debug_probe": (_I, [_I]),
@@ -251,6 +254,27 @@ def init_device(index):
     if index not in _inited:
         call("mmvae_init", int(index))
         _inited.add(index)
+
+
+class OwnedStream:
+    """One HIP stream created by the library (mmvae_stream_create), usable wherever torch takes a stream.  NOT from torch's pool:
+    the first ``torch.cuda.Stream()`` of a process creates 32 pool streams, more than the hardware queues the HIP runtime maps
+    streams onto, and every kernel of the process slows down (include/mmvae_hip.h)."""
+
+    def __init__(self, device):
+        import torch
+        h = C.c_void_p()
+        with torch.cuda.device(device):
+            call("mmvae_stream_create", C.byref(h))
+        self.handle = h.value
+        self.stream = torch.cuda.ExternalStream(self.handle, device=device)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                load().mmvae_stream_destroy(C.c_void_p(self.handle))
+        except Exception:
+            pass
 
 
 def ptr(t):

@@ -396,7 +396,8 @@ class FusedELBOStep(_FusedStepBase):
         st = self.state
         if getattr(self, "_ranges", None) is None:
             self._ranges = self.grad_ranges()
-            self._comm = torch.cuda.Stream(device=st.device)
+            self._comm_owner = _lib.OwnedStream(st.device)      # (not torch.cuda.Stream(): see _lib.OwnedStream)
+            self._comm = self._comm_owner.stream
         early, late = self._ranges
         out = self.forward_backward(image, text, True, True, _dp_split=True, **kw)
         # async collectives: the library's stream is ordered behind the stream that is current at the call (the

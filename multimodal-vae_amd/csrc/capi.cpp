@@ -463,6 +463,23 @@ int mmvae_adam_step(float* p, const float* g, float* m, float* v, long long n, l
     a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.step = state; a.lr = lr; a.b1 = b1; a.b2 = b2; a.eps = eps; a.grad_scale = grad_scale;
     return launch_adam(a, S(s));
 }
+int mmvae_stream_create(void** out) {
+    MMVAE_REQUIRE(out, "stream_create: null argument");
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+        mmvae_set_error("hipStreamCreate failed: %s", hipGetErrorString(hipGetLastError()));
+        return MMVAE_EHIP;
+    }
+    *out = s;
+    return MMVAE_OK;
+}
+int mmvae_stream_destroy(void* s) {
+    if (s && hipStreamDestroy(S(s)) != hipSuccess) { mmvae_set_error("hipStreamDestroy failed"); return MMVAE_EHIP; }
+    return MMVAE_OK;
+}
+int mmvae_gather_rows(const void* src, const long long* idx, long long rows, long long row_bytes, void* dst, void* s) {
+    return launch_gather_rows(src, idx, rows, row_bytes, dst, S(s));
+}
 int mmvae_step_status(const float* sums, void* s) {
     MMVAE_REQUIRE(sums, "step_status: null sums");
     float h[16];

@@ -1004,6 +1004,26 @@ int launch_adam(const AdamArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(adam_kernel, dim3(nblocks((a.n + 3) / 4, TPB, 512)), dim3(TPB), 0, s, a, done);   // few blocks: one ticket atomic each
     return mmvae_check_launch("adam");
 }
+static __global__ __launch_bounds__(256) void gather_rows_kernel(const char* __restrict__ src, const long long* __restrict__ idx,
+                                                                 long long row_bytes, int parts, char* __restrict__ dst) {
+    const long long row = blockIdx.x / parts;
+    const int part = blockIdx.x % parts;
+    const long long vecs = row_bytes / 16, per = (vecs + parts - 1) / parts;
+    const long long v0 = part * per, v1 = v0 + per < vecs ? v0 + per : vecs;
+    const u32x4* s = reinterpret_cast<const u32x4*>(src + idx[row] * row_bytes);
+    u32x4* d = reinterpret_cast<u32x4*>(dst + row * row_bytes);
+    for (long long v = v0 + threadIdx.x; v < v1; v += 256) d[v] = s[v];
+}
+int launch_gather_rows(const void* src, const long long* idx, long long rows, long long row_bytes, void* dst, hipStream_t s) {
+    MMVAE_REQUIRE(src && idx && dst && rows >= 1 && row_bytes >= 16 && row_bytes % 16 == 0, "gather_rows: rows of a multiple of 16 bytes");
+    MMVAE_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "gather_rows: 16-byte aligned buffers");
+    // enough workgroups in flight to cover the host link's latency: ~32 KB per workgroup
+    int parts = (int)((row_bytes + 32767) / 32768);
+    if (parts < 1) parts = 1;
+    MMVAE_REQUIRE(rows * parts < (1ll << 31), "gather_rows: too many rows");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)(rows * parts)), dim3(256), 0, s, (const char*)src, idx, row_bytes, parts, (char*)dst);
+    return mmvae_check_launch("gather_rows");
+}
 static __global__ void step_losses_kernel(StepLossArgs a) {
     const int k = threadIdx.x;
     if (k < 3) a.out[k] = a.w_bce[k] * a.sums[k] + a.w_nll[k] * a.sums[4 + k] + a.w_kl[k] * a.sums[8 + k];

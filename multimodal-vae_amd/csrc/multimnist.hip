@@ -496,7 +496,9 @@ int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const
                 d.tr = &tr;
             }
             // forks: behind conv4's data gradient (classifier + conv4 + conv3 weight gradients) and behind conv3's (conv2's)
-            const bool flush = fuse && P.wgrad_forked && l >= 2;
+            // (knob mm_forks = 1: ONE fork for the whole encoder backward, behind conv3's data gradient -- a kernel that carries a
+            //  completion event ends with a system-scope release, ~8 us on the main chain per fork: tools/step_parts.py)
+            const bool flush = fuse && P.wgrad_forked && (mmvae_knob("mm_forks", 0) ? l == 2 : l >= 2);
             if (flush) arm_fork(P);
             MMVAE_TRY(launch_gemm_gather(d, s));
             if (flush) { MMVAE_TRY(commit_fork(P, s)); MMVAE_TRY(side_flush(P, s)); }
@@ -710,7 +712,7 @@ int dec_bwd(MMPlan& P, const float* dlogit, int groups, float* dz, hipStream_t s
                 d.tr = &tr;
             }
             // the side work collected so far forks off the completion of the first and of the last data gradient
-            const bool flush = P.wgrad_forked && (l == 2 || l == 0);
+            const bool flush = P.wgrad_forked && ((l == 2 && !mmvae_knob("mm_forks", 0)) || l == 0);
             if (flush) arm_fork(P);
             MMVAE_TRY(launch_gemm_gather(d, s));
             if (flush) { MMVAE_TRY(commit_fork(P, s)); if (l == 2) MMVAE_TRY(side_flush(P, s)); }

@@ -9,12 +9,12 @@ kernel ``mmvae_u8_to_f32``; labels are padded once up front.
 from __future__ import annotations
 
 import os
-from typing import Iterator, List, Sequence, Tuple
+from typing import Iterator, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
 
-from ._lib import MMVAEError, call, ptr
+from ._lib import MMVAEError, OwnedStream, call, ptr
 from .utils import FILL, charlist_tensor, max_length
 
 PROCESSED = "processed"
@@ -65,19 +65,27 @@ class DeviceBatcher:
 
     ``images_u8``: (N,H,W) -> batches (B,1,H,W) (MultiMNIST), or (N,C,H,W) -> (B,C,H,W) (CelebA / COCO pixels).
     ``text``: (N, ...) of any dtype, copied as is: int64 tokens (B,4), fp32 attributes (B,18), fp32 caption vectors
-    (B,102,300) -- the asynchronous H2D image + caption pipeline of the COCO configuration.
+    (B,102,300) -- the asynchronous H2D image + caption pipeline of the COCO configuration (coco/train.py:117-128).
 
-    Host: one index gather per batch into a pinned staging buffer (two of them, alternating).  Copy stream: async H2D of
-    the uint8 pixels + the second modality.  Compute stream: waits for the copy event, then the u8->f32 kernel (ToTensor
-    on the device).  Two hazards, kept apart so the host never waits for the GPU's compute stream: (1) the pinned staging
-    buffer of a slot is free once that slot's previous H2D copy has finished (host waits on ``ready[slot]``, a copy-stream
-    event two batches old); (2) the device buffers of a slot are free once the step that read them is done -- a
-    device-side edge (``copy_stream.wait_event(consumed[slot])``), no host synchronisation.  So the host runs a full
-    step ahead: batch i+1 is gathered and copied while batch i trains.  ``drop_last`` because the fused plans are built
-    for a fixed batch size."""
+    Three slots (pinned staging + device buffers each), three actors:
+      * a worker thread gathers batch b+2 into its pinned staging buffers (``np.take`` releases the GIL; the COCO batch is
+        15.7 MB of caption vectors, 1.5-1.9 ms of a single core -- on the enqueue thread that made the loader-fed step
+        host-bound: bench.py --loader 3.54 ms against 2.71 ms with resident inputs);
+      * the copy stream (the library's own, ``_lib.OwnedStream``) moves batch b+1 to the device while step b runs: async H2D of the
+        uint8 pixels + the second modality, behind a device-side edge on the step that last read the slot's device buffers;
+      * the compute stream waits for the copy event of batch b, converts u8 -> f32 (ToTensor on the device) and trains.
+    The host never waits for the compute stream: a staging buffer is reused when its own H2D copy (three batches old) has finished.
+    ``drop_last`` because the fused plans are built for a fixed batch size.
+
+    ``pin_dataset=True`` (opt-in; rows must be multiples of 16 bytes): the whole dataset is pinned once and the GPU gathers the B
+    rows over the host link itself (``mmvae_gather_rows`` on the copy stream), the host uploads B indices.  Measured on COCO it
+    frees the host (0.31 ms per batch) but the gather workgroups sit on CUs for the length of the transfer and the step next to
+    them slows down more than that saves (3.8 ms per step): not the default."""
+
+    SLOTS = 3
 
     def __init__(self, images_u8: torch.Tensor, text: torch.Tensor, batch_size: int, device: torch.device, shuffle: bool = True,
-                 seed: int = 0):
+                 seed: int = 0, pin_dataset: bool = False):
         assert images_u8.dtype == torch.uint8 and images_u8.dim() in (3, 4) and len(images_u8) == len(text)
         self.images, self.text, self.B, self.device = images_u8, text, int(batch_size), device
         self.shuffle, self.seed, self.epoch = shuffle, seed, 0
@@ -85,11 +93,22 @@ class DeviceBatcher:
         oshape = (1,) + ishape if images_u8.dim() == 3 else ishape
         tshape = tuple(text.shape[1:])
         self.hw = ishape[-2:]
-        self.stage_u8 = [torch.empty((self.B,) + ishape, dtype=torch.uint8).pin_memory() for _ in range(2)]
-        self.stage_tx = [torch.empty((self.B,) + tshape, dtype=text.dtype).pin_memory() for _ in range(2)]
-        self.dev_u8 = [torch.empty((self.B,) + ishape, dtype=torch.uint8, device=device) for _ in range(2)]
-        self.dev_tx = [torch.empty((self.B,) + tshape, dtype=text.dtype, device=device) for _ in range(2)]
-        self.dev_f32 = [torch.empty((self.B,) + oshape, dtype=torch.float32, device=device) for _ in range(2)]
+        S = self.SLOTS
+        self.device_gather = bool(pin_dataset)
+        if self.device_gather:
+            self.row_u8 = int(np.prod(ishape)) if ishape else 1
+            self.row_tx = (int(np.prod(tshape)) if tshape else 1) * text.element_size()
+            assert self.row_u8 % 16 == 0 and self.row_tx % 16 == 0, "device gather: rows must be multiples of 16 bytes"
+            self.images = images_u8 = images_u8.contiguous().pin_memory()
+            self.text = text = text.contiguous().pin_memory()
+            self.idx_host = [torch.empty(self.B, dtype=torch.int64).pin_memory() for _ in range(S)]
+            self.idx_dev = [torch.empty(self.B, dtype=torch.int64, device=device) for _ in range(S)]
+        n_stage = 0 if self.device_gather else S
+        self.stage_u8 = [torch.empty((self.B,) + ishape, dtype=torch.uint8).pin_memory() for _ in range(n_stage)]
+        self.stage_tx = [torch.empty((self.B,) + tshape, dtype=text.dtype).pin_memory() for _ in range(n_stage)]
+        self.dev_u8 = [torch.empty((self.B,) + ishape, dtype=torch.uint8, device=device) for _ in range(S)]
+        self.dev_tx = [torch.empty((self.B,) + tshape, dtype=text.dtype, device=device) for _ in range(S)]
+        self.dev_f32 = [torch.empty((self.B,) + oshape, dtype=torch.float32, device=device) for _ in range(S)]
         # the copy stream is one more default-priority stream next to the step's: the engine's side streams must then run at
         # default priority too (1.93 vs 1.10 ms per step measured with this loader)
         try:
@@ -102,29 +121,48 @@ class DeviceBatcher:
         self._images_np, self._text_np = images_u8.numpy(), text.numpy()
         self._stage_u8_np = [t.numpy() for t in self.stage_u8]
         self._stage_tx_np = [t.numpy() for t in self.stage_tx]
-        self.copy_stream = torch.cuda.Stream(device=device)
-        self.ready = [torch.cuda.Event() for _ in range(2)]
-        self.consumed = [torch.cuda.Event() for _ in range(2)]
-        self._used = [False, False]
+        self._copy_owner = OwnedStream(device)              # (not torch.cuda.Stream(): see _lib.OwnedStream)
+        self.copy_stream = self._copy_owner.stream
+        self.ready = [torch.cuda.Event() for _ in range(S)]
+        self.consumed = [torch.cuda.Event() for _ in range(S)]
+        self._copied = [False] * S          # the slot's staging buffer has an H2D copy recorded in ready[slot]
+        self._read = [False] * S            # the slot's device buffers have been handed to a step (consumed[slot] recorded)
+        from concurrent.futures import ThreadPoolExecutor
+        self._worker = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mmvae-loader")
 
     def __len__(self) -> int:
         return len(self.images) // self.B
 
-    def _stage(self, slot: int, idx: torch.Tensor) -> None:
-        if self._used[slot]:
-            self.ready[slot].synchronize()                  # hazard 1: this slot's previous H2D copy left the pinned buffer
+    def _gather(self, slot: int, ix: np.ndarray) -> None:
+        """worker thread: batch rows -> the slot's pinned staging buffers"""
+        if self.device_gather:
+            if self._copied[slot]:
+                self.ready[slot].synchronize()              # the index upload of the slot's previous use has left the pinned buffer
+            self.idx_host[slot].numpy()[:] = ix
+            return
+        if self._copied[slot]:
+            self.ready[slot].synchronize()                  # this slot's previous H2D copy has left the pinned buffers
         # numpy's single-threaded take, NOT torch.index_select: next to a running HIP process the OpenMP team of a torch
         # CPU op took 8 ms per 640 kB gather on the GPU box (0.03 ms when nothing else runs) -- 8x the training step
-        ix = idx.numpy()
         np.take(self._images_np, ix, axis=0, out=self._stage_u8_np[slot])
         np.take(self._text_np, ix, axis=0, out=self._stage_tx_np[slot])
+
+    def _copy(self, slot: int) -> None:
+        """enqueue thread: the slot's staged batch -> its device buffers, on the copy stream"""
         with torch.cuda.stream(self.copy_stream):
-            if self._used[slot]:
-                self.copy_stream.wait_event(self.consumed[slot])   # hazard 2: device-side edge, the host does not wait
-            self._used[slot] = True
-            self.dev_u8[slot].copy_(self.stage_u8[slot], non_blocking=True)
-            self.dev_tx[slot].copy_(self.stage_tx[slot], non_blocking=True)
+            if self._read[slot]:
+                self.copy_stream.wait_event(self.consumed[slot])   # device-side edge: the step that read these buffers is done
+            if self.device_gather:
+                import ctypes as C
+                self.idx_dev[slot].copy_(self.idx_host[slot], non_blocking=True)
+                st = C.c_void_p(self.copy_stream.cuda_stream)
+                call("mmvae_gather_rows", ptr(self.images), ptr(self.idx_dev[slot]), self.B, self.row_u8, ptr(self.dev_u8[slot]), st)
+                call("mmvae_gather_rows", ptr(self.text), ptr(self.idx_dev[slot]), self.B, self.row_tx, ptr(self.dev_tx[slot]), st)
+            else:
+                self.dev_u8[slot].copy_(self.stage_u8[slot], non_blocking=True)
+                self.dev_tx[slot].copy_(self.stage_tx[slot], non_blocking=True)
             self.ready[slot].record(self.copy_stream)
+            self._copied[slot] = True
 
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
         n = len(self.images)
@@ -133,24 +171,38 @@ class DeviceBatcher:
             order = torch.randperm(n, generator=g)
         else:
             order = torch.arange(n)
+        order = order.numpy()
         self.epoch += 1
         nb = len(self)
         if nb == 0:
             return
-        self._stage(0, order[0:self.B])
-        for b in range(nb):
-            slot = b & 1
-            if b + 1 < nb:
-                self._stage(slot ^ 1, order[(b + 1) * self.B:(b + 2) * self.B])
-            cur = torch.cuda.current_stream(self.device)
-            cur.wait_event(self.ready[slot])
-            import ctypes as C
-            call("mmvae_u8_to_f32", ptr(self.dev_u8[slot]), self.dev_u8[slot].numel(), 255.0, ptr(self.dev_f32[slot]),
-                 C.c_void_p(cur.cuda_stream))
-            try:
-                yield self.dev_f32[slot], self.dev_tx[slot]
-            finally:                                        # also when the consumer abandons the iterator at this batch
-                self.consumed[slot].record(cur)
+        S, B = self.SLOTS, self.B
+        fut = {}
+        for b in range(min(2, nb)):                                 # the worker runs two batches ahead
+            fut[b] = self._worker.submit(self._gather, b % S, order[b * B:(b + 1) * B])
+        fut.pop(0).result()
+        self._copy(0)
+        try:
+            for b in range(nb):
+                slot = b % S
+                if b + 2 < nb:
+                    fut[b + 2] = self._worker.submit(self._gather, (b + 2) % S, order[(b + 2) * B:(b + 3) * B])
+                if b + 1 < nb:
+                    fut.pop(b + 1).result()                         # gathered while the previous step was being enqueued
+                    self._copy((b + 1) % S)                         # in flight while step b runs
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(self.ready[slot])
+                import ctypes as C
+                call("mmvae_u8_to_f32", ptr(self.dev_u8[slot]), self.dev_u8[slot].numel(), 255.0, ptr(self.dev_f32[slot]),
+                     C.c_void_p(cur.cuda_stream))
+                try:
+                    yield self.dev_f32[slot], self.dev_tx[slot]
+                finally:                                            # also when the consumer abandons the iterator at this batch
+                    self.consumed[slot].record(cur)
+                    self._read[slot] = True
+        finally:
+            for f in fut.values():                                  # an abandoned epoch: let the worker finish what it holds
+                f.result()
 
 
 __all__ = ["save_multimnist", "load_multimnist", "synthetic_multimnist", "DeviceBatcher", "FILL"]

@@ -56,6 +56,24 @@ def test_device_batcher_coco_shapes_feed_the_fused_step():
     assert len(loader) == 5 and torch.isfinite(losses).all()
 
 
+def test_device_batcher_device_gather_equals_host_gather():
+    """The batch assembled by the GPU out of the pinned dataset (mmvae_gather_rows) == the host-side gather, shuffled."""
+    from multimodal_vae_amd import data as D
+    dev = _dev()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randint(0, 256, (96, 3, 32, 32), dtype=torch.uint8, generator=g)
+    t = torch.randn(96, 102, 300, generator=g)
+    a = D.DeviceBatcher(x, t, 16, dev, shuffle=True, seed=4, pin_dataset=True)
+    b = D.DeviceBatcher(x, t, 16, dev, shuffle=True, seed=4, pin_dataset=False)
+    assert a.device_gather and not b.device_gather
+    n = 0
+    for _ in range(2):                                         # two epochs: slot reuse
+        for (ia, ta), (ib, tb) in zip(a, b):
+            assert torch.equal(ia, ib) and torch.equal(ta, tb)
+            n += 1
+    assert n == 12
+
+
 def test_driver_trains_and_writes_reference_checkpoints(tmp_path):
     from multimodal_vae_amd import train as T
     from multimodal_vae_amd.multimnist import MultimodalVAE
