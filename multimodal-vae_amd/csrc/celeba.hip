@@ -86,6 +86,7 @@ void build(CelebaPlan& P) {
     build_conv(P, P.convT[3], "image_decoder.hallucinate.9.weight", ConvGeom{32, 3, 4, 4, 2, 1, 32, 32, 64, 64, true}, -1, true, false, true);
     add_frag_packs(P, P.conv[2]);      // 8x8 / 16x16 layers: direct-B image-resident kernels (convres.hip)
     add_frag_packs(P, P.convT[1]);
+
     {   // classifier.0 consumes the NCHW flatten c*25 + y*5 + x of the (256,5,5) map held here as NHWC [5][5][256]
         LinL& f = P.fc1;
         f.w_off = off(P, "image_encoder.classifier.0.weight"); f.b_off = off(P, "image_encoder.classifier.0.bias");

@@ -663,6 +663,9 @@ int try_launch_convres(const GemmParams& p, hipStream_t stream) {
         if ((rc = try_cr<G_ca_conv3, 2, 0, 8, 4, true>(p, stream)) != 0) return rc;
         if ((rc = try_cr<G_ca_convT2, 4, 0, 8, 2, true>(p, stream)) != 0) return rc;
         if ((rc = try_cr<G_ca_convT3, 2, 16, 4, 1, false>(p, stream)) != 0) return rc;
+        // (the stride-1 8x8 <-> 5x5 pair, 1 MB of weights against 17 KB images, was tried here with 4 images per workgroup, a quarter
+        //  of the channels and the k range split over wave pairs: 213 us for its two launches against 190 on gemm_gather -- each
+        //  workgroup streams 512 KB of weights for 100 pixel rows; that layer wants the weights, not the images, resident)
     }
     MMVAE_REQUIRE(!forced, "convres: no kernel is compiled for the geometry of a launch with a staging transform");
     return 0;

@@ -451,7 +451,13 @@ inline int bn1d_bwd(PlanBase& P, const BnL& b, const BnTabs& t, bf16* d, const b
 inline hipEvent_t next_ev(PlanBase& P) {
     if (P.next_event == P.events.size()) {
         hipEvent_t e;
-        hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        // The step's events order streams of ONE device, and the kernels' own agent-scope release / acquire carry the data: the
+        // system-scope fence an event performs by default when it completes (cache writeback + invalidation for the HOST's and
+        // other devices' benefit) only slows the kernels behind it -- 671 -> 645 us per MultiMNIST step without it.  The host reads
+        // results after a stream synchronisation, the gradient exchange runs behind kernels of the caller's stream.
+        // (knob ev_flags: 0 the default fence, 2 none; hipEventReleaseToDevice alone changed nothing)
+        const int ef = mmvae_knob("ev_flags", 2);
+        hipEventCreateWithFlags(&e, hipEventDisableTiming | ((ef & 2) ? hipEventDisableSystemFence : 0u));
         P.events.push_back(e);
     }
     return P.events[P.next_event++];
