@@ -612,9 +612,7 @@ static int celeba_step_body(CelebaPlan* Pp, const CelebaStepIO& io, int training
     if (rc == MMVAE_OK) rc = enc_bwd(P, w.d_encout, 2, m1, enc_drop, s, fuse);
     P.wgrad_forked = false;
     MMVAE_TRY(rc);
-    MMVAE_TRY(edge(P, T, s));
-    MMVAE_TRY(edge(P, P.st_wgrad, s));
-    if (P.st_wgrad2 != P.st_wgrad) MMVAE_TRY(edge(P, P.st_wgrad2, s));
+    MMVAE_TRY(join_sides(P, T, s));
     hipLaunchKernelGGL(sum_slots_kernel, dim3(1), dim3(64), 0, s, w.sums, io.sums);
     MMVAE_TRY(mmvae_check_launch("sum_slots"));
     return io.defer_unpack ? MMVAE_OK : unpack(P, s);

@@ -385,45 +385,41 @@ int try_crw(WgradParams& p, hipStream_t stream, WgradSlabCtx* ctx) {
 }
 
 // =====================================================================================================================
-// Sliced weight gradient: many SMALL workgroups instead of one big resident one.
+// Tap-group weight gradient: many SMALL workgroups, whole pixels, plain-store partial sums.
 //
-// dW is [N][taps][C].  A workgroup owns one slice of it -- 32 output channels x all taps x CS gathered channels -- and one
-// group of images.  It stages, batch by batch (IB images), only what that slice needs: 32 of the N channels of the small-side
-// tensor and CS of the C channels of the big-side image (same de-interleaved LDS layout as the forward kernels, 16-byte
-// pixels), runs the pixel rows of the batch down the k axis of 32x32x16 MFMAs (both operands through transposed LDS reads; a
-// column tile of the gathered operand is TPT = 32/CS taps, the tap a per-lane address offset) and, at the end, adds its
-// 32 x taps x CS accumulators to the packed gradient with float atomics (one address is shared by the image groups only).
-//   * 30-50 KB of LDS and 4 waves: several fit on a CU next to each other and next to the main chain's image-resident
-//     kernels (the big resident kernel above needs a CU to itself and waits for one);
-//   * no slab copies and no reduce launch; traffic = both tensors once (every slice reads its own channels) + the atomics;
-//   * the operands are the materialised tensors (the by-products of the forward / data-gradient staging, GatherTransform::out).
-struct WsArgs {
+// dW is [N][taps][C].  A workgroup owns one slice of it -- 32 output channels x TG taps x all C gathered channels -- and one
+// group of images, which it streams through LDS one batch (IB images) at a time: the whole big-side image (same de-interleaved
+// layout as the forward kernels, pixel pitch C*2+16) and 32 of the N channels of the small side.  The pixel rows of the batch
+// run down the k axis of 32x32x16 MFMAs, both operands through transposed LDS reads (the gathered operand's tap is a per-lane
+// address offset, a column tile is 32 channels of one tap).  At the end the 32 x TG x C accumulators go to the image group's
+// slab copy with plain 128-byte row stores; the existing reduce kernel sums the copies (as many as there are image groups).
+// What the two earlier designs taught: keep whole pixels (16-byte channel slices pulled 4-8x their bytes
+// through L2), no float atomics (~180 G/s), and workgroups small enough (< 80 KB, 4 waves) to sit on a CU next to the main
+// chain's kernels; the price is that an image is staged by (N/32) x (tap groups) workgroups.
+struct WtArgs {
     const bf16* S;              // small-side tensor [nimg][OH*OW][N]
     const bf16* Bg;             // big-side tensor [nimg][AH][AW][C]
-    float* dW;                  // packed gradient [N][Kpad], k = tap*C + c  (+=)
+    float* slab;                // [image groups][N][Kpad] partial gradients, k = tap*C + c (plain stores)
     int Kpad;
     int ipg;                    // images per image group (a multiple of IB)
-    int dbg;                    // measurement aid: bit 0 no atomics, bit 1 no MFMA loop
+    int dbg;
 };
 
-template <class G, int CS, int IB>
-struct WsLayout {
-    using GS = crgeo::Geo<0, CS, 32, G::AH, G::AW, G::OH, G::OW, G::KH, G::KW, G::S, G::PAD, 0>;     // the slice's LDS image
-    static constexpr int OYX = G::OH * G::OW, ROWS = IB * OYX;
+template <class G, int IB>
+struct WtLayout {
+    static constexpr int OYX = G::OH * G::OW, ROWS = IB * OYX, KST = crgeo::cdiv(ROWS, 16), RPAD = KST * 16;
     static constexpr int DP = 80;                                        // small-side row pitch: 32 x bf16 + 16
-    static constexpr int A_BYTES = (IB * GS::IMG_BYTES + 15) / 16 * 16;
-    static constexpr int OFF_A = 0, OFF_D = A_BYTES, OFF_T = OFF_D + ROWS * DP, TOTAL = OFF_T + ROWS * 4;
-    static_assert(ROWS % 16 == 0, "a batch is a whole number of k-steps");
-    static_assert(TOTAL <= 64 * 1024, "the sliced weight gradient is meant to share a CU");
+    static constexpr int A_BYTES = (IB * G::IMG_BYTES + 15) / 16 * 16;
+    static constexpr int OFF_A = 0, OFF_D = A_BYTES, OFF_T = OFF_D + RPAD * DP, TOTAL = OFF_T + RPAD * 4;
+    static_assert(TOTAL <= 80 * 1024, "the tap-group weight gradient is meant to share a CU");
 };
 
-template <class G, int CS, int IB, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void wgrad_slice_kernel(const WsArgs a) {
-    using L = WsLayout<G, CS, IB>;
-    using GS = typename L::GS;
-    constexpr int NTHR = WAVES * 64, NCS = G::C / CS, NMS = G::N / 32, TAPS = G::KH * G::KW, TPT = 32 / CS;
-    constexpr int NT = crgeo::cdiv(TAPS, TPT), NTW = crgeo::cdiv(NT, WAVES), OYX = L::OYX, VPP = CS / 8;
-    static_assert(CS == 8 || CS == 16 || CS == 32, "slice width");
+template <class G, int TG, int IB, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void wgrad_tap_kernel(const WtArgs a) {
+    using L = WtLayout<G, IB>;
+    constexpr int NTHR = WAVES * 64, NMS = G::N / 32, TAPS = G::KH * G::KW, NTG = crgeo::cdiv(TAPS, TG), CT = G::C / 32;
+    constexpr int NTL = TG * CT, NTW = crgeo::cdiv(NTL, WAVES), OYX = L::OYX, VPP = G::C / 8;
+    static_assert(G::C % 32 == 0, "a column tile is 32 channels of one tap");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const a_s = smem + L::OFF_A;
     char* const d_s = smem + L::OFF_D;
@@ -431,20 +427,21 @@ __global__ __launch_bounds__(WAVES * 64) void wgrad_slice_kernel(const WsArgs a)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cs = blockIdx.x % NCS, ms = (blockIdx.x / NCS) % NMS, gi = blockIdx.x / (NCS * NMS);
+    const int tg = blockIdx.x % NTG, ms = (blockIdx.x / NTG) % NMS, gi = blockIdx.x / (NTG * NMS);
     const int img_begin = gi * a.ipg;
+    const int tap0 = tg * TG, ntaps = TAPS - tap0 < TG ? TAPS - tap0 : TG;      // this workgroup's taps
 
     // ---- staging: fetch a batch into registers (in flight during the previous batch's MFMAs), store after the barrier
     constexpr int NVA = IB * G::AH * G::AW * VPP, ITA = crgeo::cdiv(NVA, NTHR);
     constexpr int NVD = L::ROWS * 4, ITD = crgeo::cdiv(NVD, NTHR);
     i32x4c ra[ITA], rd[ITD];
     auto fetch = [&](int img0) {
-        const bf16* srcA = a.Bg + (size_t)img0 * (G::AH * G::AW * G::C) + cs * CS;
+        const bf16* srcA = a.Bg + (size_t)img0 * (G::AH * G::AW * G::C);
         const bf16* srcD = a.S + (size_t)img0 * (OYX * G::N) + ms * 32;
 #pragma unroll
         for (int it = 0; it < ITA; ++it) {
             const int v = tid + it * NTHR;
-            if (v < NVA) ra[it] = *reinterpret_cast<const i32x4c*>(srcA + (size_t)(v / VPP) * G::C + (v % VPP) * 8);
+            if (v < NVA) ra[it] = *reinterpret_cast<const i32x4c*>(srcA + (size_t)v * 8);
         }
 #pragma unroll
         for (int it = 0; it < ITD; ++it) {
@@ -460,8 +457,8 @@ __global__ __launch_bounds__(WAVES * 64) void wgrad_slice_kernel(const WsArgs a)
                 const int pix = v / VPP, cv = v - pix * VPP;
                 const int img = pix / (G::AH * G::AW), p2 = pix - img * (G::AH * G::AW);
                 const int iy = p2 / G::AW, ix = p2 - iy * G::AW;
-                const int cell = GS::cell(iy, ix);
-                if (cell >= 0) *reinterpret_cast<i32x4c*>(a_s + img * GS::IMG_BYTES + cell + cv * 16) = ra[it];
+                const int cell = G::cell(iy, ix);
+                if (cell >= 0) *reinterpret_cast<i32x4c*>(a_s + img * G::IMG_BYTES + cell + cv * 16) = ra[it];
             }
         }
 #pragma unroll
@@ -471,23 +468,27 @@ __global__ __launch_bounds__(WAVES * 64) void wgrad_slice_kernel(const WsArgs a)
         }
     };
     fetch(img_begin);
-    {   // zero the image area once (the padding cells are never written again), per-row bases of the gathered operand
+    {   // zero the image area and the padding rows of the small-side tile once (neither is written again); per-row bases of
+        // the gathered operand (padding rows: row 0's -- their small-side rows are zero, the product vanishes)
         const i32x4c z = {0, 0, 0, 0};
         for (int i = tid * 16; i < L::A_BYTES; i += NTHR * 16) *reinterpret_cast<i32x4c*>(a_s + i) = z;
-        for (int e = tid; e < L::ROWS; e += NTHR) {
-            const int img = e / OYX, q = e - img * OYX, jy = q / G::OW, jx = q - jy * G::OW;
-            tab[e] = img * GS::IMG_BYTES + jy * GS::row_stride(0) + jx * GS::col_stride(0);
+        for (int i = L::ROWS * L::DP + tid * 16; i < L::RPAD * L::DP; i += NTHR * 16) *reinterpret_cast<i32x4c*>(d_s + i) = z;
+        for (int e = tid; e < L::RPAD; e += NTHR) {
+            const int ee = e < L::ROWS ? e : 0;
+            const int img = ee / OYX, q = ee - img * OYX, jy = q / G::OW, jx = q - jy * G::OW;
+            tab[e] = img * G::IMG_BYTES + jy * G::row_stride(0) + jx * G::col_stride(0);
         }
     }
     // ---- per-lane constants of the transposed reads: lane (g4, q, p) of a 16-lane group addresses k-row q, columns 4p..4p+3
     const int g4 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3, h = lane >> 5;
-    const int col0 = 16 * (g4 & 1) + 4 * p4;                 // first of this lane's 4 columns inside a 32-column tile
+    const int col0 = 16 * (g4 & 1) + 4 * p4;                 // first of this lane's 4 channels inside a 32-channel tile
     int boff[NTW];
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
-        const int tap = (wave + j * WAVES) * TPT + col0 / CS;
-        const int tc = tap < TAPS ? tap : 0;                 // (columns past the last tap: any valid address, results dropped)
-        boff[j] = GS::tap_off(0, tc / G::KW, tc % G::KW) + (col0 % CS) * 2;
+        const int t = wave + j * WAVES;                      // tile = (tap of the group, channel tile)
+        const int tl = t / CT, ct = t - tl * CT;
+        const int tap = tap0 + (tl < ntaps ? tl : 0);        // (tiles past the group's last tap: any valid address, results dropped)
+        boff[j] = G::tap_off(0, tap / G::KW, tap % G::KW) + (ct * 32 + col0) * 2;
     }
     f32x16 acc[NTW];
 #pragma unroll
@@ -502,51 +503,63 @@ __global__ __launch_bounds__(WAVES * 64) void wgrad_slice_kernel(const WsArgs a)
         if (b + 1 < nb) fetch(img_begin + (b + 1) * IB);
         __syncthreads();
 #pragma unroll 2
-        for (int ks = (a.dbg & 2) ? L::ROWS / 16 : 0; ks < L::ROWS / 16; ++ks) {
+        for (int ks = (a.dbg & 2) ? L::KST : 0; ks < L::KST; ++ks) {
             const int row = ks * 16 + 8 * h + q4;
             const int ro0 = tab[row], ro1 = tab[row + 4];
             const char* s0 = d_s + row * L::DP + col0 * 2;
             const bf16x8 af = tr_pair(s0, s0 + 4 * L::DP);
 #pragma unroll
             for (int j = 0; j < NTW; ++j) {
-                if (wave + j * WAVES < NT) {                 // (uniform per wave)
+                if (wave + j * WAVES < NTL) {                // (uniform per wave)
                     const bf16x8 bf = tr_pair(a_s + ro0 + boff[j], a_s + ro1 + boff[j]);
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[j], 0, 0, 0);
                 }
             }
         }
     }
-    // ---- accumulators -> packed gradient: lane = column (tap, channel) of the tile, register e = output channel
+    // ---- accumulators -> this image group's slab copy: lane = channel of the tile's tap, register e = output channel
     const int n = lane & 31;
+    float* const dst = a.slab + (size_t)gi * G::N * a.Kpad + (size_t)(ms * 32) * a.Kpad;
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
-        const int nt = wave + j * WAVES, tap = nt * TPT + n / CS;
-        if (nt < NT && tap < TAPS && !(a.dbg & 1)) {
-            float* d = a.dW + (size_t)(ms * 32) * a.Kpad + tap * G::C + cs * CS + n % CS;
+        const int t = wave + j * WAVES, tl = t / CT, ct = t - tl * CT;
+        if (t < NTL && tl < ntaps && !(a.dbg & 1)) {
+            float* d = dst + (tap0 + tl) * G::C + ct * 32 + n;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) atomicAdd(d + (size_t)((e & 3) + 8 * (e >> 2) + 4 * h) * a.Kpad, acc[j][e]);
+            for (int e = 0; e < 16; ++e) d[(size_t)((e & 3) + 8 * (e >> 2) + 4 * h) * a.Kpad] = acc[j][e];
         }
     }
 }
 
-template <class G, int CS, int IB, int WAVES>
-int try_ws(const WgradParams& p, hipStream_t stream) {
+template <class G, int TG, int IB, int WAVES>
+int try_wt(const WgradParams& p, hipStream_t stream, WgradSlabCtx* ctx) {
     if (!wgeo_matches<G>(p)) return 0;
     const GatherCommon& c = p.c;
     const int nimg = c.groups * c.group_n;
-    if (nimg % IB != 0 || !p.cls[0].dWp) return 0;
-    constexpr int slices = (G::N / 32) * (G::C / CS);
-    const int nb = nimg / IB;
-    // image groups: ~2 workgroups per CU in flight, every group a whole number of batches
+    if (nimg % IB != 0 || !p.cls[0].dWp || !ctx || !ctx->pool) return 0;
+    constexpr int TAPS = G::KH * G::KW, slices = (G::N / 32) * crgeo::cdiv(TAPS, TG);
+    const int nb = nimg / IB, Kpad = p.cls[0].Kpad;
+    // image groups: about ws_wgs workgroups per CU in flight, every group a whole number of batches, slab copies within the pool
     int groups = mmvae_knob("ws_wgs", 2) * mmvae_cu_count() / slices;
     if (groups < 1) groups = 1;
     if (groups > nb) groups = nb;
     while (nb % groups != 0) --groups;
-    WsArgs a{};
-    a.S = p.P; a.Bg = c.A; a.dW = p.cls[0].dWp; a.Kpad = p.cls[0].Kpad; a.ipg = nimg / groups; a.dbg = mmvae_knob("ws_dbg", 0);
-    constexpr size_t lds = WsLayout<G, CS, IB>::TOTAL;
-    MMVAE_LAUNCH((wgrad_slice_kernel<G, CS, IB, WAVES>), dim3(groups * slices), dim3(WAVES * 64), lds, stream, a);
-    const int rc = mmvae_check_launch("wgrad_slice");
+    const size_t slab_elems = (size_t)G::N * Kpad;
+    while (groups > 1 && (ctx->used + (size_t)groups * slab_elems > ctx->cap || nb % groups != 0)) --groups;
+    float* slab = ctx->take((size_t)groups * slab_elems);
+    if (!slab) return 0;
+    WtArgs a{};
+    a.S = p.P; a.Bg = c.A; a.slab = slab; a.Kpad = Kpad; a.ipg = nimg / groups; a.dbg = mmvae_knob("ws_dbg", 0);
+    WgradSlabJob j{};
+    j.dst = p.cls[0].dWp; j.slab = slab; j.N = G::N; j.K = G::K(0); j.Kpad = Kpad; j.chunks = groups; j.chunk_stride = (long long)slab_elems;
+    j.stream = stream;
+    ctx->jobs.push_back(j);
+    constexpr size_t lds = WtLayout<G, IB>::TOTAL;
+    static std::atomic<unsigned> attr_set{0};
+    if (mmvae_first_use_on_device(attr_set))
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tap_kernel<G, TG, IB, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    MMVAE_LAUNCH((wgrad_tap_kernel<G, TG, IB, WAVES>), dim3(groups * slices), dim3(WAVES * 64), lds, stream, a);
+    const int rc = mmvae_check_launch("wgrad_tap");
     return rc == MMVAE_OK ? 1 : rc;
 }
 
@@ -558,28 +571,28 @@ typedef Geo<0, 32, 64, 25, 25, 12, 12, 5, 5, 2, 1, 0> W_mm_convT3;     // halluc
 
 }  // namespace
 
-// forward-form geometries of the weight gradients (Conv2d: gathered = the layer input; ConvTranspose2d: gathered = the output gradient)
-typedef Geo<0, 128, 256, 6, 6, 2, 2, 4, 4, 2, 0, 0> W_mm_conv4;        // features.8 and hallucinate.0
-typedef Geo<0, 32, 64, 32, 32, 16, 16, 4, 4, 2, 1, 0> W_ca_conv2;      // CelebA features.2 and hallucinate.6
-typedef Geo<0, 64, 128, 16, 16, 8, 8, 4, 4, 2, 1, 0> W_ca_conv3;       // CelebA features.5 and hallucinate.3 (and COCO's 16x16 pair)
+// forward-form geometries of the weight gradients with the forward kernels' pixel pitch (Conv2d: gathered = the layer input;
+// ConvTranspose2d: gathered = the output gradient)
+typedef Geo<0, 32, 64, 25, 25, 12, 12, 4, 4, 2, 1> T_mm_conv2;         // MultiMNIST features.2
+typedef Geo<0, 32, 64, 25, 25, 12, 12, 5, 5, 2, 1> T_mm_convT3;        // hallucinate.6
+typedef Geo<0, 64, 128, 12, 12, 6, 6, 4, 4, 2, 1> T_mm_conv3;          // features.5 and hallucinate.3
 
-int try_launch_wgrad_slice(const WgradParams& p, hipStream_t stream) {
-    if (!mmvae_knob("wgrad_slice", 0)) return 0;     // opt-in: measured slower than the streamed kernel (tried and lost)
+int try_launch_wgrad_tap(const WgradParams& p, hipStream_t stream, WgradSlabCtx* ctx) {
+    const int sel = mmvae_knob("wgrad_tap", 0);        // opt-in (1: every compiled layer, 2: hallucinate.6 only): DESIGN.md, tried and lost
+    if (!sel) return 0;
     if (p.trA || p.trP || p.c.a_bcast_n > 0 || p.c.a_mask || p.c.a_affine || p.c.a_act != ACT_NONE || p.p_affine || p.p_act != ACT_NONE) return 0;
     int rc;
-    //                        CS IB WAVES
-    if ((rc = try_ws<W_mm_conv2, 8, 2, 4>(p, stream)) != 0) return rc;
-    if ((rc = try_ws<W_mm_convT3, 8, 2, 4>(p, stream)) != 0) return rc;
-    if ((rc = try_ws<W_mm_conv3, 8, 4, 4>(p, stream)) != 0) return rc;
-    if ((rc = try_ws<W_mm_conv4, 8, 32, 4>(p, stream)) != 0) return rc;
-    if ((rc = try_ws<W_ca_conv2, 8, 1, 4>(p, stream)) != 0) return rc;
-    if ((rc = try_ws<W_ca_conv3, 8, 2, 4>(p, stream)) != 0) return rc;
+    //                       TG IB WAVES
+    if ((rc = try_wt<T_mm_convT3, 13, 1, 4>(p, stream, ctx)) != 0) return rc;      // 2 tap groups (13 + 12)
+    if (sel == 2) return 0;
+    if ((rc = try_wt<T_mm_conv2, 8, 1, 4>(p, stream, ctx)) != 0) return rc;        // 2 tap groups x 2 channel tiles of N
+    if ((rc = try_wt<T_mm_conv3, 4, 1, 4>(p, stream, ctx)) != 0) return rc;        // 4 tap groups x 4 channel tiles of N
     return 0;
 }
 
 int try_launch_convres_wgrad(WgradParams& p, hipStream_t stream, WgradSlabCtx* ctx) {
     {
-        const int rc = try_launch_wgrad_slice(p, stream);
+        const int rc = try_launch_wgrad_tap(p, stream, ctx);
         if (rc != 0) return rc;
     }
     const bool forced = (p.trA && p.trA->kind) || (p.trP && p.trP->kind);      // staging transforms exist only here

@@ -257,10 +257,12 @@ __global__ __launch_bounds__(DL_NTHR) void dec_last_mfma_kernel(const DecLastFus
 // ---------------------------------------------------------------------------------------------------------------------
 // CelebA tail (celeba/model.py:146-150): ConvTranspose2d(32, 3, 4, 2, 1) on 32x32 maps -> 64x64x3 + sigmoid + BCE, its input
 // and weight gradients.  Same three products as above with j = tap*3 + co (48 of 64 columns) as the narrow dimension; one
-// workgroup owns one image and walks it in 4 strips of 8 input rows so that P (fp32) fits LDS: a strip stages input rows
-// y0-1 .. y0+8 (BatchNorm + Swish on the way), makes P for those 10 rows, the logits of output rows 2y0-1 .. 2y0+16 (the
-// outer two only for the gradient windows of the strip's own pixels; loss / outputs for the 16 owned rows), the patches and
-// the input gradient of its 8 rows; the weight-gradient accumulators stay in registers across the strips.
+// workgroup (8 waves, 124 KB of LDS) owns one image and walks it in 4 strips of SR = 8 input rows so that P (fp32) fits: a
+// strip stages input rows y0-1 .. y0+SR (BatchNorm + Swish on the way), makes P for those SR+2 rows, the logits of output rows
+// 2y0-1 .. 2y0+2SR (the outer two only for the gradient windows of the strip's own pixels; loss / outputs for the 2SR owned
+// rows), the patches and the input gradient of its SR rows; the weight-gradient accumulators stay in registers across the
+// strips.  (SR = 4 with 4 waves and two 72 KB workgroups per CU: 334 us in the CelebA step against 245 -- the halo rows are
+// half of what a strip stages and the per-strip barriers double.)
 constexpr int CL_IH = 32, CL_IW = 32, CL_OH = 64, CL_OW = 64, CL_C = 32, CL_CO = 3, CL_J = 48, CL_SR = 8, CL_NS = CL_IH / CL_SR;
 constexpr int CL_NPIX = CL_IH * CL_IW;
 constexpr int CL_AROWS = CL_SR + 2, CL_APX = CL_AROWS * CL_IW, CL_ATILES = CL_APX / 32;       // staged rows / pixels / 32-pixel tiles

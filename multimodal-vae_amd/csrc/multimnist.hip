@@ -1040,9 +1040,7 @@ static int mm_step_body(MMPlan* Pp, const MMStepIO& io, int training, int do_bac
     P.wgrad_forked = false;
     P.in_step = false;
     MMVAE_TRY(rc);
-    MMVAE_TRY(edge(P, T, s));
-    MMVAE_TRY(edge(P, P.st_wgrad, s));
-    if (P.st_wgrad2 != P.st_wgrad) MMVAE_TRY(edge(P, P.st_wgrad2, s));
+    MMVAE_TRY(join_sides(P, T, s));
     MMVAE_TRY(launch_wgrad_reduce(&P.slab, s));
     if (dp_split) return launch_unpack_grads(P.buf.gdesc_dev, P.gk.d.data(), (int)P.gk.d.size(), P.buf.gpk, P.buf.gpk_vec, P.buf.grads, s, 0);
     if (!io.defer_unpack) MMVAE_TRY(mm_unpack_grads(Pp, s));

@@ -515,6 +515,22 @@ inline int ensure_streams(PlanBase& P) {
     return MMVAE_OK;
 }
 
+// End of a multi-stream step: the side streams meet on ONE of them first and the main stream waits once -- a wait on the main
+// stream is a barrier packet in front of its next kernel (~5.5 us each, tools/step_parts.py), a wait between side streams costs
+// the main chain nothing.
+inline int join_sides(PlanBase& P, hipStream_t T, hipStream_t s) {
+    hipStream_t hub = P.st_wgrad;
+    if (!hub || hub == s || T == s || mmvae_knob("one_join", 1) == 0) {
+        if (T != s) MMVAE_TRY(edge(P, T, s));
+        if (hub && hub != s) MMVAE_TRY(edge(P, hub, s));
+        if (P.st_wgrad2 && P.st_wgrad2 != hub && P.st_wgrad2 != s) MMVAE_TRY(edge(P, P.st_wgrad2, s));
+        return MMVAE_OK;
+    }
+    if (T != hub) MMVAE_TRY(edge(P, T, hub));
+    if (P.st_wgrad2 && P.st_wgrad2 != hub) MMVAE_TRY(edge(P, P.st_wgrad2, hub));
+    return edge(P, hub, s);
+}
+
 // Error exit of a multi-stream step: whatever was already forked onto the side streams is joined back into the caller's
 // stream (so a caller that catches the error and frees or reuses the workspace does not race with work in flight) and
 // the per-step scheduling state is reset.  Best effort: failures of the join itself are not reported over the first error.
