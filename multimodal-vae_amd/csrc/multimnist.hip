@@ -936,6 +936,10 @@ static int mm_step_body(MMPlan* Pp, const MMStepIO& io, int training, int do_bac
         MMVAE_TRY(step_begin_with_pack(sb, P.buf.desc_dev, P.pk.d.data(), (int)P.pk.d.size(), P.buf.params, P.buf.packed, P.buf.packed_vec));
     MMVAE_TRY(ensure_streams(P));
     P.in_step = true;
+    {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        P.capturing = hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive;
+    }
     arm_fork(P);                    // the text path forks off the prologue kernel's completion
     MMVAE_TRY(launch_step_begin(sb, s));
     MMVAE_TRY(commit_fork(P, s));

@@ -61,6 +61,8 @@ struct PlanBase {
     hipEvent_t fork_ev = nullptr;   // the event of the last arm_fork / commit_fork pair
     std::vector<std::function<int(hipStream_t)>> side_pending;   // side-stream work waiting for the next fork (side_later / side_flush)
     bool in_step = false;           // a fused multi-stream step is being enqueued (arm_fork / commit_fork are no-ops otherwise)
+    bool capturing = false;         // ... into a HIP graph: forks are plain event records (a kernel's completion event is not a capture node --
+                                    // the side streams would stay outside the graph and their work would be missing from every replay)
     hipEvent_t ev_early = nullptr;  // data-parallel step: the early gradient part is complete in the flat buffer
     bool wgrad_forked = false;
     unsigned dec_skip_mask = 0;     // bit k: pass k is absent from this step (weak-supervision variants): its decoder BatchNorm
@@ -106,11 +108,11 @@ inline int wgrad_async(PlanBase& P, const WgradParams& g, hipStream_t s) {
 inline void arm_fork(PlanBase& P) {
     if (!P.in_step) return;
     P.fork_ev = next_ev(P);
-    if (!mmvae_knob("no_stop_events", 0)) mmvae_arm_stop_event(P.fork_ev);
+    if (!P.capturing && !mmvae_knob("no_stop_events", 0)) mmvae_arm_stop_event(P.fork_ev);
 }
 inline int commit_fork(PlanBase& P, hipStream_t s) {
     if (!P.in_step) return MMVAE_OK;
-    const bool unclaimed = mmvae_take_stop_event() != nullptr || mmvae_knob("no_stop_events", 0);
+    const bool unclaimed = mmvae_take_stop_event() != nullptr || P.capturing || mmvae_knob("no_stop_events", 0);
     if (unclaimed && hipEventRecord(P.fork_ev, s) != hipSuccess) {
         mmvae_set_error("stream fork failed: %s", hipGetErrorString(hipGetLastError()));
         return MMVAE_EHIP;

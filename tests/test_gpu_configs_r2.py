@@ -172,6 +172,56 @@ def test_coco_b1024_one_workgroup_per_block_decoder(golden_dir):
     print("coco b1024 (8 x b128): loss rel / worst tensor", _check(st, fx, out, buffers=False))
 
 
+@pytest.mark.parametrize("family", ["celeba", "coco"])
+def test_packed_adam_equals_unpack_then_adam_other_families(family):
+    """The optimizer path the CelebA / COCO steps use by default (mmvae_adam_step_packed: gradients gathered from the packed
+    weight-gradient buffers through mmvae_<family>_grad_map) == unpack + mmvae_adam_step, bit for bit, on the same buffers."""
+    import ctypes
+    from multimodal_vae_amd._lib import call, ptr
+    from multimodal_vae_amd import core
+    from multimodal_vae_amd.init import default_init_
+    dev = _dev()
+    B = 8
+    if family == "celeba":
+        st = core.CelebaState(D, dev); default_init_(st, 5)
+        eng = core.FusedCelebaStep(st, B, seed=3)
+    else:
+        st = core.CocoState(D, dev, 6); default_init_(st, 5)
+        eng = core.FusedCocoStep(st, B, R.formula_sos(), seed=3)
+    a, b = R.formula_inputs(family, B)
+    if family == "coco":
+        b = b[:, :6].contiguous()
+    eng.forward_backward(a.to(dev).contiguous(), b.to(dev).contiguous(), True, True, _defer_unpack=True)
+    gmap = st.grad_map()
+    used = gmap[gmap >= 0]
+    assert used.numel() > 0.8 * st.nparams and used.unique().numel() == used.numel()
+    direct, gpk, gvec = st.grads.clone(), st.gpk.clone(), st.gpk_vec.clone()
+    full = direct.clone()
+    full[gmap >= 0] += gpk[gmap[gmap >= 0].long()]
+    vec = gmap < -1
+    full[vec] += gvec[(-gmap[vec] - 2).long()]
+    p0 = st.params.clone()
+    s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    pa, ma, va, sa = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0), torch.zeros(2, dtype=torch.int64, device=dev)
+    call("mmvae_adam_step", ptr(pa), ptr(full), ptr(ma), ptr(va), st.nparams, ptr(sa), 1e-4, 0.9, 0.999, 1e-8, 1.0, s)
+    pb, gb, mb, vb, sb = p0.clone(), direct.clone(), torch.zeros_like(p0), torch.zeros_like(p0), torch.zeros(2, dtype=torch.int64, device=dev)
+    call("mmvae_adam_step_packed", ptr(pb), ptr(gb), ptr(mb), ptr(vb), st.nparams, ptr(sb), 1e-4, 0.9, 0.999, 1e-8, 1.0,
+         ptr(gmap), ptr(gpk), ptr(gvec), s)
+    torch.cuda.synchronize()
+    assert torch.equal(gb, full) and torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    assert int(sa[0]) == 1 and int(sb[0]) == 1
+    # a void step (skip word set by a timed-out exchange) leaves everything alone and keeps the step count
+    sb[1] = 1 << 32                                            # the word behind the block ticket
+    pc = pb.clone()
+    call("mmvae_adam_step", ptr(pb), ptr(full), ptr(mb), ptr(vb), st.nparams, ptr(sb), 1e-4, 0.9, 0.999, 1e-8, 1.0, s)
+    torch.cuda.synchronize()
+    assert torch.equal(pb, pc) and int(sb[0]) == 1 and int(sb[1]) == 0
+    full[0] = float("nan")                                     # ... and so does the NaN mark that survives an all-reduce
+    call("mmvae_adam_step", ptr(pb), ptr(full), ptr(mb), ptr(vb), st.nparams, ptr(sb), 1e-4, 0.9, 0.999, 1e-8, 1.0, s)
+    torch.cuda.synchronize()
+    assert torch.equal(pb, pc) and int(sb[0]) == 1
+
+
 def test_single_rank_rccl_group_runs_the_data_parallel_step():
     """The data-parallel branch of the engine on real hardware once: RCCL (backend "nccl") process group of world size 1,
     GradAllReduce on the flat gradient, separate-unpack path, Adam with grad_scale = 1/world, bucketed variant included,

@@ -228,6 +228,27 @@ def test_training_reduces_loss_and_graph_matches_eager():
     a = eng.replay().losses().sum().item()
     b = eng.replay().losses().sum().item()
     assert np.isfinite(a) and np.isfinite(b) and b < first
+    # the replayed graph holds EVERY kernel of the step (side streams included: a fork that is not a capture node leaves the weight
+    # gradients and the text path out of the graph and the replay trains the image chain only): twin engines from one
+    # initialisation, six steps eager against 2 eager (capture's warm-up) + 4 replays -- same device step counters, same draws
+    sa = MultimnistState(D, dev); default_init_(sa, 11)
+    sb = MultimnistState(D, dev); default_init_(sb, 11)
+    p0 = sa.params.clone()
+    ea, eb = FusedELBOStep(sa, B, seed=5), FusedELBOStep(sb, B, seed=5)
+    for _ in range(6):
+        la = ea(img, txt).losses().cpu().numpy()
+    eb.capture(img, txt)
+    for _ in range(4):
+        lb = eb.replay().losses().cpu().numpy()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(lb, la, rtol=2e-2)
+    moved = (sa.params - p0).norm().item()
+    assert (sa.params - sb.params).norm().item() < 0.1 * moved, ((sa.params - sb.params).norm().item(), moved)
+    for n, shape, off in sa.table:                               # per tensor: nothing is left behind
+        k = int(np.prod(shape))
+        da, db = sa.params[off:off + k] - p0[off:off + k], sb.params[off:off + k] - p0[off:off + k]
+        if da.norm().item() > 1e-3 * moved:
+            assert (da - db).norm().item() < 0.35 * da.norm().item(), n
 
 
 def test_dropin_modules_match_oracle(golden_dir):
