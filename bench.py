@@ -342,7 +342,7 @@ def main():
         run()
     torch.cuda.synchronize()
     call("mmvae_debug_flops", 1)
-    run()
+    eng(a_d, b_d)                                         # (eagerly, also with --graph: a replay does not pass through the launchers)
     executed = call("mmvae_debug_flops", 1)               # GEMM FLOPs one step enqueues (host-side count)
     import gc
     gc.collect()
