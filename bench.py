@@ -431,8 +431,9 @@ def main():
     per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n_ev))
     result["ms_per_step_p10_p50_p90"] = [per[int(0.1 * (n_ev - 1))], per[(n_ev - 1) // 2], per[int(0.9 * (n_ev - 1))]]
 
+    # in-step kernel timing: EVERY rank runs the probed steps (they contain the gradient exchange), rank 0 reports
+    rows = [] if (args.no_probe or use_graph) else probe_steps(call, run, 20)
     if rank == 0:
-        rows = [] if (args.no_probe or use_graph) else probe_steps(call, run, 20)
         if rows:
             result["kernels_in_step"] = kernels_in_step(rows)
         fam_us = {}
