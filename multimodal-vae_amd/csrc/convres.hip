@@ -665,7 +665,9 @@ int try_launch_convres(const GemmParams& p, hipStream_t stream) {
         if ((rc = try_cr<G_ca_convT3, 2, 16, 4, 1, false>(p, stream)) != 0) return rc;
         // (the stride-1 8x8 <-> 5x5 pair, 1 MB of weights against 17 KB images, was tried here with 4 images per workgroup, a quarter
         //  of the channels and the k range split over wave pairs: 213 us for its two launches against 190 on gemm_gather -- each
-        //  workgroup streams 512 KB of weights for 100 pixel rows; that layer wants the weights, not the images, resident)
+        //  workgroup streams 512 KB of weights for 100 pixel rows; that layer wants the weights, not the images, resident.
+        //  With the weights through LDS chunks shared by 8 waves -- G_ca_conv4 <4, 8, 8, 8, false>, G_ca_convT1 <2, 5, 8, 4, false> --
+        //  the four launches of the pair take 440 us in the step against 447 on gemm_gather: 210-330 TFLOP/s either way)
     }
     MMVAE_REQUIRE(!forced, "convres: no kernel is compiled for the geometry of a launch with a staging transform");
     return 0;
