@@ -603,8 +603,9 @@ int try_launch_convres_wgrad(WgradParams& p, hipStream_t stream, WgradSlabCtx* c
     }
     int rc;
     //                          NI WAVES NSPLIT
-    if ((rc = try_crw<W_mm_conv2, 1, 8, 1>(p, stream, ctx)) != 0) return rc;
     if ((rc = try_crw<W_mm_convT3, 1, 8, 1>(p, stream, ctx)) != 0) return rc;
+    if (mmvae_knob("convres_wgrad", 0) == 2 && !forced) return 0;          // (2: hallucinate.6 only, the one layer it wins alone)
+    if ((rc = try_crw<W_mm_conv2, 1, 8, 1>(p, stream, ctx)) != 0) return rc;
     if ((rc = try_crw<W_mm_conv3, 1, 8, 2>(p, stream, ctx)) != 0) return rc;
     MMVAE_REQUIRE(!forced, "convres wgrad: no kernel is compiled for the geometry of a launch with a staging transform");
     return 0;
