@@ -116,11 +116,15 @@ struct WgradParams {
 // Slab pool of one step (carved from the caller's workspace) and the reductions its launches owe
 struct WgradSlabJob { float* dst; const float* slab; int N, K, Kpad, chunks; long long chunk_stride; hipStream_t stream;
                       int src_ld; };        // row length of a slab copy (0: Kpad)
+// ... and of the ring-staged kernel (wgrad_ring.hip): one job per stride-parity class, `copies` compact [N][Kc] partial copies whose
+// column k*C + c belongs to tap (ty0 + (k / ntx)*st, tx0 + (k % ntx)*st) of the layer
+struct WgradRingJob { float* dst; const float* slab; int N, Kpad, C, Kc, copies, ntx, ty0, tx0, st, kw; hipStream_t stream; };
 struct WgradSlabCtx {
     float* pool = nullptr;
     size_t cap = 0, used = 0;           // in floats
     std::vector<WgradSlabJob> jobs;
-    void reset(float* p, size_t c) { pool = p; cap = c; used = 0; jobs.clear(); }
+    std::vector<WgradRingJob> ring_jobs;
+    void reset(float* p, size_t c) { pool = p; cap = c; used = 0; jobs.clear(); ring_jobs.clear(); }
     float* take(size_t n) {             // n floats of the pool (16-byte granules) or null when it is exhausted
         n = (n + 3) / 4 * 4;
         if (!pool || used + n > cap) return nullptr;

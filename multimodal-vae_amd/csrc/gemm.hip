@@ -14,6 +14,7 @@
 #include "gemm.h"
 #include "gemm_epi.h"
 #include "convres.h"
+#include "wgrad_ring.h"
 #include <cstdlib>
 
 namespace {
@@ -897,6 +898,10 @@ int launch_wgrad(const WgradParams& pin, hipStream_t stream, WgradSlabCtx* ctx) 
     if (mmvae_knob("dbg_skip_wgrad", 0)) return MMVAE_OK;       // measurement aid: the step without its weight gradients
     MMVAE_TRY(wgrad_validate(pin));
     WgradParams p = pin;
+    {   // conv layers with a ring-staged kernel compiled for their geometry (wgrad_ring.hip)
+        const int rc = try_launch_wgrad_ring(p, stream, ctx);
+        if (rc != 0) return rc < 0 ? rc : MMVAE_OK;
+    }
     {   // conv layers with an image-resident kernel compiled for their geometry (convres_wgrad.hip)
         const int rc = try_launch_convres_wgrad(p, stream, ctx);
         if (rc != 0) return rc < 0 ? rc : MMVAE_OK;
@@ -948,6 +953,7 @@ int launch_wgrad_group(const WgradParams* list, int n, hipStream_t stream, Wgrad
 }
 
 int launch_wgrad_reduce(WgradSlabCtx* ctx, hipStream_t stream, bool only_own) {
+    MMVAE_TRY(launch_wgrad_ring_reduce(ctx, stream, only_own));
     if (!ctx || ctx->jobs.empty()) return MMVAE_OK;
     std::vector<WgradSlabJob> todo, keep;
     for (const WgradSlabJob& j : ctx->jobs) (only_own && j.stream != stream ? keep : todo).push_back(j);

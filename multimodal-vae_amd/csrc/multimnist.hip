@@ -960,7 +960,9 @@ static int mm_step_body(MMPlan* Pp, const MMStepIO& io, int training, int do_bac
         MMVAE_TRY(launch_text_encoder_fwd(a, T));
     }
     P.step_image = io.image;
-    const bool fuse = mmvae_knob("mm_fuse_bn", 1) != 0 && mmvae_knob("convres", 1) != 0 && B % 4 == 0;
+    // B % 8: the fused layers have no fallback kernel ("forced" launches) and conv4's geometry is compiled for 8 images per
+    // workgroup only; other batch sizes run the unfused bn_act + gather-GEMM chain
+    const bool fuse = mmvae_knob("mm_fuse_bn", 1) != 0 && mmvae_knob("convres", 1) != 0 && B % 8 == 0;
     MMVAE_TRY(enc_fwd(P, io.image, 2, m1, m2, enc_drop, training, enc_updates, w.encout, s, fuse));
     MMVAE_TRY(edge(P, T, s));
     // ---- product of experts + reparametrisation + KL for the three passes
@@ -1297,7 +1299,7 @@ int mm_bench_layer(MMPlan* P, void* ws, size_t wsb, const char* layer, int iters
         for (int i = 0; i < iters; ++i) {
             P->slab.reset(P->w.slab, P->w.slab_floats);
             MMVAE_TRY(fused_tail(*P, 3, 1, &last, 2, 2, s));
-            P->slab.jobs.clear();
+            P->slab.jobs.clear(); P->slab.ring_jobs.clear();
         }
         return MMVAE_OK;
     }

@@ -547,7 +547,7 @@ inline void join_after_error(PlanBase& P, hipStream_t s) {
         (void)hipGetLastError();
     }
     P.deferred.clear();
-    P.slab.jobs.clear();
+    P.slab.jobs.clear(); P.slab.ring_jobs.clear();
     P.defer_wgrad = false; P.wgrad_forked = false; P.no_splitk = false; P.in_step = false;
     (void)mmvae_take_stop_event();
     P.side_pending.clear();

@@ -1,0 +1,317 @@
+// Ring-staged weight-gradient kernel for gfx950 (v_mfma_f32_32x32x16_bf16, fp32 accumulate): the conv / transposed-conv weight
+// gradients of the stride-2 (and stride-1) layers whose images fit LDS.  Geometry and slot layout: wgrad_geo.h.
+//
+//   dW[n][(ty, tx)][c] = sum over images, pixels of  S[img][oy][ox][n] * B[img][oy*ST - PAD + ty][ox*ST - PAD + tx][c]
+//
+// What the streamed kernel (gemm.hip: wgrad_kernel) pays for and this one does not:
+//   * it gathers the big-side rows once per TAP (im2col through L2: 4.3x the algorithmic bytes on hallucinate.6) -- here a
+//     workgroup owns one stride-parity CLASS of taps: it needs the small image and ONE parity plane (a quarter) of the big
+//     image per sample, every byte crosses L2 -> LDS once per workgroup, and a tap is an immediate cell offset;
+//   * its loads go through registers with per-vector address and bounds arithmetic, one 64-row iteration at a time between
+//     two barriers -- here the slots of a ring are filled by LDS-DMA (buffer_load ... lds, 1 KB per wave instruction, the
+//     per-lane source offsets computed once per kernel, ring cells and padding rows out of range = hardware zero fill) and
+//     stay in flight across the single barrier per batch (counted vmcnt);
+//   * 16x16x32 MFMAs on 64x64 wave tiles -- here 32x32x16 with both operands through transposed LDS reads;
+//   * one partial tile per 64..128 rows -- here the accumulators of a workgroup's slice (NS x taps of the class x C) live in
+//     registers across ALL its images; a class has as many partial copies as it has image groups (chosen per class in
+//     proportion to its tap count so that every workgroup carries the same work), summed by one reduce launch.
+#include "gemm.h"
+#include "wgrad_geo.h"
+#include "wgrad_ring.h"
+#include "wgrad_ring_geos.h"
+#include <type_traits>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4r;
+typedef __attribute__((address_space(3))) void lds_void;
+
+constexpr int WR_MAXCLS = 4;
+
+struct WrArgs {
+    const bf16* S;              // small-side tensor [nimg][OH*OW][N]
+    const bf16* Bg;             // big-side tensor [nimg][AH][AW][C]
+    float* slab;                // class c, group g: slab + slab_off[c] + g * N * Kc(c)   as [N][Kc(c)], k = class tap * C + channel
+    long long slab_off[WR_MAXCLS];
+    int first[WR_MAXCLS + 1];   // first workgroup of each class (a class has MS * groups[c] workgroups)
+    int groups[WR_MAXCLS];
+    int units;                  // batches of IB images in the tensors
+    int nimg;
+    int dbg;                    // measurement aid: 1 no stores, 2 no MFMA loop, 4 no DMA
+};
+
+// two transposed 8-byte reads = one 32x32x16 operand fragment whose k axis runs over LDS rows
+__device__ __forceinline__ bf16x8 tr_pair_r(const char* a0, const char* a1) {
+    union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+    u.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4r*)a0);
+    u.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4r*)a1);
+    return u.v;
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+constexpr int OOB = (int)0x80000000;        // a buffer offset past every tensor: the hardware range check returns zeros
+
+// One LDS-DMA wave instruction: 64 lanes x 16 bytes from (descriptor base + soff + the lane's voff) to LDS bytes
+// [lds_addr, lds_addr + 1024).  Inline asm on purpose: hipcc treats the builtin form as a pending LDS write and drains vmcnt(0)
+// in front of the next ds_read -- the fills of the ring must stay in flight across the barrier and the MFMAs; the kernel counts
+// them itself (wait_vmcnt).  M0 (the LDS base of the DMA) is written in the same statement that uses it.
+__device__ __forceinline__ void dma_1k(const __amdgpu_buffer_rsrc_t r, const unsigned lds_addr, const int voff, const int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+
+template <class G, int CLS>
+__device__ __forceinline__ void wr_body(const WrArgs& a, const int ms, const int u0, const int u1, float* const copy, char* const smem) {
+    constexpr int WAVES = G::WAVES, NF = G::NF, SLOTS = G::SLOTS, KST = G::KST, CPW = G::CPW(CLS), NCT = G::NCT(CLS), CT = G::CT;
+    constexpr int SLOT = G::SLOT_BYTES, NTN = G::NTN, WC = G::WC, NTX = G::NTX(CLS), LC = G::LC(CLS);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- DMA sources of this lane's chunks of a slot (wave instruction j of wave w covers chunks (j*WAVES + w)*64 .. +63)
+    int voff[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const wrgeo::Src s = G::src(CLS, ((j * WAVES + wave) * 64) + lane);
+        voff[j] = s.tensor < 0 ? OOB : s.off;
+    }
+    const int n0 = ms * G::NS;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16*>(a.S + n0), 0, (int)((size_t)a.nimg * G::OYX * G::N * 2 - (size_t)n0 * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16*>(a.Bg), 0, (int)((size_t)a.nimg * G::AH * G::AW * G::C * 2), 0x00020000);
+    const unsigned lds0 = (unsigned)(size_t)(lds_void*)smem;
+    auto issue = [&](int u, int slot) {
+        // a batch past the group's last one: every lane out of range (the fill keeps the vmcnt bookkeeping uniform and costs
+        // no memory traffic); dbg & 4: the same for every batch
+        const bool live = u < u1 && !(a.dbg & 4);
+        const int soff_s = u * (G::IB * G::OYX * G::N * 2), soff_b = u * (G::IB * G::AH * G::AW * G::C * 2);
+        const unsigned base = lds0 + slot * SLOT + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const int vo = live ? voff[j] : OOB;
+            if (j < G::NFS) dma_1k(rs, base + j * (WAVES * 1024), vo, soff_s);
+            else dma_1k(rb, base + j * (WAVES * 1024), vo, soff_b);
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < SLOTS - 1; ++s) issue(u0 + s, s);
+
+    // ---- per-lane constants of the transposed reads: lane (h, q, p) addresses k-row 8h + q (and + 4), channels 16*(g&1) + 4p ..
+    const int h = lane >> 5, q4 = (lane & 15) >> 2;
+    const int lanecol = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    const int wr = wave % NTN, wc = wave / NTN;                  // this wave's row tile of the slice and its column-tile lane
+    const int a_base = G::sm_off(wr, 8 * h + q4) + lanecol;      // + ks*1024 (+256 for the second read)
+    int rb0[KST], rb1[KST];                                      // gathered operand: byte offset of the base cell of the lane's k-rows
+#pragma unroll
+    for (int ks = 0; ks < KST; ++ks) {
+        const int kr = ks * 16 + 8 * h + q4;
+        rb0[ks] = G::SM_BYTES + G::rowcell(CLS, kr) * 64 + lanecol;
+        rb1[ks] = G::SM_BYTES + G::rowcell(CLS, kr + 4) * 64 + lanecol;
+    }
+    int coloff[CPW];                                             // per column tile: (channel tile plane, tap cell) byte offset
+#pragma unroll
+    for (int j = 0; j < CPW; ++j) {
+        const int col = wc + j * WC, cc = col < NCT ? col : 0;
+        const int k = cc / CT, ct = cc - k * CT;
+        coloff[j] = (ct * G::NCELLP(CLS) + (k / NTX) * LC + k % NTX) * 64;
+    }
+    f32x16 acc[CPW];
+#pragma unroll
+    for (int j = 0; j < CPW; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+    // ---- main loop: one barrier per batch; the fills of the next SLOTS-1 batches are in flight while this one is multiplied
+    int slot = 0;
+    for (int u = u0; u < u1; ++u) {
+        wait_vmcnt<(SLOTS - 2) * NF>();                          // this wave's part of batch u has landed
+        __builtin_amdgcn_s_barrier();                            // ... everybody's; and everybody is done reading batch u-1
+        {
+            int ns = slot + SLOTS - 1; if (ns >= SLOTS) ns -= SLOTS;
+            issue(u + SLOTS - 1, ns);                            // into the slot batch u-1 was read from
+        }
+        const char* const sb = smem + slot * SLOT;
+        if (!(a.dbg & 2)) {
+#pragma unroll
+            for (int ks = 0; ks < KST; ++ks) {
+                const bf16x8 af = tr_pair_r(sb + a_base + ks * 1024, sb + a_base + ks * 1024 + 256);
+#pragma unroll
+                for (int j = 0; j < CPW; ++j) {                  // (a wave with one column tile fewer multiplies tile 0 again and drops it:
+                    //  the wave with the full count sets the pace anyway, and the loop stays branch-free)
+                    const bf16x8 bf = tr_pair_r(sb + rb0[ks] + coloff[j], sb + rb1[ks] + coloff[j]);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[j], 0, 0, 0);
+                }
+            }
+        }
+        if (++slot == SLOTS) slot = 0;
+    }
+    wait_vmcnt<0>();                                             // (the trailing fills are all out of range; nothing is left in flight at exit)
+
+    // ---- accumulators -> this group's copy [N][Kc]: lane = channel of the tile, register e = small-side channel
+    if (a.dbg & 1) return;
+    constexpr int Kc = G::NTAPS(CLS) * G::C;
+    float* const dst = copy + (size_t)(n0 + wr * 32 + 4 * h) * Kc + (lane & 31);
+#pragma unroll
+    for (int j = 0; j < CPW; ++j) {
+        const int col = wc + j * WC;
+        if (col < NCT) {
+            float* d = dst + col * 32;                           // column tile (k, ct) starts at k*C + ct*32 = col*32
+#pragma unroll
+            for (int e = 0; e < 16; ++e) d[(size_t)((e & 3) + 8 * (e >> 2)) * Kc] = acc[j][e];
+        }
+    }
+}
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void wr_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        wr_static_for<I + 1, N>(f);
+    }
+}
+
+template <class G>
+__global__ __launch_bounds__(G::WAVES * 64) void wgrad_ring_kernel(const WrArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    int cls = 0;
+#pragma unroll
+    for (int c = 1; c < G::NCLS; ++c) cls += (int)blockIdx.x >= a.first[c] ? 1 : 0;
+    const int rel = (int)blockIdx.x - a.first[cls];
+    const int ms = rel % G::MS, g = rel / G::MS;
+    const int ng = a.groups[cls];
+    const int u0 = (int)((long long)a.units * g / ng), u1 = (int)((long long)a.units * (g + 1) / ng);
+    wr_static_for<0, G::NCLS>([&](auto ic) {
+        constexpr int CLS = decltype(ic)::value;
+        if (cls == CLS) {
+            constexpr int Kc = G::NTAPS(CLS) * G::C;
+            wr_body<G, CLS>(a, ms, u0, u1, a.slab + a.slab_off[CLS] + (size_t)g * G::N * Kc, smem);
+        }
+    });
+}
+
+// dst[n][tap*C + c] += sum over the class's copies of copy[n][k*C + c]; one thread per 4 consecutive channels
+constexpr int WRR_MAX = 24;
+struct WrReduceArgs {
+    struct Job { float* dst; const float* slab; int N, Kpad, C, Kc, copies, ntx, ty0, tx0, st, kw, first_block; } job[WRR_MAX];
+    int n;
+};
+__global__ __launch_bounds__(256) void wgrad_ring_reduce_kernel(const WrReduceArgs a) {
+    int j = 0;
+    while (j + 1 < a.n && (int)blockIdx.x >= a.job[j + 1].first_block) ++j;
+    const WrReduceArgs::Job& q = a.job[j];
+    const int kv = q.Kc / 4;
+    const int t = (int)(blockIdx.x - q.first_block) * 256 + threadIdx.x;
+    if (t >= q.N * kv) return;
+    const int n = t / kv, k4 = (t - n * kv) * 4;
+    const int k = k4 / q.C, c = k4 - k * q.C;
+    const int tap = (q.ty0 + (k / q.ntx) * q.st) * q.kw + q.tx0 + (k % q.ntx) * q.st;
+    const float* src = q.slab + (size_t)n * q.Kc + k4;
+    const size_t stride = (size_t)q.N * q.Kc;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    int i = 0;
+    for (; i + 8 <= q.copies; i += 8) {                          // 8 independent 16-byte loads in flight
+        f32x4 v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const f32x4*>(src + (size_t)(i + e) * stride);
+        s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    for (; i < q.copies; ++i) s += *reinterpret_cast<const f32x4*>(src + (size_t)i * stride);
+    float* d = q.dst + (size_t)n * q.Kpad + tap * q.C + c;
+    f32x4 o = *reinterpret_cast<f32x4*>(d);
+    o += s;
+    *reinterpret_cast<f32x4*>(d) = o;
+}
+
+// the forward-form problem a geometry was compiled for
+template <class G>
+bool wr_matches(const WgradParams& p) {
+    const GatherCommon& c = p.c;
+    const GatherClass& k = p.cls[0];
+    return c.nclasses == 1 && c.C == G::C && c.N == G::N && c.AH == G::AH && c.AW == G::AW && c.Ald == G::C && p.ldp == G::N &&
+           k.OY == G::OH && k.OX == G::OW && c.OH == G::OH && c.OW == G::OW && k.TH == G::KH && k.TW == G::KW &&
+           c.sy == G::ST && c.sx == G::ST && c.dy == 1 && c.dx == 1 && c.osy == 1 && c.osx == 1 && k.offy == -G::PAD && k.offx == -G::PAD &&
+           k.ooy == 0 && k.oox == 0 && k.K == G::KH * G::KW * G::C;
+}
+
+template <class G>
+int try_wr(const WgradParams& p, hipStream_t stream, WgradSlabCtx* ctx) {
+    if (!wr_matches<G>(p)) return 0;
+    const GatherCommon& c = p.c;
+    const int nimg = c.groups * c.group_n;
+    if (nimg % G::IB != 0 || !p.cls[0].dWp || !ctx || !ctx->pool) return 0;
+    if ((size_t)nimg * G::AH * G::AW * G::C * 2 >= (1ull << 31) || (size_t)nimg * G::OYX * G::N * 2 >= (1ull << 31)) return 0;
+    const int units = nimg / G::IB;
+    // image groups per class in proportion to the class's column tiles: every workgroup carries about the same number of MFMAs
+    // (the 5x5 layer's classes hold 9 / 6 / 6 / 4 taps); about wr_wgs workgroups in all
+    const int target = mmvae_knob("wr_wgs", 2) * mmvae_cu_count();
+    int wsum = 0;
+    for (int i = 0; i < G::NCLS; ++i) wsum += G::NCT(i);
+    WrArgs a{};
+    a.S = p.P; a.Bg = c.A; a.units = units; a.nimg = nimg; a.dbg = mmvae_knob("wr_dbg", 0);
+    size_t need = 0;
+    int first = 0;
+    for (int i = 0; i < G::NCLS; ++i) {
+        int g = G::NCT(i) > 0 ? (int)((long long)target * G::NCT(i) / ((long long)wsum * G::MS)) : 0;
+        g = G::NCT(i) > 0 ? std::max(1, std::min(g, units)) : 0;
+        a.groups[i] = g; a.first[i] = first; first += g * G::MS;
+        a.slab_off[i] = (long long)need;
+        need += (size_t)g * G::N * G::NTAPS(i) * G::C;
+    }
+    a.first[G::NCLS] = first;
+    float* slab = ctx->take(need);
+    if (!slab) return 0;
+    a.slab = slab;
+    for (int i = 0; i < G::NCLS; ++i) {
+        if (a.groups[i] == 0) continue;
+        WgradRingJob j{};
+        j.dst = p.cls[0].dWp; j.slab = slab + a.slab_off[i]; j.N = G::N; j.Kpad = p.cls[0].Kpad; j.C = G::C; j.Kc = G::NTAPS(i) * G::C;
+        j.copies = a.groups[i]; j.ntx = G::NTX(i); j.ty0 = G::t0(G::cy(i)); j.tx0 = G::t0(G::cx(i)); j.st = G::ST; j.kw = G::KW;
+        j.stream = stream;
+        ctx->ring_jobs.push_back(j);
+    }
+    static std::atomic<unsigned> attr_set{0};
+    if (mmvae_first_use_on_device(attr_set))
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ring_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize, G::TOTAL);
+    MMVAE_LAUNCH((wgrad_ring_kernel<G>), dim3(first), dim3(G::WAVES * 64), (size_t)G::TOTAL, stream, a);
+    const int rc = mmvae_check_launch("wgrad_ring");
+    return rc == MMVAE_OK ? 1 : rc;
+}
+
+}  // namespace
+
+int try_launch_wgrad_ring(const WgradParams& p, hipStream_t stream, WgradSlabCtx* ctx) {
+    if (!mmvae_knob("wgrad_ring", 1)) return 0;
+    if (p.trA || p.trP || p.c.a_bcast_n > 0 || p.c.a_mask || p.c.a_affine || p.c.a_act != ACT_NONE || p.p_affine || p.p_act != ACT_NONE) return 0;
+    int rc;
+#define X(name, ...) if ((rc = try_wr<wrgeo::Geo<__VA_ARGS__>>(p, stream, ctx)) != 0) return rc;
+    WGRAD_RING_GEOS(X)
+#undef X
+    return 0;
+}
+
+int launch_wgrad_ring_reduce(WgradSlabCtx* ctx, hipStream_t stream, bool only_own) {
+    if (!ctx || ctx->ring_jobs.empty()) return MMVAE_OK;
+    std::vector<WgradRingJob> todo, keep;
+    for (const WgradRingJob& j : ctx->ring_jobs) (only_own && j.stream != stream ? keep : todo).push_back(j);
+    ctx->ring_jobs.swap(keep);
+    size_t done = 0;
+    while (done < todo.size()) {
+        WrReduceArgs a{};
+        int blocks = 0;
+        while (done < todo.size() && a.n < WRR_MAX) {
+            const WgradRingJob& j = todo[done++];
+            WrReduceArgs::Job& q = a.job[a.n++];
+            q.dst = j.dst; q.slab = j.slab; q.N = j.N; q.Kpad = j.Kpad; q.C = j.C; q.Kc = j.Kc; q.copies = j.copies; q.ntx = j.ntx;
+            q.ty0 = j.ty0; q.tx0 = j.tx0; q.st = j.st; q.kw = j.kw; q.first_block = blocks;
+            blocks += (j.N * (j.Kc / 4) + 255) / 256;
+        }
+        MMVAE_LAUNCH(wgrad_ring_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a);
+        MMVAE_TRY(mmvae_check_launch("wgrad_ring_reduce"));
+    }
+    return MMVAE_OK;
+}
