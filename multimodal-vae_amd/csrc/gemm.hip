@@ -895,13 +895,15 @@ static int wgrad_validate(const WgradParams& p) {
 }
 
 int launch_wgrad(const WgradParams& pin, hipStream_t stream, WgradSlabCtx* ctx) {
-    if (mmvae_knob("dbg_skip_wgrad", 0)) return MMVAE_OK;       // measurement aid: the step without its weight gradients
+    const int skip = mmvae_knob("dbg_skip_wgrad", 0);           // measurement aid: the step without (1: all, 2: the ring-staged, 3: the
+    if (skip == 1) return MMVAE_OK;                             // streamed single-problem, 4: the grouped) weight gradients
     MMVAE_TRY(wgrad_validate(pin));
     WgradParams p = pin;
     {   // conv layers with a ring-staged kernel compiled for their geometry (wgrad_ring.hip)
         const int rc = try_launch_wgrad_ring(p, stream, ctx);
         if (rc != 0) return rc < 0 ? rc : MMVAE_OK;
     }
+    if (skip == 3) return MMVAE_OK;
     {   // conv layers with an image-resident kernel compiled for their geometry (convres_wgrad.hip)
         const int rc = try_launch_convres_wgrad(p, stream, ctx);
         if (rc != 0) return rc < 0 ? rc : MMVAE_OK;
@@ -918,7 +920,7 @@ int launch_wgrad(const WgradParams& pin, hipStream_t stream, WgradSlabCtx* ctx) 
 // Several problems of the 128 x 128 tile class in one launch; anything that does not fit the grouped kernel (another tile
 // shape, more than WGRAD_MULTI_MAX problems) is launched on its own.
 int launch_wgrad_group(const WgradParams* list, int n, hipStream_t stream, WgradSlabCtx* ctx) {
-    if (mmvae_knob("dbg_skip_wgrad", 0)) return MMVAE_OK;
+    if (mmvae_knob("dbg_skip_wgrad", 0) == 1 || mmvae_knob("dbg_skip_wgrad", 0) == 4) return MMVAE_OK;
     constexpr bool no_group = false;
     int i = 0;
     while (i < n) {

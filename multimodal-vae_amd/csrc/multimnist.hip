@@ -1007,7 +1007,10 @@ static int mm_step_body(MMPlan* Pp, const MMStepIO& io, int training, int do_bac
     }
 
     // =============================== backward ===============================
-    P.wgrad_forked = true;
+    // knob mm_wgrad_inline: the image path's weight gradients stay on the main stream, right behind the data gradient that made
+    // their operands (no fork, no join, no contention with the main chain's kernels; 2: their partial copies summed by ONE launch
+    // in front of the optimizer instead of one per layer)
+    P.wgrad_forked = mmvae_knob("mm_wgrad_inline", 0) == 0;
     int rc = MMVAE_OK;
     P.deferred.clear();
     P.defer_wgrad = false;

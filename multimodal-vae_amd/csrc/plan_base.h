@@ -177,6 +177,7 @@ inline int wgrad_side_stream(PlanBase& P, hipStream_t s, hipStream_t* w) {
 inline int wgrad_on(PlanBase& P, const WgradParams& g, hipStream_t w) {
     if (mmvae_knob("wgrad_atomic", 0)) return launch_wgrad(g, w, nullptr);      // A/B: fp32 atomics into the packed gradient, no slab / reduce
     MMVAE_TRY(launch_wgrad(g, w, &P.slab));
+    if (!P.wgrad_forked && mmvae_knob("mm_wgrad_inline", 0) == 2) return MMVAE_OK;      // summed at the end of the step, one launch
     return launch_wgrad_reduce(&P.slab, w, true);
 }
 

@@ -20,6 +20,7 @@
 #include "wgrad_ring.h"
 #include "wgrad_ring_geos.h"
 #include <type_traits>
+#include <algorithm>
 
 namespace {
 
@@ -28,17 +29,19 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4r;
 typedef __attribute__((address_space(3))) void lds_void;
 
 constexpr int WR_MAXCLS = 4;
+constexpr int WR_MAXJOBS = 1024;
 
 struct WrArgs {
     const bf16* S;              // small-side tensor [nimg][OH*OW][N]
     const bf16* Bg;             // big-side tensor [nimg][AH][AW][C]
     float* slab;                // class c, group g: slab + slab_off[c] + g * N * Kc(c)   as [N][Kc(c)], k = class tap * C + channel
     long long slab_off[WR_MAXCLS];
-    int first[WR_MAXCLS + 1];   // first workgroup of each class (a class has MS * groups[c] workgroups)
-    int groups[WR_MAXCLS];
+    int groups[WR_MAXCLS];      // image groups of each class (a class has MS * groups[c] workgroups)
+    unsigned short job[WR_MAXJOBS];     // workgroup -> class << 12 | (group * MS + slice): see try_wr for the order
     int units;                  // batches of IB images in the tensors
     int nimg;
     int dbg;                    // measurement aid: 1 no stores, 2 no MFMA loop, 4 no DMA
+    unsigned long long* ts;     // measurement aid (knobs wr_ts_lo / wr_ts_hi): 8 s_memrealtime stamps (100 MHz) per workgroup, or null
 };
 
 // two transposed 8-byte reads = one 32x32x16 operand fragment whose k axis runs over LDS rows
@@ -71,6 +74,8 @@ __device__ __forceinline__ void wr_body(const WrArgs& a, const int ms, const int
     constexpr int SLOT = G::SLOT_BYTES, NTN = G::NTN, WC = G::WC, NTX = G::NTX(CLS), LC = G::LC(CLS);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned long long t_start = 0, t_setup = 0, t_first = 0, t_wait = 0, t_loop = 0, t_issue = 0;
+    if (a.ts) t_start = __builtin_amdgcn_s_memrealtime();
 
     // ---- DMA sources of this lane's chunks of a slot (wave instruction j of wave w covers chunks (j*WAVES + w)*64 .. +63)
     int voff[NF];
@@ -85,21 +90,25 @@ __device__ __forceinline__ void wr_body(const WrArgs& a, const int ms, const int
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<bf16*>(a.Bg), 0, (int)((size_t)a.nimg * G::AH * G::AW * G::C * 2), 0x00020000);
     const unsigned lds0 = (unsigned)(size_t)(lds_void*)smem;
-    auto issue = [&](int u, int slot) {
-        // a batch past the group's last one: every lane out of range (the fill keeps the vmcnt bookkeeping uniform and costs
-        // no memory traffic); dbg & 4: the same for every batch
+    // pieces [j0, j1) of the fill of batch u into `slot`.  A batch past the group's last one: every lane out of range (the fill
+    // keeps the vmcnt bookkeeping uniform and costs no memory traffic); dbg & 4: the same for every batch
+    auto issue = [&](int u, int slot, int j0, int j1) {
         const bool live = u < u1 && !(a.dbg & 4);
         const int soff_s = u * (G::IB * G::OYX * G::N * 2), soff_b = u * (G::IB * G::AH * G::AW * G::C * 2);
         const unsigned base = lds0 + slot * SLOT + wave * 1024;
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
+            if (j < j0 || j >= j1) continue;
+            if ((a.dbg & 8) && j < G::NFS) continue;             // timing aids: without the small / the big region / the all-zero pieces
+            if ((a.dbg & 16) && j >= G::NFS) continue;
+            if ((a.dbg & 32) && __builtin_amdgcn_readfirstlane(__all(voff[j] == OOB))) continue;
             const int vo = live ? voff[j] : OOB;
             if (j < G::NFS) dma_1k(rs, base + j * (WAVES * 1024), vo, soff_s);
             else dma_1k(rb, base + j * (WAVES * 1024), vo, soff_b);
         }
     };
 #pragma unroll
-    for (int s = 0; s < SLOTS - 1; ++s) issue(u0 + s, s);
+    for (int s = 0; s < SLOTS - 1; ++s) issue(u0 + s, s, 0, NF);
 
     // ---- per-lane constants of the transposed reads: lane (h, q, p) addresses k-row 8h + q (and + 4), channels 16*(g&1) + 4p ..
     const int h = lane >> 5, q4 = (lane & 15) >> 2;
@@ -128,17 +137,27 @@ __device__ __forceinline__ void wr_body(const WrArgs& a, const int ms, const int
 
     // ---- main loop: one barrier per batch; the fills of the next SLOTS-1 batches are in flight while this one is multiplied
     int slot = 0;
+    if (a.ts) t_setup = __builtin_amdgcn_s_memrealtime();
     for (int u = u0; u < u1; ++u) {
+        unsigned long long tw = 0;
+        if (a.ts) tw = __builtin_amdgcn_s_memrealtime();
         wait_vmcnt<(SLOTS - 2) * NF>();                          // this wave's part of batch u has landed
         __builtin_amdgcn_s_barrier();                            // ... everybody's; and everybody is done reading batch u-1
-        {
-            int ns = slot + SLOTS - 1; if (ns >= SLOTS) ns -= SLOTS;
-            issue(u + SLOTS - 1, ns);                            // into the slot batch u-1 was read from
-        }
+        if (a.ts) { const unsigned long long t = __builtin_amdgcn_s_memrealtime(); if (u == u0) t_first = t; else t_wait += t - tw; }
+        // the fill of batch u+SLOTS-1 goes into the slot batch u-1 was read from.  Its pieces are issued BETWEEN the k-steps
+        // (SPREAD): an LDS-DMA instruction holds the issuing wave for 100+ cycles (measured: 0.66 us of a batch's 1.1-1.6 us
+        // were the nine pieces in front of the first MFMA), behind a k-step's MFMAs that time runs under the matrix pipe
+        int ns = slot + SLOTS - 1; if (ns >= SLOTS) ns -= SLOTS;
+        constexpr bool SPREAD = SLOTS >= 3;          // (a two-slot ring needs the fill back by the next barrier: issue it at once)
+        unsigned long long ti = 0;
+        if (a.ts) ti = __builtin_amdgcn_s_memrealtime();
+        if (!SPREAD || (a.dbg & 2)) issue(u + SLOTS - 1, ns, 0, NF);
+        if (a.ts) t_issue += __builtin_amdgcn_s_memrealtime() - ti;
         const char* const sb = smem + slot * SLOT;
         if (!(a.dbg & 2)) {
 #pragma unroll
             for (int ks = 0; ks < KST; ++ks) {
+                if (SPREAD) issue(u + SLOTS - 1, ns, ks * NF / KST, (ks + 1) * NF / KST);
                 const bf16x8 af = tr_pair_r(sb + a_base + ks * 1024, sb + a_base + ks * 1024 + 256);
 #pragma unroll
                 for (int j = 0; j < CPW; ++j) {                  // (a wave with one column tile fewer multiplies tile 0 again and drops it:
@@ -151,9 +170,17 @@ __device__ __forceinline__ void wr_body(const WrArgs& a, const int ms, const int
         if (++slot == SLOTS) slot = 0;
     }
     wait_vmcnt<0>();                                             // (the trailing fills are all out of range; nothing is left in flight at exit)
+    if (a.ts) t_loop = __builtin_amdgcn_s_memrealtime();
+    auto stamp = [&]() {
+        if (a.ts && tid == 0) {
+            unsigned long long* t = a.ts + (size_t)blockIdx.x * 8;
+            t[0] = t_start; t[1] = t_setup; t[2] = t_first; t[3] = t_wait; t[4] = t_loop; t[5] = __builtin_amdgcn_s_memrealtime();
+            t[6] = (unsigned long long)(u1 - u0) | (t_issue << 16); t[7] = (unsigned long long)CLS;
+        }
+    };
 
     // ---- accumulators -> this group's copy [N][Kc]: lane = channel of the tile, register e = small-side channel
-    if (a.dbg & 1) return;
+    if (a.dbg & 1) { stamp(); return; }
     constexpr int Kc = G::NTAPS(CLS) * G::C;
     float* const dst = copy + (size_t)(n0 + wr * 32 + 4 * h) * Kc + (lane & 31);
 #pragma unroll
@@ -165,6 +192,7 @@ __device__ __forceinline__ void wr_body(const WrArgs& a, const int ms, const int
             for (int e = 0; e < 16; ++e) d[(size_t)((e & 3) + 8 * (e >> 2)) * Kc] = acc[j][e];
         }
     }
+    if (a.ts) { wait_vmcnt<0>(); stamp(); }
 }
 
 template <int I, int N, typename F>
@@ -178,10 +206,8 @@ __device__ __forceinline__ void wr_static_for(F&& f) {
 template <class G>
 __global__ __launch_bounds__(G::WAVES * 64) void wgrad_ring_kernel(const WrArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
-    int cls = 0;
-#pragma unroll
-    for (int c = 1; c < G::NCLS; ++c) cls += (int)blockIdx.x >= a.first[c] ? 1 : 0;
-    const int rel = (int)blockIdx.x - a.first[cls];
+    const int jb = a.job[blockIdx.x];
+    const int cls = jb >> 12, rel = jb & 0xfff;
     const int ms = rel % G::MS, g = rel / G::MS;
     const int ng = a.groups[cls];
     const int u0 = (int)((long long)a.units * g / ng), u1 = (int)((long long)a.units * (g + 1) / ng);
@@ -194,37 +220,47 @@ __global__ __launch_bounds__(G::WAVES * 64) void wgrad_ring_kernel(const WrArgs 
     });
 }
 
-// dst[n][tap*C + c] += sum over the class's copies of copy[n][k*C + c]; one thread per 4 consecutive channels
+// dst[n][tap*C + c] += sum over the class's copies of copy[n][k*C + c].  A block owns 32 float4 outputs; its 8 thread rows sum
+// every 8th copy each (independent loads, a short chain: a copy loop per output was a latency chain of copies/8 round trips on
+// a few dozen blocks) and meet in LDS.
 constexpr int WRR_MAX = 24;
 struct WrReduceArgs {
     struct Job { float* dst; const float* slab; int N, Kpad, C, Kc, copies, ntx, ty0, tx0, st, kw, first_block; } job[WRR_MAX];
     int n;
 };
 __global__ __launch_bounds__(256) void wgrad_ring_reduce_kernel(const WrReduceArgs a) {
+    __shared__ f32x4 part[8][32];
     int j = 0;
     while (j + 1 < a.n && (int)blockIdx.x >= a.job[j + 1].first_block) ++j;
     const WrReduceArgs::Job& q = a.job[j];
     const int kv = q.Kc / 4;
-    const int t = (int)(blockIdx.x - q.first_block) * 256 + threadIdx.x;
-    if (t >= q.N * kv) return;
-    const int n = t / kv, k4 = (t - n * kv) * 4;
-    const int k = k4 / q.C, c = k4 - k * q.C;
-    const int tap = (q.ty0 + (k / q.ntx) * q.st) * q.kw + q.tx0 + (k % q.ntx) * q.st;
+    const int o = threadIdx.x & 31, cl = threadIdx.x >> 5;
+    const int t = (int)(blockIdx.x - q.first_block) * 32 + o;
+    const bool in = t < q.N * kv;
+    const int tt = in ? t : 0;
+    const int n = tt / kv, k4 = (tt - n * kv) * 4;
     const float* src = q.slab + (size_t)n * q.Kc + k4;
     const size_t stride = (size_t)q.N * q.Kc;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    int i = 0;
-    for (; i + 8 <= q.copies; i += 8) {                          // 8 independent 16-byte loads in flight
-        f32x4 v[8];
+    int i = cl;
+    for (; i + 24 < q.copies; i += 32) {                         // 4 independent 16-byte loads in flight per thread
+        f32x4 v[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const f32x4*>(src + (size_t)(i + e) * stride);
-        s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        for (int e = 0; e < 4; ++e) v[e] = *reinterpret_cast<const f32x4*>(src + (size_t)(i + 8 * e) * stride);
+        s += (v[0] + v[1]) + (v[2] + v[3]);
     }
-    for (; i < q.copies; ++i) s += *reinterpret_cast<const f32x4*>(src + (size_t)i * stride);
+    for (; i < q.copies; i += 8) s += *reinterpret_cast<const f32x4*>(src + (size_t)i * stride);
+    part[cl][o] = s;
+    __syncthreads();
+    if (cl != 0 || !in) return;
+#pragma unroll
+    for (int e = 1; e < 8; ++e) s += part[e][o];
+    const int k = k4 / q.C, c = k4 - k * q.C;
+    const int tap = (q.ty0 + (k / q.ntx) * q.st) * q.kw + q.tx0 + (k % q.ntx) * q.st;
     float* d = q.dst + (size_t)n * q.Kpad + tap * q.C + c;
-    f32x4 o = *reinterpret_cast<f32x4*>(d);
-    o += s;
-    *reinterpret_cast<f32x4*>(d) = o;
+    f32x4 ov = *reinterpret_cast<f32x4*>(d);
+    ov += s;
+    *reinterpret_cast<f32x4*>(d) = ov;
 }
 
 // the forward-form problem a geometry was compiled for
@@ -240,29 +276,54 @@ bool wr_matches(const WgradParams& p) {
 
 template <class G>
 int try_wr(const WgradParams& p, hipStream_t stream, WgradSlabCtx* ctx) {
-    if (!wr_matches<G>(p)) return 0;
+    if (!wr_matches<G>(p) || mmvae_knob("wr_slots", 2) != G::SLOTS) return 0;
+    if (mmvae_knob("dbg_skip_wgrad", 0) == 2) return 1;         // measurement aid: the step without the ring-staged weight gradients
     const GatherCommon& c = p.c;
     const int nimg = c.groups * c.group_n;
     if (nimg % G::IB != 0 || !p.cls[0].dWp || !ctx || !ctx->pool) return 0;
     if ((size_t)nimg * G::AH * G::AW * G::C * 2 >= (1ull << 31) || (size_t)nimg * G::OYX * G::N * 2 >= (1ull << 31)) return 0;
     const int units = nimg / G::IB;
     // image groups per class in proportion to the class's column tiles: every workgroup carries about the same number of MFMAs
-    // (the 5x5 layer's classes hold 9 / 6 / 6 / 4 taps); about wr_wgs workgroups in all
-    const int target = mmvae_knob("wr_wgs", 2) * mmvae_cu_count();
+    // (the 5x5 layer's classes hold 9 / 6 / 6 / 4 taps); about one workgroup per CU in all (knob wr_wgs)
+    const int target = mmvae_knob("wr_wgs", 4) * mmvae_cu_count() / 4;      // knob in quarters of the CU count
+    // (a batch costs a workgroup a fixed part -- the DMA issue -- next to its MFMAs: measured 0.66 us + 0.10 us per column tile
+    //  on hallucinate.6; knob wr_bias = the fixed part in column tiles)
+    const int bias = mmvae_knob("wr_bias", 6);
+    auto wgt = [&](int i) { return G::NCT(i) > 0 ? G::CPW(i) * G::WC + bias : 0; };
     int wsum = 0;
-    for (int i = 0; i < G::NCLS; ++i) wsum += G::NCT(i);
+    for (int i = 0; i < G::NCLS; ++i) wsum += wgt(i);
     WrArgs a{};
     a.S = p.P; a.Bg = c.A; a.units = units; a.nimg = nimg; a.dbg = mmvae_knob("wr_dbg", 0);
+    a.ts = reinterpret_cast<unsigned long long*>(((unsigned long long)(unsigned)mmvae_knob("wr_ts_hi", 0) << 32) | (unsigned)mmvae_knob("wr_ts_lo", 0));
     size_t need = 0;
-    int first = 0;
+    int total = 0;
     for (int i = 0; i < G::NCLS; ++i) {
-        int g = G::NCT(i) > 0 ? (int)((long long)target * G::NCT(i) / ((long long)wsum * G::MS)) : 0;
+        int g = G::NCT(i) > 0 ? (int)((long long)target * wgt(i) / ((long long)wsum * G::MS)) : 0;
         g = G::NCT(i) > 0 ? std::max(1, std::min(g, units)) : 0;
-        a.groups[i] = g; a.first[i] = first; first += g * G::MS;
+        a.groups[i] = g; total += g * G::MS;
         a.slab_off[i] = (long long)need;
         need += (size_t)g * G::N * G::NTAPS(i) * G::C;
     }
-    a.first[G::NCLS] = first;
+    if (total > WR_MAXJOBS) return 0;
+    {   // Workgroup order.  The workgroups that read the same images (the classes and channel slices of one image range) should
+        // share an XCD and run at the same time: the small image then crosses the fabric once and the other three classes hit it in
+        // the XCD's L2 (the kernel runs at the fabric's rate: 57 MB of fills for 30 MB of operands on hallucinate.6).  Blocks b and
+        // b + 8 share an XCD (round-robin dispatch; speed only, never correctness): sort the jobs by their first image and deal
+        // runs of RUN consecutive jobs to the 8 block residues in turn.
+        struct J { int u0, code; };
+        std::vector<J> js;
+        for (int i = 0; i < G::NCLS; ++i)
+            for (int g = 0; g < a.groups[i]; ++g)
+                for (int m = 0; m < G::MS; ++m) js.push_back(J{(int)((long long)units * g / a.groups[i]), (i << 12) | (g * G::MS + m)});
+        std::stable_sort(js.begin(), js.end(), [](const J& x, const J& y) { return x.u0 < y.u0; });
+        const int run = std::max(1, mmvae_knob("wr_run", G::NCLS * G::MS));
+        const int blk = 8 * run, full = total / blk * blk;
+        for (int i = 0; i < total; ++i) {
+            int b = i;
+            if (i < full && mmvae_knob("wr_xcd", 1)) b = i / blk * blk + (i % run) * 8 + (i / run) % 8;
+            a.job[b] = (unsigned short)js[i].code;
+        }
+    }
     float* slab = ctx->take(need);
     if (!slab) return 0;
     a.slab = slab;
@@ -277,7 +338,7 @@ int try_wr(const WgradParams& p, hipStream_t stream, WgradSlabCtx* ctx) {
     static std::atomic<unsigned> attr_set{0};
     if (mmvae_first_use_on_device(attr_set))
         hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ring_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize, G::TOTAL);
-    MMVAE_LAUNCH((wgrad_ring_kernel<G>), dim3(first), dim3(G::WAVES * 64), (size_t)G::TOTAL, stream, a);
+    MMVAE_LAUNCH((wgrad_ring_kernel<G>), dim3(total), dim3(G::WAVES * 64), (size_t)G::TOTAL, stream, a);
     const int rc = mmvae_check_launch("wgrad_ring");
     return rc == MMVAE_OK ? 1 : rc;
 }
@@ -308,7 +369,7 @@ int launch_wgrad_ring_reduce(WgradSlabCtx* ctx, hipStream_t stream, bool only_ow
             WrReduceArgs::Job& q = a.job[a.n++];
             q.dst = j.dst; q.slab = j.slab; q.N = j.N; q.Kpad = j.Kpad; q.C = j.C; q.Kc = j.Kc; q.copies = j.copies; q.ntx = j.ntx;
             q.ty0 = j.ty0; q.tx0 = j.tx0; q.st = j.st; q.kw = j.kw; q.first_block = blocks;
-            blocks += (j.N * (j.Kc / 4) + 255) / 256;
+            blocks += (j.N * (j.Kc / 4) + 31) / 32;
         }
         MMVAE_LAUNCH(wgrad_ring_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a);
         MMVAE_TRY(mmvae_check_launch("wgrad_ring_reduce"));

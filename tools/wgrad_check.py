@@ -55,23 +55,43 @@ for L in sel:
         print(f"   {idx.numel()} elements differ; first: {idx[:8].tolist()}  g0 {g0[idx[:4]].tolist()}  g1 {g1[idx[:4]].tolist()}")
     if os.environ.get("WR_DBG"):
         ts = []
-        for dbg in (1, 2, 4, 6, 7):
+        for dbg in (1, 2, 4, 6, 7, 8, 16, 32):
             call("mmvae_debug_set", b"wr_dbg", dbg)
             run(L, 1, 3)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(s); run(L, 1, 20); e1.record(s); torch.cuda.synchronize()
             ts.append(f"dbg{dbg}={e0.elapsed_time(e1) * 1e3 / 20:.1f}")
         call("mmvae_debug_set", b"wr_dbg", 0)
-        print("      (1 no stores, 2 no MFMA loop, 4 no DMA traffic)  " + "  ".join(ts), flush=True)
+        print("      (1 no stores, 2 no MFMA loop, 4 no DMA traffic, 8 no small-side fills, 16 no big-side fills, 32 no all-zero pieces)  " + "  ".join(ts), flush=True)
+    if os.environ.get("WR_TS"):
+        tsb = torch.zeros(4096 * 8, dtype=torch.int64, device=dev)
+        call("mmvae_debug_set", b"wr_ts_lo", ctypes.c_int(tsb.data_ptr() & 0xffffffff).value)
+        call("mmvae_debug_set", b"wr_ts_hi", ctypes.c_int(tsb.data_ptr() >> 32).value)
+        run(L, 1, 1); torch.cuda.synchronize()
+        call("mmvae_debug_set", b"wr_ts_lo", 0); call("mmvae_debug_set", b"wr_ts_hi", 0)
+        t = tsb.view(-1, 8).cpu()
+        t = t[t[:, 0] > 0].double()
+        base = t[:, 0].min()
+        mhz = float(os.environ.get("WR_MHZ", "100"))          # s_memtime ticks per microsecond (100 MHz constant clock on gfx950)
+        print(f"      {t.shape[0]} workgroups; span {(t[:, 5].max() - base) / mhz:.1f} us; last start +{(t[:, 0].max() - base) / mhz:.1f} us; "
+              f"lifetime mean {((t[:, 5] - t[:, 0]) / mhz).mean():.1f} max {((t[:, 5] - t[:, 0]) / mhz).max():.1f} us")
+        for cls in range(4):
+            m = t[:, 7] == cls
+            if not m.any(): continue
+            x = t[m]
+            iss = (x[:, 6].long() >> 16).double(); x[:, 6] = (x[:, 6].long() & 0xffff).double()
+            print(f"      class {cls}: {int(m.sum())} wgs, batches {x[:, 6].mean():.1f}; DMA issue {(iss / mhz).mean():.2f}; setup {((x[:, 1] - x[:, 0]) / mhz).mean():.2f}  first fill wait "
+                  f"{((x[:, 2] - x[:, 1]) / mhz).mean():.2f}  loop {((x[:, 4] - x[:, 2]) / mhz).mean():.2f} (of it waiting {(x[:, 3] / mhz).mean():.2f})  "
+                  f"epilogue {((x[:, 5] - x[:, 4]) / mhz).mean():.2f} us", flush=True)
     if os.environ.get("WR_WGS"):
         ts = []
-        for wgs in (1, 2, 3, 4, 6):
+        for wgs in (1, 2, 3, 4, 6, 8):
             call("mmvae_debug_set", b"wr_wgs", wgs)
             run(L, 1, 3)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(s); run(L, 1, 20); e1.record(s); torch.cuda.synchronize()
             ts.append(f"wgs{wgs}={e0.elapsed_time(e1) * 1e3 / 20:.1f}")
-        call("mmvae_debug_set", b"wr_wgs", 2)
-        print("      workgroups per CU:  " + "  ".join(ts), flush=True)
+        call("mmvae_debug_set", b"wr_wgs", 4)
+        print("      workgroups per 4 CUs:  " + "  ".join(ts), flush=True)
 print("FAILED" if bad else "all layers agree")
 sys.exit(1 if bad else 0)
