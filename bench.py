@@ -13,13 +13,16 @@ The JSON line carries, next to the contract fields:
   executed_flops_per_step  GEMM FLOPs this engine actually enqueues per step (encoder passes deduplicated, zero-padded taps
                    included; counted by the launchers), and step_mfma_frac_executed on that count
   step_hbm_frac    algorithmic bytes per step (0.59 GB at B=256) x steps/s / 8 TB/s
-  roofline         the kernel family with the largest GPU-time share of the step (rocprofv3 --kernel-trace --stats of this
-                   command: profiles/r03_<workload>_kernel_stats.csv) -- the image-resident conv kernel `convres_kernel` --
-                   measured IN THE STEP: every launch of 20 extra steps carries its own HIP start/stop events
-                   (mmvae_debug_probe), achieved = sum of the launches' ALGORITHMIC FLOPs / sum of their durations, with the
-                   other streams' kernels running beside them.  `frac_isolated`: the same launches replayed alone
-                   (mmvae_mm_bench_layer).  `launches`: the per-launch numbers.  `traffic`: PMC-measured HBM-side bytes of the
-                   family's longest launch (profiles/r03_traffic.json) next to its algorithmic bytes
+  roofline         the GEMM kernel FAMILY with the largest GPU-time share of the step, measured IN THE STEP: every launch of 20
+                   extra steps carries its own HIP start/stop events (mmvae_debug_probe); achieved = sum of the family's
+                   ALGORITHMIC FLOPs / sum of the durations of ALL its launches, with the other streams' kernels running beside
+                   them.  A family is what does one job together: the weight-gradient kernels (wgrad_ring_kernel, wgrad_kernel,
+                   wgrad_multi_kernel) AND the reduce launches that sum their partial copies are one family -- the reduce launches
+                   carry time and no FLOPs.  `launches`: the per-launch numbers.  `frac_isolated*`: the same launches replayed
+                   alone (mmvae_mm_bench_layer).  `traffic`: PMC-measured HBM-side bytes of the family's longest launch
+                   (profiles/r04_traffic.json) next to its algorithmic bytes.  Agrees with the rocprofv3 --kernel-trace --stats
+                   summary of this command under profiles/r04_<workload>_kernel_stats.csv
+  roofline_second  the same for the runner-up family (the image-resident conv kernel `convres_kernel` or the weight gradients)
   kernels_in_step  every probed kernel of the step (all workloads): launches per step, in-step microseconds, TFLOP/s
   roofline_wgrad / roofline_dgrad   weight- and data-gradient launches of the last 64->32 layer replayed alone (as in round 2)
 """
@@ -81,14 +84,17 @@ def synthetic_sos():
 def measured_traffic(kernel_key):
     """HBM-side bytes per launch of a roofline kernel from rocprofv3 PMC passes (one pass per counter, no trace domains;
     FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH "HBM"): profiles/r03_traffic.json, written from the
-    raw counter rows committed next to it.  None when the kernel has not been measured."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r03_traffic.json")) as f:
-            t = json.load(f)
-        e = t.get(kernel_key)
-        return (e["bytes"], e["source"]) if e else (None, None)
-    except Exception:
-        return None, None
+    raw counter rows committed next to it.  None when the kernel has not been measured.  The newest round's file that holds
+    the key wins (profiles/r04_traffic.json, then r03)."""
+    for name in ("r04_traffic.json", "r03_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                e = json.load(f).get(kernel_key)
+            if e:
+                return e["bytes"], "profiles/%s: %s" % (name, e["source"])
+        except Exception:
+            pass
+    return None, None
 
 
 def host_cores():
@@ -192,7 +198,7 @@ def probe_steps(call, run, steps):
     for line in buf.value.decode().splitlines():
         tag, kernel, us, flops = line.split("\t")
         kernel = kernel.strip("() ")
-        e = acc.setdefault((tag, kernel), {"tag": tag, "kernel": kernel, "family": kernel.split("<")[0].strip(), "n": 0, "us": 0.0, "flops": float(flops)})
+        e = acc.setdefault((tag, kernel), {"tag": tag, "kernel": kernel, "family": kernel_family(kernel), "n": 0, "us": 0.0, "flops": float(flops)})
         e["n"] += 1
         e["us"] += float(us)
     out = []
@@ -202,9 +208,23 @@ def probe_steps(call, run, steps):
     return out
 
 
+WGRAD_FAMILY = "weight gradient (wgrad_ring_kernel, wgrad_kernel, wgrad_multi_kernel + their reduce launches)"
+
+
+def kernel_family(kernel):
+    """Kernels that do ONE job together are one family: every weight-gradient GEMM kernel and the reduce launches that sum
+    their partial copies (the reduce launches carry time and no FLOPs -- a family that left them out would look better than
+    it is)."""
+    base = kernel.split("<")[0].strip()
+    if base.startswith("wgrad_"):
+        return WGRAD_FAMILY
+    return base
+
+
 def family_roofline(rows, family):
-    """Sum of algorithmic FLOPs / sum of in-step launch time over one step's launches of `family`."""
-    sel = [r for r in rows if r["family"] == family and r["flops"] > 0]
+    """Sum of algorithmic FLOPs / sum of in-step launch time over ALL of one step's launches of `family` (launches without
+    FLOPs -- reduce kernels -- count with their time)."""
+    sel = [r for r in rows if r["family"] == family]
     us = sum(r["us"] * r["launches_per_step"] for r in sel)
     fl = sum(r["flops"] * r["launches_per_step"] for r in sel)
     n = sum(r["launches_per_step"] for r in sel)
@@ -212,14 +232,15 @@ def family_roofline(rows, family):
     return {"kernel": "%s: %d launches per step, timed inside the step" % (family, round(n)), "bound": "mfma", "achieved": ach,
             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "us_per_launch": us / max(n, 1),
             "flops_per_launch": fl / max(n, 1), "us_per_step": us,
-            "launches": [{"tag": r["tag"], "us": round(r["us"], 2), "tflops": round(r["flops"] / (r["us"] * 1e-6) / 1e12, 1)}
-                         for r in sorted(sel, key=lambda r: -r["us"])]}
+            "launches": [{"tag": r["tag"] if r["flops"] > 0 else r["kernel"].split("<")[0], "n": round(r["launches_per_step"], 2), "us": round(r["us"], 2),
+                          "tflops": round(r["flops"] / (r["us"] * 1e-6) / 1e12, 1)}
+                         for r in sorted(sel, key=lambda r: -r["us"] * r["launches_per_step"])]}
 
 
 def kernels_in_step(rows, top=16):
     tot = {}
     for r in rows:
-        e = tot.setdefault(r["kernel"] if r["family"] != "convres_kernel" else r["family"], {"launches_per_step": 0.0, "us_per_step": 0.0, "flops": 0.0})
+        e = tot.setdefault(r["kernel"] if r["family"] not in ("convres_kernel", WGRAD_FAMILY) else r["family"], {"launches_per_step": 0.0, "us_per_step": 0.0, "flops": 0.0})
         e["launches_per_step"] += r["launches_per_step"]
         e["us_per_step"] += r["us"] * r["launches_per_step"]
         e["flops"] += r["flops"] * r["launches_per_step"]
@@ -233,6 +254,9 @@ def kernels_in_step(rows, top=16):
 # MultiMNIST layers that run on convres_kernel (multimodal-vae_amd/csrc/convres.hip), by their mmvae_mm_bench_layer names
 MM_CONVRES_LAYERS = ["enc_conv2", "enc_conv3", "enc_conv4", "dec_convT1", "dec_convT2", "dec_convT3",
                      "enc_conv2_dgrad", "enc_conv3_dgrad", "enc_conv4_dgrad", "dec_convT1_dgrad", "dec_convT2_dgrad", "dec_convT3_dgrad"]
+
+
+MM_WGRAD_LAYERS = ["dec_convT1_wgrad", "dec_convT2_wgrad", "dec_convT3_wgrad", "enc_conv2_wgrad", "enc_conv3_wgrad", "enc_conv4_wgrad"]
 
 
 def roofline_entry(eng, call, layer, kernel, B, D):
@@ -436,29 +460,46 @@ def main():
     if rank == 0:
         if rows:
             result["kernels_in_step"] = kernels_in_step(rows)
-        fam_us = {}
+        fam_us, fam_fl = {}, {}
         for r in rows:
-            if r["flops"] > 0:
-                fam_us[r["family"]] = fam_us.get(r["family"], 0.0) + r["us"] * r["launches_per_step"]
+            fam_us[r["family"]] = fam_us.get(r["family"], 0.0) + r["us"] * r["launches_per_step"]
+            fam_fl[r["family"]] = fam_fl.get(r["family"], 0.0) + r["flops"] * r["launches_per_step"]
+        fam_us = {k: v for k, v in fam_us.items() if fam_fl[k] > 0}           # GEMM families only
         if fam_us:
-            # ---- roofline: the GEMM kernel family with the most GPU time in the step, all of its launches, timed in the step
-            fam = max(fam_us, key=fam_us.get)
-            result["roofline"] = family_roofline(rows, fam)
-            result["roofline"]["traffic"] = None
-            if wl == "multimnist" and fam == "convres_kernel":
-                iso_us = sum(time_layer(eng, call, l.encode()) for l in MM_CONVRES_LAYERS)
-                iso_fl = sum(call("mmvae_mm_layer_algo_flops", eng.h, l.encode()) for l in MM_CONVRES_LAYERS)
-                result["roofline"]["frac_isolated"] = iso_fl / (iso_us * 1e-6) / 1e12 / PEAK_BF16_TFLOPS
-                result["roofline"]["us_per_step_isolated"] = iso_us
-                # HBM-side traffic of the family's longest launch (the forward of the last 64->32 ConvTranspose2d)
-                traffic, src = measured_traffic("dec_convT3:%d:%d" % (B, D))
-                result["roofline"]["traffic"] = traffic
-                result["roofline"]["traffic_source"] = src
-                result["roofline"]["traffic_launch"] = "dec_convT3"
-                result["roofline"]["algorithmic_bytes_of_that_launch"] = call("mmvae_mm_layer_algo_bytes", eng.h, b"dec_convT3")
+            # ---- roofline: the GEMM kernel FAMILY with the most GPU time in the step -- all of its launches, reduce launches
+            # included -- timed in the step; the runner-up family in `roofline_second`
+            order = sorted(fam_us, key=fam_us.get, reverse=True)
+            for slot, fam in zip(("roofline", "roofline_second"), order[:2]):
+                e = family_roofline(rows, fam)
+                e["traffic"] = None
+                if wl == "multimnist" and fam == "convres_kernel":
+                    iso_us = sum(time_layer(eng, call, l.encode()) for l in MM_CONVRES_LAYERS)
+                    iso_fl = sum(call("mmvae_mm_layer_algo_flops", eng.h, l.encode()) for l in MM_CONVRES_LAYERS)
+                    e["frac_isolated"] = iso_fl / (iso_us * 1e-6) / 1e12 / PEAK_BF16_TFLOPS
+                    e["us_per_step_isolated"] = iso_us
+                    # HBM-side traffic of the family's longest launch (the forward of the last 64->32 ConvTranspose2d)
+                    e["traffic"], e["traffic_source"] = measured_traffic("dec_convT3:%d:%d" % (B, D))
+                    e["traffic_launch"] = "dec_convT3"
+                    e["algorithmic_bytes_of_that_launch"] = call("mmvae_mm_layer_algo_bytes", eng.h, b"dec_convT3")
+                if wl == "multimnist" and fam == WGRAD_FAMILY:
+                    # the conv layers' weight gradients replayed alone (kernel + reduce, as in the step; the Linear / GRU ones have
+                    # no replay hook) and the PMC traffic of the family's longest launch
+                    iso_us = sum(time_layer(eng, call, l.encode()) for l in MM_WGRAD_LAYERS)
+                    iso_fl = sum(call("mmvae_mm_layer_algo_flops", eng.h, l.encode()) for l in MM_WGRAD_LAYERS)
+                    e["frac_isolated_conv_layers"] = iso_fl / (iso_us * 1e-6) / 1e12 / PEAK_BF16_TFLOPS
+                    e["us_isolated_conv_layers"] = iso_us
+                    e["traffic"], e["traffic_source"] = measured_traffic("dec_convT3_wgrad:%d:%d" % (B, D))
+                    e["traffic_launch"] = "dec_convT3_wgrad (kernel + reduce)"
+                    e["algorithmic_bytes_of_that_launch"] = call("mmvae_mm_layer_algo_bytes", eng.h, b"dec_convT3_wgrad")
+                if wl == "celeba":
+                    key = {WGRAD_FAMILY: "ca_wgrad", "gemm_gather_kernel": "ca_gemm_gather", "convres_kernel": "ca_convres"}.get(fam)
+                    if key:
+                        e["traffic"], e["traffic_source"] = measured_traffic("%s:%d:%d" % (key, B, D))
+                        e["traffic_launch"] = "every launch of the family in one step (rocprofv3 --pmc over bench.py --workload celeba)"
+                result[slot] = e
         if wl == "multimnist":
             result["roofline_fwd_isolated"] = roofline_entry(eng, call, "dec_convT3", "convres_kernel", B, D)
-            result["roofline_wgrad"] = roofline_entry(eng, call, "dec_convT3_wgrad", "wgrad_kernel + wgrad_reduce_kernel", B, D)
+            result["roofline_wgrad"] = roofline_entry(eng, call, "dec_convT3_wgrad", "wgrad_ring_kernel + wgrad_ring_reduce_kernel", B, D)
             result["roofline_dgrad"] = roofline_entry(eng, call, "dec_convT3_dgrad", "convres_kernel", B, D)
         if "roofline" not in result:
             # no probe: the whole step against the MFMA roof on the executed GEMM FLOPs

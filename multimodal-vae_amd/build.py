@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmmvae_hip.so")
-SOURCES = ["gemm.hip", "convres.hip", "convres_wgrad.hip", "wgrad_ring.hip", "gemm_small.hip", "elementwise.hip", "text.hip", "thin.hip", "dec_last.hip", "conv1.hip", "multimnist.hip", "mnist.hip", "mnist_f32.hip", "gemm_f32.hip", "celeba.hip", "coco.hip", "coco_text.hip", "coco_text_bf16.hip", "mlp_tail.hip", "capi.cpp", "comm.cpp", "util.cpp"]
+SOURCES = ["gemm.hip", "convres.hip", "wgrad_ring.hip", "gemm_small.hip", "elementwise.hip", "text.hip", "thin.hip", "dec_last.hip", "conv1.hip", "multimnist.hip", "mnist.hip", "mnist_f32.hip", "gemm_f32.hip", "celeba.hip", "coco.hip", "coco_text.hip", "coco_text_bf16.hip", "mlp_tail.hip", "capi.cpp", "comm.cpp", "util.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result", "-Wno-unused-value", "-ffp-contract=fast"]
 
 

@@ -26,8 +26,22 @@ void mmvae_count_flops(double flops);
 // side-stream priority policy (include/mmvae_hip.h: mmvae_set_stream_policy); -1 until somebody asked
 int mmvae_stream_policy();
 void mmvae_stream_policy_freeze();      // the side streams exist from here on
-// test / A-B knobs set through mmvae_debug_set (include/mmvae_hip.h); `dflt` when the key was never set
-int mmvae_knob(const char* key, int dflt);
+// test / A-B knobs set through mmvae_debug_set (include/mmvae_hip.h); `dflt` when the key was never set.  The table lives in
+// util.cpp behind a mutex; a launcher's call site keeps the value it looked up until the next mmvae_debug_set (a generation
+// counter), so the launch path pays one atomic load and a compare per knob, not a lock and a string scan.
+#include <atomic>
+int mmvae_knob_lookup(const char* key, int dflt);
+extern std::atomic<unsigned> g_mmvae_knob_gen;
+struct MmvaeKnobSite { std::atomic<unsigned> gen{0xffffffffu}; std::atomic<int> val{0}; };
+static inline int mmvae_knob_cached(MmvaeKnobSite& s, const char* key, int dflt) {
+    const unsigned g = g_mmvae_knob_gen.load(std::memory_order_acquire);
+    if (s.gen.load(std::memory_order_acquire) == g) return s.val.load(std::memory_order_relaxed);
+    const int v = mmvae_knob_lookup(key, dflt);
+    s.val.store(v, std::memory_order_relaxed);
+    s.gen.store(g, std::memory_order_release);
+    return v;
+}
+#define mmvae_knob(key, dflt) ([&]() -> int { static MmvaeKnobSite mmvae_site_; return mmvae_knob_cached(mmvae_site_, key, dflt); }())
 
 #define MMVAE_REQUIRE(cond, ...)                      \
     do {                                              \

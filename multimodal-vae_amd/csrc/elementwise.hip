@@ -1001,7 +1001,7 @@ int launch_adam(const AdamArgs& a, hipStream_t s) {
     MMVAE_REQUIRE(a.step != nullptr, "adam: step counter is null");
     // the word after the step counter is the block ticket (both live in the caller's 16-byte state block)
     unsigned* done = reinterpret_cast<unsigned*>(a.step + 1);
-    hipLaunchKernelGGL(adam_kernel, dim3(nblocks((a.n + 3) / 4, TPB, 512)), dim3(TPB), 0, s, a, done);   // few blocks: one ticket atomic each
+    hipLaunchKernelGGL(adam_kernel, dim3(nblocks((a.n + 3) / 4, TPB, mmvae_knob("adam_blocks", 512))), dim3(TPB), 0, s, a, done);   // few blocks: one ticket atomic each
     return mmvae_check_launch("adam");
 }
 static __global__ __launch_bounds__(256) void gather_rows_kernel(const char* __restrict__ src, const long long* __restrict__ idx,
@@ -1061,7 +1061,7 @@ int launch_nll_bwd(const long long* tg, int rows, int classes, float coef, const
 int launch_step_begin(const StepBeginArgs& a, hipStream_t s) {
     for (int r = 0; r < 4; ++r)
         MMVAE_REQUIRE(a.zero_ptr[r] == nullptr || (a.zero_bytes[r] % 16 == 0 && ((uintptr_t)a.zero_ptr[r] & 15) == 0), "step_begin: zero range %d is not 16-byte aligned", r);
-    MMVAE_LAUNCH(step_begin_kernel, dim3(2048 + (a.pack_blocks > 0 ? a.pack_blocks : 0)), dim3(TPB), 0, s, a);
+    MMVAE_LAUNCH(step_begin_kernel, dim3(mmvae_knob("begin_blocks", 2048) + (a.pack_blocks > 0 ? a.pack_blocks : 0)), dim3(TPB), 0, s, a);
     return mmvae_check_launch("step_begin");
 }
 // fills the pack part of a step prologue (StepBeginArgs::pack_*) from a descriptor table

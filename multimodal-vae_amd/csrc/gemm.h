@@ -103,9 +103,6 @@ struct WgradParams {
     const float2* p_affine; // optional transform of the plain operand [groups][N]
     int p_act;
     int rows_per_block;     // multiple of 64
-    // staging transforms of the two operands (image-resident weight-gradient kernel only, convres_wgrad.hip), or null
-    const GatherTransform* trA;     // gathered operand (c.A)
-    const GatherTransform* trP;     // plain operand (P)
     // slab form (filled by the launcher): partial tiles go to slab + chunk*slab_chunk_stride + slab_cls_off[class] as
     // [rows][Kpad] with plain stores and wgrad_reduce_kernel sums the chunk copies into dWp; null: fp32 atomics into dWp
     float* slab;

@@ -904,10 +904,6 @@ int launch_wgrad(const WgradParams& pin, hipStream_t stream, WgradSlabCtx* ctx) 
         if (rc != 0) return rc < 0 ? rc : MMVAE_OK;
     }
     if (skip == 3) return MMVAE_OK;
-    {   // conv layers with an image-resident kernel compiled for their geometry (convres_wgrad.hip)
-        const int rc = try_launch_convres_wgrad(p, stream, ctx);
-        if (rc != 0) return rc < 0 ? rc : MMVAE_OK;
-    }
     dim3 grid; size_t lds;
     MMVAE_TRY(wgrad_setup(p, ctx, grid, lds, stream));
     const WgradCfg cfg = wgrad_cfg(p);

@@ -2,6 +2,7 @@
 // Reference: multimnist/model.py:21-93 (MultimodalVAE), :150-216 (image enc/dec), :219-307 (text enc/dec),
 //            multimnist/train.py:69-87 (loss_function), :146-173 (3-pass step).
 #include "multimnist.h"
+#include <memory>
 #include "mlp_tail.h"
 #include "plan_base.h"
 #include "thin.h"
@@ -341,12 +342,15 @@ int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const
     MMPlan::W& w = P.w;
     const int B = P.B, rows = variants * B, D2 = 2 * P.D;
     const float ms = 1.f / (1.f - DROP_P);
+    // fused step: the three classifier weight gradients (0.04-0.4 GFLOP each, every one a launch at the kernel-latency floor) go
+    // out as ONE grouped launch behind conv4's data gradient
+    auto cls_w = std::make_shared<std::vector<WgradParams>>();
     if (P.mlp_tail) {      // both data gradients in one row-block launch; the weight gradients follow on the side stream
         {
             GatherPlan pl = dense_plan(rows, 200, 200, D2);
             WgradParams g = wgrad_of(P, pl, &P.fc[2].gk, 1, rows);
             g.c.A = w.ay2; g.P = d_out; g.ldp = D2;
-            if (fuse) { MMPlan* pp = &P; side_later(P, [pp, g](hipStream_t ws_) { return wgrad_on(*pp, g, ws_); }); }   // behind conv4's data gradient
+            if (fuse) cls_w->push_back(g);
             else MMVAE_TRY(wgrad_async(P, g, s));
         }
         Mlp2BwdArgs a{};
@@ -360,7 +364,7 @@ int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const
         GatherPlan pl = dense_plan(rows, 400, 400, 200);
         WgradParams g = wgrad_of(P, pl, &P.fc[1].gk, 1, rows);
         g.c.A = w.ay1; g.P = w.dy2; g.ldp = 200;
-        if (fuse) { MMPlan* pp = &P; side_later(P, [pp, g](hipStream_t ws_) { return wgrad_on(*pp, g, ws_); }); }
+        if (fuse) cls_w->push_back(g);
         else MMVAE_TRY(wgrad_async(P, g, s));
     } else {
     {   // fc3
@@ -395,7 +399,11 @@ int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const
         g.P = w.dy1; g.ldp = 400;
         if (P.mlp_tail && fuse) {
             MMPlan* pp = &P;
-            side_later(P, [pp, g](hipStream_t ws_) { return wgrad_on(*pp, g, ws_); });
+            cls_w->push_back(g);
+            side_later(P, [pp, cls_w](hipStream_t ws_) {
+                MMVAE_TRY(launch_wgrad_group(cls_w->data(), (int)cls_w->size(), ws_, &pp->slab));
+                return pp->batch_reduce ? MMVAE_OK : launch_wgrad_reduce(&pp->slab, ws_, true);
+            });
         } else {
             MMVAE_TRY(wgrad_async(P, g, s));
         }
@@ -440,31 +448,12 @@ int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const
         WgradParams gw = wgrad_of(P, L.fwd, L.gk, 1, B);
         gw.c.A = a[l - 1]; gw.P = x.dr; gw.ldp = L.g.Cout;
         if (fuse) {
-            // fused layers (conv3, conv2): the image-resident weight-gradient kernel stages db through the BatchNorm backward
-            // itself (and adds the BatchNorm parameter gradients); conv3's gathered operand a2 = Swish(BatchNorm(r2)) comes
-            // out of the raw tensor the same way.  conv4 keeps the streamed kernel on its materialised operands
+            // fused layers (conv3, conv2): the weight gradient runs on a side stream on operands that are by-products of the main
+            // chain's staging (GatherTransform::out) or are materialised right in front of it, off the main chain
             MMPlan* pp = &P;
-            GatherTransform tp{}, ta{};
-            if (fl) {
-                tp.kind = 2; tp.r = r[l]; tp.red = w.red_e[l - 1]; tp.mr = w.mr_e[l - 1]; tp.gamma = P.buf.params + b.w_off;
-                tp.dgamma = P.buf.grads + b.w_off; tp.dbeta = P.buf.grads + b.b_off;
-                tp.inv_cnt = 1.f / (float)(B * pix); tp.groups = 1;
-                gw.P = dr[l];
-                if (l == 2) {
-                    const int prows = B * P.conv[1].g.OH * P.conv[1].g.OW;
-                    ta.kind = 1;
-                    ta.fin = bn_fin_args(P, P.bn[P.conv[1].bn], prows, 1, w.st_e[0], 0, nullptr, nullptr, 1);
-                    gw.c.A = r[1];
-                }
-            }
-            if (mmvae_knob("mm_wkernel", 0) && fl) {
-                side_later(P, [pp, gw, tp, ta](hipStream_t ws_) mutable {
-                    gw.trA = ta.kind ? &ta : nullptr; gw.trP = tp.kind ? &tp : nullptr;
-                    return wgrad_on(*pp, gw, ws_);
-                });
-            } else {        // the streamed weight-gradient kernel on operands materialised right in front of it (side stream)
-                // With staging by-products (GatherTransform::out) the forward of conv3 / conv4 left a2 / a3 behind and conv3's
-                // data gradient below leaves its BatchNorm-backward dr behind: nothing to materialise in front of the kernel
+            {
+                // With staging by-products the forward of conv3 / conv4 left a2 / a3 behind and conv3's data gradient below
+                // leaves its BatchNorm-backward dr behind: nothing to materialise in front of the kernel
                 const bool byp = mmvae_knob("mm_stage_out", 1) != 0;
                 const bool actp = l >= 2 && !byp;      // a[l-1] = Swish(BatchNorm(r[l-1])) was never materialised (conv3, conv4)
                 const bool bnb = fl && !(byp && l == 2);
@@ -665,21 +654,7 @@ int dec_bwd(MMPlan& P, const float* dlogit, int groups, float* dz, hipStream_t s
             MMPlan* pp = &P;
             const ConvL& Lp = P.convT[l >= 1 ? l - 1 : 0];
             const int prpg = B * Lp.g.OH * Lp.g.OW;
-            if (l >= 1 && mmvae_knob("mm_wkernel", 0)) {
-                // opt-in: the image-resident weight-gradient kernel (convres_wgrad.hip) stages both operands itself -- the layer
-                // input aq[l] = Swish(BatchNorm(q[l])) out of the raw tensor, the output gradient's BatchNorm backward out of db
-                GatherTransform tp{}, ta{};
-                tp.kind = 1;
-                tp.fin = bn_fin_args(P, P.bn[Lp.bn], prpg, groups, w.st_d[l - 1], 0, nullptr, nullptr, training);
-                ta.kind = 2; ta.r = q[l + 1]; ta.red = w.red_d[l]; ta.mr = w.mr_d[l]; ta.gamma = P.buf.params + b.w_off;
-                ta.dgamma = P.buf.grads + b.w_off; ta.dbeta = P.buf.grads + b.b_off;
-                ta.inv_cnt = 1.f / (float)(B * pix); ta.groups = groups;
-                gw.c.A = dq[l + 1]; gw.P = q[l];
-                side_later(P, [pp, gw, tp, ta](hipStream_t ws_) mutable {
-                    gw.trA = &ta; gw.trP = &tp;
-                    return wgrad_on(*pp, gw, ws_);
-                });
-            } else {
+            {
                 // the streamed weight-gradient kernel on operands materialised right in front of it, on the side stream: the
                 // BatchNorm backward of db (its own buffer: the data gradient on the main chain still reads db) and, above the
                 // first layer, the layer input aq[l] = Swish(BatchNorm(q[l])) that the forward never wrote

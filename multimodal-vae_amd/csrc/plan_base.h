@@ -65,6 +65,8 @@ struct PlanBase {
                                     // the side streams would stay outside the graph and their work would be missing from every replay)
     hipEvent_t ev_early = nullptr;  // data-parallel step: the early gradient part is complete in the flat buffer
     bool wgrad_forked = false;
+    bool batch_reduce = false;      // set by side_flush: the weight gradients it issues leave their partial copies to ONE reduce
+                                    // launch per stream at the end of the flush (was: one behind every weight gradient)
     unsigned dec_skip_mask = 0;     // bit k: pass k is absent from this step (weak-supervision variants): its decoder BatchNorm
                                     // group leaves the running statistics alone
     bool no_pack = false;           // the plan never reads the packed bf16 weights (fp32 MNIST path): pack_weights is a no-op
@@ -147,10 +149,13 @@ inline int side_flush(PlanBase& P, hipStream_t s) {
     if (P.side_pending.empty()) return MMVAE_OK;
     const bool serial = mmvae_serial();
     int rc = MMVAE_OK;
+    P.batch_reduce = mmvae_knob("batch_reduce", 1) != 0;
     if (!P.wgrad_forked || serial) {
         for (auto& fn : P.side_pending)
             if (rc == MMVAE_OK) rc = fn(s);
         P.side_pending.clear();
+        if (rc == MMVAE_OK && P.batch_reduce && !(mmvae_knob("mm_wgrad_inline", 0) == 2)) rc = launch_wgrad_reduce(&P.slab, s, true);
+        P.batch_reduce = false;
         return rc;
     }
     // the pieces are independent of each other: they alternate between the weight-gradient streams (each of these kernels is a
@@ -163,6 +168,9 @@ inline int side_flush(PlanBase& P, hipStream_t s) {
         if (rc == MMVAE_OK) rc = fn(w[i]);
     }
     P.side_pending.clear();
+    for (int i = 0; i < 2; ++i)
+        if (forked[i] && P.batch_reduce && rc == MMVAE_OK) rc = launch_wgrad_reduce(&P.slab, w[i], true);
+    P.batch_reduce = false;
     return rc;
 }
 
@@ -178,6 +186,7 @@ inline int wgrad_on(PlanBase& P, const WgradParams& g, hipStream_t w) {
     if (mmvae_knob("wgrad_atomic", 0)) return launch_wgrad(g, w, nullptr);      // A/B: fp32 atomics into the packed gradient, no slab / reduce
     MMVAE_TRY(launch_wgrad(g, w, &P.slab));
     if (!P.wgrad_forked && mmvae_knob("mm_wgrad_inline", 0) == 2) return MMVAE_OK;      // summed at the end of the step, one launch
+    if (P.batch_reduce) return MMVAE_OK;                                                 // summed at the end of the flush
     return launch_wgrad_reduce(&P.slab, w, true);
 }
 
@@ -549,7 +558,7 @@ inline void join_after_error(PlanBase& P, hipStream_t s) {
     }
     P.deferred.clear();
     P.slab.jobs.clear(); P.slab.ring_jobs.clear();
-    P.defer_wgrad = false; P.wgrad_forked = false; P.no_splitk = false; P.in_step = false;
+    P.defer_wgrad = false; P.wgrad_forked = false; P.batch_reduce = false; P.no_splitk = false; P.in_step = false;
     (void)mmvae_take_stop_event();
     P.side_pending.clear();
 }

@@ -57,11 +57,12 @@ extern "C" int mmvae_set_stream_policy(int flat) {
 #include <cstring>
 namespace {
 struct Knob { char key[32]; int value; };
-Knob g_knobs[32];
+Knob g_knobs[96];
 int g_nknobs = 0;
 std::mutex g_knob_mu;
 }
-int mmvae_knob(const char* key, int dflt) {
+std::atomic<unsigned> g_mmvae_knob_gen{0};
+int mmvae_knob_lookup(const char* key, int dflt) {
     std::lock_guard<std::mutex> g(g_knob_mu);
     for (int i = 0; i < g_nknobs; ++i)
         if (strcmp(g_knobs[i].key, key) == 0) return g_knobs[i].value;
@@ -71,10 +72,11 @@ extern "C" int mmvae_debug_set(const char* key, int value) {
     if (!key || strlen(key) >= sizeof(g_knobs[0].key)) { mmvae_set_error("debug_set: bad key"); return MMVAE_EINVAL; }
     std::lock_guard<std::mutex> g(g_knob_mu);
     for (int i = 0; i < g_nknobs; ++i)
-        if (strcmp(g_knobs[i].key, key) == 0) { g_knobs[i].value = value; return MMVAE_OK; }
-    if (g_nknobs == 32) { mmvae_set_error("debug_set: table full"); return MMVAE_ENOSPC; }
+        if (strcmp(g_knobs[i].key, key) == 0) { g_knobs[i].value = value; g_mmvae_knob_gen.fetch_add(1); return MMVAE_OK; }
+    if (g_nknobs == (int)(sizeof(g_knobs) / sizeof(g_knobs[0]))) { mmvae_set_error("debug_set: table full"); return MMVAE_ENOSPC; }
     strcpy(g_knobs[g_nknobs].key, key);
     g_knobs[g_nknobs++].value = value;
+    g_mmvae_knob_gen.fetch_add(1);
     return MMVAE_OK;
 }
 

@@ -99,9 +99,6 @@ __device__ __forceinline__ void wr_body(const WrArgs& a, const int ms, const int
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
             if (j < j0 || j >= j1) continue;
-            if ((a.dbg & 8) && j < G::NFS) continue;             // timing aids: without the small / the big region / the all-zero pieces
-            if ((a.dbg & 16) && j >= G::NFS) continue;
-            if ((a.dbg & 32) && __builtin_amdgcn_readfirstlane(__all(voff[j] == OOB))) continue;
             const int vo = live ? voff[j] : OOB;
             if (j < G::NFS) dma_1k(rs, base + j * (WAVES * 1024), vo, soff_s);
             else dma_1k(rb, base + j * (WAVES * 1024), vo, soff_b);
@@ -155,16 +152,27 @@ __device__ __forceinline__ void wr_body(const WrArgs& a, const int ms, const int
         if (a.ts) t_issue += __builtin_amdgcn_s_memrealtime() - ti;
         const char* const sb = smem + slot * SLOT;
         if (!(a.dbg & 2)) {
+            // fragments of k-step ks+1 are read while the MFMAs of k-step ks run (two register sets): with one wave per SIMD nothing
+            // else covers the LDS latency (measured 60 cycles per MFMA with the reads one MFMA ahead, 32 is the pipe's rate)
+            bf16x8 af[2], bfr[2][CPW];
+            af[0] = tr_pair_r(sb + a_base, sb + a_base + 256);
+#pragma unroll
+            for (int j = 0; j < CPW; ++j) bfr[0][j] = tr_pair_r(sb + rb0[0] + coloff[j], sb + rb1[0] + coloff[j]);
 #pragma unroll
             for (int ks = 0; ks < KST; ++ks) {
                 if (SPREAD) issue(u + SLOTS - 1, ns, ks * NF / KST, (ks + 1) * NF / KST);
-                const bf16x8 af = tr_pair_r(sb + a_base + ks * 1024, sb + a_base + ks * 1024 + 256);
+                if (ks + 1 < KST) {
+                    af[(ks + 1) & 1] = tr_pair_r(sb + a_base + (ks + 1) * 1024, sb + a_base + (ks + 1) * 1024 + 256);
 #pragma unroll
-                for (int j = 0; j < CPW; ++j) {                  // (a wave with one column tile fewer multiplies tile 0 again and drops it:
-                    //  the wave with the full count sets the pace anyway, and the loop stays branch-free)
-                    const bf16x8 bf = tr_pair_r(sb + rb0[ks] + coloff[j], sb + rb1[ks] + coloff[j]);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[j], 0, 0, 0);
+                    for (int j = 0; j < CPW; ++j)
+                        bfr[(ks + 1) & 1][j] = tr_pair_r(sb + rb0[ks + 1] + coloff[j], sb + rb1[ks + 1] + coloff[j]);
                 }
+                __builtin_amdgcn_sched_barrier(0);               // (keep the reads in front of the MFMAs they overlap with)
+#pragma unroll
+                for (int j = 0; j < CPW; ++j)                    // (a wave with one column tile fewer multiplies tile 0 again and drops it:
+                    //  the wave with the full count sets the pace anyway, and the loop stays branch-free)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1], bfr[ks & 1][j], acc[j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (++slot == SLOTS) slot = 0;
@@ -276,7 +284,7 @@ bool wr_matches(const WgradParams& p) {
 
 template <class G>
 int try_wr(const WgradParams& p, hipStream_t stream, WgradSlabCtx* ctx) {
-    if (!wr_matches<G>(p) || mmvae_knob("wr_slots", 2) != G::SLOTS) return 0;
+    if (!wr_matches<G>(p)) return 0;
     if (mmvae_knob("dbg_skip_wgrad", 0) == 2) return 1;         // measurement aid: the step without the ring-staged weight gradients
     const GatherCommon& c = p.c;
     const int nimg = c.groups * c.group_n;
@@ -285,7 +293,7 @@ int try_wr(const WgradParams& p, hipStream_t stream, WgradSlabCtx* ctx) {
     const int units = nimg / G::IB;
     // image groups per class in proportion to the class's column tiles: every workgroup carries about the same number of MFMAs
     // (the 5x5 layer's classes hold 9 / 6 / 6 / 4 taps); about one workgroup per CU in all (knob wr_wgs)
-    const int target = mmvae_knob("wr_wgs", 4) * mmvae_cu_count() / 4;      // knob in quarters of the CU count
+    const int target = mmvae_knob("wr_wgs", 3) * mmvae_cu_count() / 4;      // knob in quarters of the CU count
     // (a batch costs a workgroup a fixed part -- the DMA issue -- next to its MFMAs: measured 0.66 us + 0.10 us per column tile
     //  on hallucinate.6; knob wr_bias = the fixed part in column tiles)
     const int bias = mmvae_knob("wr_bias", 6);
@@ -347,7 +355,7 @@ int try_wr(const WgradParams& p, hipStream_t stream, WgradSlabCtx* ctx) {
 
 int try_launch_wgrad_ring(const WgradParams& p, hipStream_t stream, WgradSlabCtx* ctx) {
     if (!mmvae_knob("wgrad_ring", 1)) return 0;
-    if (p.trA || p.trP || p.c.a_bcast_n > 0 || p.c.a_mask || p.c.a_affine || p.c.a_act != ACT_NONE || p.p_affine || p.p_act != ACT_NONE) return 0;
+    if (p.c.a_bcast_n > 0 || p.c.a_mask || p.c.a_affine || p.c.a_act != ACT_NONE || p.p_affine || p.p_act != ACT_NONE) return 0;
     int rc;
 #define X(name, ...) if ((rc = try_wr<wrgeo::Geo<__VA_ARGS__>>(p, stream, ctx)) != 0) return rc;
     WGRAD_RING_GEOS(X)

@@ -8,6 +8,5 @@
     X(mm_convT3,    32, 64, 25, 25, 12, 12, 5, 5, 2, 1, 64, 1, 4, 2)   /* MultiMNIST hallucinate.6 (big side = output gradient) */ \
     X(mm_conv2,     32, 64, 25, 25, 12, 12, 4, 4, 2, 1, 64, 1, 4, 2)   /* features.2 (big side = layer input) */                 \
     X(mm_conv3,     64, 128, 12, 12, 6, 6, 4, 4, 2, 1, 64, 2, 4, 2)    /* features.5 and hallucinate.3 */                      \
-    X(mm_convT3_s3, 32, 64, 25, 25, 12, 12, 5, 5, 2, 1, 64, 1, 4, 3)   /* the same layers with a three-slot ring (knob wr_slots) */ \
-    X(mm_conv2_s3,  32, 64, 25, 25, 12, 12, 4, 4, 2, 1, 64, 1, 4, 3)                                                               \
-    X(mm_conv3_s3,  64, 128, 12, 12, 6, 6, 4, 4, 2, 1, 64, 2, 4, 3)
+    X(ca_conv2,     32, 64, 32, 32, 16, 16, 4, 4, 2, 1, 64, 1, 4, 2)   /* CelebA features.2 and hallucinate.6 (celeba/model.py:104,146) */ \
+    X(ca_conv3,     64, 128, 16, 16, 8, 8, 4, 4, 2, 1, 64, 2, 4, 2)    /* CelebA features.5 and hallucinate.3 */

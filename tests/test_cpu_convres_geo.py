@@ -36,4 +36,4 @@ def test_wgrad_ring_geometry_addresses(tmp_path):
                     os.path.join(ROOT, "tests", "host", "wgrad_geo_check.cpp"), "-o", exe], check=True)
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
     assert out.strip().endswith("ok"), out[-400:]
-    assert "mm_convT3" in out and "mm_conv3" in out
+    assert "mm_convT3" in out and "mm_conv3" in out and "ca_conv3" in out
