@@ -188,3 +188,16 @@ def test_celeba_param_table_and_state_dict(lib):
         vae(image=torch.zeros(2, 3, 64, 64))
     with pytest.raises(AssertionError):
         vae()
+
+
+def test_bench_reference_flop_constants_match_the_counted_fixture():
+    """bench.py prices the step with the reference's FLOP count; the numbers are counted on the imported reference by
+    `python oracle/make_golden.py --flops` (FlopCounterMode over the 3 passes + backward of multimnist/train.py:154-168 and its
+    CelebA / COCO twins) and committed as tests/golden/reference_flops.json."""
+    import json, os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    t = json.load(open(os.path.join(root, "tests", "golden", "reference_flops.json")))
+    for ds in ("multimnist", "celeba", "coco"):
+        assert abs(bench.FLOP_PER_SAMPLE[ds] - t[ds]["flops_per_sample_fwd_bwd"]) / t[ds]["flops_per_sample_fwd_bwd"] < 1e-4, ds

@@ -33,9 +33,9 @@ ev = torch.cuda.Event(); ev.record(); resident("after an event")
 with torch.cuda.stream(os_.stream):
     y = x.to(dev, non_blocking=True)
 torch.cuda.synchronize(); resident("after an async H2D copy on that stream")
-for pin in (False,):
+for pin, cow in ((False, False), (False, True)):
     try:
-        L = DeviceBatcher(u8, b, B, dev, shuffle=True, seed=1, pin_dataset=pin)
+        L = DeviceBatcher(u8, b, B, dev, shuffle=True, seed=1, pin_dataset=pin, copy_on_worker=cow)
     except AssertionError as e:
         print("pin", pin, "not applicable:", e); continue
     def run(n, step, hold=None):
@@ -50,8 +50,8 @@ for pin in (False,):
         torch.cuda.synchronize()
         return th / n * 1e3, (time.perf_counter() - t0) / n * 1e3
     run(20, True)
-    print(f"{wl} pin={pin}: loader alone  host {run(200, False)[0]:.3f} ms/iter  wall {run(200, False)[1]:.3f}")
-    print(f"{wl} pin={pin}: loader + step host {run(200, True)[0]:.3f} ms/iter  wall {run(200, True)[1]:.3f}")
+    print(f"{wl} pin={pin} copy_on_worker={cow}: loader alone  host {run(200, False)[0]:.3f} ms/iter  wall {run(200, False)[1]:.3f}")
+    print(f"{wl} pin={pin} copy_on_worker={cow}: loader + step host {run(200, True)[0]:.3f} ms/iter  wall {run(200, True)[1]:.3f}")
 ims, txs = a[:B].to(dev).contiguous(), b[:B].to(dev).contiguous()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(200): eng(ims, txs)
