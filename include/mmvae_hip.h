@@ -333,7 +333,7 @@ typedef struct {
     long long* optimizer_state;             /* the 16-byte state block this step's mmvae_adam_step* call will get, or NULL.  The caption
                                                decoder's workgroups exchange hidden-state slices through memory and give up after a
                                                bounded spin (a device that cannot keep them co-resident); such a step is void: its `sums`
-                                               are NaN, its gradient is marked (element 0 = NaN, which survives a SUM all-reduce) and
+                                               are NaN, its gradient is marked (element 0 = the NaN 0x7fc0dead, whose payload survives a SUM all-reduce) and
                                                the skip word of this block is set -- mmvae_adam_step* then leaves parameters, moments
                                                and step count untouched.  mmvae_step_status reports it to the host */
 } mmvae_coco_step_io;
@@ -410,7 +410,9 @@ int mmvae_debug_probe(int on);
 int mmvae_debug_probe_read(char* buf, long long cap);
 /* torch.optim.Adam (multimnist/train.py:129,173) on flat fp32 buffers.  `state`: 16 zero-initialised device bytes the caller keeps
  * next to the moments -- int64 step count, then two words of the kernel's own (block ticket, skip flag).  The update is dropped
- * (and the step count kept) when the skip flag is set or g[0] is NaN: see mmvae_coco_step_io.optimizer_state. */
+ * (and the step count kept) when the skip flag is set or g[0] carries the void mark (the NaN bit pattern 0x7fc0dead, sign ignored):
+ * see mmvae_coco_step_io.optimizer_state.  Any other NaN in the gradient is a value: it goes through the update and shows in the
+ * parameters, as with torch.optim.Adam. */
 int mmvae_adam_step(float* p, const float* g, float* m, float* v, long long n, long long* state, float lr, float beta1,
                     float beta2, float eps, float grad_scale, void* stream);
 /* The same update with the unpack of the packed weight gradients fused in (mmvae_mm_step_io.defer_unpack = 1):

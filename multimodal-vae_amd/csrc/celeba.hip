@@ -488,6 +488,9 @@ int use_ws(CelebaPlan* P, void* ws, size_t bytes, bool module = true) {
     P->wgrad_forked = false;
     P->dec_skip_mask = 0;
     P->slab.reset(P->w.slab, P->w.slab_floats);
+    // side work or a completion event a FAILED earlier call left behind must not run against this call's buffers
+    P->side_pending.clear(); P->batch_reduce = false;
+    (void)mmvae_take_stop_event();
     return MMVAE_OK;
 }
 int unpack(CelebaPlan& P, hipStream_t s) {

@@ -376,6 +376,9 @@ int use_ws(CocoPlan* P, void* ws, size_t bytes, bool module = true) {
     P->wgrad_forked = false;
     P->dec_skip_mask = 0;
     P->slab.reset(P->w.slab, P->w.slab_floats);
+    // side work or a completion event a FAILED earlier call left behind must not run against this call's buffers
+    P->side_pending.clear(); P->batch_reduce = false;
+    (void)mmvae_take_stop_event();
     P->dec_wg_pending = false;
     P->comb_fresh = false; P->dw16_fresh = false; P->dec_wg_composed = false;
     P->cl_alarm_f = P->cl_alarm_b = nullptr;

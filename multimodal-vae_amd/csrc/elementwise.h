@@ -134,6 +134,9 @@ struct Latent3BwdArgs {
 };
 int launch_latent3_bwd(const Latent3BwdArgs& a, hipStream_t s);
 
+// bit pattern of the "void step" mark in element 0 of a flat gradient (plan_base.h sum_slots_kernel): a quiet NaN with a payload no
+// arithmetic produces on its own
+#define MMVAE_VOID_MARK 0x7fc0deadu
 struct AdamArgs {
     float* p; const float* g; float* m; float* v;
     long long n;

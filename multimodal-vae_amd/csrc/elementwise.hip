@@ -648,7 +648,8 @@ __global__ __launch_bounds__(TPB) void latent3_bwd_kernel(const Latent3BwdArgs a
 __global__ __launch_bounds__(TPB) void adam_kernel(const AdamArgs a, unsigned* done) {
     const long long t = *a.step + 1;
     // a step that gave up on a device-side exchange marked itself (plan_base.h sum_slots_kernel): no update, no step count
-    const bool skip = done[1] != 0u || a.g[0] != a.g[0];
+    // (the mark is a NaN with a payload of its own, compared bit by bit without the sign: any other NaN is a real gradient value)
+    const bool skip = done[1] != 0u || (__float_as_uint(a.g[0]) & 0x7fffffffu) == MMVAE_VOID_MARK;
     const float bc1 = 1.0f - powf(a.b1, (float)t);
     const float bc2 = 1.0f - powf(a.b2, (float)t);
     const float step_size = a.lr / bc1;

@@ -573,8 +573,10 @@ inline int check_bound(const PlanBase* P) {
 // kernel of the step sets when it gave up waiting for a peer (the cluster exchange of the COCO caption decoder): the
 // step's numbers are then garbage, and the loss sums say so (NaN) instead of looking plausible.
 // A failed step must also never reach the parameters: `adam_state` (the caller's 16-byte optimizer state block, elementwise.h
-// AdamArgs::step) gets its skip word set, and element 0 of the flat gradient becomes NaN -- a mark that survives the SUM
-// all-reduce of a data-parallel job, so that EVERY rank's Adam kernel drops the update (adam_kernel).
+// AdamArgs::step) gets its skip word set, and element 0 of the flat gradient becomes a NaN with the payload MMVAE_VOID_MARK -- a
+// mark that survives the SUM all-reduce of a data-parallel job (NaN + x keeps the NaN's payload), so that EVERY rank's Adam
+// kernel drops the update (adam_kernel).  A NaN of any other payload -- a genuinely diverged gradient -- is NOT a mark: it goes
+// through the update and shows in the parameters, as with torch.optim.Adam in the reference (multimnist/train.py:173).
 static __global__ void sum_slots_kernel(const float* slots, float* out, const unsigned* alarm0 = nullptr, const unsigned* alarm1 = nullptr,
                                         long long* adam_state = nullptr, float* grads = nullptr) {
     const int j = threadIdx.x;
@@ -586,7 +588,7 @@ static __global__ void sum_slots_kernel(const float* slots, float* out, const un
     out[j] = s;
     if (alarm && j == 0) {
         if (adam_state) reinterpret_cast<unsigned*>(adam_state + 1)[1] = 1u;
-        if (grads) grads[0] = __builtin_nanf("");
+        if (grads) grads[0] = __uint_as_float(MMVAE_VOID_MARK);
     }
 }
 static __global__ void cast_z_kernel(const float* z, int rows, int D, bf16* out, int ldz) {

@@ -68,13 +68,18 @@ class DeviceBatcher:
     (B,102,300) -- the asynchronous H2D image + caption pipeline of the COCO configuration (coco/train.py:117-128).
 
     Three slots (pinned staging + device buffers each), three actors:
-      * a worker thread gathers batch b+2 into its pinned staging buffers (``np.take`` releases the GIL; the COCO batch is
-        15.7 MB of caption vectors, 1.5-1.9 ms of a single core -- on the enqueue thread that made the loader-fed step
-        host-bound: bench.py --loader 3.54 ms against 2.71 ms with resident inputs);
-      * the copy stream (the library's own, ``_lib.OwnedStream``) moves batch b+1 to the device while step b runs: async H2D of the
-        uint8 pixels + the second modality, behind a device-side edge on the step that last read the slot's device buffers;
-      * the compute stream waits for the copy event of batch b, converts u8 -> f32 (ToTensor on the device) and trains.
-    The host never waits for the compute stream: a staging buffer is reused when its own H2D copy (three batches old) has finished.
+      * a worker thread stages batch b+2: it waits ON THE HOST for the step that last read the slot's device buffers
+        (``consumed[slot].synchronize()``), gathers the rows into the slot's pinned staging buffers (``np.take`` releases the GIL;
+        the COCO batch is 15.7 MB of caption vectors, 1.5-1.9 ms of a single core) and enqueues the slot's H2D copy on the copy
+        stream (the library's own, ``_lib.OwnedStream``): uint8 pixels + the second modality;
+      * the copy stream moves batches b+1, b+2 to the device while step b runs;
+      * the enqueue thread only waits (device-side) for the copy event of batch b, converts u8 -> f32 (ToTensor on the device) and
+        trains.
+    Round 4: the slot reuse used to be a DEVICE-side edge -- ``copy_stream.wait_event(consumed[slot])`` -- and that one call made
+    the loader-fed MultiMNIST step 1.5 ms against 0.65 ms with resident inputs (tools/loader_knock.py: without it 0.66): a copy
+    stream parked on an event of the compute stream stalls this runtime's queues (DESIGN.md section 5 met the same with the
+    overlapped gradient exchange).  Pacing the reuse on the worker's host thread costs the enqueue thread nothing and the worker is
+    two batches ahead anyway.  ``MMVAE_LOADER_HOST_PACED=0`` brings the device-side edge back (measurement aid).
     ``drop_last`` because the fused plans are built for a fixed batch size.
 
     ``pin_dataset=True`` (opt-in; rows must be multiples of 16 bytes): the whole dataset is pinned once and the GPU gathers the B
@@ -85,15 +90,19 @@ class DeviceBatcher:
     SLOTS = 3
 
     def __init__(self, images_u8: torch.Tensor, text: torch.Tensor, batch_size: int, device: torch.device, shuffle: bool = True,
-                 seed: int = 0, pin_dataset: bool = False, copy_on_worker: bool = True):
+                 seed: int = 0, pin_dataset: bool = False, copy_on_worker: bool = True, slots: int = 0):
         assert images_u8.dtype == torch.uint8 and images_u8.dim() in (3, 4) and len(images_u8) == len(text)
         self.images, self.text, self.B, self.device = images_u8, text, int(batch_size), device
         self.shuffle, self.seed, self.epoch = shuffle, seed, 0
         self.copy_on_worker = bool(copy_on_worker)
+        self.host_paced = bool(int(os.environ.get("MMVAE_LOADER_HOST_PACED", "1"))) and self.copy_on_worker
         ishape = tuple(images_u8.shape[1:])
         oshape = (1,) + ishape if images_u8.dim() == 3 else ishape
         tshape = tuple(text.shape[1:])
         self.hw = ishape[-2:]
+        if slots:
+            self.SLOTS = int(slots)
+        assert self.SLOTS >= 3
         S = self.SLOTS
         self.device_gather = bool(pin_dataset)
         if self.device_gather:
@@ -150,8 +159,10 @@ class DeviceBatcher:
 
     def _copy(self, slot: int) -> None:
         """enqueue thread: the slot's staged batch -> its device buffers, on the copy stream"""
+        if self._read[slot] and self.host_paced:
+            self.consumed[slot].synchronize()                   # host-side: the step that read these device buffers is done
         with torch.cuda.stream(self.copy_stream):
-            if self._read[slot]:
+            if self._read[slot] and not self.host_paced:
                 self.copy_stream.wait_event(self.consumed[slot])   # device-side edge: the step that read these buffers is done
             if self.device_gather:
                 import ctypes as C
@@ -180,7 +191,12 @@ class DeviceBatcher:
         S, B = self.SLOTS, self.B
         fut = {}
         stage = self._stage if self.copy_on_worker else self._gather
-        for b in range(min(2, nb)):                                 # the worker runs two batches ahead
+        # the worker runs AHEAD batches ahead of the step being enqueued: every slot but the one in use.  (The chain "step done ->
+        # its slot's next H2D copy -> the step that reads it" goes through the runtime's copy path with a latency of several
+        # step times on this stack: with 3 slots the loader-fed MultiMNIST step ran at 3 steps per ~4.6 ms = 1.5 ms per step
+        # against 0.65 with resident inputs, tools/loader_knock.py; the depth of the ring, not the copy rate, bounds the rate.)
+        AHEAD = (S - 1) if self.copy_on_worker else 2
+        for b in range(min(AHEAD, nb)):
             fut[b] = self._worker.submit(stage, b % S, order[b * B:(b + 1) * B])
         if not self.copy_on_worker:
             fut.pop(0).result()
@@ -188,8 +204,8 @@ class DeviceBatcher:
         try:
             for b in range(nb):
                 slot = b % S
-                if b + 2 < nb:
-                    fut[b + 2] = self._worker.submit(stage, (b + 2) % S, order[(b + 2) * B:(b + 3) * B])
+                if b + AHEAD < nb:
+                    fut[b + AHEAD] = self._worker.submit(stage, (b + AHEAD) % S, order[(b + AHEAD) * B:(b + AHEAD + 1) * B])
                 if self.copy_on_worker:
                     fut.pop(b).result()                             # gathered AND its H2D copy enqueued by the worker, two steps ago
                 elif b + 1 < nb:

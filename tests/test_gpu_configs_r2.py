@@ -216,10 +216,22 @@ def test_packed_adam_equals_unpack_then_adam_other_families(family):
     call("mmvae_adam_step", ptr(pb), ptr(full), ptr(mb), ptr(vb), st.nparams, ptr(sb), 1e-4, 0.9, 0.999, 1e-8, 1.0, s)
     torch.cuda.synchronize()
     assert torch.equal(pb, pc) and int(sb[0]) == 1 and int(sb[1]) == 0
-    full[0] = float("nan")                                     # ... and so does the NaN mark that survives an all-reduce
+    # ... and so does the void mark in element 0 (a NaN with the payload 0x7fc0dead), also after it went through the SUM of an
+    # all-reduce with another rank's finite value
+    mark = torch.tensor([0x7FC0DEAD], dtype=torch.int32, device=dev).view(torch.float32)
+    g0 = float(full[0])
+    full[0:1] = mark + torch.tensor([0.25], device=dev)
+    assert (int(full[0:1].view(torch.int32)) & 0x7FFFFFFF) == 0x7FC0DEAD     # NaN + x keeps the payload
     call("mmvae_adam_step", ptr(pb), ptr(full), ptr(mb), ptr(vb), st.nparams, ptr(sb), 1e-4, 0.9, 0.999, 1e-8, 1.0, s)
     torch.cuda.synchronize()
     assert torch.equal(pb, pc) and int(sb[0]) == 1
+    # an ordinary NaN is a gradient value, not a mark: the update runs and the NaN shows in the parameter, as with torch.optim.Adam
+    # (multimnist/train.py:173)
+    full[0] = float("nan")
+    call("mmvae_adam_step", ptr(pb), ptr(full), ptr(mb), ptr(vb), st.nparams, ptr(sb), 1e-4, 0.9, 0.999, 1e-8, 1.0, s)
+    torch.cuda.synchronize()
+    assert int(sb[0]) == 2 and bool(torch.isnan(pb[0])) and not bool(torch.isnan(pb[1:]).any())
+    full[0] = g0
 
 
 def test_single_rank_rccl_group_runs_the_data_parallel_step():
