@@ -413,7 +413,7 @@ def main():
     # dataset of 8 batches on the host, gathered / copied / converted batch by batch while the previous step runs
     if args.loader:
         from multimodal_vae_amd.data import DeviceBatcher
-        nb_ds = 8
+        nb_ds = int(os.environ.get("MMVAE_BENCH_DATASET_BATCHES", "8"))
         rng = np.random.default_rng(seed + 99)
         a_h, b_h = synthetic_batch_for(wl, nb_ds * B, seed + 99)
         img_u8 = (a_h * 255.0).round().clamp(0, 255).to(torch.uint8)
@@ -444,7 +444,7 @@ def main():
                                  "vs_resident": (args.steps / dtl) / steps_per_s,
                                  "h2d_bytes_per_step": int(img_u8[0].numel() * B + b_h[0].numel() * b_h.element_size() * B),
                                  "loader": "data.DeviceBatcher: %d-batch host dataset, gather into pinned staging on a worker thread, async H2D on a "
-                                           "copy stream, u8->f32 on the device, three slots" % nb_ds}
+                                           "copy stream, u8->f32 on the device, four slots, slot reuse paced on the worker thread" % nb_ds}
 
     # ---- per-step distribution: HIP events around single steps, outside the timed region
     n_ev = min(100, args.steps)

@@ -67,12 +67,13 @@ class DeviceBatcher:
     ``text``: (N, ...) of any dtype, copied as is: int64 tokens (B,4), fp32 attributes (B,18), fp32 caption vectors
     (B,102,300) -- the asynchronous H2D image + caption pipeline of the COCO configuration (coco/train.py:117-128).
 
-    Three slots (pinned staging + device buffers each), three actors:
-      * a worker thread stages batch b+2: it waits ON THE HOST for the step that last read the slot's device buffers
+    Four slots (pinned staging + device buffers each; three measured 7 % slower: the worker may run only as far ahead of the GPU as
+    there are free slots), three actors:
+      * a worker thread stages batch b+3: it waits ON THE HOST for the step that last read the slot's device buffers
         (``consumed[slot].synchronize()``), gathers the rows into the slot's pinned staging buffers (``np.take`` releases the GIL;
         the COCO batch is 15.7 MB of caption vectors, 1.5-1.9 ms of a single core) and enqueues the slot's H2D copy on the copy
         stream (the library's own, ``_lib.OwnedStream``): uint8 pixels + the second modality;
-      * the copy stream moves batches b+1, b+2 to the device while step b runs;
+      * the copy stream moves batches b+1 .. b+3 to the device while step b runs;
       * the enqueue thread only waits (device-side) for the copy event of batch b, converts u8 -> f32 (ToTensor on the device) and
         trains.
     Round 4: the slot reuse used to be a DEVICE-side edge -- ``copy_stream.wait_event(consumed[slot])`` -- and that one call made
@@ -87,15 +88,16 @@ class DeviceBatcher:
     frees the host (0.31 ms per batch) but the gather workgroups sit on CUs for the length of the transfer and the step next to
     them slows down more than that saves (3.8 ms per step): not the default."""
 
-    SLOTS = 3
+    SLOTS = 4
 
     def __init__(self, images_u8: torch.Tensor, text: torch.Tensor, batch_size: int, device: torch.device, shuffle: bool = True,
                  seed: int = 0, pin_dataset: bool = False, copy_on_worker: bool = True, slots: int = 0):
         assert images_u8.dtype == torch.uint8 and images_u8.dim() in (3, 4) and len(images_u8) == len(text)
         self.images, self.text, self.B, self.device = images_u8, text, int(batch_size), device
         self.shuffle, self.seed, self.epoch = shuffle, seed, 0
-        self.copy_on_worker = bool(copy_on_worker)
-        self.host_paced = bool(int(os.environ.get("MMVAE_LOADER_HOST_PACED", "1"))) and self.copy_on_worker
+        self.copy_on_worker = True          # (round 3's enqueue-thread copy path is gone; the argument is kept for callers)
+        self.host_paced = bool(int(os.environ.get("MMVAE_LOADER_HOST_PACED", "1")))
+        self._carry, self._next_order, self._gbase = {}, None, 0
         ishape = tuple(images_u8.shape[1:])
         oshape = (1,) + ishape if images_u8.dim() == 3 else ishape
         tshape = tuple(text.shape[1:])
@@ -176,41 +178,43 @@ class DeviceBatcher:
             self.ready[slot].record(self.copy_stream)
             self._copied[slot] = True
 
-    def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
+    def _epoch_order(self) -> np.ndarray:
         n = len(self.images)
         if self.shuffle:
             g = torch.Generator().manual_seed(self.seed + self.epoch)
             order = torch.randperm(n, generator=g)
         else:
             order = torch.arange(n)
-        order = order.numpy()
         self.epoch += 1
+        return order.numpy()
+
+    def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
         nb = len(self)
         if nb == 0:
             return
         S, B = self.SLOTS, self.B
-        fut = {}
-        stage = self._stage if self.copy_on_worker else self._gather
-        # the worker runs AHEAD batches ahead of the step being enqueued: every slot but the one in use.  (The chain "step done ->
-        # its slot's next H2D copy -> the step that reads it" goes through the runtime's copy path with a latency of several
-        # step times on this stack: with 3 slots the loader-fed MultiMNIST step ran at 3 steps per ~4.6 ms = 1.5 ms per step
-        # against 0.65 with resident inputs, tools/loader_knock.py; the depth of the ring, not the copy rate, bounds the rate.)
-        AHEAD = (S - 1) if self.copy_on_worker else 2
+        AHEAD = S - 1               # the worker stages this many batches ahead of the step being enqueued: every slot but the one in use
+        # The ring runs ACROSS epochs: the last steps of an epoch already stage the first batches of the next one (its order is
+        # drawn early), so an epoch boundary does not drain the pipeline (an 8-batch epoch lost 12 % to that).
+        order = self._next_order if self._next_order is not None else self._epoch_order()
+        fut, self._carry, self._next_order = self._carry, {}, None
+        g0 = self._gbase            # global index of this epoch's first batch: slots rotate continuously
         for b in range(min(AHEAD, nb)):
-            fut[b] = self._worker.submit(stage, b % S, order[b * B:(b + 1) * B])
-        if not self.copy_on_worker:
-            fut.pop(0).result()
-            self._copy(0)
+            if b not in fut:
+                fut[b] = self._worker.submit(self._stage, (g0 + b) % S, order[b * B:(b + 1) * B])
+        carry, next_order, b = {}, None, -1
         try:
             for b in range(nb):
-                slot = b % S
-                if b + AHEAD < nb:
-                    fut[b + AHEAD] = self._worker.submit(stage, (b + AHEAD) % S, order[(b + AHEAD) * B:(b + AHEAD + 1) * B])
-                if self.copy_on_worker:
-                    fut.pop(b).result()                             # gathered AND its H2D copy enqueued by the worker, two steps ago
-                elif b + 1 < nb:
-                    fut.pop(b + 1).result()                         # gathered while the previous step was being enqueued
-                    self._copy((b + 1) % S)                         # in flight while step b runs
+                nxt = b + AHEAD
+                if nxt < nb:
+                    fut[nxt] = self._worker.submit(self._stage, (g0 + nxt) % S, order[nxt * B:(nxt + 1) * B])
+                elif nxt - nb < nb:
+                    if next_order is None:
+                        next_order = self._epoch_order()
+                    k = nxt - nb
+                    carry[k] = self._worker.submit(self._stage, (g0 + nxt) % S, next_order[k * B:(k + 1) * B])
+                fut.pop(b).result()                                 # gathered AND its H2D copy enqueued by the worker, AHEAD steps ago
+                slot = (g0 + b) % S
                 cur = torch.cuda.current_stream(self.device)
                 cur.wait_event(self.ready[slot])
                 import ctypes as C
@@ -222,7 +226,13 @@ class DeviceBatcher:
                     self.consumed[slot].record(cur)
                     self._read[slot] = True
         finally:
-            for f in fut.values():                                  # an abandoned epoch: let the worker finish what it holds
+            if b == nb - 1:                                         # every batch was handed out: the prefetch goes to the next epoch
+                self._carry, self._next_order = carry, next_order
+                carry = {}
+            elif next_order is not None:                            # abandoned: the early draw of the next order is taken back
+                self.epoch -= 1
+            self._gbase = g0 + b + 1                                # the next epoch's batch k takes slot (gbase + k) % S: the handed-over ones hold theirs
+            for f in list(fut.values()) + list(carry.values()):     # an abandoned epoch: let the worker finish what it holds
                 f.result()
 
     def _stage(self, slot: int, ix: np.ndarray) -> None:
