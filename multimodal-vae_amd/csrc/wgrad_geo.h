@@ -30,8 +30,11 @@ struct Src {            // where a 16-byte chunk of the slot comes from
     int off;            // byte offset from (tensor base + first image of the batch [+ the channel slice for the small side])
 };
 
-template <int C_, int N_, int AH_, int AW_, int OH_, int OW_, int KH_, int KW_, int ST_, int PAD_, int NS_, int IB_, int WAVES_, int SLOTS_>
+// WGQ_: workgroups of a launch in quarters of the CU count (0: the launcher's default) -- layers with a large dW want few image
+// groups, every group is one more partial copy of dW
+template <int C_, int N_, int AH_, int AW_, int OH_, int OW_, int KH_, int KW_, int ST_, int PAD_, int NS_, int IB_, int WAVES_, int SLOTS_, int WGQ_ = 0>
 struct Geo {
+    static constexpr int WGQ = WGQ_;
     static constexpr int C = C_, N = N_, AH = AH_, AW = AW_, OH = OH_, OW = OW_, KH = KH_, KW = KW_, ST = ST_, PAD = PAD_;
     static constexpr int NS = NS_, IB = IB_, WAVES = WAVES_, SLOTS = SLOTS_;
     static_assert(C % 32 == 0 && N % NS == 0 && NS % 32 == 0, "channel tiles are 32 wide");

@@ -293,7 +293,7 @@ int try_wr(const WgradParams& p, hipStream_t stream, WgradSlabCtx* ctx) {
     const int units = nimg / G::IB;
     // image groups per class in proportion to the class's column tiles: every workgroup carries about the same number of MFMAs
     // (the 5x5 layer's classes hold 9 / 6 / 6 / 4 taps); about one workgroup per CU in all (knob wr_wgs)
-    const int target = mmvae_knob("wr_wgs", 3) * mmvae_cu_count() / 4;      // knob in quarters of the CU count
+    const int target = (G::WGQ > 0 ? mmvae_knob("wr_wgs_big", G::WGQ) : mmvae_knob("wr_wgs", 3)) * mmvae_cu_count() / 4;   // in quarters of the CU count
     // (a batch costs a workgroup a fixed part -- the DMA issue -- next to its MFMAs: measured 0.66 us + 0.10 us per column tile
     //  on hallucinate.6; knob wr_bias = the fixed part in column tiles)
     const int bias = mmvae_knob("wr_bias", 6);
