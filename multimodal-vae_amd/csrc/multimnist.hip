@@ -816,7 +816,9 @@ MMPlan* mm_create(int D, int B) {
     if (D < 1 || D > 127 || B < 1) { mmvae_set_error("mm_create: need 1 <= n_latents <= 127 and batch >= 1"); return nullptr; }
     MMPlan* P = new MMPlan();
     P->D = D; P->B = B;
-    P->single_wgrad_stream = false;     // round 3: the weight-gradient chain is the step's tail; two streams side by side: 758 -> 718 us
+    // round 3: two weight-gradient streams side by side (the chain was the step's tail: 758 -> 718 us); round 4, with the ring-staged
+    // kernels on half the chip each: ONE stream again (643 -> 634 us; knob one_wgrad_stream)
+    P->single_wgrad_stream = true;
     build_plan(*P);
     Workspace ws(nullptr, 0);
     carve(*P, ws);

@@ -52,7 +52,7 @@ struct PlanBase {
     bool bound = false;
     // side streams: independent branches of the step (second-modality path, weight gradients) run beside the main
     // chain; forks/joins are event edges, so nothing syncs the host (and a captured HIP graph gets parallel branches)
-    hipStream_t st_text = nullptr, st_wgrad = nullptr, st_wgrad2 = nullptr;
+    hipStream_t st_text = nullptr, st_wgrad = nullptr, st_wgrad2 = nullptr, st_wgrad2_own = nullptr;
     int wgrad_rr = 0;               // weight gradients alternate between the two side streams
     bool defer_wgrad = false;       // collect weight-gradient launches instead of issuing them (flush_wgrads)
     std::vector<WgradParams> deferred;
@@ -520,9 +520,9 @@ inline int ensure_streams(PlanBase& P) {
                     return MMVAE_EHIP;
                 }
         }
-        P.st_text = shared[0]; P.st_wgrad = shared[1]; P.st_wgrad2 = shared[2];
+        P.st_text = shared[0]; P.st_wgrad = shared[1]; P.st_wgrad2 = shared[2]; P.st_wgrad2_own = shared[2];
     }
-    if (P.single_wgrad_stream) P.st_wgrad2 = P.st_wgrad;
+    P.st_wgrad2 = (P.single_wgrad_stream || mmvae_knob("one_wgrad_stream", 0)) ? P.st_wgrad : P.st_wgrad2_own;
     P.next_event = 0; P.wgrad_rr = 0;
     return MMVAE_OK;
 }

@@ -292,8 +292,12 @@ int try_wr(const WgradParams& p, hipStream_t stream, WgradSlabCtx* ctx) {
     if ((size_t)nimg * G::AH * G::AW * G::C * 2 >= (1ull << 31) || (size_t)nimg * G::OYX * G::N * 2 >= (1ull << 31)) return 0;
     const int units = nimg / G::IB;
     // image groups per class in proportion to the class's column tiles: every workgroup carries about the same number of MFMAs
-    // (the 5x5 layer's classes hold 9 / 6 / 6 / 4 taps); about one workgroup per CU in all (knob wr_wgs)
-    const int target = (G::WGQ > 0 ? mmvae_knob("wr_wgs_big", G::WGQ) : mmvae_knob("wr_wgs", 3)) * mmvae_cu_count() / 4;   // in quarters of the CU count
+    // (the 5x5 layer's classes hold 9 / 6 / 6 / 4 taps); the workgroup count of the launch: `target` below
+    // in quarters of the CU count.  Inside the step a launch that leaves half the chip to the main chain costs the step less than one
+    // that takes every CU for a shorter time (MultiMNIST: 652 -> 648 us per step at half the chip, 634 with ONE weight-gradient
+    // stream); the 9-17 GFLOP layers of CelebA run shorter on the whole chip (1.873 against 1.888 ms per step)
+    const double macs = (double)nimg * G::OYX * G::KH * G::KW * G::C * G::N;
+    const int target = (G::WGQ > 0 ? mmvae_knob("wr_wgs_big", G::WGQ) : mmvae_knob("wr_wgs", macs >= 4e9 ? 4 : 2)) * mmvae_cu_count() / 4;
     // (a batch costs a workgroup a fixed part -- the DMA issue -- next to its MFMAs: measured 0.66 us + 0.10 us per column tile
     //  on hallucinate.6; knob wr_bias = the fixed part in column tiles)
     const int bias = mmvae_knob("wr_bias", 6);
