@@ -32,13 +32,16 @@ struct Src {            // where a 16-byte chunk of the slot comes from
 
 // WGQ_: workgroups of a launch in quarters of the CU count (0: the launcher's default) -- layers with a large dW want few image
 // groups, every group is one more partial copy of dW
-template <int C_, int N_, int AH_, int AW_, int OH_, int OW_, int KH_, int KW_, int ST_, int PAD_, int NS_, int IB_, int WAVES_, int SLOTS_, int WGQ_ = 0>
+// TGN_: the tap rows of a parity class are split over TGN workgroup classes (all of them read the class's plane): a stride-1 layer
+// has ONE parity class of KH*KW taps, more accumulators than a workgroup's registers hold
+template <int C_, int N_, int AH_, int AW_, int OH_, int OW_, int KH_, int KW_, int ST_, int PAD_, int NS_, int IB_, int WAVES_, int SLOTS_, int WGQ_ = 0,
+          int TGN_ = 1>
 struct Geo {
-    static constexpr int WGQ = WGQ_;
+    static constexpr int WGQ = WGQ_, TGN = TGN_;
     static constexpr int C = C_, N = N_, AH = AH_, AW = AW_, OH = OH_, OW = OW_, KH = KH_, KW = KW_, ST = ST_, PAD = PAD_;
     static constexpr int NS = NS_, IB = IB_, WAVES = WAVES_, SLOTS = SLOTS_;
     static_assert(C % 32 == 0 && N % NS == 0 && NS % 32 == 0, "channel tiles are 32 wide");
-    static constexpr int NCLS = ST * ST;
+    static constexpr int NCLS = ST * ST * TGN;                // workgroup classes: (parity class, tap-row group)
     static constexpr int NTN = NS / 32, CT = C / 32, MS = N / NS;
     static_assert(NTN == 1 || NTN == 2 || NTN == 4, "a wave owns one row tile of the slice: NS/32 must divide the wave count");
     static_assert(WAVES % NTN == 0, "wave grid");
@@ -51,15 +54,17 @@ struct Geo {
     static constexpr int t0(int p) { return (p + PAD) % ST; }                        // first tap of parity p; the others follow at t0 + k*ST
     static constexpr int ntap(int p, int K) { return t0(p) < K ? (K - 1 - t0(p)) / ST + 1 : 0; }
     static constexpr int dmin(int p) { return shift(t0(p)); }                        // shifts of a parity are consecutive: dmin + k
-    // ---- class c = cy*ST + cx
-    static constexpr int cy(int c) { return c / ST; }
-    static constexpr int cx(int c) { return c % ST; }
-    static constexpr int NTY(int c) { return ntap(cy(c), KH); }
+    // ---- class c = (cy*ST + cx)*TGN + tap-row group
+    static constexpr int cy(int c) { return c / TGN / ST; }
+    static constexpr int cx(int c) { return c / TGN % ST; }
+    static constexpr int tg(int c) { return c % TGN; }
+    static constexpr int NTY(int c) { return ntap(cy(c), KH) / TGN; }                // (tests/host/wgrad_geo_check.cpp: the split is even)
+    static constexpr int KY0(int c) { return tg(c) * NTY(c); }                       // first tap row of the group inside its parity class
     static constexpr int NTX(int c) { return ntap(cx(c), KW); }
     static constexpr int NTAPS(int c) { return NTY(c) * NTX(c); }
     static constexpr int NCT(int c) { return NTAPS(c) * CT; }                        // column tiles (tap, channel tile)
     static constexpr int CPW(int c) { return cdiv(NCT(c), WC); }                     // column tiles per wave
-    static constexpr int DYMIN(int c) { return dmin(cy(c)); }
+    static constexpr int DYMIN(int c) { return dmin(cy(c)) + KY0(c); }
     static constexpr int DXMIN(int c) { return dmin(cx(c)); }
     static constexpr int LR(int c) { return OH + NTY(c) - 1; }                       // plane rows / columns held in LDS (ring included)
     static constexpr int LC(int c) { return OW + NTX(c) - 1; }
@@ -69,7 +74,7 @@ struct Geo {
     static constexpr int NCELL(int c) { return IB * IMGCELLS(c); }
     static constexpr int NCELLP(int c) { return rup(NCELL(c), 16); }
     // k-th tap of the class (ky-major) -> tap of the layer, and its cell offset against the row's base cell
-    static constexpr int tap_ty(int c, int k) { return t0(cy(c)) + (k / NTX(c)) * ST; }
+    static constexpr int tap_ty(int c, int k) { return t0(cy(c)) + (KY0(c) + k / NTX(c)) * ST; }
     static constexpr int tap_tx(int c, int k) { return t0(cx(c)) + (k % NTX(c)) * ST; }
     static constexpr int tapcell(int c, int k) { return (k / NTX(c)) * LC(c) + k % NTX(c); }
     // base cell of pixel row kr of the batch (rows past the batch: cell 0 -- their small-side rows are zero)

@@ -28,7 +28,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4r;
 typedef __attribute__((address_space(3))) void lds_void;
 
-constexpr int WR_MAXCLS = 4;
+constexpr int WR_MAXCLS = 8;
 constexpr int WR_MAXJOBS = 1024;
 
 struct WrArgs {
@@ -343,7 +343,7 @@ int try_wr(const WgradParams& p, hipStream_t stream, WgradSlabCtx* ctx) {
         if (a.groups[i] == 0) continue;
         WgradRingJob j{};
         j.dst = p.cls[0].dWp; j.slab = slab + a.slab_off[i]; j.N = G::N; j.Kpad = p.cls[0].Kpad; j.C = G::C; j.Kc = G::NTAPS(i) * G::C;
-        j.copies = a.groups[i]; j.ntx = G::NTX(i); j.ty0 = G::t0(G::cy(i)); j.tx0 = G::t0(G::cx(i)); j.st = G::ST; j.kw = G::KW;
+        j.copies = a.groups[i]; j.ntx = G::NTX(i); j.ty0 = G::tap_ty(i, 0); j.tx0 = G::tap_tx(i, 0); j.st = G::ST; j.kw = G::KW;
         j.stream = stream;
         ctx->ring_jobs.push_back(j);
     }

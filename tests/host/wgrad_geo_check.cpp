@@ -28,6 +28,7 @@ void check(const char* name) {
     // taps are partitioned by the classes; the class-local order (ky-major) is the layer's order restricted to the class
     std::set<int> seen;
     for (int c = 0; c < G::NCLS; ++c) {
+        CHECK(G::ntap(G::cy(c), G::KH) % G::TGN == 0, "%s: %d tap rows of a parity class do not split into %d groups", name, G::ntap(G::cy(c), G::KH), G::TGN);
         int prev = -1;
         for (int k = 0; k < G::NTAPS(c); ++k) {
             const int ty = G::tap_ty(c, k), tx = G::tap_tx(c, k);
@@ -38,7 +39,7 @@ void check(const char* name) {
             prev = ty * G::KW + tx;
             // the reduce kernel's formula
             const int ntx = G::NTX(c);
-            CHECK((G::t0(G::cy(c)) + (k / ntx) * G::ST) == ty && (G::t0(G::cx(c)) + (k % ntx) * G::ST) == tx, "%s: reduce tap formula", name);
+            CHECK((G::tap_ty(c, 0) + (k / ntx) * G::ST) == ty && (G::tap_tx(c, 0) + (k % ntx) * G::ST) == tx, "%s: reduce tap formula", name);
         }
         CHECK(G::slot_bytes_of(c) <= G::SLOT_BYTES, "%s: slot", name);
         CHECK(G::bg_off(c, G::CT - 1, G::NCELLP(c) - 1) + 64 <= G::SLOT_BYTES, "%s: big region overruns the slot", name);
