@@ -534,7 +534,8 @@ inline int join_sides(PlanBase& P, hipStream_t T, hipStream_t s) {
     hipStream_t hub = P.st_wgrad;
     // (with ONE weight-gradient stream there are two side streams: the main stream waiting for each of them directly measured
     //  628 against 634 us per MultiMNIST step)
-    if (!hub || hub == s || T == s || mmvae_knob("one_join", P.st_wgrad2 == P.st_wgrad ? 0 : 1) == 0) {
+    const int oj = mmvae_knob("one_join", -1);          // (-1: not set.  A call site caches the value it looked up: the default must not vary)
+    if (!hub || hub == s || T == s || (oj >= 0 ? oj == 0 : P.st_wgrad2 == P.st_wgrad)) {
         if (T != s) MMVAE_TRY(edge(P, T, s));
         if (hub && hub != s) MMVAE_TRY(edge(P, hub, s));
         if (P.st_wgrad2 && P.st_wgrad2 != hub && P.st_wgrad2 != s) MMVAE_TRY(edge(P, P.st_wgrad2, s));

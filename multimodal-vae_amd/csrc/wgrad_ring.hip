@@ -297,7 +297,8 @@ int try_wr(const WgradParams& p, hipStream_t stream, WgradSlabCtx* ctx) {
     // that takes every CU for a shorter time (MultiMNIST: 652 -> 648 us per step at half the chip, 634 with ONE weight-gradient
     // stream); the 9-17 GFLOP layers of CelebA run shorter on the whole chip (1.873 against 1.888 ms per step)
     const double macs = (double)nimg * G::OYX * G::KH * G::KW * G::C * G::N;
-    const int target = (G::WGQ > 0 ? mmvae_knob("wr_wgs_big", G::WGQ) : mmvae_knob("wr_wgs", macs >= 4e9 ? 4 : 2)) * mmvae_cu_count() / 4;
+    const int wq = mmvae_knob("wr_wgs", -1);            // (-1: not set.  A call site caches the value it looked up: the default must not vary)
+    const int target = (G::WGQ > 0 ? mmvae_knob("wr_wgs_big", G::WGQ) : wq >= 0 ? wq : macs >= 4e9 ? 4 : 2) * mmvae_cu_count() / 4;
     // (a batch costs a workgroup a fixed part -- the DMA issue -- next to its MFMAs: measured 0.66 us + 0.10 us per column tile
     //  on hallucinate.6; knob wr_bias = the fixed part in column tiles)
     const int bias = mmvae_knob("wr_bias", 6);
