@@ -403,7 +403,7 @@ int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const
             side_later(P, [pp, cls_w](hipStream_t ws_) {
                 MMVAE_TRY(launch_wgrad_group(cls_w->data(), (int)cls_w->size(), ws_, &pp->slab));
                 return pp->batch_reduce ? MMVAE_OK : launch_wgrad_reduce(&pp->slab, ws_, true);
-            });
+            }, mmvae_knob("mm_cls_lane", 1));
         } else {
             MMVAE_TRY(wgrad_async(P, g, s));
         }
@@ -462,11 +462,13 @@ int enc_bwd(MMPlan& P, const bf16* d_out, int variants, const uint8_t* m1, const
                 const bf16* rin = r[l >= 2 ? l - 1 : 1]; bf16* ao = a[l >= 2 ? l - 1 : 1]; const float2* st = w.st_e[l >= 2 ? l - 2 : 0];
                 WgradParams g0 = wgrad_of(P, L.fwd, L.gk, 1, B);
                 g0.c.A = a[l - 1]; g0.P = x.dr; g0.ldp = L.g.Cout;
+                // lane 1: the LAST weight gradients of the step (conv3's, conv2's) go to the second-modality stream -- it has run dry
+                // by then, and the weight-gradient stream still holds the classifier's and conv4's
                 side_later(P, [pp, x, g0, bnb, actp, bp, rin, ao, st, prows](hipStream_t ws_) {
                     if (bnb) MMVAE_TRY(launch_bn_bwd_apply(x, ws_));
                     if (actp) MMVAE_TRY(bn_act_side(*pp, bp, rin, ao, prows, prows, 1, st, 1, ws_));
                     return wgrad_on(*pp, g0, ws_);
-                });
+                }, l == 1 ? 1 : l == 2 ? mmvae_knob("mm_conv3_lane", 0) : mmvae_knob("mm_conv4_lane", 0));
             }
             if (fuse && l == 1) MMVAE_TRY(side_flush(P, s));    // conv2's: its operands came out of conv3's data gradient (current event)
         }

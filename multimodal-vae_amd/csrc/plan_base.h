@@ -7,6 +7,7 @@
 #include <map>
 #include <mutex>
 #include <functional>
+#include <utility>
 #include <cstdlib>
 
 constexpr float BN_EPS = 1e-5f, BN_MOM = 0.1f, DROP_P = 0.1f;
@@ -59,12 +60,15 @@ struct PlanBase {
     std::vector<hipEvent_t> events;
     size_t next_event = 0;
     hipEvent_t fork_ev = nullptr;   // the event of the last arm_fork / commit_fork pair
-    std::vector<std::function<int(hipStream_t)>> side_pending;   // side-stream work waiting for the next fork (side_later / side_flush)
+    // side-stream work waiting for the next fork (side_later / side_flush); lane 1: onto the second-modality stream (st_text) instead
+    // of a weight-gradient stream -- the tail of the step, when that stream has run dry
+    std::vector<std::pair<std::function<int(hipStream_t)>, int>> side_pending;
     bool in_step = false;           // a fused multi-stream step is being enqueued (arm_fork / commit_fork are no-ops otherwise)
     bool capturing = false;         // ... into a HIP graph: forks are plain event records (a kernel's completion event is not a capture node --
                                     // the side streams would stay outside the graph and their work would be missing from every replay)
     hipEvent_t ev_early = nullptr;  // data-parallel step: the early gradient part is complete in the flat buffer
     bool wgrad_forked = false;
+    bool spare_used = false;        // side_flush put work on the spare weight-gradient stream (st_wgrad2_own): join_sides joins it
     bool batch_reduce = false;      // set by side_flush: the weight gradients it issues leave their partial copies to ONE reduce
                                     // launch per stream at the end of the flush (was: one behind every weight gradient)
     unsigned dec_skip_mask = 0;     // bit k: pass k is absent from this step (weak-supervision variants): its decoder BatchNorm
@@ -144,7 +148,7 @@ inline int wgrad_fork(PlanBase& P, hipStream_t s, hipStream_t* w) {
 // Side-stream work (weight gradients and the elementwise passes in front of them) is collected and issued behind the NEXT
 // fork the main chain makes anyway: every fork costs the main chain ~5-6 us, and the one weight-gradient stream carries a
 // backlog through most of the backward pass, so a fork per layer bought nothing.
-inline void side_later(PlanBase& P, std::function<int(hipStream_t)> fn) { P.side_pending.push_back(std::move(fn)); }
+inline void side_later(PlanBase& P, std::function<int(hipStream_t)> fn, int lane = 0) { P.side_pending.push_back({std::move(fn), lane}); }
 inline int side_flush(PlanBase& P, hipStream_t s) {
     if (P.side_pending.empty()) return MMVAE_OK;
     const bool serial = mmvae_serial();
@@ -152,7 +156,7 @@ inline int side_flush(PlanBase& P, hipStream_t s) {
     P.batch_reduce = mmvae_knob("batch_reduce", 1) != 0;
     if (!P.wgrad_forked || serial) {
         for (auto& fn : P.side_pending)
-            if (rc == MMVAE_OK) rc = fn(s);
+            if (rc == MMVAE_OK) rc = fn.first(s);
         P.side_pending.clear();
         if (rc == MMVAE_OK && P.batch_reduce && !(mmvae_knob("mm_wgrad_inline", 0) == 2)) rc = launch_wgrad_reduce(&P.slab, s, true);
         P.batch_reduce = false;
@@ -160,15 +164,18 @@ inline int side_flush(PlanBase& P, hipStream_t s) {
     }
     // the pieces are independent of each other: they alternate between the weight-gradient streams (each of these kernels is a
     // latency chain on a fraction of the chip; two of them side by side finish sooner than one after the other)
-    hipStream_t w[2] = {P.st_wgrad, P.st_wgrad2};
-    bool forked[2] = {false, false};
+    hipStream_t w[4] = {P.st_wgrad, P.st_wgrad2, P.st_text, P.st_wgrad2_own};
+    bool forked[4] = {false, false, false, false};
+    const int lanes = mmvae_knob("side_lanes", 3);          // bit 0: lane 1 -> the second-modality stream, bit 1: lane 2 -> the spare weight-gradient stream
     for (auto& fn : P.side_pending) {
-        const int i = (w[0] == w[1]) ? 0 : (P.wgrad_rr++ & 1);
+        const int i = (fn.second == 1 && P.st_text && (lanes & 1)) ? 2 : (fn.second == 2 && P.st_wgrad2_own && (lanes & 2)) ? 3 :
+                      (w[0] == w[1]) ? 0 : (P.wgrad_rr++ & 1);
         if (!forked[i]) { forked[i] = true; if (rc == MMVAE_OK) rc = fork_to(P, w[i]); }
-        if (rc == MMVAE_OK) rc = fn(w[i]);
+        if (i == 3) P.spare_used = true;
+        if (rc == MMVAE_OK) rc = fn.first(w[i]);
     }
     P.side_pending.clear();
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
         if (forked[i] && P.batch_reduce && rc == MMVAE_OK) rc = launch_wgrad_reduce(&P.slab, w[i], true);
     P.batch_reduce = false;
     return rc;
@@ -539,10 +546,14 @@ inline int join_sides(PlanBase& P, hipStream_t T, hipStream_t s) {
         if (T != s) MMVAE_TRY(edge(P, T, s));
         if (hub && hub != s) MMVAE_TRY(edge(P, hub, s));
         if (P.st_wgrad2 && P.st_wgrad2 != hub && P.st_wgrad2 != s) MMVAE_TRY(edge(P, P.st_wgrad2, s));
+        if (P.spare_used && P.st_wgrad2_own && P.st_wgrad2_own != P.st_wgrad2 && P.st_wgrad2_own != s) MMVAE_TRY(edge(P, P.st_wgrad2_own, s));
+        P.spare_used = false;
         return MMVAE_OK;
     }
     if (T != hub) MMVAE_TRY(edge(P, T, hub));
     if (P.st_wgrad2 && P.st_wgrad2 != hub) MMVAE_TRY(edge(P, P.st_wgrad2, hub));
+    if (P.spare_used && P.st_wgrad2_own && P.st_wgrad2_own != P.st_wgrad2 && P.st_wgrad2_own != hub) MMVAE_TRY(edge(P, P.st_wgrad2_own, hub));
+    P.spare_used = false;
     return edge(P, hub, s);
 }
 
@@ -551,8 +562,8 @@ inline int join_sides(PlanBase& P, hipStream_t T, hipStream_t s) {
 // the per-step scheduling state is reset.  Best effort: failures of the join itself are not reported over the first error.
 inline void join_after_error(PlanBase& P, hipStream_t s) {
     if (P.st_text) {
-        hipStream_t side[3] = {P.st_text, P.st_wgrad, P.st_wgrad2};
-        for (int i = 0; i < 3; ++i) {
+        hipStream_t side[4] = {P.st_text, P.st_wgrad, P.st_wgrad2, P.st_wgrad2_own};
+        for (int i = 0; i < 4; ++i) {
             if (!side[i] || side[i] == s || (i > 0 && side[i] == side[i - 1])) continue;
             hipEvent_t e = next_ev(P);
             if (hipEventRecord(e, side[i]) == hipSuccess) (void)hipStreamWaitEvent(s, e, 0);
@@ -561,7 +572,7 @@ inline void join_after_error(PlanBase& P, hipStream_t s) {
     }
     P.deferred.clear();
     P.slab.jobs.clear(); P.slab.ring_jobs.clear();
-    P.defer_wgrad = false; P.wgrad_forked = false; P.batch_reduce = false; P.no_splitk = false; P.in_step = false;
+    P.defer_wgrad = false; P.wgrad_forked = false; P.batch_reduce = false; P.spare_used = false; P.no_splitk = false; P.in_step = false;
     (void)mmvae_take_stop_event();
     P.side_pending.clear();
 }
