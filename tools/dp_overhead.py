@@ -13,7 +13,10 @@ from multimodal_vae_amd.init import default_init_
 from bench import synthetic_batch
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-modes = sys.argv[2:] or ["packed", "dp", "dp_overlap"]
+modes = [a for a in sys.argv[2:] if "=" not in a] or ["packed", "dp", "dp_overlap"]
+from multimodal_vae_amd._lib import call
+for kv in [a for a in sys.argv[2:] if "=" in a]:              # knob=value (mmvae_debug_set)
+    k, v = kv.split("="); call("mmvae_debug_set", k.encode(), int(v))
 dev = torch.device("cuda:0"); torch.cuda.set_device(0)
 s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
