@@ -42,6 +42,8 @@ struct WrArgs {
     int nimg;
     int dbg;                    // measurement aid: 1 no stores, 2 no MFMA loop, 4 no DMA
     unsigned long long* ts;     // measurement aid (knobs wr_ts_lo / wr_ts_hi): 8 s_memrealtime stamps (100 MHz) per workgroup, or null
+    float* atomic_dst;          // non-null: no partial copies -- the accumulators are ADDED (fp32 atomics) into the zeroed packed gradient
+    int atomic_kpad;            //           [N][Kpad], k = tap * C + c (layers with a small dW: the adds of all groups are a few MB)
 };
 
 // two transposed 8-byte reads = one 32x32x16 operand fragment whose k axis runs over LDS rows
@@ -190,6 +192,22 @@ __device__ __forceinline__ void wr_body(const WrArgs& a, const int ms, const int
     // ---- accumulators -> this group's copy [N][Kc]: lane = channel of the tile, register e = small-side channel
     if (a.dbg & 1) { stamp(); return; }
     constexpr int Kc = G::NTAPS(CLS) * G::C;
+    if (a.atomic_dst) {
+        float* const dsta = a.atomic_dst + (size_t)(n0 + wr * 32 + 4 * h) * a.atomic_kpad + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < CPW; ++j) {
+            const int col = wc + j * WC;
+            if (col < NCT) {
+                const int k = col / CT, ct = col - k * CT;
+                const int tap = (G::tap_ty(CLS, 0) + (k / NTX) * G::ST) * G::KW + G::tap_tx(CLS, 0) + (k % NTX) * G::ST;
+                float* d = dsta + tap * G::C + ct * 32;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) atomicAdd(d + (size_t)((e & 3) + 8 * (e >> 2)) * a.atomic_kpad, acc[j][e]);
+            }
+        }
+        if (a.ts) { wait_vmcnt<0>(); stamp(); }
+        return;
+    }
     float* const dst = copy + (size_t)(n0 + wr * 32 + 4 * h) * Kc + (lane & 31);
 #pragma unroll
     for (int j = 0; j < CPW; ++j) {
@@ -337,10 +355,15 @@ int try_wr(const WgradParams& p, hipStream_t stream, WgradSlabCtx* ctx) {
             a.job[b] = (unsigned short)js[i].code;
         }
     }
-    float* slab = ctx->take(need);
+    // small dW (features.2: 128 KB, hallucinate.6: 200 KB): the groups' accumulators go into the packed gradient by fp32 atomics
+    // (a few MB of adds in all, spread over the kernel's tail) -- no partial copies, no reduce launch behind the kernel.  Not
+    // bit-reproducible from run to run (the order of the adds), like every atomically accumulated bias / BatchNorm gradient here.
+    const bool atomic = (size_t)G::N * G::KH * G::KW * G::C * 4 <= (size_t)mmvae_knob("wr_atomic_kb", 256) * 1024;
+    float* slab = atomic ? p.cls[0].dWp : ctx->take(need);
     if (!slab) return 0;
     a.slab = slab;
-    for (int i = 0; i < G::NCLS; ++i) {
+    if (atomic) { a.atomic_dst = p.cls[0].dWp; a.atomic_kpad = p.cls[0].Kpad; }
+    for (int i = 0; i < G::NCLS && !atomic; ++i) {
         if (a.groups[i] == 0) continue;
         WgradRingJob j{};
         j.dst = p.cls[0].dWp; j.slab = slab + a.slab_off[i]; j.N = G::N; j.Kpad = p.cls[0].Kpad; j.C = G::C; j.Kc = G::NTAPS(i) * G::C;
