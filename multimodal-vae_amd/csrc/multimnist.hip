@@ -908,13 +908,19 @@ static int mm_step_body(MMPlan* Pp, const MMStepIO& io, int training, int do_bac
     if (do_backward) {
         sb.zero_ptr[1] = P.buf.gpk; sb.zero_bytes[1] = (size_t)P.gk.mat_elems * sizeof(float);
         sb.zero_ptr[2] = P.buf.grads; sb.zero_bytes[2] = (size_t)(P.nparams / 4) * 16;     // tail (< 4 floats) below
+        const int skipz = mmvae_knob("dbg_begin_skip_zero", 0);      // measurement aid (results are garbage): 1 gpk, 2 grads, 3 both
+        if (skipz & 1) sb.zero_ptr[1] = nullptr;
+        if (skipz & 2) sb.zero_ptr[2] = nullptr;
     }
     sb.p = DROP_P; sb.seed = io.seed; sb.step = io.step_ctr;
     if (training && !eps) { sb.eps = w.eps; sb.n_eps = (long long)B3 * D; eps = w.eps; }
     if (training && io.enc_dropout && !m1) { sb.mask[0] = w.m1; sb.n_mask[0] = (long long)2 * B * 400; m1 = w.m1; }
     if (training && io.enc_dropout && !m2) { sb.mask[1] = w.m2; sb.n_mask[1] = (long long)2 * B * 200; m2 = w.m2; }
     if (training && io.gru_dropout && !gk) { sb.mask[2] = w.gkeep; sb.n_mask[2] = (long long)4 * B3 * 100; gk = w.gkeep; }
-    if (io.pack_first)
+    const int skipb = mmvae_knob("dbg_begin_skip", 0);              // measurement aid (results are garbage): 1 no pack, 2 no random draws, 4 no workspace zeroing
+    if (skipb & 2) { sb.eps = nullptr; sb.mask[0] = sb.mask[1] = sb.mask[2] = nullptr; }
+    if (skipb & 4) sb.zero_ptr[0] = nullptr;
+    if (io.pack_first && !(skipb & 1))
         MMVAE_TRY(step_begin_with_pack(sb, P.buf.desc_dev, P.pk.d.data(), (int)P.pk.d.size(), P.buf.params, P.buf.packed, P.buf.packed_vec));
     MMVAE_TRY(ensure_streams(P));
     P.in_step = true;

@@ -304,3 +304,25 @@ def test_no_cpu_fallback():
     vae = M.MultimodalVAE(D)
     with pytest.raises(MMVAEError):
         vae(image=torch.zeros(2, 1, 50, 50), text=torch.zeros(2, 4, dtype=torch.long))
+
+
+@pytest.mark.parametrize("B", [12, 20])
+def test_fused_step_at_batches_not_a_multiple_of_8(B):
+    """Batch sizes that are multiples of 4 but not of 8 (round-3 ADVICE: the fused BatchNorm staging has kernels compiled for 8
+    images per workgroup only and no fallback; such batches now run the unfused chain): losses and every gradient tensor against the
+    oracle on the same inputs, forced to the oracle's greedy tokens."""
+    from multimodal_vae_amd.core import FusedELBOStep
+    dev = _dev()
+    st, P = _state_with_formula_params(dev)
+    image, text = R.formula_inputs("multimnist", B)
+    g = torch.Generator().manual_seed(77 + B)
+    eps = [torch.randn(B, D, generator=g) for _ in range(3)]
+    o_losses, o_outs = R.multimnist_step_losses(P, image, text, True, 1e-3, eps, None, None, None, 0.0, 0.0)
+    ft = torch.stack([o[1].detach().argmax(-1) for o in o_outs]).long()          # the oracle's greedy path (B,4) per pass
+    (o_losses[0] + o_losses[1] + o_losses[2]).backward()
+    eng = FusedELBOStep(st, B)
+    eng.enc_dropout = eng.gru_dropout = False
+    out = eng.forward_backward(image.to(dev), text.to(dev), True, True, eps=torch.stack(eps).to(dev).contiguous(),
+                               force_tokens=ft.reshape(3 * B, 4).to(dev).contiguous())
+    np.testing.assert_allclose(out.losses().cpu().numpy(), np.array([float(x.detach()) for x in o_losses]), rtol=1e-3)
+    _grad_checks(st, P, tot_tol=2e-3, tensor_tol=4e-2, label="multimnist b%d" % B)
