@@ -970,6 +970,7 @@ static int mm_step_body(MMPlan* Pp, const MMStepIO& io, int training, int do_bac
     if (io.tokens) td.tokens_out = io.tokens;
     td.target = io.text; td.nll_sum = w.sums + 4; td.dwords = do_backward ? w.dwords : nullptr;
     for (int k = 0; k < 3; ++k) td.nll_coef[k] = sk[k] ? 0.f : io.lambda_yx[k] / (float)(B * TXT_T);
+    if (const int half = mmvae_knob("dbg_text_rows_div", 0)) td.R = max(16, td.R / half);      // measurement aid (garbage results): the text decoder on a fraction of its rows
     MMVAE_TRY(launch_text_decoder_fwd(td, T));
     if (do_backward) MMVAE_TRY(txt_dec_bwd(P, td, w.dwords, w.dz_txt, T));
     // decoders on 3B rows, BatchNorm statistics per pass; last layer fused with sigmoid + BCE (+ gradient)
