@@ -34,10 +34,13 @@ struct Src {            // where a 16-byte chunk of the slot comes from
 // groups, every group is one more partial copy of dW
 // TGN_: the tap rows of a parity class are split over TGN workgroup classes (all of them read the class's plane): a stride-1 layer
 // has ONE parity class of KH*KW taps, more accumulators than a workgroup's registers hold
+// PAIR_: a workgroup of 2*WAVES waves takes TWO classes through ONE fill of the small image (waves 0..WAVES-1 the heavier class of
+// the pair, the others the lighter one): the small image crosses the fabric twice per sample instead of four times, and every
+// SIMD holds two waves, one of each class
 template <int C_, int N_, int AH_, int AW_, int OH_, int OW_, int KH_, int KW_, int ST_, int PAD_, int NS_, int IB_, int WAVES_, int SLOTS_, int WGQ_ = 0,
-          int TGN_ = 1>
+          int TGN_ = 1, int PAIR_ = 0>
 struct Geo {
-    static constexpr int WGQ = WGQ_, TGN = TGN_;
+    static constexpr int WGQ = WGQ_, TGN = TGN_, PAIR = PAIR_;
     static constexpr int C = C_, N = N_, AH = AH_, AW = AW_, OH = OH_, OW = OW_, KH = KH_, KW = KW_, ST = ST_, PAD = PAD_;
     static constexpr int NS = NS_, IB = IB_, WAVES = WAVES_, SLOTS = SLOTS_;
     static_assert(C % 32 == 0 && N % NS == 0 && NS % 32 == 0, "channel tiles are 32 wide");
@@ -101,20 +104,39 @@ struct Geo {
     static constexpr int sm_off(int nt, int kr) { return (nt * RPAD + kr) * 64; }
     static constexpr int bg_off(int c, int ct, int cell) { return SM_BYTES + (ct * NCELLP(c) + cell) * 64; }
 
-    // source of 16-byte chunk `ch` of a class-c slot
-    static constexpr Src src(int c, int ch) {
-        if (ch < SM_CHUNKS) {
-            const int nt = ch / (RPAD * 4), rem = ch % (RPAD * 4), kr = rem / 4, j = rem % 4;
-            if (nt >= NTN || kr >= ROWS) return Src{-1, 0};
-            return Src{0, (kr * N + nt * 32) * 2 + j * 16};
-        }
-        const int ch2 = ch - SM_CHUNKS;
+    // source of 16-byte chunk `ch` of the small region / chunk `ch2` of class c's big region
+    static constexpr Src src_small(int ch) {
+        const int nt = ch / (RPAD * 4), rem = ch % (RPAD * 4), kr = rem / 4, j = rem % 4;
+        if (nt >= NTN || kr >= ROWS) return Src{-1, 0};
+        return Src{0, (kr * N + nt * 32) * 2 + j * 16};
+    }
+    static constexpr Src src_big(int c, int ch2) {
         const int ct = ch2 / (NCELLP(c) * 4), rem = ch2 % (NCELLP(c) * 4), cell = rem / 4, j = rem % 4;
         if (ct >= CT || cell >= NCELL(c)) return Src{-1, 0};
         const int ib = cell / IMGCELLS(c), cc = cell % IMGCELLS(c);
         const int py = cc / LC(c) + DYMIN(c), px = cc % LC(c) + DXMIN(c);
         if (py < 0 || py >= PH(c) || px < 0 || px >= PW(c)) return Src{-1, 0};
         return Src{1, (((ib * AH + py * ST + cy(c)) * AW + px * ST + cx(c)) * C + ct * 32) * 2 + j * 16};
+    }
+    // source of 16-byte chunk `ch` of a class-c slot
+    static constexpr Src src(int c, int ch) { return ch < SM_CHUNKS ? src_small(ch) : src_big(c, ch - SM_CHUNKS); }
+
+    // ---- class pairs (PAIR): pair p = (the p-th heaviest class, the p-th lightest); slot = [small][big of A][big of B] in 1 KB pieces
+    static constexpr int NPAIR = NCLS / 2;
+    static constexpr int pair_a(int p) { return NCLS - 1 - p; }
+    static constexpr int pair_b(int p) { return p; }
+    static constexpr int p_bga(int) { return SM_USED; }
+    static constexpr int p_bgb(int p) { return SM_USED + BG_BYTES(pair_a(p)); }
+    static constexpr int p_bytes(int p) { return SM_USED + BG_BYTES(pair_a(p)) + BG_BYTES(pair_b(p)); }
+    static constexpr int p_max() { int r = 0; for (int p = 0; p < NPAIR; ++p) r = cmax(r, p_bytes(p)); return r; }
+    static constexpr int P_SLOT = rup(p_max(), 1024);
+    static constexpr int P_TOTAL = SLOTS * P_SLOT;
+    static constexpr int P_NF = cdiv(P_SLOT / 1024, 2 * WAVES);                      // DMA instructions per wave per fill (2*WAVES waves)
+    static constexpr Src src_pair(int p, int ch) {
+        if (ch < SM_USED / 16) return src_small(ch);
+        if (ch < p_bgb(p) / 16) return src_big(pair_a(p), ch - SM_USED / 16);
+        if (ch < p_bytes(p) / 16) return src_big(pair_b(p), ch - p_bgb(p) / 16);
+        return Src{-1, 0};
     }
 };
 

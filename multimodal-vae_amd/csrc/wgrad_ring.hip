@@ -221,6 +221,149 @@ __device__ __forceinline__ void wr_body(const WrArgs& a, const int ms, const int
     if (a.ts) { wait_vmcnt<0>(); stamp(); }
 }
 
+
+// Pair form (Geo::PAIR): 2*WAVES waves, the two classes of pair P behind ONE fill of the small image.  Waves 0..WAVES-1 multiply
+// class A = pair_a(P), the others class B; the batch loop, its barrier and the DMA issue are common.
+template <class G, int P>
+__device__ __forceinline__ void wr_body_pair(const WrArgs& a, const int ms, const int u0, const int u1, const int g, char* const smem) {
+    constexpr int WAVES = G::WAVES, W2 = 2 * WAVES, NF = G::P_NF, KST = G::KST, CT = G::CT, SLOT = G::P_SLOT, NTN = G::NTN, WC = G::WC;
+    constexpr int CA = G::pair_a(P), CB = G::pair_b(P), NPIECES = G::p_bytes(P) / 1024, SMP = G::SM_USED / 1024;
+    static_assert(G::SLOTS == 2, "the pair form waits for the whole fill at the barrier");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wave / WAVES, w4 = wave - half * WAVES;
+    unsigned long long t_start = 0, t_setup = 0, t_first = 0, t_wait = 0, t_loop = 0, t_issue = 0;
+    if (a.ts) t_start = __builtin_amdgcn_s_memrealtime();
+
+    int voff[NF];                                                // piece j of this wave = piece j*W2 + wave of the slot
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const wrgeo::Src s = G::src_pair(P, ((j * W2 + wave) * 64) + lane);
+        voff[j] = s.tensor < 0 ? OOB : s.off;
+    }
+    const int n0 = ms * G::NS;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16*>(a.S + n0), 0, (int)((size_t)a.nimg * G::OYX * G::N * 2 - (size_t)n0 * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16*>(a.Bg), 0, (int)((size_t)a.nimg * G::AH * G::AW * G::C * 2), 0x00020000);
+    const unsigned lds0 = (unsigned)(size_t)(lds_void*)smem;
+    auto issue = [&](int u, int slot) {
+        const bool live = u < u1 && !(a.dbg & 4);
+        const int soff_s = u * (G::IB * G::OYX * G::N * 2), soff_b = u * (G::IB * G::AH * G::AW * G::C * 2);
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const int piece = j * W2 + wave;                     // (wave-uniform)
+            if (piece >= NPIECES) continue;
+            const bool sm = piece < SMP;
+            const __amdgpu_buffer_rsrc_t r = sm ? rs : rb;
+            dma_1k(r, lds0 + slot * SLOT + piece * 1024, live ? voff[j] : OOB, sm ? soff_s : soff_b);
+        }
+    };
+    issue(u0, 0);
+
+    const int h = lane >> 5, q4 = (lane & 15) >> 2;
+    const int lanecol = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    const int wr = w4 % NTN, wc = w4 / NTN;
+    const int a_base = G::sm_off(wr, 8 * h + q4) + lanecol;
+    auto stamp = [&](int cls) {
+        if (a.ts && (tid & (WAVES * 64 - 1)) == 0 && half == 0) {
+            unsigned long long* t = a.ts + (size_t)blockIdx.x * 8;
+            t[0] = t_start; t[1] = t_setup; t[2] = t_first; t[3] = t_wait; t[4] = t_loop; t[5] = __builtin_amdgcn_s_memrealtime();
+            t[6] = (unsigned long long)(u1 - u0) | (t_issue << 16); t[7] = (unsigned long long)cls;
+        }
+    };
+    // one class's share of the workgroup: everything that depends on the class is inside; both shares run the same barriers
+    auto run = [&](auto cls_tag, const int bg_off) {
+        constexpr int CLS = decltype(cls_tag)::value;
+        constexpr int CPW = G::CPW(CLS), NCT = G::NCT(CLS), NTX = G::NTX(CLS), LC = G::LC(CLS), Kc = G::NTAPS(CLS) * G::C;
+        int rb0[KST], rb1[KST];
+#pragma unroll
+        for (int ks = 0; ks < KST; ++ks) {
+            const int kr = ks * 16 + 8 * h + q4;
+            rb0[ks] = bg_off + G::rowcell(CLS, kr) * 64 + lanecol;
+            rb1[ks] = bg_off + G::rowcell(CLS, kr + 4) * 64 + lanecol;
+        }
+        int coloff[CPW];
+#pragma unroll
+        for (int j = 0; j < CPW; ++j) {
+            const int col = wc + j * WC, cc = col < NCT ? col : 0;
+            const int k = cc / CT, ct = cc - k * CT;
+            coloff[j] = (ct * G::NCELLP(CLS) + (k / NTX) * LC + k % NTX) * 64;
+        }
+        f32x16 acc[CPW];
+#pragma unroll
+        for (int j = 0; j < CPW; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+        int slot = 0;
+        if (a.ts) t_setup = __builtin_amdgcn_s_memrealtime();
+        for (int u = u0; u < u1; ++u) {
+            unsigned long long tw = 0;
+            if (a.ts) tw = __builtin_amdgcn_s_memrealtime();
+            wait_vmcnt<0>();                                     // this wave's pieces of batch u have landed
+            __builtin_amdgcn_s_barrier();                        // ... everybody's; and everybody is done reading batch u-1
+            if (a.ts) { const unsigned long long t = __builtin_amdgcn_s_memrealtime(); if (u == u0) t_first = t; else t_wait += t - tw; }
+            unsigned long long ti = 0;
+            if (a.ts) ti = __builtin_amdgcn_s_memrealtime();
+            issue(u + 1, slot ^ 1);                              // into the slot batch u-1 was read from
+            if (a.ts) t_issue += __builtin_amdgcn_s_memrealtime() - ti;
+            const char* const sb = smem + slot * SLOT;
+            if (!(a.dbg & 2)) {
+                bf16x8 af[2], bfr[2][CPW];
+                af[0] = tr_pair_r(sb + a_base, sb + a_base + 256);
+#pragma unroll
+                for (int j = 0; j < CPW; ++j) bfr[0][j] = tr_pair_r(sb + rb0[0] + coloff[j], sb + rb1[0] + coloff[j]);
+#pragma unroll
+                for (int ks = 0; ks < KST; ++ks) {
+                    if (ks + 1 < KST) {
+                        af[(ks + 1) & 1] = tr_pair_r(sb + a_base + (ks + 1) * 1024, sb + a_base + (ks + 1) * 1024 + 256);
+#pragma unroll
+                        for (int j = 0; j < CPW; ++j)
+                            bfr[(ks + 1) & 1][j] = tr_pair_r(sb + rb0[ks + 1] + coloff[j], sb + rb1[ks + 1] + coloff[j]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < CPW; ++j)
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1], bfr[ks & 1][j], acc[j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            slot ^= 1;
+        }
+        wait_vmcnt<0>();
+        if (a.ts) t_loop = __builtin_amdgcn_s_memrealtime();
+        if (a.dbg & 1) { stamp(CLS); return; }
+        if (a.atomic_dst) {
+            float* const dsta = a.atomic_dst + (size_t)(n0 + wr * 32 + 4 * h) * a.atomic_kpad + (lane & 31);
+#pragma unroll
+            for (int j = 0; j < CPW; ++j) {
+                const int col = wc + j * WC;
+                if (col < NCT) {
+                    const int k = col / CT, ct = col - k * CT;
+                    const int tap = (G::tap_ty(CLS, 0) + (k / NTX) * G::ST) * G::KW + G::tap_tx(CLS, 0) + (k % NTX) * G::ST;
+                    float* d = dsta + tap * G::C + ct * 32;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) atomicAdd(d + (size_t)((e & 3) + 8 * (e >> 2)) * a.atomic_kpad, acc[j][e]);
+                }
+            }
+        } else {
+            float* const dst = a.slab + a.slab_off[CLS] + (size_t)g * G::N * Kc + (size_t)(n0 + wr * 32 + 4 * h) * Kc + (lane & 31);
+#pragma unroll
+            for (int j = 0; j < CPW; ++j) {
+                const int col = wc + j * WC;
+                if (col < NCT) {
+                    float* d = dst + col * 32;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) d[(size_t)((e & 3) + 8 * (e >> 2)) * Kc] = acc[j][e];
+                }
+            }
+        }
+        if (a.ts) { wait_vmcnt<0>(); stamp(CLS); }
+    };
+    if (half == 0) run(std::integral_constant<int, CA>{}, G::p_bga(P));
+    else run(std::integral_constant<int, CB>{}, G::p_bgb(P));
+}
+
 template <int I, int N, typename F>
 __device__ __forceinline__ void wr_static_for(F&& f) {
     if constexpr (I < N) {
@@ -230,13 +373,20 @@ __device__ __forceinline__ void wr_static_for(F&& f) {
 }
 
 template <class G>
-__global__ __launch_bounds__(G::WAVES * 64) void wgrad_ring_kernel(const WrArgs a) {
+__global__ __launch_bounds__(G::WAVES * 64 * (G::PAIR ? 2 : 1)) void wgrad_ring_kernel(const WrArgs a) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int jb = a.job[blockIdx.x];
-    const int cls = jb >> 12, rel = jb & 0xfff;
+    const int cls = jb >> 12, rel = jb & 0xfff;          // (pair form: `cls` is the pair, groups[] / job[] are per pair)
     const int ms = rel % G::MS, g = rel / G::MS;
     const int ng = a.groups[cls];
     const int u0 = (int)((long long)a.units * g / ng), u1 = (int)((long long)a.units * (g + 1) / ng);
+    if constexpr (G::PAIR != 0) {
+        wr_static_for<0, G::NPAIR>([&](auto ip) {
+            constexpr int P = decltype(ip)::value;
+            if (cls == P) wr_body_pair<G, P>(a, ms, u0, u1, g, smem);
+        });
+        return;
+    }
     wr_static_for<0, G::NCLS>([&](auto ic) {
         constexpr int CLS = decltype(ic)::value;
         if (cls == CLS) {
@@ -303,6 +453,10 @@ bool wr_matches(const WgradParams& p) {
 template <class G>
 int try_wr(const WgradParams& p, hipStream_t stream, WgradSlabCtx* ctx) {
     if (!wr_matches<G>(p)) return 0;
+    // pair form: opt-in.  Measured (gpurun_out/s2, DESIGN tried-and-lost): the loop is faster (hallucinate.6 without its epilogue 16.6
+    // against 23.9 us: 65 instead of 45 MFMAs per SIMD and batch in the same 1.6 us), but at equal workgroup count every class has
+    // twice the partial copies -- the atomic epilogue takes 6-9 us per workgroup instead of 3-5 -- and the step is 591-612 against 589 us
+    if (G::PAIR && !mmvae_knob("wr_pair", 0)) return 0;          // (the one-class-per-workgroup geometry of the same layer follows in the list)
     if (mmvae_knob("dbg_skip_wgrad", 0) == 2) return 1;         // measurement aid: the step without the ring-staged weight gradients
     const GatherCommon& c = p.c;
     const int nimg = c.groups * c.group_n;
@@ -320,34 +474,41 @@ int try_wr(const WgradParams& p, hipStream_t stream, WgradSlabCtx* ctx) {
     // (a batch costs a workgroup a fixed part -- the DMA issue -- next to its MFMAs: measured 0.66 us + 0.10 us per column tile
     //  on hallucinate.6; knob wr_bias = the fixed part in column tiles)
     const int bias = mmvae_knob("wr_bias", 6);
-    auto wgt = [&](int i) { return G::NCT(i) > 0 ? G::CPW(i) * G::WC + bias : 0; };
+    constexpr int NJ = G::PAIR ? G::NPAIR : G::NCLS;             // job classes: parity classes, or pairs of them
+    auto wgt = [&](int i) {
+        if (G::PAIR) return G::CPW(G::pair_a(i)) * G::WC + G::CPW(G::pair_b(i)) * G::WC + bias;
+        return G::NCT(i) > 0 ? G::CPW(i) * G::WC + bias : 0;
+    };
     int wsum = 0;
-    for (int i = 0; i < G::NCLS; ++i) wsum += wgt(i);
+    for (int i = 0; i < NJ; ++i) wsum += wgt(i);
     WrArgs a{};
     a.S = p.P; a.Bg = c.A; a.units = units; a.nimg = nimg; a.dbg = mmvae_knob("wr_dbg", 0);
     a.ts = reinterpret_cast<unsigned long long*>(((unsigned long long)(unsigned)mmvae_knob("wr_ts_hi", 0) << 32) | (unsigned)mmvae_knob("wr_ts_lo", 0));
     size_t need = 0;
     int total = 0;
-    for (int i = 0; i < G::NCLS; ++i) {
-        int g = G::NCT(i) > 0 ? (int)((long long)target * wgt(i) / ((long long)wsum * G::MS)) : 0;
-        g = G::NCT(i) > 0 ? std::max(1, std::min(g, units)) : 0;
+    int copies[WR_MAXCLS] = {};
+    for (int i = 0; i < NJ; ++i) {
+        int g = wgt(i) > 0 ? (int)((long long)target * wgt(i) / ((long long)wsum * G::MS)) : 0;
+        g = wgt(i) > 0 ? std::max(1, std::min(g, units)) : 0;
         a.groups[i] = g; total += g * G::MS;
+        if (G::PAIR) { copies[G::pair_a(i)] = g; copies[G::pair_b(i)] = g; } else copies[i] = g;
+    }
+    for (int i = 0; i < G::NCLS; ++i) {
         a.slab_off[i] = (long long)need;
-        need += (size_t)g * G::N * G::NTAPS(i) * G::C;
+        need += (size_t)copies[i] * G::N * G::NTAPS(i) * G::C;
     }
     if (total > WR_MAXJOBS) return 0;
     {   // Workgroup order.  The workgroups that read the same images (the classes and channel slices of one image range) should
-        // share an XCD and run at the same time: the small image then crosses the fabric once and the other three classes hit it in
-        // the XCD's L2 (the kernel runs at the fabric's rate: 57 MB of fills for 30 MB of operands on hallucinate.6).  Blocks b and
-        // b + 8 share an XCD (round-robin dispatch; speed only, never correctness): sort the jobs by their first image and deal
-        // runs of RUN consecutive jobs to the 8 block residues in turn.
+        // share an XCD and run at the same time: the small image then crosses the fabric once and the other classes may hit it in
+        // the XCD's L2.  Blocks b and b + 8 share an XCD (round-robin dispatch; speed only, never correctness): sort the jobs by
+        // their first image and deal runs of RUN consecutive jobs to the 8 block residues in turn.
         struct J { int u0, code; };
         std::vector<J> js;
-        for (int i = 0; i < G::NCLS; ++i)
+        for (int i = 0; i < NJ; ++i)
             for (int g = 0; g < a.groups[i]; ++g)
                 for (int m = 0; m < G::MS; ++m) js.push_back(J{(int)((long long)units * g / a.groups[i]), (i << 12) | (g * G::MS + m)});
         std::stable_sort(js.begin(), js.end(), [](const J& x, const J& y) { return x.u0 < y.u0; });
-        const int run = std::max(1, mmvae_knob("wr_run", G::NCLS * G::MS));
+        const int run = std::max(1, mmvae_knob("wr_run", NJ * G::MS));
         const int blk = 8 * run, full = total / blk * blk;
         for (int i = 0; i < total; ++i) {
             int b = i;
@@ -364,17 +525,18 @@ int try_wr(const WgradParams& p, hipStream_t stream, WgradSlabCtx* ctx) {
     a.slab = slab;
     if (atomic) { a.atomic_dst = p.cls[0].dWp; a.atomic_kpad = p.cls[0].Kpad; }
     for (int i = 0; i < G::NCLS && !atomic; ++i) {
-        if (a.groups[i] == 0) continue;
+        if (copies[i] == 0) continue;
         WgradRingJob j{};
         j.dst = p.cls[0].dWp; j.slab = slab + a.slab_off[i]; j.N = G::N; j.Kpad = p.cls[0].Kpad; j.C = G::C; j.Kc = G::NTAPS(i) * G::C;
-        j.copies = a.groups[i]; j.ntx = G::NTX(i); j.ty0 = G::tap_ty(i, 0); j.tx0 = G::tap_tx(i, 0); j.st = G::ST; j.kw = G::KW;
+        j.copies = copies[i]; j.ntx = G::NTX(i); j.ty0 = G::tap_ty(i, 0); j.tx0 = G::tap_tx(i, 0); j.st = G::ST; j.kw = G::KW;
         j.stream = stream;
         ctx->ring_jobs.push_back(j);
     }
+    constexpr int lds = G::PAIR ? G::P_TOTAL : G::TOTAL;
     static std::atomic<unsigned> attr_set{0};
     if (mmvae_first_use_on_device(attr_set))
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ring_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize, G::TOTAL);
-    MMVAE_LAUNCH((wgrad_ring_kernel<G>), dim3(total), dim3(G::WAVES * 64), (size_t)G::TOTAL, stream, a);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_ring_kernel<G>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    MMVAE_LAUNCH((wgrad_ring_kernel<G>), dim3(total), dim3(G::WAVES * 64 * (G::PAIR ? 2 : 1)), (size_t)lds, stream, a);
     const int rc = mmvae_check_launch("wgrad_ring");
     return rc == MMVAE_OK ? 1 : rc;
 }

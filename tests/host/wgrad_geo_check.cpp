@@ -113,10 +113,78 @@ void check(const char* name) {
            G::KST, G::max_cpw(), G::NF, G::NFS, fails ? "FAIL" : "ok");
 }
 
+
+// Pair form (Geo::PAIR): one slot = [small][big of class A][big of class B], filled by src_pair in 1 KB pieces; the waves of class X
+// read their big region at its base p_bga / p_bgb with the class's own cell layout.
+template <class G>
+void check_pair(const char* name) {
+    if constexpr (G::PAIR != 0) {
+        static_assert(G::NCLS % 2 == 0 && G::SLOTS == 2, "pairs of classes, two slots");
+        static_assert(G::P_TOTAL <= 160 * 1024, "LDS budget");
+        static_assert(G::SM_USED % 1024 == 0, "the small region ends on a DMA piece");
+        std::set<int> covered;
+        for (int p = 0; p < G::NPAIR; ++p) {
+            const int cls[2] = {G::pair_a(p), G::pair_b(p)}, base[2] = {G::p_bga(p), G::p_bgb(p)};
+            CHECK(covered.insert(cls[0]).second && covered.insert(cls[1]).second, "%s: pair %d repeats a class", name, p);
+            CHECK(G::BG_BYTES(cls[0]) % 1024 == 0 && G::BG_BYTES(cls[1]) % 1024 == 0, "%s: pair %d: a DMA piece straddles two regions", name, p);
+            CHECK(G::p_bytes(p) <= G::P_SLOT && G::P_NF * 2 * G::WAVES * 1024 >= G::p_bytes(p), "%s: pair %d: pieces", name, p);
+            std::vector<Elem> lds(G::P_SLOT / 2, Elem{-2, 0, 0, 0});
+            for (int ch = 0; ch < G::P_SLOT / 16; ++ch) {
+                const wrgeo::Src s = G::src_pair(p, ch);
+                // (the kernel picks the descriptor per 1 KB piece: pieces below SM_USED are small-side)
+                CHECK(s.tensor < 0 || (s.tensor == 0) == (ch * 16 < G::SM_USED), "%s: pair %d chunk %d: tensor %d on the wrong side of SM_USED", name, p, ch, s.tensor);
+                for (int e = 0; e < 8; ++e) {
+                    Elem v = ZERO;
+                    if (s.tensor == 0) {
+                        const int el = s.off / 2 + e, n = el % G::N, row = el / G::N;
+                        CHECK(row < G::ROWS, "%s: small source row %d", name, row);
+                        v = Elem{(short)(row / G::OYX), (short)((row % G::OYX) / G::OW), (short)((row % G::OYX) % G::OW), (short)n};
+                    } else if (s.tensor == 1) {
+                        const int el = s.off / 2 + e, chn = el % G::C, px = el / G::C;
+                        const int x = px % G::AW, y = (px / G::AW) % G::AH, img = px / (G::AW * G::AH);
+                        CHECK(img < G::IB, "%s: big source image %d", name, img);
+                        v = Elem{(short)(100 + img), (short)y, (short)x, (short)chn};
+                    }
+                    lds[ch * 8 + e] = v;
+                }
+            }
+            for (int kr = 0; kr < G::RPAD; ++kr) {
+                for (int nt = 0; nt < G::NTN; ++nt)
+                    for (int e = 0; e < 32; ++e) {
+                        const Elem got = lds[G::sm_off(nt, kr) / 2 + e];
+                        Elem want = ZERO;
+                        if (kr < G::ROWS) want = Elem{(short)(kr / G::OYX), (short)((kr % G::OYX) / G::OW), (short)((kr % G::OYX) % G::OW), (short)(nt * 32 + e)};
+                        CHECK(same(got, want), "%s: pair %d small row %d tile %d elem %d", name, p, kr, nt, e);
+                    }
+                if (kr >= G::ROWS) continue;
+                const int img = kr / G::OYX, oy = (kr % G::OYX) / G::OW, ox = (kr % G::OYX) % G::OW;
+                for (int side = 0; side < 2; ++side) {
+                    const int c = cls[side];
+                    for (int k = 0; k < G::NTAPS(c); ++k) {
+                        const int ty = G::tap_ty(c, k), tx = G::tap_tx(c, k);
+                        const int iy = oy * G::ST - G::PAD + ty, ix = ox * G::ST - G::PAD + tx;
+                        const bool inside = iy >= 0 && iy < G::AH && ix >= 0 && ix < G::AW;
+                        const int cell = G::rowcell(c, kr) + G::tapcell(c, k);
+                        for (int ct = 0; ct < G::CT; ++ct)
+                            for (int e = 0; e < 32; ++e) {
+                                const Elem got = lds[(base[side] + (ct * G::NCELLP(c) + cell) * 64) / 2 + e];
+                                const Elem want = inside ? Elem{(short)(100 + img), (short)iy, (short)ix, (short)(ct * 32 + e)} : ZERO;
+                                CHECK(same(got, want), "%s: pair %d class %d row %d tap (%d,%d) tile %d elem %d: got (%d,%d,%d,%d)", name, p, c, kr, ty, tx, ct, e,
+                                      got.img, got.y, got.x, got.ch);
+                            }
+                    }
+                }
+            }
+        }
+        CHECK((int)covered.size() == G::NCLS, "%s: the pairs cover %d of %d classes", name, (int)covered.size(), G::NCLS);
+        printf("%-14s pair form: slot %6d B x %d  DMA pieces/wave %d  %s\n", name, G::P_SLOT, G::SLOTS, G::P_NF, fails ? "FAIL" : "ok");
+    }
+}
+
 #include "wgrad_ring_geos.h"
 
 int main() {
-#define X(name, ...) check<wrgeo::Geo<__VA_ARGS__>>(#name);
+#define X(name, ...) check<wrgeo::Geo<__VA_ARGS__>>(#name); check_pair<wrgeo::Geo<__VA_ARGS__>>(#name);
     WGRAD_RING_GEOS(X)
 #undef X
     if (fails) { printf("%d failures\n", fails); return 1; }

@@ -31,8 +31,9 @@ def test_ring_kernel_equals_streamed_kernel(B):
     eng(img.to(dev), txt.to(dev)); st.ensure_packed(); torch.cuda.synchronize()
     sp = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-    def run(layer, ring, atomic_kb):
+    def run(layer, ring, atomic_kb, pair=0):
         call("mmvae_debug_set", b"wgrad_ring", ring)
+        call("mmvae_debug_set", b"wr_pair", pair)
         call("mmvae_debug_set", b"wr_atomic_kb", atomic_kb)
         st.gpk.zero_()
         call("mmvae_mm_bench_layer", eng.h, eng.ws.data_ptr(), eng.ws.numel(), layer.encode(), 1, sp)
@@ -43,10 +44,12 @@ def test_ring_kernel_equals_streamed_kernel(B):
             ref = run(layer, 0, 256)
             assert int((ref != 0).sum()) > 0 and bool(torch.isfinite(ref).all()), layer
             for atomic_kb in (0, 4096):                      # partial copies + reduce / fp32 atomics into the packed gradient
-                got = run(layer, 1, atomic_kb)
-                rel = float((ref - got).norm() / ref.norm())
-                assert rel < 2e-5, (layer, atomic_kb, rel)   # same bf16 operands, fp32 accumulation in another order
-                assert torch.equal(got == 0, ref == 0) or rel < 2e-5
+                for pair in (1, 0):                          # two parity classes per 8-wave workgroup / one per 4-wave workgroup
+                    got = run(layer, 1, atomic_kb, pair)
+                    rel = float((ref - got).norm() / ref.norm())
+                    assert rel < 2e-5, (layer, atomic_kb, pair, rel)   # same bf16 operands, fp32 accumulation in another order
+                    assert torch.equal(got == 0, ref == 0) or rel < 2e-5
     finally:
         call("mmvae_debug_set", b"wgrad_ring", 1)
         call("mmvae_debug_set", b"wr_atomic_kb", 256)
+        call("mmvae_debug_set", b"wr_pair", 0)
