@@ -17,7 +17,8 @@ struct PackDesc {
     long long bias_off;     // >= 0: column K of every row holds a bias folded into the GEMM (operand column K == 1.0)
     int b_nhi, b_nlo;       // source strides of that bias vector
     int first_block;        // prefix sum of 256-thread blocks over the table
-    int part;               // gradient descriptors: 1 = complete early in the step (decoders), 0 = with the encoders' backward
+    int part;               // gradient descriptors: 1 = complete early in the step (decoders), 0 = with the encoders' backward;
+                            // weight descriptors: the stage of the step that refreshes the copy (StepBeginArgs::pack_parts), 0 = the prologue
     int frag;               // 1: MFMA-fragment-major destination -- 16-row tile nt, 32-column k-step ks: the 64 lanes' 8-element
                             // vectors (lane = 16*(k/8 % 4) + n % 16) are one contiguous 1 KB block at ((nt*(Kpad/32) + ks)*64 + lane)*8
 };
@@ -172,6 +173,8 @@ struct StepBeginArgs {
     unsigned long long seed; const long long* step;
     // optional: the weight pack of the previous optimizer step rides in the same launch (step_begin_with_pack)
     const PackDesc* pack_table; int pack_nd; const float* pack_params; bf16* packed_bf; float* packed_f32; int pack_blocks;
+    unsigned pack_parts;                          // 0: every descriptor; else bit p: the descriptors with PackDesc::part == p (a step that
+                                                  // refreshes the copies its first kernels read in the prologue and the rest on a side stream)
 };
 int launch_step_begin(const StepBeginArgs& a, hipStream_t s);
 int step_begin_with_pack(StepBeginArgs& a, const PackDesc* table_dev, const PackDesc* table_host, int nd, const float* params,

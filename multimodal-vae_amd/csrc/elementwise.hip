@@ -14,13 +14,20 @@ inline int nblocks(long long n, int per = TPB, int cap = 4096) {
 }
 
 // ------------------------------------------------------------------ pack / unpack
+// the descriptor whose block range holds `block` (first_block ascending, first_block[0] == 0).  One load per lane + a ballot per 64
+// descriptors: the binary search this replaces was a chain of log2(nd) DEPENDENT global loads in front of every block's work
+// (~3.5 us per block: the pack of the step prologue took 12 us for 20 MB, a launch that skipped most descriptors still 15 us).
 __device__ __forceinline__ int find_desc(const PackDesc* t, int nd, int block) {
-    int lo = 0, hi = nd - 1;
-    while (lo < hi) {
-        int mid = (lo + hi + 1) >> 1;
-        if (t[mid].first_block <= block) lo = mid; else hi = mid - 1;
+    const int lane = threadIdx.x & 63;
+    int found = 0;
+    for (int base = 0; base < nd; base += 64) {
+        const int i = base + lane;
+        const bool le = i < nd && t[i].first_block <= block;
+        const unsigned long long m = __ballot(le);
+        found += __popcll(m);
+        if (m != ~0ull) break;
     }
-    return lo;
+    return __builtin_amdgcn_readfirstlane(found > 0 ? found - 1 : 0);
 }
 // q = r / d, rem = r % d for 0 <= r < 2^23 with inv = 1.0f/d (one correction step each way)
 __device__ __forceinline__ int fast_divmod_ew(int r, int d, float inv, int& rem) {
@@ -40,9 +47,10 @@ __device__ __forceinline__ long long pack_src(const PackDesc& d, int n, int k) {
 
 // one thread = 8 consecutive columns of one packed row (16-byte bf16 store); Kpad is a multiple of 8
 __device__ __forceinline__ void pack_block(const PackDesc* __restrict__ table, int nd, const float* __restrict__ params,
-                                           bf16* __restrict__ packed_bf, float* __restrict__ packed_f32, int block) {
+                                           bf16* __restrict__ packed_bf, float* __restrict__ packed_f32, int block, unsigned parts = 0u) {
     const int di = find_desc(table, nd, block);
     const PackDesc d = table[di];
+    if (parts != 0u && !((parts >> (d.part & 31)) & 1u)) return;
     // 32-bit index math with reciprocal divisions (packed matrices have < 2^23 vectors; launch_pack checks)
     const int v = (int)(block - d.first_block) * TPB + threadIdx.x;
     const int vpr = d.Kpad / 8;
@@ -457,7 +465,7 @@ __global__ __launch_bounds__(TPB) void step_begin_kernel(const StepBeginArgs a) 
     // the first pack_blocks workgroups refresh the bf16 GEMM copies of the weights (what pack_kernel does: after an
     // optimizer step); the others zero the accumulators and draw the step's random numbers -- independent work, one launch
     if ((int)blockIdx.x < a.pack_blocks) {
-        pack_block(a.pack_table, a.pack_nd, a.pack_params, a.packed_bf, a.packed_f32, blockIdx.x);
+        pack_block(a.pack_table, a.pack_nd, a.pack_params, a.packed_bf, a.packed_f32, blockIdx.x, a.pack_parts);
         return;
     }
     const long long gtid = (long long)(blockIdx.x - a.pack_blocks) * TPB + threadIdx.x, gstride = (long long)(gridDim.x - a.pack_blocks) * TPB;

@@ -20,6 +20,7 @@ struct MMPlan : PlanBase {
     // text packs
     struct GruIdx { int wih, whh, wihT, whhT, g_wih, g_whh; long long bih, bhh; } te_f, te_r, td0, td1;
     const float* step_image = nullptr;      // the image batch of the running fused step (conv1's weight gradient rebuilds its patches)
+    hipEvent_t ev_dz = nullptr;             // fused step: completion of the text decoder's backward kernel (what the main chain joins on)
     int te_h2p, te_h2pT, g_te_h2p, td_z2h, td_z2hT, g_td_z2h, td_h2o, td_h2oT, g_td_h2o;
     // fused classifier tail (mlp_tail.hip; n_latents = 100 only): fragment-major copies of classifier.3 / classifier.6
     bool mlp_tail = false;
@@ -185,6 +186,26 @@ void build_plan(MMPlan& P) {
     {
         const long long w = off(P, "text_decoder.h2o.weight");
         P.td_h2o = rt(w, 12, 100 + D, false); P.td_h2oT = rt(w, 12, 100 + D, true); P.g_td_h2o = gw(w, 12, 100 + D, P.kx);
+    }
+    // Stage of the fused step that refreshes each bf16 copy after an optimizer step (mm_step_body; PackDesc::part of the WEIGHT table):
+    //   0  the prologue on the main stream: what the image encoder's FORWARD reads (it starts right behind the prologue)
+    //   1  the second-modality stream, in front of the text encoder: every text_encoder.* / text_decoder.* copy
+    //   2  the second-modality stream, behind the text encoder's forward: image_decoder.* and the copies only the image encoder's
+    //      BACKWARD reads (data-gradient forms) -- the main chain joins that stream before the product of experts, long before it needs them
+    // The gather that makes these copies is the slowest part of the prologue (12 of 26 us on the main chain with everything in stage 0).
+    for (PackDesc& d : P.pk.d) {
+        d.part = 0;
+        for (const ParamInfo& pi : P.params)
+            if (d.src_off >= pi.offset && d.src_off < pi.offset + pi.numel)
+                d.part = pi.name.rfind("text_", 0) == 0 ? 1 : pi.name.rfind("image_decoder.", 0) == 0 ? 2 : 0;
+    }
+    {
+        auto late = [&](int idx) { if (idx >= 0) P.pk.d[idx].part = 2; };
+        for (int l = 0; l < 4; ++l)
+            for (int i = 0; i < 4; ++i) { late(P.conv[l].pk_dgrad[i]); late(P.conv[l].pk_dgrad_f[i]); }
+        for (int i = 0; i < 4; ++i) late(P.fc[0].pk_dgrad4[i]);
+        late(P.fc[1].pk_dgrad); late(P.fc[2].pk_dgrad);
+        if (P.mlp_tail) { late(P.mt_w3t); late(P.mt_w2t); }
     }
     // gradient descriptors of the decoders (image_decoder.*, text_decoder.*): complete before the encoders' backward has run
     // (MMStepIO::dp_split scatters them into the flat gradient buffer early)
@@ -790,7 +811,20 @@ int txt_dec_bwd(MMPlan& P, const TextDecArgs& f, const float* dwords, float* dz,
     a.g_embed = G + off(P, "text_decoder.embed.weight");
     a.g_b[0] = G + P.td0.bih; a.g_b[1] = G + P.td0.bhh; a.g_b[2] = G + P.td1.bih; a.g_b[3] = G + P.td1.bhh;
     a.g_h2o_bias = G + off(P, "text_decoder.h2o.bias"); a.g_z2h_bias = G + off(P, "text_decoder.z2h.bias");
+    // In the fused step the main chain needs dz (and the NLL sums) of THIS kernel, not the weight gradients enqueued behind it on the
+    // same stream: the join is the kernel's own completion event (a join on "everything enqueued on T so far" made the main chain wait
+    // for ~45 us of weight-gradient launches; measured on the traces of round 4: the second-modality stream was co-critical)
+    P.ev_dz = nullptr;
+    const bool own_ev = P.in_step && s == P.st_text && mmvae_knob("mm_dz_event", 1) != 0;
+    if (own_ev) {
+        P.ev_dz = next_ev(P);
+        if (!P.capturing && !mmvae_knob("no_stop_events", 0)) mmvae_arm_stop_event(P.ev_dz);
+    }
     MMVAE_TRY(launch_text_decoder_bwd(a, s));
+    if (own_ev && (mmvae_take_stop_event() != nullptr || P.capturing || mmvae_knob("no_stop_events", 0)) && hipEventRecord(P.ev_dz, s) != hipSuccess) {
+        mmvae_set_error("text decoder event failed: %s", hipGetErrorString(hipGetLastError()));
+        return MMVAE_EHIP;
+    }
     // the six weight gradients of the text decoder: one grouped launch (128x128 tile class) + the thin h2o one
     WgradParams list[6];
     int nl = 0;
@@ -903,14 +937,21 @@ static int mm_step_body(MMPlan* Pp, const MMStepIO& io, int training, int do_bac
     //      device step counter) unless the caller injected them
     const float* eps = io.eps;
     const uint8_t *m1 = io.enc_mask1, *m2 = io.enc_mask2, *gk = io.gru_keep;
-    StepBeginArgs sb{};
+    // Staged prologue (knob mm_stage_begin, default on): the main stream's launch zeroes the workspace accumulators, draws the random
+    // numbers and refreshes only the weight copies the image encoder's forward reads; the gradient buffers (first written in the
+    // backward pass) and the other copies are done on the second-modality stream, which the main chain joins in front of the
+    // product of experts anyway.  26 -> 9 us of prologue on the main chain.
+    const bool serial0 = mmvae_serial();
+    const bool staged = mmvae_knob("mm_stage_begin", 1) != 0 && !serial0;
+    StepBeginArgs sb{}, sb2{};
     sb.zero_ptr[0] = w.zero_begin; sb.zero_bytes[0] = w.zero_bytes;
+    StepBeginArgs& sz = staged ? sb2 : sb;
     if (do_backward) {
-        sb.zero_ptr[1] = P.buf.gpk; sb.zero_bytes[1] = (size_t)P.gk.mat_elems * sizeof(float);
-        sb.zero_ptr[2] = P.buf.grads; sb.zero_bytes[2] = (size_t)(P.nparams / 4) * 16;     // tail (< 4 floats) below
+        sz.zero_ptr[1] = P.buf.gpk; sz.zero_bytes[1] = (size_t)P.gk.mat_elems * sizeof(float);
+        sz.zero_ptr[2] = P.buf.grads; sz.zero_bytes[2] = (size_t)(P.nparams / 4) * 16;     // tail (< 4 floats) below
         const int skipz = mmvae_knob("dbg_begin_skip_zero", 0);      // measurement aid (results are garbage): 1 gpk, 2 grads, 3 both
-        if (skipz & 1) sb.zero_ptr[1] = nullptr;
-        if (skipz & 2) sb.zero_ptr[2] = nullptr;
+        if (skipz & 1) sz.zero_ptr[1] = nullptr;
+        if (skipz & 2) sz.zero_ptr[2] = nullptr;
     }
     sb.p = DROP_P; sb.seed = io.seed; sb.step = io.step_ctr;
     if (training && !eps) { sb.eps = w.eps; sb.n_eps = (long long)B3 * D; eps = w.eps; }
@@ -920,8 +961,11 @@ static int mm_step_body(MMPlan* Pp, const MMStepIO& io, int training, int do_bac
     const int skipb = mmvae_knob("dbg_begin_skip", 0);              // measurement aid (results are garbage): 1 no pack, 2 no random draws, 4 no workspace zeroing
     if (skipb & 2) { sb.eps = nullptr; sb.mask[0] = sb.mask[1] = sb.mask[2] = nullptr; }
     if (skipb & 4) sb.zero_ptr[0] = nullptr;
-    if (io.pack_first && !(skipb & 1))
+    const bool pack_now = io.pack_first && !(skipb & 1);
+    if (pack_now) {
         MMVAE_TRY(step_begin_with_pack(sb, P.buf.desc_dev, P.pk.d.data(), (int)P.pk.d.size(), P.buf.params, P.buf.packed, P.buf.packed_vec));
+        if (staged) sb.pack_parts = 1u << 0;
+    }
     MMVAE_TRY(ensure_streams(P));
     P.in_step = true;
     {
@@ -943,9 +987,22 @@ static int mm_step_body(MMPlan* Pp, const MMStepIO& io, int training, int do_bac
     hipStream_t T = serial ? s : P.st_text;
     // ---- encoders: image features once for passes 1 and 2 (main), text encoder once for passes 1 and 3 (side)
     if (T != s) MMVAE_TRY(fork_to(P, T));
+    if (staged && pack_now) {       // stage 1: the text copies, in front of the text encoder
+        StepBeginArgs st1{};
+        MMVAE_TRY(step_begin_with_pack(st1, P.buf.desc_dev, P.pk.d.data(), (int)P.pk.d.size(), P.buf.params, P.buf.packed, P.buf.packed_vec));
+        st1.pack_parts = 1u << 1;
+        MMVAE_TRY(launch_step_begin(st1, T));
+    }
     {
         TextEncArgs a = te_args(P, io.text, w.txtout, do_backward);
         MMVAE_TRY(launch_text_encoder_fwd(a, T));
+    }
+    if (staged && (pack_now || sb2.zero_ptr[1] || sb2.zero_ptr[2])) {      // stage 2: gradient buffers + the copies of the decoders / the backward pass
+        if (pack_now) {
+            MMVAE_TRY(step_begin_with_pack(sb2, P.buf.desc_dev, P.pk.d.data(), (int)P.pk.d.size(), P.buf.params, P.buf.packed, P.buf.packed_vec));
+            sb2.pack_parts = 1u << 2;
+        }
+        MMVAE_TRY(launch_step_begin(sb2, T));
     }
     P.step_image = io.image;
     // B % 8: the fused layers have no fallback kernel ("forced" launches) and conv4's geometry is compiled for 8 images per
@@ -1004,7 +1061,17 @@ static int mm_step_body(MMPlan* Pp, const MMStepIO& io, int training, int do_bac
     P.deferred.clear();
     P.defer_wgrad = false;
     if (img_groups > 0) rc = dec_bwd(P, w.dlogit, img_groups, w.dz_img, s, fuse_tail, fuse, 3, training);
-    if (rc == MMVAE_OK) rc = edge(P, T, s);          // dz of the text decoder
+    if (rc == MMVAE_OK) {                            // dz of the text decoder
+        const int k = mmvae_knob("dbg_skip_edges", 0);
+        if (P.ev_dz && T != s) {
+            if (k != 1 && k != 3 && hipStreamWaitEvent(s, P.ev_dz, 0) != hipSuccess) {
+                mmvae_set_error("stream join failed: %s", hipGetErrorString(hipGetLastError()));
+                rc = MMVAE_EHIP;
+            }
+        } else {
+            rc = edge(P, T, s);
+        }
+    }
     const bool dp_split = io.dp_split && !io.defer_unpack;
     if (dp_split && rc == MMVAE_OK) {
         // Data-parallel step: every gradient of image_decoder.* and text_decoder.* has been issued -- on s (which has just

@@ -78,6 +78,7 @@ struct TextDecArgs {
     bf16* h0p_bf; bf16* mid_bf; bf16* h1p_bf;   // [4][R][128]
     bf16* hz_bf;                   // [4][R][kx]
     bf16* z_bf;                    // [R][kz]
+    unsigned long long* ts;        // measurement aid (knobs txt_ts_lo / txt_ts_hi, set by the launcher): s_memrealtime stamps of workgroup 0's phases, or null
 };
 int launch_text_decoder_fwd(const TextDecArgs& a, hipStream_t s);
 

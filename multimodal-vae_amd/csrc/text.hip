@@ -55,6 +55,56 @@ __device__ __forceinline__ void rowtile_gemm(const bf16* A, int lda, int ksteps,
     }
 }
 
+// The same product with the wave's weight fragments held by the CALLER (registers that live across the whole recurrence, or an LDS
+// copy of the fragment-major pack): the weights of a GRU do not change between time steps, and re-reading them from L2 was 6-8 us
+// of every GEMM phase (in-kernel stamps: 264 KB per workgroup and step at about half the per-CU L2 rate).
+template <int KS, int MAXT>
+__device__ __forceinline__ void load_wfrags(bf16x8 (&bw)[MAXT][KS], const bf16* __restrict__ Wp, int ntiles, int wave, int lane) {
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        const int nt = min(wave + t * NW, ntiles - 1);
+        const bf16* w = Wp + ((size_t)nt * KS * 64 + lane) * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) bw[t][ks] = *reinterpret_cast<const bf16x8*>(w + ks * 512);
+    }
+}
+template <int KS, int MAXT>
+__device__ __forceinline__ void rowtile_gemm_w(const bf16* A, int lda, const bf16x8 (&bw)[MAXT][KS], int ntiles, float* out, int ldo, int wave, int lane) {
+    const int fr = lane & 15, fq = lane >> 4;
+    bf16x8 af[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) af[ks] = *reinterpret_cast<const bf16x8*>(A + fr * lda + ks * 32 + fq * 8);
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        const int nt = wave + t * NW;
+        if (nt >= ntiles) break;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], bw[t][ks], acc, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[(fq * 4 + j) * ldo + nt * 16 + fr] = acc[j];
+    }
+}
+// ... with the fragments in LDS (wl: the pack's own layout, one conflict-free ds_read_b128 per fragment)
+template <int KS, int MAXT>
+__device__ __forceinline__ void rowtile_gemm_lds(const bf16* A, int lda, const bf16* wl, int ntiles, float* out, int ldo, int wave, int lane) {
+    const int fr = lane & 15, fq = lane >> 4;
+    bf16x8 af[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) af[ks] = *reinterpret_cast<const bf16x8*>(A + fr * lda + ks * 32 + fq * 8);
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        const int nt = wave + t * NW;
+        if (nt >= ntiles) break;
+        const bf16* w = wl + ((size_t)nt * KS * 64 + lane) * 8;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], *reinterpret_cast<const bf16x8*>(w + ks * 512), acc, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[(fq * 4 + j) * ldo + nt * 16 + fr] = acc[j];
+    }
+}
+
 // GRU gate math for 16 rows (PyTorch gate order r,z,n). hf: fp32 state in/out, hb: bf16 copy for the next MFMA.
 // save: [5][R][100] (r, z, n, W_hn h + b_hn, h_prev) or null.
 __device__ __forceinline__ void gru_gates(const float* gi, const float* gh, const float* bih,
@@ -292,7 +342,7 @@ __device__ __forceinline__ DecLds dec_lds(char* smem, int kx, int kz) {
     L.h1b = L.midb + TR * (HP + 8);
     return L;
 }
-inline size_t dec_lds_bytes(int kx, int kz) {
+__host__ __device__ inline size_t dec_lds_bytes(int kx, int kz) {
     return (size_t)(2 * TR * GL + 2 * TR * H + TR * 128 + TR * 16 + 2528) * 4 +
            (size_t)(2 * TR * (kx + 8) + TR * (kz + 8) + 3 * TR * (HP + 8)) * 2;
 }
@@ -411,6 +461,178 @@ __global__ __launch_bounds__(NTHR) void text_decoder_fwd_kernel(const TextDecArg
 #pragma unroll
         for (int p = 0; p < 4; ++p)
             if (nll[p] != 0.f) atomicAdd(a.nll_sum + (blockIdx.x % MMVAE_LOSS_SLOTS) * 16 + p, nll[p]);
+    }
+}
+
+
+// GRU gate math with the by-products of the NEXT phase written in the same pass (one barrier less per layer and time step):
+//   drop: hb2[row][j] = keep ? h_new * scale : 0   (the inter-layer dropout of nn.GRU: layer 1's input)
+//   else: hb2[row][j] = h_new                        (layer 1's state copied into the [h1 | z] operand of the output projection)
+__device__ __forceinline__ void gru_gates2(const float* gi, const float* gh, const float* bih, const float* bhh, float* hf, bf16* hb, int ldh,
+                                           int r0, int R, float* save, bf16* hb2, int ldh2, const uint8_t* keep, float keep_scale, bool drop, int tid) {
+    for (int idx = tid; idx < TR * H; idx += NTHR) {
+        const int row = idx / H, j = idx - row * H;
+        const float* a = gi + row * GL;
+        const float* b = gh + row * GL;
+        const float r = sigm(a[j] + bih[j] + b[j] + bhh[j]);
+        const float z = sigm(a[H + j] + bih[H + j] + b[H + j] + bhh[H + j]);
+        const float ghn = b[2 * H + j] + bhh[2 * H + j];
+        const float n = tanh_fast(a[2 * H + j] + bih[2 * H + j] + r * ghn);
+        const float hp = hf[row * H + j];
+        const float hn = (1.0f - z) * n + z * hp;
+        hf[row * H + j] = hn;
+        hb[row * ldh + j] = (bf16)hn;
+        float v2 = hn;
+        if (drop && keep && r0 + row < R) v2 = keep[(size_t)(r0 + row) * H + j] ? hn * keep_scale : 0.f;
+        hb2[row * ldh2 + j] = (bf16)v2;
+        if (save && r0 + row < R) {
+            const size_t o = (size_t)(r0 + row) * H + j, pl = (size_t)R * H;
+            save[o] = r; save[pl + o] = z; save[2 * pl + o] = n; save[3 * pl + o] = ghn; save[4 * pl + o] = hp;
+        }
+    }
+}
+
+// Forward of the text decoder with FIVE barriers per time step (the first version above has ten): the dropout of layer 0's output
+// and the copy of layer 1's state ride in the gate passes, and the log-softmax / NLL / greedy argmax run on 16 lanes per row
+// (shuffle reductions) in the same phase that embeds the fed-back token for the next step.
+// KSX: k-steps of the [c_in | z] operand (kx / 32; 7 at n_latents = 100): the fragment registers of a GEMM are sized by it, and the
+// two GEMMs of a phase have all their weight loads in flight together -- one step too many spilled to scratch in the hot loop
+template <int KSX>
+__global__ __launch_bounds__(NTHR) void text_decoder_fwd2_kernel(const TextDecArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DecLds L = dec_lds(smem, a.kx, a.kz);
+    constexpr int LH = HP + 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = blockIdx.x * TR, R = a.R, D = a.D;
+    zero_bf(L.x0b, 2 * TR * L.LX + TR * L.LZ + 3 * TR * LH, tid);
+    float* c_emb = L.cst; float* c_b = L.cst + 1200; float* c_h2o = L.cst + 2400; float* c_z2h = L.cst + 2416;
+    for (int i = tid; i < 1200; i += NTHR) c_emb[i] = a.embed[i];
+    for (int i = tid; i < 300; i += NTHR) {
+        c_b[i] = a.l0.bih[i]; c_b[300 + i] = a.l0.bhh[i]; c_b[600 + i] = a.l1.bih[i]; c_b[900 + i] = a.l1.bhh[i];
+    }
+    if (tid < TXT_V) c_h2o[tid] = a.h2o_bias[tid];
+    if (tid < H) c_z2h[tid] = a.z2h_bias[tid];
+    __syncthreads();
+    for (int idx = tid; idx < TR * D; idx += NTHR) {
+        int row = idx / D, j = idx - row * D;
+        float z = (r0 + row < R) ? a.z[(size_t)(r0 + row) * D + j] : 0.f;
+        L.zf[row * 128 + j] = z;
+        bf16 zb = (bf16)z;
+        L.zb[row * L.LZ + j] = zb;
+        L.x0b[row * L.LX + H + j] = zb;
+        L.hzb[row * L.LX + H + j] = zb;
+    }
+    for (int idx = tid; idx < TR * H; idx += NTHR) {       // x0 of step 0: swish(embed(SOS))   (multimnist/utils.py:17, model.py:299)
+        const int row = idx / H, j = idx - row * H;
+        const float e = c_emb[10 * H + j];
+        L.x0b[row * L.LX + j] = (bf16)(e / (1.0f + expf(-e)));
+    }
+    __syncthreads();
+    save_tile(L.zb, L.LZ, a.kz, a.z_bf, a.kz, r0, R, tid);
+    rowtile_gemm<4, 1>(L.zb, L.LZ, a.kz / 32, a.z2h, a.kz, 7, L.gi, GL, wave, lane);
+    __syncthreads();
+    for (int idx = tid; idx < TR * H; idx += NTHR) {
+        int row = idx / H, j = idx - row * H;
+        float h = L.gi[row * GL + j] + c_z2h[j];
+        L.h0f[idx] = h; L.h1f[idx] = h;
+        L.h0b[row * LH + j] = (bf16)h; L.h1b[row * LH + j] = (bf16)h;
+    }
+    // ---- the GRU weights stay on the CU for the whole recurrence: W_ih0, W_hh0, W_ih1 as this wave's fragments in registers
+    //      (21 + 12 + 12 fragments), W_hh1 as a copy of its fragment-major pack in LDS (19 tiles x 4 k-steps x 1 KB)
+    static_assert(KSX == 7, "the resident form is sized for kx = 224 (n_latents = 100)");
+    constexpr int NT = GL / 16;                               // 19 column tiles
+    bf16* wl = reinterpret_cast<bf16*>(smem + dec_lds_bytes(KSX * 32, 128));
+    for (int i = tid; i < NT * 4 * 64; i += NTHR)
+        *reinterpret_cast<bf16x8*>(wl + (size_t)i * 8) = *reinterpret_cast<const bf16x8*>(a.l1.whh + (size_t)i * 8);
+    // (all four in registers spilled 53 VGPRs: W_hh0's fragments are re-read once per step instead -- issued behind layer 1's MFMAs,
+    //  a whole phase ahead of their use, so the L2 latency is never waited for)
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 w_ih0[3][KSX], w_ih1[3][4];
+    load_wfrags<KSX, 3>(w_ih0, a.l0.wih, NT, wave, lane);
+    load_wfrags<4, 3>(w_ih1, a.l1.wih, NT, wave, lane);
+    __syncthreads();
+    float nll[4] = {0.f, 0.f, 0.f, 0.f};
+    const size_t pl128 = (size_t)R * HP, plx = (size_t)R * a.kx;
+    // softmax phase: thread (row, c) = (tid / 16, tid % 16) of the first 256 threads
+    const int srow = (tid >> 4) & 15, sc = tid & 15;
+    const bool srow_ok = r0 + srow < R;
+    int nts = 0;
+    auto stamp = [&]() { if (a.ts && blockIdx.x == 0 && tid == 0) a.ts[nts++] = __builtin_amdgcn_s_memrealtime(); };
+    stamp();
+#pragma unroll 1
+    for (int i = 0; i < TXT_T; ++i) {
+        save_tile(L.x0b, L.LX, a.kx, a.x0_bf ? a.x0_bf + i * plx : nullptr, a.kx, r0, R, tid);
+        save_tile(L.h0b, LH, HP, a.h0p_bf ? a.h0p_bf + i * pl128 : nullptr, HP, r0, R, tid);
+        save_tile(L.h1b, LH, HP, a.h1p_bf ? a.h1p_bf + i * pl128 : nullptr, HP, r0, R, tid);
+        rowtile_gemm_w<KSX, 3>(L.x0b, L.LX, w_ih0, NT, L.gi, GL, wave, lane);
+        rowtile_gemm<4, 3>(L.h0b, LH, HP / 32, a.l0.whh, HP, NT, L.gh, GL, wave, lane);
+        __syncthreads();
+        stamp();
+        gru_gates2(L.gi, L.gh, c_b, c_b + 300, L.h0f, L.h0b, LH, r0, R, a.gates ? a.gates + (size_t)(i * 2 + 0) * 5 * R * H : nullptr,
+                   L.midb, LH, a.keep ? a.keep + (size_t)i * R * H : nullptr, a.keep_scale, true, tid);
+        __syncthreads();
+        stamp();
+        save_tile(L.midb, LH, HP, a.mid_bf ? a.mid_bf + i * pl128 : nullptr, HP, r0, R, tid);
+        rowtile_gemm_w<4, 3>(L.midb, LH, w_ih1, NT, L.gi, GL, wave, lane);
+        rowtile_gemm_lds<4, 3>(L.h1b, LH, wl, NT, L.gh, GL, wave, lane);
+        __syncthreads();
+        stamp();
+        gru_gates2(L.gi, L.gh, c_b + 600, c_b + 900, L.h1f, L.h1b, LH, r0, R, a.gates ? a.gates + (size_t)(i * 2 + 1) * 5 * R * H : nullptr,
+                   L.hzb, L.LX, nullptr, 1.f, false, tid);
+        __syncthreads();
+        stamp();
+        save_tile(L.hzb, L.LX, a.kx, a.hz_bf ? a.hz_bf + i * plx : nullptr, a.kx, r0, R, tid);
+        rowtile_gemm<KSX, 1>(L.hzb, L.LX, a.kx / 32, a.h2o, a.kx, 1, L.lg, 16, wave, lane);
+        __syncthreads();
+        stamp();
+        if (tid < 256) {            // (whole waves: the shuffles below need every lane of a 16-lane group)
+            const bool cv = sc < TXT_V;
+            const float v = cv ? L.lg[srow * 16 + sc] + c_h2o[sc] : -INFINITY;
+            float mx = v;
+#pragma unroll
+            for (int o = 8; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
+            float se = cv ? expf(v - mx) : 0.f;
+#pragma unroll
+            for (int o = 8; o >= 1; o >>= 1) se += __shfl_xor(se, o, 16);
+            const float lp = v - (mx + logf(se));
+            float bv = cv ? lp : -INFINITY; int best = sc;          // first maximum, like torch.max
+#pragma unroll
+            for (int o = 8; o >= 1; o >>= 1) {
+                const float ov = __shfl_xor(bv, o, 16); const int oi = __shfl_xor(best, o, 16);
+                if (ov > bv || (ov == bv && oi < best)) { bv = ov; best = oi; }
+            }
+            int tok = 10;
+            if (srow_ok) {
+                const size_t o = ((size_t)(r0 + srow) * TXT_T + i) * TXT_V;
+                if (cv) a.words[o + sc] = lp;
+                if (a.tokens_out && sc == 0) a.tokens_out[(size_t)(r0 + srow) * TXT_T + i] = best;
+                if (a.target) {
+                    const int pass = (r0 + srow) / a.rows_per_pass, b = (r0 + srow) - pass * a.rows_per_pass;
+                    const int tg = (int)a.target[(size_t)b * TXT_T + i];
+                    if (cv && sc == tg) {
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) nll[p] += (p == (pass & 3)) ? -lp : 0.f;
+                    }
+                    if (a.dwords && cv) a.dwords[o + sc] = (sc == tg) ? -a.nll_coef[pass & 3] : 0.f;
+                }
+                tok = a.force_tokens ? (int)a.force_tokens[(size_t)(r0 + srow) * TXT_T + i] : best;
+            }
+            // c_in of the next step = swish(embed(token))   (model.py:299-300); rows past the batch keep feeding SOS
+            if (i + 1 < TXT_T)
+                for (int j = sc; j < H; j += 16) {
+                    const float e = c_emb[tok * H + j];
+                    L.x0b[srow * L.LX + j] = (bf16)(e / (1.0f + expf(-e)));
+                }
+        }
+        __syncthreads();
+        stamp();
+    }
+    if (a.target && a.nll_sum) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const float sum = wave_sum(nll[p]);
+            if (lane == 0 && sum != 0.f) atomicAdd(a.nll_sum + (blockIdx.x % MMVAE_LOSS_SLOTS) * 16 + p, sum);
+        }
     }
 }
 
@@ -541,8 +763,8 @@ __global__ __launch_bounds__(NTHR) void text_decoder_bwd_kernel(const TextDecBwd
 }
 
 template <typename K>
-void set_lds_attr(K kernel) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+void set_lds_attr(K kernel, int bytes = 128 * 1024) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
 }  // namespace
@@ -565,13 +787,19 @@ int launch_text_encoder_bwd(const TextEncBwdArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(text_encoder_bwd_kernel, dim3(ceil_div(a.f.B, TR)), dim3(NTHR), lds, s, a);
     return mmvae_check_launch("text_encoder_bwd");
 }
-int launch_text_decoder_fwd(const TextDecArgs& a, hipStream_t s) {
+int launch_text_decoder_fwd(const TextDecArgs& a_in, hipStream_t s) {
+    const TextDecArgs& a = a_in;
     if (mmvae_knob("dbg_skip_text", 0)) return MMVAE_OK;          // measurement aid: the step without its text kernels
     MMVAE_REQUIRE(a.R >= 1 && a.D >= 1 && a.D <= 128 && a.kx == round_up(H + a.D, 32) && a.kz == round_up(a.D, 32) && a.kx <= 256,
                   "text decoder: R=%d D=%d kx=%d kz=%d", a.R, a.D, a.kx, a.kz);
     static std::atomic<unsigned> once{0};
-    if (mmvae_first_use_on_device(once)) set_lds_attr(text_decoder_fwd_kernel);
-    hipLaunchKernelGGL(text_decoder_fwd_kernel, dim3(ceil_div(a.R, TR)), dim3(NTHR), dec_lds_bytes(a.kx, a.kz), s, a);
+    if (mmvae_first_use_on_device(once)) { set_lds_attr(text_decoder_fwd_kernel); set_lds_attr(text_decoder_fwd2_kernel<7>, 160 * 1024); }
+    // the weights-resident form is compiled for kx = 224, kz = 128 (n_latents = 97..100: the reference's 100); other sizes stream
+    if (mmvae_knob("text_fwd2", 1) && a_in.kx == 224 && a_in.kz == 128 && a_in.l0.kih == 224 && a_in.l1.kih == HP) {
+        TextDecArgs a = a_in;
+        a.ts = reinterpret_cast<unsigned long long*>(((unsigned long long)(unsigned)mmvae_knob("txt_ts_hi", 0) << 32) | (unsigned)mmvae_knob("txt_ts_lo", 0));
+        hipLaunchKernelGGL(text_decoder_fwd2_kernel<7>, dim3(ceil_div(a.R, TR)), dim3(NTHR), dec_lds_bytes(224, 128) + (size_t)(GL / 16) * 4 * 1024, s, a);
+    } else hipLaunchKernelGGL(text_decoder_fwd_kernel, dim3(ceil_div(a.R, TR)), dim3(NTHR), dec_lds_bytes(a.kx, a.kz), s, a);
     return mmvae_check_launch("text_decoder_fwd");
 }
 int launch_text_decoder_bwd(const TextDecBwdArgs& a, hipStream_t s) {
@@ -580,6 +808,6 @@ int launch_text_decoder_bwd(const TextDecBwdArgs& a, hipStream_t s) {
     size_t lds = (size_t)(TR * 256 + 3 * TR * H + TR * 128 + TXT_V * H) * 4 + (size_t)(2 * TR * (GK + 8) + TR * 40 + TR * 136) * 2;
     static std::atomic<unsigned> once{0};
     if (mmvae_first_use_on_device(once)) set_lds_attr(text_decoder_bwd_kernel);
-    hipLaunchKernelGGL(text_decoder_bwd_kernel, dim3(ceil_div(a.f.R, TR)), dim3(NTHR), lds, s, a);
+    MMVAE_LAUNCH(text_decoder_bwd_kernel, dim3(ceil_div(a.f.R, TR)), dim3(NTHR), lds, s, a);      // (the fused step joins on this kernel's completion event)
     return mmvae_check_launch("text_decoder_bwd");
 }

@@ -326,3 +326,42 @@ def test_fused_step_at_batches_not_a_multiple_of_8(B):
                                force_tokens=ft.reshape(3 * B, 4).to(dev).contiguous())
     np.testing.assert_allclose(out.losses().cpu().numpy(), np.array([float(x.detach()) for x in o_losses]), rtol=1e-3)
     _grad_checks(st, P, tot_tol=2e-3, tensor_tol=4e-2, label="multimnist b%d" % B)
+
+
+@pytest.mark.parametrize("staged", [1, 0])
+def test_step_prologue_refreshes_every_weight_copy(staged):
+    """The fused step refreshes the bf16 GEMM copies of the weights itself after an optimizer step -- in stages: what the image
+    encoder's forward reads in the prologue on the main stream, the text copies and the decoders' / backward-only copies on the
+    second-modality stream (csrc/multimnist.hip build_plan, mm_step_body).  A copy left out would be one optimizer step stale, silently:
+    after a step the whole packed buffer must equal a full pack of the parameters the step started from, bit for bit."""
+    from multimodal_vae_amd.core import FusedELBOStep, MultimnistState
+    from multimodal_vae_amd.init import default_init_
+    from multimodal_vae_amd._lib import call
+    dev = _dev()
+    B = 16
+    rng = np.random.default_rng(3)
+    img = torch.from_numpy((rng.random((B, 1, 50, 50)) < 0.2).astype(np.float32)).to(dev)
+    txt = torch.from_numpy(rng.integers(0, 10, size=(B, 4)).astype(np.int64)).to(dev)
+    st = MultimnistState(D, dev); default_init_(st, 21)
+    eng = FusedELBOStep(st, B, lr=1e-2)           # a large step: every weight moves by more than a bf16 ulp
+    call("mmvae_debug_set", b"mm_stage_begin", staged)
+    try:
+        eng(img, txt)
+        for _ in range(2):
+            assert st.pack_pending
+            p_start = st.params.clone()
+            eng(img, txt)                          # prologue: packs p_start; then forward, backward, Adam
+            torch.cuda.synchronize()
+            got, gotv = st.packed.clone(), st.packed_vec.clone()
+            p_end = st.params.clone()
+            assert not torch.equal(p_start, p_end)
+            st.params.copy_(p_start); st.pack_weights(); torch.cuda.synchronize()
+            ref, refv = st.packed.clone(), st.packed_vec.clone()
+            st.params.copy_(p_end); st.pack_pending = True
+            assert torch.equal(got.view(torch.int16), ref.view(torch.int16)), int((got.view(torch.int16) != ref.view(torch.int16)).sum())
+            assert torch.equal(gotv, refv)
+            st.params.copy_(p_end); st.pack_weights(); torch.cuda.synchronize()      # and it is not the pack of the NEW parameters
+            assert not torch.equal(st.packed.view(torch.int16), got.view(torch.int16))
+            st.pack_pending = True
+    finally:
+        call("mmvae_debug_set", b"mm_stage_begin", 1)
