@@ -76,6 +76,15 @@ int mmvae_mm_pack_weights(mmvae_mm_t*, void* stream);    /* refresh bf16 GEMM-la
  * -(index + 2) into gpk_vec, -1 none.  Built once per parameter layout; input of mmvae_adam_step_packed. */
 int mmvae_mm_grad_map(mmvae_mm_t*, int* map, void* stream);
 
+/* Optimizer arguments of mmvae_mm_step_io.early_adam (torch.optim.Adam semantics, as mmvae_adam_step_packed). */
+struct mmvae_early_adam {
+    float* m; float* v;                     /* Adam moments, flat like the parameters */
+    long long* state;                       /* the 16-byte optimizer state block (mmvae_adam_step) */
+    float lr, beta1, beta2, eps, grad_scale;
+    const int* gmap;                        /* mmvae_mm_grad_map */
+    int* ran;                               /* host int: set to 1 when the step issued the early part, 0 when it did not (serial mode, a step
+                                             * without an image-decoder backward, ...): the caller then updates every range itself */
+};
 /* One 3-pass ELBO step (multimnist/train.py:150-168): forward of (image,text), (image), (text), the three
  * loss_function sums and -- if do_backward -- the gradient of loss_1+loss_2+loss_3 written to `grads`
  * (the step zeroes `grads` first, i.e. it includes optimizer.zero_grad()). */
@@ -109,6 +118,10 @@ typedef struct {
                                              * complete in `grads` before the encoders' backward has run -- order a communication
                                              * stream behind them with mmvae_mm_wait_early_grads and all-reduce those two parameter
                                              * ranges while the rest of the step runs; the other ranges are complete when the step is */
+    const struct mmvae_early_adam* early_adam;  /* NULL, or (with defer_unpack = 1, no data parallelism): the optimizer update of image_decoder.* and
+                                             * text_decoder.* is issued INSIDE the step, on the weight-gradient stream, as soon as their gradients are
+                                             * complete -- it runs beside the encoders' backward instead of behind the whole step.  The caller finishes
+                                             * the optimizer step with mmvae_adam_step_packed_ranges over the remaining ranges when *ran was set. */
 } mmvae_mm_step_io;
 int mmvae_mm_step(mmvae_mm_t*, const mmvae_mm_step_io*, int training, int do_backward, void* stream);
 /* `stream` waits (hipStreamWaitEvent) for the early gradient part of the most recent dp_split step of this plan.
@@ -420,6 +433,14 @@ int mmvae_adam_step(float* p, const float* g, float* m, float* v, long long n, l
 int mmvae_adam_step_packed(float* p, float* g, float* m, float* v, long long n, long long* state, float lr, float beta1,
                            float beta2, float eps, float grad_scale, const int* gmap, const float* gpk, const float* gpk_vec,
                            void* stream);
+/* ... over `nr` (<= 4) element ranges (offset, length: multiples of 4 elements) of the flat buffers of n elements.  advance = 1: this call
+ * completes the optimizer step (the step count advances); 0: an earlier part of it. */
+int mmvae_adam_step_packed_ranges(float* p, float* g, float* m, float* v, long long n, const long long* ranges, int nr, int advance,
+                                  long long* state, float lr, float beta1, float beta2, float eps, float grad_scale, const int* gmap,
+                                  const float* gpk, const float* gpk_vec, void* stream);
+/* The (offset, length) runs of the flat buffers that mmvae_mm_step_io.early_adam updates inside the step (image_decoder.*, text_decoder.*):
+ * writes up to `cap` pairs to `ranges`, returns their number. */
+int mmvae_mm_early_ranges(const mmvae_mm_t*, long long* ranges, int cap);
 
 #ifdef __cplusplus
 }

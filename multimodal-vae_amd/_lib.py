@@ -29,6 +29,16 @@ class StepIO(C.Structure):
         ("defer_unpack", C.c_int),
         ("pack_first", C.c_int),
         ("dp_split", C.c_int),
+        ("early_adam", C.c_void_p),
+    ]
+
+
+class EarlyAdam(C.Structure):
+    """struct mmvae_early_adam"""
+    _fields_ = [
+        ("m", C.c_void_p), ("v", C.c_void_p), ("state", C.c_void_p),
+        ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("grad_scale", C.c_float),
+        ("gmap", C.c_void_p), ("ran", C.POINTER(C.c_int)),
     ]
 
 
@@ -157,6 +167,8 @@ SIGNATURES = {
     "mmvae_debug_probe_read": (_I, [_P, _LL]),
     "mmvae_adam_step": (_I, [_P, _P, _P, _P, _LL, _P, _F, _F, _F, _F, _F, _P]),
     "mmvae_adam_step_packed": (_I, [_P, _P, _P, _P, _LL, _P, _F, _F, _F, _F, _F, _P, _P, _P, _P]),
+    "mmvae_adam_step_packed_ranges": (_I, [_P, _P, _P, _P, _LL, C.POINTER(_LL), _I, _I, _P, _F, _F, _F, _F, _F, _P, _P, _P, _P]),
+    "mmvae_mm_early_ranges": (_I, [_P, C.POINTER(_LL), _I]),
 }
 
 
@@ -217,7 +229,7 @@ SIGNATURES["mmvae_coco_text_encoder_fwd"] = (_I, [_P, _P, _SZ, _P, _P, _P])
 SIGNATURES["mmvae_coco_text_encoder_bwd"] = (_I, [_P, _P, _SZ, _P, _P, _P])
 SIGNATURES["mmvae_coco_text_decoder_fwd"] = (_I, [_P, _P, _SZ, _P, _P, _P, _I, _P, _P])
 SIGNATURES["mmvae_coco_text_decoder_bwd"] = (_I, [_P, _P, _SZ, _P, _P, _P, _P, _P, _P, _P])
-_STATUS = {n for n, (r, _) in SIGNATURES.items() if r is _I and not n.endswith(("_num_params", "_num_bn", "_precision", "_coco_steps", "_comm_world", "_probe_read"))}
+_STATUS = {n for n, (r, _) in SIGNATURES.items() if r is _I and not n.endswith(("_num_params", "_num_bn", "_precision", "_coco_steps", "_comm_world", "_probe_read", "_early_ranges"))}
 
 _lib = None
 _inited = set()

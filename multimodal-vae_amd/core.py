@@ -335,7 +335,8 @@ class FusedELBOStep(_FusedStepBase):
 
     def forward_backward(self, image, text, training=True, backward=True, eps=None, enc_mask1=None, enc_mask2=None,
                          gru_keep=None, force_tokens=None, recon_image=None, recon_text=None, mu=None, logvar=None,
-                         tokens=None, passes=None, lambda_xy=None, lambda_yx=None, _defer_unpack=False, _dp_split=False) -> StepOutputs:
+                         tokens=None, passes=None, lambda_xy=None, lambda_yx=None, _defer_unpack=False, _dp_split=False,
+                         _early_adam=None) -> StepOutputs:
         """``passes`` = which of (joint, image-only, text-only) exist in this step and ``lambda_xy/lambda_yx`` = their loss
         weights: the weak-supervision steps of multimnist/paired_weak.py:84-117 and modal_weak.py:87-117."""
         assert image.is_contiguous() and text.is_contiguous() and image.dtype == torch.float32 and text.dtype == torch.int64
@@ -356,6 +357,7 @@ class FusedELBOStep(_FusedStepBase):
         io.defer_unpack = int(bool(_defer_unpack))
         io.pack_first = int(self.state.pack_pending)
         io.dp_split = int(bool(_dp_split))
+        io.early_adam = _early_adam
         # optimizer.zero_grad() (train.py:150) happens inside the step's prologue kernel when backward is requested
         call("mmvae_mm_step", self.h, C.byref(io), int(training), int(backward), _stream())
         self.state.pack_pending = False
@@ -416,6 +418,54 @@ class FusedELBOStep(_FusedStepBase):
                 w.wait()
         call("mmvae_adam_step", ptr(st.params), ptr(st.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq), st.nparams,
              ptr(self.adam_state), self.lr, self.betas[0], self.betas[1], self.eps, 1.0 / self.world_size, _stream())
+        self._after_update()
+        return out
+
+    early_adam = True       # the decoders' Adam update is issued inside the step, beside the encoders' backward (mmvae_early_adam)
+
+    def _early_setup(self):
+        """ctypes block handed to mmvae_mm_step_io.early_adam + the ranges the call behind the step still has to update."""
+        st = self.state
+        rg = (C.c_longlong * 8)()
+        n = call("mmvae_mm_early_ranges", self.h, rg, 4)
+        early = [(int(rg[2 * i]), int(rg[2 * i + 1])) for i in range(n)]
+        late, pos = [], 0
+        for off, ln in sorted(early):
+            if off > pos:
+                late.append((pos, off - pos))
+            pos = off + ln
+        if pos < st.nparams:
+            late.append((pos, st.nparams - pos))
+        self._ea_ran = C.c_int(0)
+        ea = _lib.EarlyAdam()
+        ea.m, ea.v, ea.state = self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.adam_state.data_ptr()
+        ea.lr, ea.beta1, ea.beta2, ea.eps, ea.grad_scale = self.lr, self.betas[0], self.betas[1], self.eps, 1.0
+        ea.gmap = st.grad_map().data_ptr()
+        ea.ran = C.pointer(self._ea_ran)
+        self._ea = ea
+        self._ea_late = (C.c_longlong * (2 * len(late)))(*[x for r in late for x in r])
+        self._ea_nlate = len(late)
+        self._ea_ok = 0 < n and 0 < len(late) <= 4 and all(o % 4 == 0 and l % 4 == 0 for o, l in late[:-1]) and late[-1][0] % 4 == 0
+
+    def _call_packed(self, image, text, **kw) -> StepOutputs:
+        """backward + optimizer.step() with the decoders' part of the update inside the step (multimnist/train.py:168,173)."""
+        if self._dp_active() or self.separate_unpack or not self.early_adam:
+            return _FusedStepBase._call_packed(self, image, text, **kw)
+        if getattr(self, "_ea", None) is None:
+            self._early_setup()
+        if not self._ea_ok:
+            return _FusedStepBase._call_packed(self, image, text, **kw)
+        st = self.state
+        self._ea.lr = self.lr
+        out = self.forward_backward(image, text, True, True, _defer_unpack=True, _early_adam=C.addressof(self._ea), **kw)
+        if self._ea_ran.value:      # the step updated image_decoder.* / text_decoder.*: the rest, and the step count
+            call("mmvae_adam_step_packed_ranges", ptr(st.params), ptr(st.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq), st.nparams,
+                 self._ea_late, self._ea_nlate, 1, ptr(self.adam_state), self.lr, self.betas[0], self.betas[1], self.eps, 1.0,
+                 ptr(st.grad_map()), ptr(st.gpk), ptr(st.gpk_vec), _stream())
+        else:
+            call("mmvae_adam_step_packed", ptr(st.params), ptr(st.grads), ptr(self.exp_avg), ptr(self.exp_avg_sq), st.nparams,
+                 ptr(self.adam_state), self.lr, self.betas[0], self.betas[1], self.eps, 1.0, ptr(st.grad_map()), ptr(st.gpk),
+                 ptr(st.gpk_vec), _stream())
         self._after_update()
         return out
 

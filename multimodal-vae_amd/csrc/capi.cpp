@@ -200,6 +200,14 @@ int mmvae_mm_step(mmvae_mm_t* p, const mmvae_mm_step_io* io, int training, int d
     s.defer_unpack = io->defer_unpack;
     s.pack_first = io->pack_first;
     s.dp_split = io->dp_split;
+    if (io->early_adam) {
+        const mmvae_early_adam& e = *io->early_adam;
+        MMVAE_REQUIRE(e.m && e.v && e.state && e.gmap && e.ran, "mmvae_mm_step: early_adam with a null field");
+        s.early_adam = true;
+        s.ea_m = e.m; s.ea_v = e.v; s.ea_state = e.state; s.ea_lr = e.lr; s.ea_b1 = e.beta1; s.ea_b2 = e.beta2; s.ea_eps = e.eps;
+        s.ea_scale = e.grad_scale; s.ea_gmap = e.gmap; s.ea_ran = e.ran;
+        *e.ran = 0;
+    }
     return mm_step_fwd_bwd(p, s, training, do_backward, S(stream));
     API_GUARD_END
 }
@@ -499,6 +507,21 @@ int mmvae_step_losses(const float* sums, const float* w_bce, const float* w_nll,
     a.sums = sums; a.out = losses;
     for (int k = 0; k < 3; ++k) { a.w_bce[k] = w_bce[k]; a.w_nll[k] = w_nll[k]; a.w_kl[k] = w_kl[k]; }
     return launch_step_losses(a, S(s));
+}
+int mmvae_adam_step_packed_ranges(float* p, float* g, float* m, float* v, long long n, const long long* ranges, int nr, int advance,
+                                  long long* state, float lr, float b1, float b2, float eps, float grad_scale, const int* gmap,
+                                  const float* gpk, const float* gpk_vec, void* s) {
+    MMVAE_REQUIRE(gmap && gpk && gpk_vec && ranges && nr >= 1 && nr <= 4, "adam_step_packed_ranges: null argument or more than 4 ranges");
+    AdamArgs a{};
+    a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.step = state; a.lr = lr; a.b1 = b1; a.b2 = b2; a.eps = eps; a.grad_scale = grad_scale;
+    a.gmap = gmap; a.gpk = gpk; a.gpk_vec = gpk_vec; a.g_out = g;
+    a.nr = nr; a.no_advance = advance ? 0 : 1;
+    for (int r = 0; r < nr; ++r) { a.roff[r] = ranges[2 * r]; a.rlen[r] = ranges[2 * r + 1]; }
+    return launch_adam(a, S(s));
+}
+int mmvae_mm_early_ranges(const mmvae_mm_t* p, long long* ranges, int cap) {
+    if (!p || !ranges) return 0;
+    return mm_early_ranges(p, ranges, cap);
 }
 int mmvae_adam_step_packed(float* p, float* g, float* m, float* v, long long n, long long* state, float lr, float b1, float b2,
                            float eps, float grad_scale, const int* gmap, const float* gpk, const float* gpk_vec, void* s) {

@@ -147,6 +147,10 @@ struct AdamArgs {
     // optional: the part of the gradient that is still in the packed weight-gradient buffers (fused unpack):
     // g_total[i] = g[i] + gpk[gmap[i]] (gmap >= 0) or + gpk_vec[-gmap[i]-2] (gmap < -1); written back to g_out[i]
     const int* gmap; const float* gpk; const float* gpk_vec; float* g_out;
+    // optional: the update covers `nr` element ranges (offset, length: multiples of 4) of the flat buffers instead of [0, n) -- an
+    // optimizer step issued in parts (the decoders' parameters while the encoders' backward still runs).  Only the part with
+    // `advance` set counts the step; 0 ranges = the whole buffer, advancing.
+    int nr; long long roff[4], rlen[4]; int no_advance;
 };
 int launch_adam(const AdamArgs& a, hipStream_t s);
 // dst[i] = src[idx[i]] for `rows` rows of row_bytes (a multiple of 16) each; src may be pinned HOST memory (the device reads it

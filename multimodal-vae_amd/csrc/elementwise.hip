@@ -662,9 +662,17 @@ __global__ __launch_bounds__(TPB) void adam_kernel(const AdamArgs a, unsigned* d
     const float bc2 = 1.0f - powf(a.b2, (float)t);
     const float step_size = a.lr / bc1;
     const float inv_sqrt_bc2 = rsqrtf(bc2);
-    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i * 4 < a.n && !skip; i += (long long)gridDim.x * TPB) {
-        const long long e = i * 4;
-        if (e + 4 <= a.n) {
+    // element ranges of this launch (launch_adam: one range [0, n) unless the caller gave its own), walked as one list of 4-element vectors
+    long long vbase[5];
+    vbase[0] = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) vbase[r + 1] = vbase[r] + (r < a.nr ? (a.rlen[r] + 3) / 4 : 0);
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < vbase[4] && !skip; i += (long long)gridDim.x * TPB) {
+        int r = 0;
+#pragma unroll
+        for (int q = 1; q < 4; ++q) r += (q < a.nr && i >= vbase[q]) ? 1 : 0;
+        const long long e = a.roff[r] + (i - vbase[r]) * 4, r_end = a.roff[r] + a.rlen[r];
+        if (e + 4 <= r_end) {
             f32x4 g = *reinterpret_cast<const f32x4*>(a.g + e);
             if (a.gmap) {       // gradient of the GEMM weights still in its packed layout: gather, add, keep the flat copy
                 const int4 mi = *reinterpret_cast<const int4*>(a.gmap + e);
@@ -689,7 +697,7 @@ __global__ __launch_bounds__(TPB) void adam_kernel(const AdamArgs a, unsigned* d
             *reinterpret_cast<f32x4*>(a.v + e) = v;
             *reinterpret_cast<f32x4*>(a.p + e) = p;
         } else {
-            for (long long q = e; q < a.n; ++q) {
+            for (long long q = e; q < r_end; ++q) {
                 float gq = a.g[q];
                 if (a.gmap) {
                     const int mq = a.gmap[q];
@@ -711,7 +719,7 @@ __global__ __launch_bounds__(TPB) void adam_kernel(const AdamArgs a, unsigned* d
         if (ticket == gridDim.x - 1) {
             done[0] = 0u;
             done[1] = 0u;
-            if (!skip) *a.step = t;
+            if (!skip && !a.no_advance) *a.step = t;
             __threadfence();
         }
     }
@@ -1006,11 +1014,20 @@ int launch_latent3_bwd(const Latent3BwdArgs& a, hipStream_t s) {
     MMVAE_LAUNCH(latent3_bwd_kernel, dim3(ceil_div(a.f.D, 64), ceil_div(a.f.B, L3B_ROWS)), dim3(TPB), 0, s, a);
     return mmvae_check_launch("latent3_bwd");
 }
-int launch_adam(const AdamArgs& a, hipStream_t s) {
+int launch_adam(const AdamArgs& a_in, hipStream_t s) {
+    AdamArgs a = a_in;
     MMVAE_REQUIRE(a.step != nullptr, "adam: step counter is null");
+    MMVAE_REQUIRE(a.nr >= 0 && a.nr <= 4, "adam: at most 4 element ranges");
+    if (a.nr == 0) { a.nr = 1; a.roff[0] = 0; a.rlen[0] = a.n; }
+    long long vecs = 0;
+    for (int r = 0; r < a.nr; ++r) {
+        MMVAE_REQUIRE(a.roff[r] >= 0 && a.rlen[r] >= 0 && a.roff[r] % 4 == 0 && a.roff[r] + a.rlen[r] <= a.n &&
+                      (a.rlen[r] % 4 == 0 || a.roff[r] + a.rlen[r] == a.n), "adam: range %d = (%lld, %lld) of %lld elements", r, a.roff[r], a.rlen[r], a.n);
+        vecs += (a.rlen[r] + 3) / 4;
+    }
     // the word after the step counter is the block ticket (both live in the caller's 16-byte state block)
     unsigned* done = reinterpret_cast<unsigned*>(a.step + 1);
-    hipLaunchKernelGGL(adam_kernel, dim3(nblocks((a.n + 3) / 4, TPB, mmvae_knob("adam_blocks", 512))), dim3(TPB), 0, s, a, done);   // few blocks: one ticket atomic each
+    hipLaunchKernelGGL(adam_kernel, dim3(nblocks(vecs > 0 ? vecs : 1, TPB, mmvae_knob("adam_blocks", 512))), dim3(TPB), 0, s, a, done);   // few blocks: one ticket atomic each
     return mmvae_check_launch("adam");
 }
 static __global__ __launch_bounds__(256) void gather_rows_kernel(const char* __restrict__ src, const long long* __restrict__ idx,

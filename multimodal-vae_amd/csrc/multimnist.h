@@ -35,9 +35,16 @@ struct MMStepIO {
     int dp_split = 0;                   // 1 (data-parallel step): the decoders' gradients (image_decoder.*, text_decoder.*) are
                                         // unpacked into the flat buffer as soon as they are complete -- mm_wait_early_grads --
                                         // so that their all-reduce overlaps the encoders' backward; the rest at the end as usual
+    // the optimizer update of the decoders' parameters inside the step (include/mmvae_hip.h: mmvae_early_adam)
+    bool early_adam = false;
+    float* ea_m = nullptr; float* ea_v = nullptr; long long* ea_state = nullptr;
+    float ea_lr = 0.f, ea_b1 = 0.f, ea_b2 = 0.f, ea_eps = 0.f, ea_scale = 1.f;
+    const int* ea_gmap = nullptr; int* ea_ran = nullptr;
 };
 
 struct MMPlan;
+// (offset, length) runs of image_decoder.* / text_decoder.* in the flat buffers; returns their number (<= cap)
+int mm_early_ranges(const MMPlan* P, long long* ranges, int cap);
 MMPlan* mm_create(int D, int B);
 void mm_destroy(MMPlan*);
 int mm_D(const MMPlan*);

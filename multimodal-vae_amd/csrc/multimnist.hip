@@ -21,6 +21,7 @@ struct MMPlan : PlanBase {
     struct GruIdx { int wih, whh, wihT, whhT, g_wih, g_whh; long long bih, bhh; } te_f, te_r, td0, td1;
     const float* step_image = nullptr;      // the image batch of the running fused step (conv1's weight gradient rebuilds its patches)
     hipEvent_t ev_dz = nullptr;             // fused step: completion of the text decoder's backward kernel (what the main chain joins on)
+    hipEvent_t ev_txtgrads = nullptr;       // fused step: every gradient of text_decoder.* is complete (recorded on the second-modality stream)
     int te_h2p, te_h2pT, g_te_h2p, td_z2h, td_z2hT, g_td_z2h, td_h2o, td_h2oT, g_td_h2o;
     // fused classifier tail (mlp_tail.hip; n_latents = 100 only): fragment-major copies of classifier.3 / classifier.6
     bool mlp_tail = false;
@@ -842,7 +843,17 @@ int txt_dec_bwd(MMPlan& P, const TextDecArgs& f, const float* dwords, float* dz,
     wg(P.g_td_z2h, w.dhinit, 100, 112, w.td_zbf, P.kz, R);
     wg(P.g_td_h2o, w.dlogit_bf, 12, 16, w.td_hz, P.kx, 4 * R);
     MMVAE_TRY(launch_wgrad_group(list, nl, s, &P.slab));
-    return launch_wgrad_reduce(&P.slab, s, true);
+    MMVAE_TRY(launch_wgrad_reduce(&P.slab, s, true));
+    // every gradient of text_decoder.* is complete on this stream here: the early optimizer part waits for this event
+    P.ev_txtgrads = nullptr;
+    if (own_ev) {
+        P.ev_txtgrads = next_ev(P);
+        if (hipEventRecord(P.ev_txtgrads, s) != hipSuccess) {
+            mmvae_set_error("text decoder event failed: %s", hipGetErrorString(hipGetLastError()));
+            return MMVAE_EHIP;
+        }
+    }
+    return MMVAE_OK;
 }
 
 }  // namespace
@@ -867,6 +878,18 @@ MMPlan* mm_create(int D, int B) {
     return P;
 }
 void mm_destroy(MMPlan* P) { delete P; }
+int mm_early_ranges(const MMPlan* P, long long* ranges, int cap) {
+    int n = 0;
+    for (const ParamInfo& pi : P->params) {
+        if (pi.name.rfind("image_decoder.", 0) != 0 && pi.name.rfind("text_decoder.", 0) != 0) continue;
+        if (n > 0 && ranges[2 * (n - 1)] + ranges[2 * (n - 1) + 1] == pi.offset) { ranges[2 * (n - 1) + 1] += pi.numel; continue; }
+        if (n == cap) return 0;                    // (does not fit: the caller updates everything itself)
+        ranges[2 * n] = pi.offset; ranges[2 * n + 1] = pi.numel; ++n;
+    }
+    for (int r = 0; r < n; ++r)
+        if (ranges[2 * r] % 4 != 0 || ranges[2 * r + 1] % 4 != 0) return 0;
+    return n;
+}
 int mm_D(const MMPlan* P) { return P->D; }
 int mm_B(const MMPlan* P) { return P->B; }
 const std::vector<ParamInfo>& mm_params(const MMPlan* P) { return P->params; }
@@ -1061,6 +1084,27 @@ static int mm_step_body(MMPlan* Pp, const MMStepIO& io, int training, int do_bac
     P.deferred.clear();
     P.defer_wgrad = false;
     if (img_groups > 0) rc = dec_bwd(P, w.dlogit, img_groups, w.dz_img, s, fuse_tail, fuse, 3, training);
+    // ---- early optimizer part (MMStepIO::early_adam): every gradient of image_decoder.* is complete on the weight-gradient stream (its
+    //      last flush forked off the first layer's data gradient, which also closed the BatchNorm parameter gradients), text_decoder.*
+    //      behind ev_txtgrads on the second-modality stream.  Their Adam update runs in the gap that stream has until the encoders'
+    //      weight gradients arrive, beside the encoders' backward -- the optimizer launch behind the step shrinks to the encoders' ranges.
+    if (io.early_adam && rc == MMVAE_OK && img_groups > 0 && fuse && fuse_tail && P.wgrad_forked && !serial && T != s && !io.dp_split &&
+        io.defer_unpack && P.ev_txtgrads && P.side_pending.empty() && P.st_wgrad2 == P.st_wgrad && mmvae_knob("mm_early_adam", 1)) {
+        hipStream_t Wst = P.st_wgrad;
+        AdamArgs ad{};
+        ad.p = P.buf.params; ad.g = P.buf.grads; ad.m = io.ea_m; ad.v = io.ea_v; ad.n = P.nparams; ad.step = io.ea_state;
+        ad.lr = io.ea_lr; ad.b1 = io.ea_b1; ad.b2 = io.ea_b2; ad.eps = io.ea_eps; ad.grad_scale = io.ea_scale;
+        ad.gmap = io.ea_gmap; ad.gpk = P.buf.gpk; ad.gpk_vec = P.buf.gpk_vec; ad.g_out = P.buf.grads;
+        long long rg[8];
+        ad.nr = mm_early_ranges(&P, rg, 4);
+        for (int r = 0; r < ad.nr; ++r) { ad.roff[r] = rg[2 * r]; ad.rlen[r] = rg[2 * r + 1]; }
+        ad.no_advance = 1;
+        if (ad.nr > 0) {
+            if (hipStreamWaitEvent(Wst, P.ev_txtgrads, 0) != hipSuccess) { mmvae_set_error("early optimizer part: %s", hipGetErrorString(hipGetLastError())); rc = MMVAE_EHIP; }
+            if (rc == MMVAE_OK) rc = launch_adam(ad, Wst);
+            if (rc == MMVAE_OK) *io.ea_ran = 1;
+        }
+    }
     if (rc == MMVAE_OK) {                            // dz of the text decoder
         const int k = mmvae_knob("dbg_skip_edges", 0);
         if (P.ev_dz && T != s) {

@@ -85,21 +85,21 @@ __device__ __forceinline__ void rowtile_gemm_w(const bf16* A, int lda, const bf1
         for (int j = 0; j < 4; ++j) out[(fq * 4 + j) * ldo + nt * 16 + fr] = acc[j];
     }
 }
-// ... with the fragments in LDS (wl: the pack's own layout, one conflict-free ds_read_b128 per fragment)
-template <int KS, int MAXT>
-__device__ __forceinline__ void rowtile_gemm_lds(const bf16* A, int lda, const bf16* wl, int ntiles, float* out, int ldo, int wave, int lane) {
+// ... with the fragments of k-steps 0..2 in LDS (wl: [tile][3][64 lanes][8], one conflict-free ds_read_b128 per fragment) and k-step 3 in registers
+__device__ __forceinline__ void rowtile_gemm_lds3(const bf16* A, int lda, const bf16* wl, const bf16x8 (&wk3)[3], int ntiles, float* out, int ldo, int wave, int lane) {
     const int fr = lane & 15, fq = lane >> 4;
-    bf16x8 af[KS];
+    bf16x8 af[4];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) af[ks] = *reinterpret_cast<const bf16x8*>(A + fr * lda + ks * 32 + fq * 8);
+    for (int ks = 0; ks < 4; ++ks) af[ks] = *reinterpret_cast<const bf16x8*>(A + fr * lda + ks * 32 + fq * 8);
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t) {
+    for (int t = 0; t < 3; ++t) {
         const int nt = wave + t * NW;
         if (nt >= ntiles) break;
-        const bf16* w = wl + ((size_t)nt * KS * 64 + lane) * 8;
+        const bf16* w = wl + ((size_t)nt * 3 * 64 + lane) * 8;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], *reinterpret_cast<const bf16x8*>(w + ks * 512), acc, 0, 0, 0);
+        for (int ks = 0; ks < 3; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], *reinterpret_cast<const bf16x8*>(w + ks * 512), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[3], wk3[t], acc, 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) out[(fq * 4 + j) * ldo + nt * 16 + fr] = acc[j];
     }
@@ -538,12 +538,17 @@ __global__ __launch_bounds__(NTHR) void text_decoder_fwd2_kernel(const TextDecAr
         L.h0b[row * LH + j] = (bf16)h; L.h1b[row * LH + j] = (bf16)h;
     }
     // ---- the GRU weights stay on the CU for the whole recurrence: W_ih0, W_hh0, W_ih1 as this wave's fragments in registers
-    //      (21 + 12 + 12 fragments), W_hh1 as a copy of its fragment-major pack in LDS (19 tiles x 4 k-steps x 1 KB)
+    //      W_hh1: k-steps 0..2 as a copy of its fragment-major pack in LDS (19 tiles x 3 KB; all four would not fit the 160 KB), k-step 3 in registers
     static_assert(KSX == 7, "the resident form is sized for kx = 224 (n_latents = 100)");
     constexpr int NT = GL / 16;                               // 19 column tiles
     bf16* wl = reinterpret_cast<bf16*>(smem + dec_lds_bytes(KSX * 32, 128));
-    for (int i = tid; i < NT * 4 * 64; i += NTHR)
-        *reinterpret_cast<bf16x8*>(wl + (size_t)i * 8) = *reinterpret_cast<const bf16x8*>(a.l1.whh + (size_t)i * 8);
+    for (int i = tid; i < NT * 3 * 64; i += NTHR) {           // LDS vector (tile, ks < 3, lane) <- pack vector (tile, ks, lane)
+        const int nt = i / 192, rem = i - nt * 192;
+        *reinterpret_cast<bf16x8*>(wl + (size_t)i * 8) = *reinterpret_cast<const bf16x8*>(a.l1.whh + ((size_t)nt * 256 + rem) * 8);
+    }
+    bf16x8 w_hh1_k3[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) w_hh1_k3[t] = *reinterpret_cast<const bf16x8*>(a.l1.whh + ((size_t)min(wave + t * NW, NT - 1) * 256 + 192 + lane) * 8);
     // (all four in registers spilled 53 VGPRs: W_hh0's fragments are re-read once per step instead -- issued behind layer 1's MFMAs,
     //  a whole phase ahead of their use, so the L2 latency is never waited for)
     __builtin_amdgcn_sched_barrier(0);
@@ -574,7 +579,7 @@ __global__ __launch_bounds__(NTHR) void text_decoder_fwd2_kernel(const TextDecAr
         stamp();
         save_tile(L.midb, LH, HP, a.mid_bf ? a.mid_bf + i * pl128 : nullptr, HP, r0, R, tid);
         rowtile_gemm_w<4, 3>(L.midb, LH, w_ih1, NT, L.gi, GL, wave, lane);
-        rowtile_gemm_lds<4, 3>(L.h1b, LH, wl, NT, L.gh, GL, wave, lane);
+        rowtile_gemm_lds3(L.h1b, LH, wl, w_hh1_k3, NT, L.gh, GL, wave, lane);
         __syncthreads();
         stamp();
         gru_gates2(L.gi, L.gh, c_b + 600, c_b + 900, L.h1f, L.h1b, LH, r0, R, a.gates ? a.gates + (size_t)(i * 2 + 1) * 5 * R * H : nullptr,
@@ -798,7 +803,7 @@ int launch_text_decoder_fwd(const TextDecArgs& a_in, hipStream_t s) {
     if (mmvae_knob("text_fwd2", 1) && a_in.kx == 224 && a_in.kz == 128 && a_in.l0.kih == 224 && a_in.l1.kih == HP) {
         TextDecArgs a = a_in;
         a.ts = reinterpret_cast<unsigned long long*>(((unsigned long long)(unsigned)mmvae_knob("txt_ts_hi", 0) << 32) | (unsigned)mmvae_knob("txt_ts_lo", 0));
-        hipLaunchKernelGGL(text_decoder_fwd2_kernel<7>, dim3(ceil_div(a.R, TR)), dim3(NTHR), dec_lds_bytes(224, 128) + (size_t)(GL / 16) * 4 * 1024, s, a);
+        hipLaunchKernelGGL(text_decoder_fwd2_kernel<7>, dim3(ceil_div(a.R, TR)), dim3(NTHR), dec_lds_bytes(224, 128) + (size_t)(GL / 16) * 3 * 1024, s, a);
     } else hipLaunchKernelGGL(text_decoder_fwd_kernel, dim3(ceil_div(a.R, TR)), dim3(NTHR), dec_lds_bytes(a.kx, a.kz), s, a);
     return mmvae_check_launch("text_decoder_fwd");
 }

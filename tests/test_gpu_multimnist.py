@@ -365,3 +365,37 @@ def test_step_prologue_refreshes_every_weight_copy(staged):
             st.pack_pending = True
     finally:
         call("mmvae_debug_set", b"mm_stage_begin", 1)
+
+
+def test_early_optimizer_part_equals_one_adam_launch():
+    """mmvae_mm_step_io.early_adam: the Adam update of image_decoder.* / text_decoder.* issued inside the step (on the weight-gradient
+    stream, beside the encoders' backward) + mmvae_adam_step_packed_ranges over the encoders behind the step is torch.optim.Adam
+    (multimnist/train.py:129,173) on the step's own gradient: every range updated exactly once, one step counted."""
+    from multimodal_vae_amd.core import FusedELBOStep, MultimnistState
+    from multimodal_vae_amd.init import default_init_
+    dev = _dev()
+    B = 16
+    rng = np.random.default_rng(5)
+    img = torch.from_numpy((rng.random((B, 1, 50, 50)) < 0.2).astype(np.float32)).to(dev)
+    txt = torch.from_numpy(rng.integers(0, 10, size=(B, 4)).astype(np.int64)).to(dev)
+    for early in (True, False):
+        st = MultimnistState(D, dev); default_init_(st, 31)
+        eng = FusedELBOStep(st, B, seed=9)
+        eng.early_adam = early
+        lr, (b1, b2), eps = eng.lr, eng.betas, eng.eps
+        m = torch.zeros_like(st.params, dtype=torch.float64); v = torch.zeros_like(m)
+        for t in range(1, 4):
+            p_before = st.params.double().clone()
+            eng(img, txt)
+            torch.cuda.synchronize()
+            assert (eng._ea_ran.value == 1) if early else (getattr(eng, "_ea_ran", None) is None or eng._ea_ran.value == 0)
+            g = st.grads.double()                  # the completed flat gradient of THIS step (the optimizer kernel wrote it back)
+            m = b1 * m + (1 - b1) * g; v = b2 * v + (1 - b2) * g * g
+            want = p_before - (lr / (1 - b1 ** t)) * m / (v.sqrt() / (1 - b2 ** t) ** 0.5 + eps)
+            assert int(eng.adam_state[0].item()) == t
+            # (fp32 arithmetic of the kernel against float64 here: 1 - beta2 alone is 1.7e-4 off in fp32)
+            assert float((eng.exp_avg.double() - m).abs().max()) <= 1e-4 * float(m.abs().max())
+            assert float((eng.exp_avg_sq.double() - v).abs().max()) <= 1e-3 * float(v.abs().max())
+            moved = float((want - p_before).norm())
+            assert float((st.params.double() - want).norm()) < 2e-3 * moved, (early, t, float((st.params.double() - want).norm()), moved)
+            m, v = eng.exp_avg.double().clone(), eng.exp_avg_sq.double().clone()      # (follow the kernel's moments: no drift over the steps)
