@@ -431,10 +431,13 @@ def main():
                         break
         loader_steps(max(10, args.warmup // 4))
         barrier()
+        gc.collect()
+        gc.disable()        # as in the resident-input loop above: a generational collection in the enqueue thread stalls the GPU for milliseconds
         t0 = time.perf_counter()
         loader_steps(args.steps)
         barrier()
         dtl = time.perf_counter() - t0
+        gc.enable()
         if world > 1:
             import torch.distributed as dist
             t = torch.tensor([dtl], device=dev, dtype=torch.float64)

@@ -397,6 +397,12 @@ int mmvae_mse_bwd(const float* a, const float* b, long long n, float coef, const
 /* Input pipeline: the ToTensor() transform of the reference's loaders (multimnist/train.py:113-121; dataset tensors are
  * uint8 (N,50,50), multimnist/datasets.py:180-181) done on the device: dst[i] = src[i] / denom (denom = 255, IEEE division: bit-equal to ToTensor) */
 int mmvae_u8_to_f32(const uint8_t* src, long long n, float denom, float* dst, void* stream);
+/* ... behind `wait_event` (a hipEvent_t, or NULL): `stream` waits for the event, then converts -- one call of the enqueue thread per batch */
+int mmvae_u8_to_f32_after(const uint8_t* src, long long n, float denom, float* dst, void* wait_event, void* stream);
+/* One staged batch to the device: up to two asynchronous host-to-device copies (pinned sources; bytes_b may be 0) on `stream`, then
+ * `event` (a hipEvent_t) recorded behind them.  One call of the loader's worker thread per batch (coco/train.py:117-128,144-147: the
+ * reference's DataLoader + .cuda() per batch): a foreign-function call holds no interpreter lock while the runtime takes its own. */
+int mmvae_h2d_stage(void* dst_a, const void* src_a, size_t bytes_a, void* dst_b, const void* src_b, size_t bytes_b, void* event, void* stream);
 /* torch.optim.Adam defaults (multimnist/train.py:129,173) on flat buffers; state = device int64[2] {step, ticket},
  * zero-initialised by the caller; grad_scale multiplies g first (1/world_size after a sum all-reduce). */
 /* The three losses of train()'s closure from a step's `sums` block (multimnist/train.py:33-62: the weighted sum each

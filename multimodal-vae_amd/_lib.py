@@ -158,6 +158,8 @@ SIGNATURES = {
     "mmvae_mse_fwd": (_I, [_P, _P, _LL, _P, _P]),
     "mmvae_mse_bwd": (_I, [_P, _P, _LL, _F, _P, _P, _P]),
     "mmvae_u8_to_f32": (_I, [_P, _LL, _F, _P, _P]),
+    "mmvae_u8_to_f32_after": (_I, [_P, _LL, _F, _P, _P, _P]),
+    "mmvae_h2d_stage": (_I, [_P, _P, _SZ, _P, _P, _SZ, _P, _P]),
     "mmvae_stream_create": (_I, [_P]),
     "mmvae_stream_destroy": (_I, [_P]),
     "mmvae_gather_rows": (_I, [_P, _P, _LL, _LL, _P, _P]),

@@ -465,6 +465,21 @@ int mmvae_keep_mask(uint8_t* out, long long n, float p, unsigned long long seed,
 int mmvae_mse_fwd(const float* a, const float* b, long long n, float* out, void* s) { return launch_mse_fwd(a, b, n, out, S(s)); }
 int mmvae_mse_bwd(const float* a, const float* b, long long n, float coef, const float* gs, float* da, void* s) { return launch_mse_bwd(a, b, n, coef, gs, da, S(s)); }
 int mmvae_u8_to_f32(const uint8_t* src, long long n, float denom, float* dst, void* s) { return launch_u8_to_f32(src, n, denom, dst, S(s)); }
+int mmvae_u8_to_f32_after(const uint8_t* src, long long n, float denom, float* dst, void* wait_event, void* s) {
+    if (wait_event && hipStreamWaitEvent(S(s), reinterpret_cast<hipEvent_t>(wait_event), 0) != hipSuccess) {
+        mmvae_set_error("u8_to_f32_after: hipStreamWaitEvent: %s", hipGetErrorString(hipGetLastError()));
+        return MMVAE_EHIP;
+    }
+    return launch_u8_to_f32(src, n, denom, dst, S(s));
+}
+int mmvae_h2d_stage(void* dst_a, const void* src_a, size_t bytes_a, void* dst_b, const void* src_b, size_t bytes_b, void* event, void* s) {
+    MMVAE_REQUIRE(dst_a && src_a && bytes_a > 0 && event && (bytes_b == 0 || (dst_b && src_b)), "h2d_stage: null argument");
+    hipError_t e = hipMemcpyAsync(dst_a, src_a, bytes_a, hipMemcpyHostToDevice, S(s));
+    if (e == hipSuccess && bytes_b > 0) e = hipMemcpyAsync(dst_b, src_b, bytes_b, hipMemcpyHostToDevice, S(s));
+    if (e == hipSuccess) e = hipEventRecord(reinterpret_cast<hipEvent_t>(event), S(s));
+    if (e != hipSuccess) { mmvae_set_error("h2d_stage: %s", hipGetErrorString(e)); (void)hipGetLastError(); return MMVAE_EHIP; }
+    return MMVAE_OK;
+}
 int mmvae_adam_step(float* p, const float* g, float* m, float* v, long long n, long long* state, float lr, float b1, float b2,
                     float eps, float grad_scale, void* s) {
     AdamArgs a{};

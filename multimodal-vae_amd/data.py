@@ -116,10 +116,22 @@ class DeviceBatcher:
             self.idx_host = [torch.empty(self.B, dtype=torch.int64).pin_memory() for _ in range(S)]
             self.idx_dev = [torch.empty(self.B, dtype=torch.int64, device=device) for _ in range(S)]
         n_stage = 0 if self.device_gather else S
-        self.stage_u8 = [torch.empty((self.B,) + ishape, dtype=torch.uint8).pin_memory() for _ in range(n_stage)]
-        self.stage_tx = [torch.empty((self.B,) + tshape, dtype=text.dtype).pin_memory() for _ in range(n_stage)]
-        self.dev_u8 = [torch.empty((self.B,) + ishape, dtype=torch.uint8, device=device) for _ in range(S)]
-        self.dev_tx = [torch.empty((self.B,) + tshape, dtype=text.dtype, device=device) for _ in range(S)]
+        # ONE pinned staging buffer and ONE device buffer per slot, [uint8 pixels | pad to 256 B | second modality]: the batch crosses
+        # in a single hipMemcpyAsync (each asynchronous copy call costs the process ~50 us of runtime lock next to a running step:
+        # two of them per batch made the enqueue thread the bottleneck of the loader-fed MultiMNIST step)
+        nb_u8 = self.B * (int(np.prod(ishape)) if ishape else 1)
+        nb_tx = self.B * (int(np.prod(tshape)) if tshape else 1) * text.element_size()
+        off_tx = (nb_u8 + 255) // 256 * 256
+        self._slot_bytes = off_tx + nb_tx
+
+        def views(buf):
+            return (buf[:nb_u8].view((self.B,) + ishape), buf[off_tx:off_tx + nb_tx].view(text.dtype).view((self.B,) + tshape))
+        self._stage_buf = [torch.empty(self._slot_bytes, dtype=torch.uint8).pin_memory() for _ in range(n_stage)]
+        self._dev_buf = [torch.empty(self._slot_bytes, dtype=torch.uint8, device=device) for _ in range(S)]
+        self.stage_u8 = [views(b)[0] for b in self._stage_buf]
+        self.stage_tx = [views(b)[1] for b in self._stage_buf]
+        self.dev_u8 = [views(b)[0] for b in self._dev_buf]
+        self.dev_tx = [views(b)[1] for b in self._dev_buf]
         self.dev_f32 = [torch.empty((self.B,) + oshape, dtype=torch.float32, device=device) for _ in range(S)]
         # the copy stream is one more default-priority stream next to the step's: the engine's side streams must then run at
         # default priority too (1.93 vs 1.10 ms per step measured with this loader)
@@ -137,6 +149,12 @@ class DeviceBatcher:
         self.copy_stream = self._copy_owner.stream
         self.ready = [torch.cuda.Event() for _ in range(S)]
         self.consumed = [torch.cuda.Event() for _ in range(S)]
+        for e in self.ready:                # (torch creates the hipEvent_t at the first record: the worker hands the handle to the library)
+            e.record(self.copy_stream)
+        self._ready_h = [int(e.cuda_event) for e in self.ready]
+        self._copy_h = int(self.copy_stream.cuda_stream)
+        self._bytes_u8 = self.dev_u8[0].numel()
+        self._bytes_tx = self.dev_tx[0].numel() * self.dev_tx[0].element_size()
         self._copied = [False] * S          # the slot's staging buffer has an H2D copy recorded in ready[slot]
         self._read = [False] * S            # the slot's device buffers have been handed to a step (consumed[slot] recorded)
         from concurrent.futures import ThreadPoolExecutor
@@ -163,6 +181,15 @@ class DeviceBatcher:
         """enqueue thread: the slot's staged batch -> its device buffers, on the copy stream"""
         if self._read[slot] and self.host_paced:
             self.consumed[slot].synchronize()                   # host-side: the step that read these device buffers is done
+        if self.host_paced and not self.device_gather:
+            # ONE foreign call for the two copies and the event (round 4: the torch-level calls -- stream context, two copy_, record --
+            # held the interpreter lock of the enqueue thread's 49 launches per step: the loader-fed step was HOST-bound, 0.62 ms
+            # of enqueue loop per 0.58 ms step)
+            import ctypes as C
+            call("mmvae_h2d_stage", ptr(self._dev_buf[slot]), ptr(self._stage_buf[slot]), self._slot_bytes,
+                 None, None, 0, C.c_void_p(self._ready_h[slot]), C.c_void_p(self._copy_h))
+            self._copied[slot] = True
+            return
         with torch.cuda.stream(self.copy_stream):
             if self._read[slot] and not self.host_paced:
                 self.copy_stream.wait_event(self.consumed[slot])   # device-side edge: the step that read these buffers is done
@@ -216,10 +243,9 @@ class DeviceBatcher:
                 fut.pop(b).result()                                 # gathered AND its H2D copy enqueued by the worker, AHEAD steps ago
                 slot = (g0 + b) % S
                 cur = torch.cuda.current_stream(self.device)
-                cur.wait_event(self.ready[slot])
                 import ctypes as C
-                call("mmvae_u8_to_f32", ptr(self.dev_u8[slot]), self.dev_u8[slot].numel(), 255.0, ptr(self.dev_f32[slot]),
-                     C.c_void_p(cur.cuda_stream))
+                call("mmvae_u8_to_f32_after", ptr(self.dev_u8[slot]), self._bytes_u8, 255.0, ptr(self.dev_f32[slot]),
+                     C.c_void_p(self._ready_h[slot]), C.c_void_p(cur.cuda_stream))       # wait for the copy's event, then ToTensor
                 try:
                     yield self.dev_f32[slot], self.dev_tx[slot]
                 finally:                                            # also when the consumer abandons the iterator at this batch

@@ -32,7 +32,7 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(300): eng(ims, txs)
 torch.cuda.synchronize(); print(f"resident                         wall {(time.perf_counter() - t0) / 300 * 1e3:.3f} ms")
 for hp in (0, 1):
-    for S in (3, 4):
+    for S in (3, 4, 6, 8):
         os.environ["MMVAE_LOADER_HOST_PACED"] = str(hp)
         L = DeviceBatcher(u8, b, B, dev, shuffle=True, seed=1, slots=S)
         run(L, 30)
