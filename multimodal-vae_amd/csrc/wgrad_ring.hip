@@ -470,7 +470,9 @@ int try_wr(const WgradParams& p, hipStream_t stream, WgradSlabCtx* ctx) {
     // stream); the 9-17 GFLOP layers of CelebA run shorter on the whole chip (1.873 against 1.888 ms per step)
     const double macs = (double)nimg * G::OYX * G::KH * G::KW * G::C * G::N;
     const int wq = mmvae_knob("wr_wgs", -1);            // (-1: not set.  A call site caches the value it looked up: the default must not vary)
-    const int target = (G::WGQ > 0 ? mmvae_knob("wr_wgs_big", G::WGQ) : wq >= 0 ? wq : macs >= 4e9 ? 4 : 2) * mmvae_cu_count() / 4;
+    // (re-tuned after the critical-path work of the round's second half -- the second-modality stream is no longer waited for and the
+    //  decoders' optimizer part runs in this stream's gap: three quarters of the chip 574.8 us per step, half 579.3, all of it 579.8)
+    const int target = (G::WGQ > 0 ? mmvae_knob("wr_wgs_big", G::WGQ) : wq >= 0 ? wq : macs >= 4e9 ? 4 : 3) * mmvae_cu_count() / 4;
     // (a batch costs a workgroup a fixed part -- the DMA issue -- next to its MFMAs: measured 0.66 us + 0.10 us per column tile
     //  on hallucinate.6; knob wr_bias = the fixed part in column tiles)
     const int bias = mmvae_knob("wr_bias", 6);
