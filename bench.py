@@ -435,6 +435,7 @@ def main():
         gc.disable()        # as in the resident-input loop above: a generational collection in the enqueue thread stalls the GPU for milliseconds
         t0 = time.perf_counter()
         loader_steps(args.steps)
+        t_host = time.perf_counter() - t0          # the enqueue thread's loop alone: equal to the wall time = the loop is host-bound
         barrier()
         dtl = time.perf_counter() - t0
         gc.enable()
@@ -445,6 +446,7 @@ def main():
             dtl = float(t.item())
         result["with_loader"] = {"value": args.steps / dtl, "unit": "ELBO-steps/s", "ms_per_step": 1e3 * dtl / args.steps,
                                  "vs_resident": (args.steps / dtl) / steps_per_s,
+                                 "enqueue_loop_ms_per_step": 1e3 * t_host / args.steps,
                                  "h2d_bytes_per_step": int(img_u8[0].numel() * B + b_h[0].numel() * b_h.element_size() * B),
                                  "loader": "data.DeviceBatcher: %d-batch host dataset, gather into pinned staging on a worker thread, async H2D on a "
                                            "copy stream, u8->f32 on the device, four slots, slot reuse paced on the worker thread" % nb_ds}
