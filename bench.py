@@ -429,7 +429,8 @@ def main():
                     done += 1
                     if done == n:
                         break
-        loader_steps(max(10, args.warmup // 4))
+        loader_steps(max(100, args.warmup))          # (the loader-fed loop has a transient of its own -- first touches of the pinned dataset over
+        #                                              the host link, the worker thread's start: the first ~200 steps run 5-8 % slower)
         barrier()
         gc.collect()
         gc.disable()        # as in the resident-input loop above: a generational collection in the enqueue thread stalls the GPU for milliseconds

@@ -398,11 +398,24 @@ int mmvae_mse_bwd(const float* a, const float* b, long long n, float coef, const
  * uint8 (N,50,50), multimnist/datasets.py:180-181) done on the device: dst[i] = src[i] / denom (denom = 255, IEEE division: bit-equal to ToTensor) */
 int mmvae_u8_to_f32(const uint8_t* src, long long n, float denom, float* dst, void* stream);
 /* ... behind `wait_event` (a hipEvent_t, or NULL): `stream` waits for the event, then converts -- one call of the enqueue thread per batch */
+/* Batch gather + ToTensor in one kernel: dst[r][i] = src[idx[r]][i] / denom for `rows` rows of `row_elems` uint8 elements (a multiple of 4).
+ * `src` and `idx` may be PINNED HOST memory: the device reads the rows over the host link itself -- no runtime copy call, no
+ * staging buffer, no conversion kernel on the compute stream (the loader's device-gather path for small batches). */
+int mmvae_gather_rows_u8_f32(const uint8_t* src, const long long* idx, long long rows, long long row_elems, float denom, float* dst, void* stream);
 int mmvae_u8_to_f32_after(const uint8_t* src, long long n, float denom, float* dst, void* wait_event, void* stream);
 /* One staged batch to the device: up to two asynchronous host-to-device copies (pinned sources; bytes_b may be 0) on `stream`, then
  * `event` (a hipEvent_t) recorded behind them.  One call of the loader's worker thread per batch (coco/train.py:117-128,144-147: the
  * reference's DataLoader + .cuda() per batch): a foreign-function call holds no interpreter lock while the runtime takes its own. */
 int mmvae_h2d_stage(void* dst_a, const void* src_a, size_t bytes_a, void* dst_b, const void* src_b, size_t bytes_b, void* event, void* stream);
+/* Events for a host-side pipeline next to the step (the loader's "copy done" / "buffers consumed" edges): created WITHOUT the
+ * system-scope fence a default event performs when it completes (a write-back of the device caches for the host's benefit: one per
+ * step on the compute stream slowed the kernels behind it by tens of microseconds) and without timing.  They order streams of one
+ * device and tell the host THAT work finished, not what it wrote -- read results after a stream synchronisation. */
+int mmvae_stream_wait_event(void* stream, void* event);   /* device-side: `stream` waits for `event` */
+int mmvae_event_create(void** out);
+int mmvae_event_destroy(void* event);
+int mmvae_event_record(void* event, void* stream);
+int mmvae_event_synchronize(void* event);            /* blocks the calling host thread */
 /* torch.optim.Adam defaults (multimnist/train.py:129,173) on flat buffers; state = device int64[2] {step, ticket},
  * zero-initialised by the caller; grad_scale multiplies g first (1/world_size after a sum all-reduce). */
 /* The three losses of train()'s closure from a step's `sums` block (multimnist/train.py:33-62: the weighted sum each

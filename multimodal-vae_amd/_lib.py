@@ -160,6 +160,12 @@ SIGNATURES = {
     "mmvae_u8_to_f32": (_I, [_P, _LL, _F, _P, _P]),
     "mmvae_u8_to_f32_after": (_I, [_P, _LL, _F, _P, _P, _P]),
     "mmvae_h2d_stage": (_I, [_P, _P, _SZ, _P, _P, _SZ, _P, _P]),
+    "mmvae_gather_rows_u8_f32": (_I, [_P, _P, _LL, _LL, _F, _P, _P]),
+    "mmvae_stream_wait_event": (_I, [_P, _P]),
+    "mmvae_event_create": (_I, [C.POINTER(C.c_void_p)]),
+    "mmvae_event_destroy": (_I, [_P]),
+    "mmvae_event_record": (_I, [_P, _P]),
+    "mmvae_event_synchronize": (_I, [_P]),
     "mmvae_stream_create": (_I, [_P]),
     "mmvae_stream_destroy": (_I, [_P]),
     "mmvae_gather_rows": (_I, [_P, _P, _LL, _LL, _P, _P]),
@@ -268,6 +274,33 @@ def init_device(index):
     if index not in _inited:
         call("mmvae_init", int(index))
         _inited.add(index)
+
+
+class OwnedEvent:
+    """One HIP event created by the library (mmvae_event_create: no timing, no system-scope fence), with the three methods a
+    host-side pipeline needs.  ``torch.cuda.Event()`` performs a system-scope release when it completes -- a cache write-back per
+    record on the compute stream (include/mmvae_hip.h)."""
+
+    def __init__(self):
+        h = C.c_void_p()
+        call("mmvae_event_create", C.byref(h))
+        self.handle = h.value
+        self._h = C.c_void_p(h.value)
+
+    def record(self, stream=None):
+        import torch
+        s = stream if stream is not None else torch.cuda.current_stream()
+        call("mmvae_event_record", self._h, C.c_void_p(s.cuda_stream))
+
+    def synchronize(self):
+        call("mmvae_event_synchronize", self._h)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                call("mmvae_event_destroy", self._h)
+        except Exception:
+            pass
 
 
 class OwnedStream:

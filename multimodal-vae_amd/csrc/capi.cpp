@@ -472,6 +472,35 @@ int mmvae_u8_to_f32_after(const uint8_t* src, long long n, float denom, float* d
     }
     return launch_u8_to_f32(src, n, denom, dst, S(s));
 }
+int mmvae_gather_rows_u8_f32(const uint8_t* src, const long long* idx, long long rows, long long row_elems, float denom, float* dst, void* s) {
+    return launch_gather_rows_u8_f32(src, idx, rows, row_elems, denom, dst, S(s));
+}
+int mmvae_stream_wait_event(void* s, void* e) {
+    MMVAE_REQUIRE(e, "stream_wait_event: null event");
+    if (hipStreamWaitEvent(S(s), reinterpret_cast<hipEvent_t>(e), 0) != hipSuccess) { mmvae_set_error("hipStreamWaitEvent: %s", hipGetErrorString(hipGetLastError())); return MMVAE_EHIP; }
+    return MMVAE_OK;
+}
+int mmvae_event_create(void** out) {
+    MMVAE_REQUIRE(out, "event_create: null argument");
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) {
+        mmvae_set_error("hipEventCreate failed: %s", hipGetErrorString(hipGetLastError()));
+        return MMVAE_EHIP;
+    }
+    *out = e;
+    return MMVAE_OK;
+}
+int mmvae_event_destroy(void* e) { return e && hipEventDestroy(reinterpret_cast<hipEvent_t>(e)) != hipSuccess ? MMVAE_EHIP : MMVAE_OK; }
+int mmvae_event_record(void* e, void* s) {
+    MMVAE_REQUIRE(e, "event_record: null event");
+    if (hipEventRecord(reinterpret_cast<hipEvent_t>(e), S(s)) != hipSuccess) { mmvae_set_error("hipEventRecord: %s", hipGetErrorString(hipGetLastError())); return MMVAE_EHIP; }
+    return MMVAE_OK;
+}
+int mmvae_event_synchronize(void* e) {
+    MMVAE_REQUIRE(e, "event_synchronize: null event");
+    if (hipEventSynchronize(reinterpret_cast<hipEvent_t>(e)) != hipSuccess) { mmvae_set_error("hipEventSynchronize: %s", hipGetErrorString(hipGetLastError())); return MMVAE_EHIP; }
+    return MMVAE_OK;
+}
 int mmvae_h2d_stage(void* dst_a, const void* src_a, size_t bytes_a, void* dst_b, const void* src_b, size_t bytes_b, void* event, void* s) {
     MMVAE_REQUIRE(dst_a && src_a && bytes_a > 0 && event && (bytes_b == 0 || (dst_b && src_b)), "h2d_stage: null argument");
     hipError_t e = hipMemcpyAsync(dst_a, src_a, bytes_a, hipMemcpyHostToDevice, S(s));

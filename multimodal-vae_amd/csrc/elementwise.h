@@ -156,6 +156,8 @@ int launch_adam(const AdamArgs& a, hipStream_t s);
 // dst[i] = src[idx[i]] for `rows` rows of row_bytes (a multiple of 16) each; src may be pinned HOST memory (the device reads it
 // over the host link: the loader's batch gather without a host-side copy)
 int launch_gather_rows(const void* src, const long long* idx, long long rows, long long row_bytes, void* dst, hipStream_t s);
+// dst[r][i] = src[idx[r]][i] / denom (uint8 rows of a multiple of 4 elements -> fp32 rows): gather and ToTensor in one kernel
+int launch_gather_rows_u8_f32(const unsigned char* src, const long long* idx, long long rows, long long row_elems, float denom, float* dst, hipStream_t s);
 // loss_k = w_bce[k] * sums[k] + w_nll[k] * sums[4+k] + w_kl[k] * sums[8+k]   (the closing arithmetic of loss_function, train.py:33-62)
 struct StepLossArgs { const float* sums; float* out; float w_bce[3], w_nll[3], w_kl[3]; };
 int launch_step_losses(const StepLossArgs& a, hipStream_t s);

@@ -1040,7 +1040,36 @@ static __global__ __launch_bounds__(256) void gather_rows_kernel(const char* __r
     u32x4* d = reinterpret_cast<u32x4*>(dst + row * row_bytes);
     for (long long v = v0 + threadIdx.x; v < v1; v += 256) d[v] = s[v];
 }
+// rows of a multiple of 4 bytes (MultiMNIST: 2 500-byte images): one workgroup per row, 4-byte vectors
+static __global__ __launch_bounds__(256) void gather_rows4_kernel(const char* __restrict__ src, const long long* __restrict__ idx,
+                                                                  long long row_bytes, char* __restrict__ dst) {
+    const long long row = blockIdx.x;
+    const unsigned* s = reinterpret_cast<const unsigned*>(src + idx[row] * row_bytes);
+    unsigned* d = reinterpret_cast<unsigned*>(dst + row * row_bytes);
+    for (long long v = threadIdx.x; v < row_bytes / 4; v += 256) d[v] = s[v];
+}
+static __global__ __launch_bounds__(256) void gather_rows_u8_f32_kernel(const unsigned char* __restrict__ src, const long long* __restrict__ idx,
+                                                                       long long row_elems, float denom, float* __restrict__ dst) {
+    const long long row = blockIdx.x;
+    const unsigned* s = reinterpret_cast<const unsigned*>(src + idx[row] * row_elems);
+    f32x4* d = reinterpret_cast<f32x4*>(dst + row * row_elems);
+    for (long long v = threadIdx.x; v < row_elems / 4; v += 256) {
+        const unsigned w = s[v];
+        d[v] = f32x4{(float)(w & 255u) / denom, (float)((w >> 8) & 255u) / denom, (float)((w >> 16) & 255u) / denom, (float)(w >> 24) / denom};     // IEEE division: bit-equal to ToTensor
+    }
+}
+int launch_gather_rows_u8_f32(const unsigned char* src, const long long* idx, long long rows, long long row_elems, float denom, float* dst, hipStream_t s) {
+    MMVAE_REQUIRE(src && idx && dst && rows >= 1 && rows < (1ll << 31) && row_elems >= 4 && row_elems % 4 == 0 && ((uintptr_t)src & 3) == 0 &&
+                  ((uintptr_t)dst & 15) == 0, "gather_rows_u8_f32: rows of a multiple of 4 elements, aligned buffers");
+    hipLaunchKernelGGL(gather_rows_u8_f32_kernel, dim3((unsigned)rows), dim3(256), 0, s, src, idx, row_elems, denom, dst);
+    return mmvae_check_launch("gather_rows_u8_f32");
+}
 int launch_gather_rows(const void* src, const long long* idx, long long rows, long long row_bytes, void* dst, hipStream_t s) {
+    if (src && idx && dst && rows >= 1 && row_bytes >= 4 && row_bytes % 16 != 0) {
+        MMVAE_REQUIRE(row_bytes % 4 == 0 && ((uintptr_t)src & 3) == 0 && ((uintptr_t)dst & 3) == 0 && rows < (1ll << 31), "gather_rows: rows of a multiple of 4 bytes, 4-byte aligned buffers");
+        hipLaunchKernelGGL(gather_rows4_kernel, dim3((unsigned)rows), dim3(256), 0, s, (const char*)src, idx, row_bytes, (char*)dst);
+        return mmvae_check_launch("gather_rows");
+    }
     MMVAE_REQUIRE(src && idx && dst && rows >= 1 && row_bytes >= 16 && row_bytes % 16 == 0, "gather_rows: rows of a multiple of 16 bytes");
     MMVAE_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "gather_rows: 16-byte aligned buffers");
     // enough workgroups in flight to cover the host link's latency: ~32 KB per workgroup

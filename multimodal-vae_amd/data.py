@@ -83,15 +83,16 @@ class DeviceBatcher:
     two batches ahead anyway.  ``MMVAE_LOADER_HOST_PACED=0`` brings the device-side edge back (measurement aid).
     ``drop_last`` because the fused plans are built for a fixed batch size.
 
-    ``pin_dataset=True`` (opt-in; rows must be multiples of 16 bytes): the whole dataset is pinned once and the GPU gathers the B
-    rows over the host link itself (``mmvae_gather_rows`` on the copy stream), the host uploads B indices.  Measured on COCO it
+    ``pin_dataset=True`` (default for batches up to 2 MB; rows must be multiples of 4 bytes): the whole dataset is pinned once and the
+    GPU gathers the B rows over the host link itself on the copy stream (``mmvae_gather_rows_u8_f32``: gather + ToTensor in one kernel,
+    ``mmvae_gather_rows`` for the second modality), reading the B indices from a pinned buffer too -- no runtime copy call at all.  Measured on COCO it
     frees the host (0.31 ms per batch) but the gather workgroups sit on CUs for the length of the transfer and the step next to
     them slows down more than that saves (3.8 ms per step): not the default."""
 
     SLOTS = 4
 
     def __init__(self, images_u8: torch.Tensor, text: torch.Tensor, batch_size: int, device: torch.device, shuffle: bool = True,
-                 seed: int = 0, pin_dataset: bool = False, copy_on_worker: bool = True, slots: int = 0):
+                 seed: int = 0, pin_dataset: Optional[bool] = None, copy_on_worker: bool = True, slots: int = 0):
         assert images_u8.dtype == torch.uint8 and images_u8.dim() in (3, 4) and len(images_u8) == len(text)
         self.images, self.text, self.B, self.device = images_u8, text, int(batch_size), device
         self.shuffle, self.seed, self.epoch = shuffle, seed, 0
@@ -106,11 +107,18 @@ class DeviceBatcher:
             self.SLOTS = int(slots)
         assert self.SLOTS >= 3
         S = self.SLOTS
+        if pin_dataset is None:
+            # auto: small batches (MultiMNIST 0.65 MB, MNIST 0.1 MB) are gathered by the device straight from the pinned dataset -- no
+            # runtime copy call, no staging, ToTensor in the gather kernel; large ones (CelebA 6 MB, COCO 16 MB of captions) are staged
+            # and copied: their gather workgroups would sit on CUs for the length of the transfer
+            row_u8 = int(np.prod(ishape)) if ishape else 1
+            row_tx = (int(np.prod(tshape)) if tshape else 1) * text.element_size()
+            pin_dataset = row_u8 % 4 == 0 and row_tx % 4 == 0 and self.B * (row_u8 + row_tx) <= (2 << 20)
         self.device_gather = bool(pin_dataset)
         if self.device_gather:
             self.row_u8 = int(np.prod(ishape)) if ishape else 1
             self.row_tx = (int(np.prod(tshape)) if tshape else 1) * text.element_size()
-            assert self.row_u8 % 16 == 0 and self.row_tx % 16 == 0, "device gather: rows must be multiples of 16 bytes"
+            assert self.row_u8 % 4 == 0 and self.row_tx % 4 == 0, "device gather: rows must be multiples of 4 bytes"
             self.images = images_u8 = images_u8.contiguous().pin_memory()
             self.text = text = text.contiguous().pin_memory()
             self.idx_host = [torch.empty(self.B, dtype=torch.int64).pin_memory() for _ in range(S)]
@@ -147,11 +155,20 @@ class DeviceBatcher:
         self._stage_tx_np = [t.numpy() for t in self.stage_tx]
         self._copy_owner = OwnedStream(device)              # (not torch.cuda.Stream(): see _lib.OwnedStream)
         self.copy_stream = self._copy_owner.stream
-        self.ready = [torch.cuda.Event() for _ in range(S)]
-        self.consumed = [torch.cuda.Event() for _ in range(S)]
-        for e in self.ready:                # (torch creates the hipEvent_t at the first record: the worker hands the handle to the library)
-            e.record(self.copy_stream)
-        self._ready_h = [int(e.cuda_event) for e in self.ready]
+        if self.host_paced:
+            # the library's events: no system-scope fence when they complete.  A default torch.cuda.Event writes the device caches back
+            # for the host at every record -- one per step on the compute stream (`consumed`) and one per batch on the copy stream
+            # cost the loader-fed MultiMNIST step tens of microseconds
+            from ._lib import OwnedEvent
+            self.ready = [OwnedEvent() for _ in range(S)]
+            self.consumed = [OwnedEvent() for _ in range(S)]
+            self._ready_h = [e.handle for e in self.ready]
+        else:
+            self.ready = [torch.cuda.Event() for _ in range(S)]
+            self.consumed = [torch.cuda.Event() for _ in range(S)]
+            for e in self.ready:            # (torch creates the hipEvent_t at the first record)
+                e.record(self.copy_stream)
+            self._ready_h = [int(e.cuda_event) for e in self.ready]
         self._copy_h = int(self.copy_stream.cuda_stream)
         self._bytes_u8 = self.dev_u8[0].numel()
         self._bytes_tx = self.dev_tx[0].numel() * self.dev_tx[0].element_size()
@@ -195,10 +212,11 @@ class DeviceBatcher:
                 self.copy_stream.wait_event(self.consumed[slot])   # device-side edge: the step that read these buffers is done
             if self.device_gather:
                 import ctypes as C
-                self.idx_dev[slot].copy_(self.idx_host[slot], non_blocking=True)
+                # (the gather kernels read the B indices straight from the slot's PINNED index buffer: no runtime copy call at all)
                 st = C.c_void_p(self.copy_stream.cuda_stream)
-                call("mmvae_gather_rows", ptr(self.images), ptr(self.idx_dev[slot]), self.B, self.row_u8, ptr(self.dev_u8[slot]), st)
-                call("mmvae_gather_rows", ptr(self.text), ptr(self.idx_dev[slot]), self.B, self.row_tx, ptr(self.dev_tx[slot]), st)
+                # pixels: gather + ToTensor in one kernel, straight into the fp32 batch (nothing but the wait is left on the compute stream)
+                call("mmvae_gather_rows_u8_f32", ptr(self.images), ptr(self.idx_host[slot]), self.B, self.row_u8, 255.0, ptr(self.dev_f32[slot]), st)
+                call("mmvae_gather_rows", ptr(self.text), ptr(self.idx_host[slot]), self.B, self.row_tx, ptr(self.dev_tx[slot]), st)
             else:
                 self.dev_u8[slot].copy_(self.stage_u8[slot], non_blocking=True)
                 self.dev_tx[slot].copy_(self.stage_tx[slot], non_blocking=True)
@@ -244,7 +262,10 @@ class DeviceBatcher:
                 slot = (g0 + b) % S
                 cur = torch.cuda.current_stream(self.device)
                 import ctypes as C
-                call("mmvae_u8_to_f32_after", ptr(self.dev_u8[slot]), self._bytes_u8, 255.0, ptr(self.dev_f32[slot]),
+                if self.device_gather:
+                    call("mmvae_stream_wait_event", C.c_void_p(cur.cuda_stream), C.c_void_p(self._ready_h[slot]))
+                else:
+                    call("mmvae_u8_to_f32_after", ptr(self.dev_u8[slot]), self._bytes_u8, 255.0, ptr(self.dev_f32[slot]),
                      C.c_void_p(self._ready_h[slot]), C.c_void_p(cur.cuda_stream))       # wait for the copy's event, then ToTensor
                 try:
                     yield self.dev_f32[slot], self.dev_tx[slot]
